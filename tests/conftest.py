@@ -1,0 +1,71 @@
+"""pytest configuration: the ``gpu`` marker and shared fixtures.
+
+``-m "not gpu"`` runs everywhere (oracle vs goldens, host logic, C-ABI symbol
+checks); ``-m gpu`` needs a real MI355X and goes through the C-ABI library.
+Nothing here reads /root/reference: that tree does not exist on the GPU box.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _npz(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def golden_real():
+    return _npz("golden_real.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_rand():
+    return _npz("golden_rand.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_kat():
+    return _npz("golden_kat.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_stress():
+    return _npz("golden_nms_stress.npz")
+
+
+@pytest.fixture(scope="session")
+def cfg():
+    z = _npz("cfg_coco.npz")
+    return {"anchors": [float(a) for a in z["anchors"]], "classes": int(z["classes"]),
+            "anchor_num": int(z["anchor_num"]), "width": int(z["width"]), "height": int(z["height"])}
+
+
+@pytest.fixture(scope="session")
+def images_u8():
+    return _npz("images_u8.npz")["images"]
+
+
+@pytest.fixture(scope="session")
+def coco_weights():
+    from oracle import yfv2_oracle
+    return yfv2_oracle.load_weights(os.path.join(GOLDEN, "weights_coco.npz"))
+
+
+def unpack_ragged(z, prefix):
+    """inverse of make_golden.pack_ragged -> (list of rows, list of idx)"""
+    cnt = z[prefix + "_count"]
+    off = np.concatenate(([0], np.cumsum(cnt)))
+    rows = [z[prefix + "_rows"][off[i]:off[i + 1]] for i in range(len(cnt))]
+    idx = [z[prefix + "_idx"][off[i]:off[i + 1]] for i in range(len(cnt))]
+    return rows, idx

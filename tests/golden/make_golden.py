@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REAL reference.
+
+Runs only in the build container, where /root/reference exists (it does not
+exist on the GPU box; tests read the committed .npz files instead).  The
+reference's own Python code is imported - never copied - with sys.modules stubs
+for the three imports that are absent here:
+
+  torchsummary  (model/backbone/shufflenetv2.py:3)     -> no-op
+  cv2           (utils/utils.py:1)                      -> empty module
+  torchvision   (utils/utils.py:5; nms at :286)         -> oracle.nms_greedy
+
+Outputs (all small, committed):
+  weights_coco.npz     modelzoo/coco2017-0.241078ap-model.pth as float arrays
+  images_u8.npz        the 6 shipped JPEGs, PIL-bilinear to 352x352, BGR CHW uint8
+  golden_real.npz      reference logits / decoded / NMS rows+idx for those images
+  golden_rand.npz      same for a seeded torch.rand batch (2 images)
+  golden_kat.npz       hand-made one-hot logit tuples -> decoded rows (known answers)
+  golden_nms_stress.npz synthetic decoded tensors (clusters, ties, many classes)
+                       -> reference non_max_suppression rows
+
+usage: PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+from oracle import yfv2_oracle as oracle  # noqa: E402
+
+
+def import_reference():
+    ts = types.ModuleType("torchsummary"); ts.summary = lambda *a, **k: None
+    sys.modules["torchsummary"] = ts
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    tv = types.ModuleType("torchvision"); ops = types.ModuleType("torchvision.ops")
+
+    def nms(boxes, scores, thr):
+        return torch.from_numpy(oracle.nms_greedy(boxes.numpy(), scores.numpy(), thr))
+
+    ops.nms = nms; tv.ops = ops
+    sys.modules["torchvision"] = tv; sys.modules["torchvision.ops"] = ops
+    sys.path.insert(0, REF)
+    import model.detector as det  # noqa
+    import utils.utils as uu  # noqa
+    return det, uu
+
+
+def ref_nms_per_image(uu, dec, conf, iou):
+    """Call the reference NMS one image at a time (fresh 1 s timer each call,
+    utils.py:248,292-294) and recover survivor indices in 1815-row order by
+    re-deriving them from the two masks (utils.py:254,268)."""
+    rows, idxs = [], []
+    for b in range(dec.shape[0]):
+        x = torch.from_numpy(dec[b:b + 1].copy())
+        out = uu.non_max_suppression(x, conf_thres=conf, iou_thres=iou)[0].numpy()
+        rows.append(out.astype(np.float32))
+    # indices from the oracle restatement; rows must match bit-for-bit
+    o_rows, o_idx = oracle.non_max_suppression(dec, conf, iou)
+    for b in range(dec.shape[0]):
+        assert rows[b].shape == o_rows[b].shape, (b, rows[b].shape, o_rows[b].shape)
+        assert np.array_equal(rows[b].view(np.uint32), o_rows[b].view(np.uint32)), "oracle NMS != reference NMS"
+    return rows, o_idx
+
+
+def pack_ragged(prefix, rows, idxs, out):
+    out[prefix + "_count"] = np.asarray([r.shape[0] for r in rows], np.int32)
+    out[prefix + "_rows"] = np.concatenate(rows, 0).astype(np.float32) if rows else np.zeros((0, 6), np.float32)
+    out[prefix + "_idx"] = np.concatenate(idxs, 0).astype(np.int32) if idxs else np.zeros((0,), np.int32)
+
+
+def main():
+    from PIL import Image
+    torch.set_num_threads(1)  # one fixed summation order for the goldens
+    det, uu = import_reference()
+    cfg = uu.load_datafile(os.path.join(REF, "data/coco.data"))
+    sd = torch.load(os.path.join(REF, "modelzoo/coco2017-0.241078ap-model.pth"), map_location="cpu")
+    model = det.Detector(cfg["classes"], cfg["anchor_num"], True)
+    print(model.load_state_dict(sd))
+    model.eval()
+
+    np.savez_compressed(os.path.join(HERE, "weights_coco.npz"), **{k: v.numpy() for k, v in sd.items()})
+    np.savez(os.path.join(HERE, "cfg_coco.npz"), anchors=np.asarray(cfg["anchors"], np.float64),
+             classes=cfg["classes"], anchor_num=cfg["anchor_num"], width=cfg["width"], height=cfg["height"])
+
+    names = ["img/000004.jpg", "img/000139.jpg", "img/000148.jpg", "img/000181.jpg", "img/000230.jpg",
+             "sample/ncnn/test.jpg"]
+    imgs = []
+    for n in names:
+        im = Image.open(os.path.join(REF, n)).convert("RGB").resize((cfg["width"], cfg["height"]), Image.BILINEAR)
+        a = np.asarray(im)[:, :, ::-1]  # RGB -> BGR like cv2.imread (test.py:34)
+        imgs.append(np.ascontiguousarray(a.transpose(2, 0, 1)))
+    imgs = np.stack(imgs).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "images_u8.npz"), images=imgs, names=np.asarray(names))
+
+    w = {k: v for k, v in sd.items()}
+
+    def run(x, tag, path):
+        with torch.no_grad():
+            preds = model(x)
+        dec = uu.handel_preds(preds, cfg, torch.device("cpu")).numpy()
+        out = {"x_is": tag, "x_sum64": np.float64(x.double().sum().item()), "x_probe": x.flatten()[::100003].numpy()}
+        for k, p in zip(("reg2", "obj2", "cls2", "reg3", "obj3", "cls3"), preds):
+            out["logit_" + k] = p.numpy()
+        out["decoded"] = dec
+        for ct, it, nm in ((0.3, 0.4, "nms_03_04"), (0.01, 0.4, "nms_001_04"), (0.3, 0.45, "nms_03_045")):
+            rows, idxs = ref_nms_per_image(uu, dec, ct, it)
+            pack_ragged(nm, rows, idxs, out)
+        # sanity: the oracle restatement agrees with the reference on its own machine
+        o_preds = oracle.forward(w, x)
+        for a, b in zip(preds, o_preds):
+            assert torch.equal(a, b), "oracle.forward != reference forward (same threads, same ops)"
+        o_dec = oracle.decode(preds, cfg["anchors"], cfg["height"])
+        d = np.abs(o_dec - dec)
+        print(tag, "decode max abs diff oracle-vs-ref:", d.max(), "rel:", (d / np.maximum(1, np.abs(dec))).max())
+        np.savez_compressed(path, **out)
+        return dec
+
+    x_real = torch.from_numpy(imgs).float() / 255.0  # test.py:38
+    dec_real = run(x_real, "images_u8/255", os.path.join(HERE, "golden_real.npz"))
+    torch.manual_seed(1234)
+    x_rand = torch.rand(2, 3, cfg["height"], cfg["width"])
+    run(x_rand, "torch.manual_seed(1234); torch.rand(2,3,352,352)", os.path.join(HERE, "golden_rand.npz"))
+
+    # --- known-answer logits: one hot anchor per scale ---------------
+    B = 1
+    preds = [torch.full((B, 12, 22, 22), -20.0), torch.full((B, 3, 22, 22), -20.0), torch.zeros((B, 80, 22, 22)),
+             torch.full((B, 12, 11, 11), -20.0), torch.full((B, 3, 11, 11), -20.0), torch.zeros((B, 80, 11, 11))]
+    # scale 0, cell (y=5,x=7), anchor 1 ; scale 1, cell (y=3,x=4), anchor 2: zero logits -> sigmoid .5
+    preds[0][0, 4:8, 5, 7] = 0.0; preds[1][0, 1, 5, 7] = 3.0; preds[2][0, 17, 5, 7] = 9.0
+    preds[3][0, 8:12, 3, 4] = 0.0; preds[4][0, 2, 3, 4] = 2.0; preds[5][0, 63, 3, 4] = 7.0
+    dec = uu.handel_preds(preds, cfg, torch.device("cpu")).numpy()
+    kat = {"decoded": dec}
+    for k, p in zip(("reg2", "obj2", "cls2", "reg3", "obj3", "cls3"), preds):
+        kat["logit_" + k] = p.numpy()
+    r0 = (5 * 22 + 7) * 3 + 1; r1 = 1452 + (3 * 11 + 4) * 3 + 2
+    print("KAT rows", r0, dec[0, r0, :5], r1, dec[0, r1, :5])
+    kat["rows"] = np.asarray([r0, r1])
+    np.savez_compressed(os.path.join(HERE, "golden_kat.npz"), **kat)
+
+    # --- NMS stress: synthetic decoded tensors --------------------------------------------
+    rng = np.random.default_rng(7)
+    S = 6
+    dec = np.zeros((S, 1815, 85), np.float32)
+    # start from real decodes so the bulk looks plausible, then overwrite blocks of rows
+    dec[:] = dec_real[rng.integers(0, dec_real.shape[0], S)]
+    for s in range(S):
+        n = (40, 300, 900, 1815, 64, 500)[s]
+        rows = rng.choice(1815, n, replace=False)
+        k = max(1, n // 12)
+        cx = rng.uniform(20, 330, k); cy = rng.uniform(20, 330, k)
+        which = rng.integers(0, k, n)
+        dec[s, rows, 0] = cx[which] + rng.normal(0, 6, n)
+        dec[s, rows, 1] = cy[which] + rng.normal(0, 6, n)
+        dec[s, rows, 2] = rng.uniform(10, 120, n); dec[s, rows, 3] = rng.uniform(10, 120, n)
+        dec[s, rows, 4] = rng.uniform(0.05, 1.0, n)
+        logits = rng.normal(0, 1, (n, 80)); ncls = (80, 3, 80, 5, 1, 80)[s]
+        logits[np.arange(n), rng.integers(0, ncls, n)] += 6
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        dec[s, rows, 5:] = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    # image 4: exact score ties + identical boxes (tie-break = lower index first)
+    rows = np.sort(rng.choice(1815, 64, replace=False))
+    dec[4, rows, 0:4] = np.asarray([100, 100, 50, 50], np.float32)
+    dec[4, rows[::2], 0] += 200.0
+    dec[4, rows, 4] = 0.75
+    dec[4, rows, 5:] = 0; dec[4, rows, 5 + 11] = 0.5
+    stress = {"decoded": dec}
+    for ct, it, nm in ((0.3, 0.4, "nms_03_04"), (0.01, 0.4, "nms_001_04"), (0.25, 0.6, "nms_025_06")):
+        r, i = ref_nms_per_image(uu, dec, ct, it)
+        pack_ragged(nm, r, i, stress)
+        print(nm, [x.shape[0] for x in r])
+    np.savez_compressed(os.path.join(HERE, "golden_nms_stress.npz"), **stress)
+    for f in sorted(os.listdir(HERE)):
+        print("%10d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
+
+
+if __name__ == "__main__":
+    main()

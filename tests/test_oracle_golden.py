@@ -1,0 +1,121 @@
+"""Pin the CPU oracle (oracle/yfv2_oracle.py) against outputs of the reference
+itself (tests/golden/*.npz, produced by tests/golden/make_golden.py importing
+/root/reference).  CPU only.
+
+Tolerances: the goldens were produced single-threaded; a different thread count
+or CPU ISA changes oneDNN's summation order, so logits are compared at 2e-5
+(measured reference-vs-reference noise is <= 1.7e-5) rather than
+bit-exactly.  Decode from *golden logits* is <= 2 ulp (torch's strided-vs-
+contiguous sigmoid).  NMS from *golden decoded* is bit-exact.
+"""
+import numpy as np
+import torch
+
+from conftest import unpack_ragged
+from oracle import yfv2_oracle as oracle
+
+LOGIT_KEYS = ("reg2", "obj2", "cls2", "reg3", "obj3", "cls3")
+
+
+def _logits(z):
+    return [torch.from_numpy(z["logit_" + k]) for k in LOGIT_KEYS]
+
+
+def test_forward_real_images(golden_real, images_u8, coco_weights):
+    x = torch.from_numpy(images_u8).float() / 255.0
+    assert abs(x.double().sum().item() - float(golden_real["x_sum64"])) < 1e-6
+    preds = oracle.forward(coco_weights, x)
+    for p, k in zip(preds, LOGIT_KEYS):
+        assert p.shape == golden_real["logit_" + k].shape
+        np.testing.assert_allclose(p.numpy(), golden_real["logit_" + k], rtol=0, atol=2e-5)
+
+
+def test_forward_seeded_rand(golden_rand, coco_weights):
+    torch.manual_seed(1234)
+    x = torch.rand(2, 3, 352, 352)
+    np.testing.assert_array_equal(x.flatten()[::100003].numpy(), golden_rand["x_probe"])
+    preds = oracle.forward(coco_weights, x)
+    for p, k in zip(preds, LOGIT_KEYS):
+        np.testing.assert_allclose(p.numpy(), golden_rand["logit_" + k], rtol=0, atol=2e-5)
+
+
+def _ulp_close(a, b, ulps):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    tol = ulps * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32))
+    return np.all(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol + 1e-12)
+
+
+def test_decode_from_golden_logits(golden_real, golden_rand, golden_kat, cfg):
+    for z in (golden_real, golden_rand, golden_kat):
+        dec = oracle.decode(_logits(z), cfg["anchors"], cfg["height"])
+        assert dec.shape == z["decoded"].shape and dec.dtype == np.float32
+        assert _ulp_close(dec, z["decoded"], 2)
+
+
+def test_decode_known_answers(golden_kat):
+    """Row order (y,x,anchor), grid, stride and anchors: SURVEY.md 8(c) row 3."""
+    dec = golden_kat["decoded"][0]
+    r0, r1 = golden_kat["rows"]
+    assert (r0, r1) == (352, 1565)
+    np.testing.assert_allclose(dec[352, :4], [120.0, 88.0, 37.88, 51.48], rtol=1e-6)
+    np.testing.assert_allclose(dec[1565, :4], [144.0, 112.0, 279.92, 258.87], rtol=1e-6)
+    assert dec[352, 5:].argmax() == 17 and dec[1565, 5:].argmax() == 63
+
+
+def _check_nms(z, prefix, conf, iou):
+    rows, idx = oracle.non_max_suppression(z["decoded"], conf, iou)
+    g_rows, g_idx = unpack_ragged(z, prefix)
+    assert len(rows) == len(g_rows)
+    for b in range(len(rows)):
+        assert rows[b].shape == g_rows[b].shape, (prefix, b)
+        assert np.array_equal(rows[b].view(np.uint32), g_rows[b].view(np.uint32)), (prefix, b)
+        assert np.array_equal(idx[b], g_idx[b]), (prefix, b)
+
+
+def test_nms_bit_exact_real(golden_real, golden_rand):
+    for z in (golden_real, golden_rand):
+        _check_nms(z, "nms_03_04", 0.3, 0.4)
+        _check_nms(z, "nms_001_04", 0.01, 0.4)
+        _check_nms(z, "nms_03_045", 0.3, 0.45)
+
+
+def test_nms_bit_exact_stress(golden_stress):
+    _check_nms(golden_stress, "nms_03_04", 0.3, 0.4)
+    _check_nms(golden_stress, "nms_001_04", 0.01, 0.4)
+    _check_nms(golden_stress, "nms_025_06", 0.25, 0.6)
+    # the stress set must actually hit max_det and the tie-break path
+    assert golden_stress["nms_03_04_count"].max() == 300
+
+
+def test_survivor_indices_match_survey(golden_real):
+    """SURVEY.md 'Sanity goldens': img/000139.jpg -> rows 491, 1662, 1061."""
+    _, idx = unpack_ragged(golden_real, "nms_03_04")
+    assert list(idx[1]) == [491, 1662, 1061]
+    assert list(idx[2]) == [1670]
+
+
+def test_nms_edge_cases():
+    empty = np.zeros((2, 1815, 85), np.float32)
+    rows, idx = oracle.non_max_suppression(empty, 0.3, 0.4)
+    assert all(r.shape == (0, 6) for r in rows) and all(i.shape == (0,) for i in idx)
+    # obj passes, conf does not
+    one = empty.copy(); one[0, 7, :5] = [10, 10, 4, 4, 0.9]; one[0, 7, 5] = 0.2
+    rows, _ = oracle.non_max_suppression(one, 0.3, 0.4)
+    assert rows[0].shape == (0, 6)
+    # class filter (utils.py:271-272)
+    one[0, 7, 5 + 3] = 0.9
+    rows, idx = oracle.non_max_suppression(one, 0.3, 0.4, classes=[3])
+    assert rows[0].shape == (1, 6) and idx[0][0] == 7 and rows[0][0, 5] == 3.0
+    rows, _ = oracle.non_max_suppression(one, 0.3, 0.4, classes=[4])
+    assert rows[0].shape == (0, 6)
+
+
+def test_random_weights_are_complete(coco_weights):
+    rw = oracle.random_weights(0)
+    assert set(rw) == set(coco_weights)
+    for k in rw:
+        assert tuple(rw[k].shape) == tuple(coco_weights[k].shape), k
+    preds = oracle.forward(rw, torch.rand(1, 3, 352, 352))
+    assert all(torch.isfinite(p).all() for p in preds)
+    assert float(preds[2].abs().max()) > 1e-3  # activations neither vanish nor explode
+    assert float(preds[2].abs().max()) < 1e3
