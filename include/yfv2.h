@@ -1,0 +1,143 @@
+/* yfv2.h - C ABI of libyfv2.so: the MI355X-native (gfx950) Yolo-FastestV2 forward
+ * detection path.  This header is the drop-in boundary: plain C, raw device
+ * pointers and sizes, no torch / C++ types.  The reference (dog-qiuqiu/
+ * Yolo-FastestV2) is pure Python and has no FFI of its own; each entry point
+ * below replaces the named reference Python symbol (file:line under the
+ * reference tree), and yolo_fastestv2_amd/ binds them with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative yfv2_status; nothing
+ *     throws across the ABI; yfv2_last_error() gives the message for a handle
+ *     (or for the calling thread when the handle is NULL / creation failed).
+ *   - the caller owns every buffer it passes; the library owns only its weight
+ *     blob and workspace (allocated in yfv2_create for `max_batch` images).
+ *   - all work is enqueued on the caller's HIP stream (`stream` is a
+ *     hipStream_t passed as void*; NULL = the default stream).  No hidden
+ *     device synchronisation, except in yfv2_profile_forward and
+ *     yfv2_debug_activation, which are measurement/debug helpers and say so.
+ *   - all pointers named x / out6 / boxes / dets / idx / count are DEVICE
+ *     pointers; weights passed to yfv2_load_weights are HOST pointers.
+ *   - one handle per device, not thread-safe (one stream at a time).
+ *   - there is no CPU fallback: if no gfx950 device is usable, yfv2_create
+ *     fails with YFV2_ERR_DEVICE.
+ */
+#ifndef YFV2_H
+#define YFV2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YFV2_ABI_VERSION 1
+#define YFV2_API __attribute__((visibility("default")))
+#define YFV2_MAX_DET 300 /* utils/utils.py:243 max_det */
+
+typedef enum yfv2_status {
+  YFV2_OK = 0,
+  YFV2_ERR_ARG = -1,     /* NULL / out-of-range argument */
+  YFV2_ERR_CONFIG = -2,  /* unsupported model configuration */
+  YFV2_ERR_DEVICE = -3,  /* no usable gfx950 device / HIP runtime error */
+  YFV2_ERR_WEIGHTS = -4, /* missing / mis-shaped tensor in yfv2_load_weights */
+  YFV2_ERR_STATE = -5,   /* call order (e.g. forward before load_weights) */
+  YFV2_ERR_BATCH = -6    /* B < 1 or B > max_batch */
+} yfv2_status;
+
+typedef struct yfv2_ctx* yfv2_handle;
+
+/* Mirrors the cfg dict the reference reads from its ".data" file
+ * (utils/utils.py:13-65: classes, anchor_num, width, height, anchors) plus
+ * the workspace size. */
+typedef struct yfv2_config {
+  int32_t classes;     /* 80  */
+  int32_t anchor_num;  /* 3 (the reference hard-codes 3: utils/utils.py:300,326) */
+  int32_t height;      /* 352; multiple of 32 */
+  int32_t width;       /* 352; multiple of 32, <= 384 */
+  double anchors[12];  /* data/coco.data:17, float64 like utils/utils.py:305 */
+  int32_t max_batch;   /* workspace is sized for this many images */
+  int32_t device;      /* HIP device ordinal */
+} yfv2_config;
+
+/* One named fp32 tensor of a reference state_dict (host memory). */
+typedef struct yfv2_tensor_desc {
+  const char* name;  /* reference key, e.g. "backbone.stage2.0.branch_main.0.weight" */
+  const float* data; /* host pointer, contiguous fp32 */
+  int64_t numel;
+} yfv2_tensor_desc;
+
+/* ---- lifetime -------------------------------------------------------------- */
+
+/* replaces: model/detector.py:8-19 Detector.__init__ (+ .to(device)) */
+YFV2_API int yfv2_create(yfv2_handle* out, const yfv2_config* cfg);
+YFV2_API void yfv2_destroy(yfv2_handle h);
+YFV2_API const char* yfv2_last_error(yfv2_handle h);
+YFV2_API int yfv2_abi_version(void);
+
+/* replaces: nn.Module.load_state_dict (test.py:28, evaluation.py:53).  Takes the
+ * reference key set (BN running stats included, num_batches_tracked ignored),
+ * folds BN to per-channel scale/shift (eval mode, eps 1e-5), re-lays-out the
+ * filters for the kernels and uploads them.  Synchronous. */
+YFV2_API int yfv2_load_weights(yfv2_handle h, const yfv2_tensor_desc* tensors, int32_t n);
+
+/* Replace the 6 anchor pairs used by yfv2_decode / yfv2_detect (the reference passes
+ * cfg["anchors"] to handel_preds on every call, utils/utils.py:305-306). Host-side only. */
+YFV2_API int yfv2_set_anchors(yfv2_handle h, const double anchors[12]);
+
+/* ---- the hot path ---------------------------------------------------------- */
+
+/* replaces: model/detector.py:21-47 Detector.forward (export_onnx=False).
+ * x: (B,3,H,W) fp32 NCHW in [0,1].  out6: six NCHW fp32 logit tensors in the
+ * reference's return order (reg_2, obj_2, cls_2, reg_3, obj_3, cls_3) with
+ * shapes (B,4A,H/16,W/16) (B,A,..) (B,classes,..) and the same at H/32. */
+YFV2_API int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream);
+
+/* replaces: utils/utils.py:303-358 handel_preds (+ make_grid :298-300).
+ * boxes: (B, rows, 5+classes) fp32, rows = A*(H/16*W/16 + H/32*W/32) = 1815,
+ * row order (y, x, anchor) per scale, scale 0 then 1; columns cx,cy,w,h,obj,cls. */
+YFV2_API int yfv2_decode(yfv2_handle h, const float* const out6[6], int32_t B, float* boxes, void* stream);
+
+/* replaces: utils/utils.py:232-296 non_max_suppression incl. xywh2xyxy :67-74
+ * and torchvision.ops.nms (called at :286), without the 1 s wall-clock abort.
+ * conf_thres is compared in fp32 (as the reference's tensor>python-float does),
+ * iou_thres in double (as torchvision's kernel does).  classes may be NULL.
+ * dets: (B,300,6) fp32 rows x1,y1,x2,y2,conf,cls, descending conf, first
+ * count[b] rows valid; idx: (B,300) int32 = row index of each survivor in the
+ * decode order; count: (B) int32. */
+YFV2_API int yfv2_nms(yfv2_handle h, const float* boxes, int32_t B, float conf_thres, double iou_thres,
+             const int32_t* classes, int32_t n_classes, float* dets, int32_t* idx, int32_t* count,
+             void* stream);
+
+/* forward -> decode -> NMS in one call (test.py:42,48,49 / utils/utils.py:379-383).
+ * Intermediate logits and the decoded tensor live in the handle's workspace. */
+YFV2_API int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, double iou_thres,
+                float* dets, int32_t* idx, int32_t* count, void* stream);
+
+/* ---- introspection / measurement (bench.py, tests) ------------------------- */
+
+YFV2_API int32_t yfv2_num_rows(yfv2_handle h);   /* 1815 for 352x352, A=3 */
+YFV2_API int32_t yfv2_num_stages(yfv2_handle h); /* launches in one forward */
+
+/* Static description of launch `i` of the forward plan: kernel name, which
+ * reference layers it covers, and its ALGORITHMIC work per image (flops =
+ * 2*MACs; bytes = activation bytes read + written once, fp32), the figures
+ * DESIGN.md / bench.py's roofline use. */
+YFV2_API int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_cap, double* flops_per_image,
+                    double* bytes_per_image);
+
+/* Measurement helper (synchronises): runs the forward `iters` times with a
+ * hipEvent pair around every launch on `stream` and writes the mean duration
+ * of each launch in milliseconds to ms[0..num_stages). */
+YFV2_API int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], int32_t iters,
+                         float* ms, void* stream);
+
+/* Debug/parity helper: copy one internal NHWC activation of the LAST forward
+ * to host as (B,H,W,C).  which: 0 stem+pool, 1 stage2, 2 stage3 (C2), 3 stage4
+ * (C3), 4 S2 (fpn 22x22), 5 S3 (fpn 11x11).  Returns the element count. */
+YFV2_API int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YFV2_H */

@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP path, through the C ABI (libyfv2.so), against the
+CPU oracle and the committed reference goldens.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances (BASELINE.md 5 / SURVEY.md 8(c); north_star says 1e-4 fp32):
+  logits            |d| <= 1e-4
+  obj / cls scores  |d| <= 1e-5
+  box coords        |d| <= 1e-4 * max(1, |ref|)
+  NMS (identical decoded tensor in): rows and survivor indices BIT-EXACT
+  end-to-end at test.py thresholds (0.3/0.4): identical survivor indices
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, unpack_ragged
+from oracle import yfv2_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_KEYS = ("reg2", "obj2", "cls2", "reg3", "obj3", "cls3")
+LOGIT_ATOL = 1e-4
+SCORE_ATOL = 1e-5
+BOX_RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def yfv2():
+    import yolo_fastestv2_amd
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    assert os.path.exists(yolo_fastestv2_amd.LIB_PATH), "libyfv2.so not built"
+    return yolo_fastestv2_amd
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(yfv2, dev, coco_weights):
+    m = yfv2.Detector(80, 3, True).to(dev)
+    missing = m.load_state_dict(coco_weights)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.eval()
+
+
+@pytest.fixture(scope="module")
+def post_engine(yfv2, dev, cfg):
+    eng = yfv2.get_engine(dev, cfg["height"], cfg["width"], cfg["classes"], cfg["anchor_num"])
+    eng.set_anchors(cfg["anchors"])
+    return eng
+
+
+def _assert_decoded_close(got, ref, what=""):
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    box_ok = d[..., :4] <= BOX_RTOL * np.maximum(1.0, np.abs(ref[..., :4]))
+    assert box_ok.all(), "%s box coords: worst abs %g rel %g" % (
+        what, d[..., :4].max(), (d[..., :4] / np.maximum(1.0, np.abs(ref[..., :4]))).max())
+    assert d[..., 4:].max() <= SCORE_ATOL, "%s scores: worst %g" % (what, d[..., 4:].max())
+
+
+# ---------------------------------------------------------------------------------------
+# forward
+# ---------------------------------------------------------------------------------------
+def test_stage_activations_vs_oracle(model, dev, images_u8, coco_weights):
+    """Per-stage NHWC activations of the HIP path vs the oracle (localises a
+    mismatch to stem / stage2 / stage3 / stage4 / fpn)."""
+    x = torch.from_numpy(images_u8[:3]).float() / 255.0
+    ref = oracle.forward_stages(coco_weights, x)
+    model(x.to(dev))
+    eng = model.engine_for(x.to(dev))
+    for which, key in enumerate(("stem", "stage2", "c2", "c3", "s2", "s3")):
+        r = ref[key].permute(0, 2, 3, 1).contiguous()  # NCHW -> NHWC
+        got = eng.debug_activation(which, x.shape[0]).reshape(r.shape)
+        err = float((got - r).abs().max())
+        assert err <= LOGIT_ATOL, "stage %s: max abs err %g (ref max %g)" % (key, err, float(r.abs().max()))
+
+
+def test_forward_real_images_vs_reference_golden(model, dev, images_u8, golden_real):
+    x = (torch.from_numpy(images_u8).float() / 255.0).to(dev)
+    preds = model(x)
+    assert len(preds) == 6
+    for p, k in zip(preds, LOGIT_KEYS):
+        g = golden_real["logit_" + k]
+        assert tuple(p.shape) == g.shape and p.dtype == torch.float32 and p.device.type == "cuda"
+        err = np.abs(p.cpu().numpy() - g).max()
+        assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)
+
+
+def test_forward_seeded_rand_vs_reference_golden(model, dev, golden_rand):
+    torch.manual_seed(1234)
+    x = torch.rand(2, 3, 352, 352)
+    np.testing.assert_array_equal(x.flatten()[::100003].numpy(), golden_rand["x_probe"])
+    preds = model(x.to(dev))
+    for p, k in zip(preds, LOGIT_KEYS):
+        err = np.abs(p.cpu().numpy() - golden_rand["logit_" + k]).max()
+        assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)
+
+
+def test_forward_random_weights_odd_batches(yfv2, dev):
+    """Ragged sizes: batch 1, 3 and 5 (pixel counts that are not multiples of the
+    16/32/64-pixel MFMA tiles) with random-init weights, vs the oracle."""
+    w = yfv2.random_state_dict(3)
+    m = yfv2.Detector(80, 3, True).to(dev)
+    m.load_state_dict(w)
+    m.eval()
+    torch.manual_seed(5)
+    for B in (1, 3, 5):
+        x = torch.rand(B, 3, 352, 352)
+        ref = oracle.forward(w, x)
+        got = m(x.to(dev))
+        for g, r, k in zip(got, ref, LOGIT_KEYS):
+            scale = max(1.0, float(r.abs().max()))
+            err = float((g.cpu() - r).abs().max())
+            assert err <= LOGIT_ATOL * scale, "B=%d %s: max abs err %g (scale %g)" % (B, k, err, scale)
+
+
+def test_batch_invariance_and_permutation(model, dev, images_u8):
+    """Size-independent property at the bench batch size: every image's logits are
+    bit-identical whatever its position in a 256-batch, and equal to its batch-1 result."""
+    base = torch.from_numpy(images_u8).float() / 255.0
+    g = torch.Generator().manual_seed(11)
+    sel = torch.randint(0, base.shape[0], (256,), generator=g)
+    gain = 0.8 + 0.4 * torch.rand(256, 1, 1, 1, generator=g)
+    x = (base[sel] * gain).clamp(0, 1).to(dev)
+    perm = torch.randperm(256, generator=g)
+    a = [t.clone() for t in model(x)]
+    b = model(x[perm.to(dev)])
+    for ta, tb in zip(a, b):
+        assert torch.equal(ta[perm.to(dev)], tb), "logits depend on batch position"
+    one = model(x[17:18])
+    for ta, t1 in zip(a, one):
+        assert torch.equal(ta[17:18], t1), "logits depend on batch size"
+    assert all(torch.isfinite(t).all() for t in a)
+
+
+# ---------------------------------------------------------------------------------------
+# decode
+# ---------------------------------------------------------------------------------------
+def test_decode_from_golden_logits(post_engine, dev, golden_real, golden_rand, golden_kat):
+    for name, z in (("real", golden_real), ("rand", golden_rand), ("kat", golden_kat)):
+        preds = [torch.from_numpy(z["logit_" + k]).to(dev) for k in LOGIT_KEYS]
+        dec = post_engine.decode(preds).cpu().numpy()
+        assert dec.shape == z["decoded"].shape
+        _assert_decoded_close(dec, z["decoded"], name)
+
+
+def test_decode_known_answers(post_engine, dev, golden_kat):
+    preds = [torch.from_numpy(golden_kat["logit_" + k]).to(dev) for k in LOGIT_KEYS]
+    dec = post_engine.decode(preds).cpu().numpy()[0]
+    np.testing.assert_allclose(dec[352, :4], [120.0, 88.0, 37.88, 51.48], rtol=1e-6)
+    np.testing.assert_allclose(dec[1565, :4], [144.0, 112.0, 279.92, 258.87], rtol=1e-6)
+    assert dec[352, 5:].argmax() == 17 and dec[1565, 5:].argmax() == 63
+    np.testing.assert_allclose(dec[:, 5:].sum(1), 1.0, atol=1e-5)
+
+
+def test_handel_preds_surface(yfv2, model, dev, cfg, images_u8, golden_real):
+    """Reference call shape: handel_preds(preds, cfg, device) -> CPU fp32 (B,1815,85)."""
+    x = (torch.from_numpy(images_u8).float() / 255.0).to(dev)
+    out = yfv2.handel_preds(model(x), cfg, dev)
+    assert out.device.type == "cpu" and out.dtype == torch.float32 and tuple(out.shape) == (6, 1815, 85)
+    _assert_decoded_close(out.numpy(), golden_real["decoded"], "handel_preds")
+
+
+# ---------------------------------------------------------------------------------------
+# NMS
+# ---------------------------------------------------------------------------------------
+def _check_nms_exact(yfv2, z, prefix, conf, iou):
+    rows, idx = yfv2.nms_with_indices(torch.from_numpy(z["decoded"]), conf, iou)
+    g_rows, g_idx = unpack_ragged(z, prefix)
+    assert len(rows) == len(g_rows)
+    for b in range(len(rows)):
+        assert rows[b].device.type == "cpu" and rows[b].dtype == torch.float32 and rows[b].shape[1] == 6
+        assert tuple(rows[b].shape) == g_rows[b].shape, (prefix, b, tuple(rows[b].shape), g_rows[b].shape)
+        assert np.array_equal(rows[b].numpy().view(np.uint32), g_rows[b].view(np.uint32)), (prefix, b)
+        assert np.array_equal(idx[b].numpy(), g_idx[b]), (prefix, b)
+
+
+def test_nms_bit_exact_vs_reference_golden(yfv2, golden_real, golden_rand):
+    for z in (golden_real, golden_rand):
+        _check_nms_exact(yfv2, z, "nms_03_04", 0.3, 0.4)
+        _check_nms_exact(yfv2, z, "nms_001_04", 0.01, 0.4)
+        _check_nms_exact(yfv2, z, "nms_03_045", 0.3, 0.45)
+
+
+def test_nms_bit_exact_stress(yfv2, golden_stress):
+    """Clusters, 1815 candidates, exact ties, > max_det survivors."""
+    _check_nms_exact(yfv2, golden_stress, "nms_03_04", 0.3, 0.4)
+    _check_nms_exact(yfv2, golden_stress, "nms_001_04", 0.01, 0.4)
+    _check_nms_exact(yfv2, golden_stress, "nms_025_06", 0.25, 0.6)
+
+
+def test_nms_edge_cases(yfv2, golden_real):
+    empty = torch.zeros(3, 1815, 85)
+    out = yfv2.non_max_suppression(empty, 0.3, 0.4)
+    assert len(out) == 3 and all(tuple(o.shape) == (0, 6) for o in out)
+    # class filter (utils.py:271-272) vs the oracle
+    dec = golden_real["decoded"]
+    for classes in ([0], [2, 7], [79]):
+        rows, idx = yfv2.nms_with_indices(torch.from_numpy(dec), 0.01, 0.4, classes=classes)
+        o_rows, o_idx = oracle.non_max_suppression(dec, 0.01, 0.4, classes=classes)
+        for b in range(dec.shape[0]):
+            assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)), (classes, b)
+            assert np.array_equal(idx[b].numpy(), o_idx[b])
+
+
+def test_nms_idempotent_full_batch(yfv2, post_engine, dev, golden_stress):
+    """Size-independent property at batch 256: NMS of the survivors alone keeps all of them,
+    and the device result equals the oracle on the device's own decoded input."""
+    base = torch.from_numpy(golden_stress["decoded"])
+    dec = base[torch.arange(256) % base.shape[0]].clone()
+    dec[:, :, 4] *= torch.linspace(0.5, 1.0, 256).view(-1, 1)
+    dets, idx, cnt = post_engine.nms(dec.to(dev), 0.25, 0.45)
+    rows, ids = yfv2.unpack_detections(dets, idx, cnt)
+    o_rows, o_idx = oracle.non_max_suppression(dec.numpy(), 0.25, 0.45)
+    for b in range(256):
+        assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)), b
+        assert np.array_equal(ids[b].numpy(), o_idx[b]), b
+    keep_only = torch.zeros_like(dec)
+    for b in range(256):
+        keep_only[b, ids[b]] = dec[b, ids[b]]
+    _, ids2 = yfv2.nms_with_indices(keep_only, 0.25, 0.45)
+    for b in range(256):
+        assert torch.equal(ids2[b], ids[b]), b
+
+
+# ---------------------------------------------------------------------------------------
+# end to end
+# ---------------------------------------------------------------------------------------
+def test_end_to_end_survivors_match_reference(yfv2, model, dev, cfg, images_u8, golden_real):
+    """test.py flow (forward -> handel_preds -> NMS 0.3/0.4): identical survivor indices,
+    rows within the box/score tolerances."""
+    x = (torch.from_numpy(images_u8).float() / 255.0).to(dev)
+    dec = yfv2.handel_preds(model(x), cfg, dev)
+    out = yfv2.non_max_suppression(dec, conf_thres=0.3, iou_thres=0.4)
+    rows, idx = yfv2.nms_with_indices(dec, 0.3, 0.4)
+    g_rows, g_idx = unpack_ragged(golden_real, "nms_03_04")
+    for b in range(x.shape[0]):
+        assert torch.equal(out[b], rows[b])
+        assert list(idx[b].numpy()) == list(g_idx[b]), "image %d: survivors %s vs reference %s" % (b, idx[b].tolist(), list(g_idx[b]))
+        r, g = rows[b].numpy(), g_rows[b]
+        assert (np.abs(r[:, :4] - g[:, :4]) <= BOX_RTOL * np.maximum(1, np.abs(g[:, :4]))).all()
+        assert np.abs(r[:, 4] - g[:, 4]).max() <= SCORE_ATOL and np.array_equal(r[:, 5], g[:, 5])
+
+
+def test_detect_fused_call_equals_three_calls(yfv2, model, dev, cfg, images_u8):
+    x = (torch.from_numpy(images_u8).float() / 255.0).to(dev)
+    eng = model.engine_for(x)
+    eng.set_anchors(cfg["anchors"])
+    d1 = eng.detect(x, 0.3, 0.4)
+    d2 = eng.nms(eng.decode(eng.forward(x)), 0.3, 0.4)
+    r1, i1 = yfv2.unpack_detections(*d1)
+    r2, i2 = yfv2.unpack_detections(*d2)
+    for a, b, c, d in zip(r1, r2, i1, i2):
+        assert torch.equal(a, b) and torch.equal(c, d)
+
+
+def test_errors_are_loud(yfv2, model, dev):
+    with pytest.raises(RuntimeError):
+        model(torch.rand(1, 3, 352, 352))  # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        model.engine_for(torch.rand(1, 3, 352, 352, device=dev)).forward(torch.rand(1, 3, 320, 352, device=dev))
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(torch.rand(1, 3, 352, 352, device=dev))
+    model.eval()
+    with pytest.raises(yfv2.Yfv2Error):
+        yfv2.Engine(dev, 352, 352, 80, 3, max_batch=1).forward(torch.rand(1, 3, 352, 352, device=dev))  # no weights

@@ -1,0 +1,86 @@
+"""ctypes binding of libyfv2.so (the C ABI declared in include/yfv2.h).
+
+There is deliberately NO fallback: if the shared library is missing or does not
+export the ABI this module raises, and every product entry point fails loudly.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (or
+``make -C yolo_fastestv2_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyfv2.so")
+ABI_VERSION = 1
+MAX_DET = 300
+
+OK, ERR_ARG, ERR_CONFIG, ERR_DEVICE, ERR_WEIGHTS, ERR_STATE, ERR_BATCH = 0, -1, -2, -3, -4, -5, -6
+
+
+class Config(C.Structure):
+    _fields_ = [("classes", C.c_int32), ("anchor_num", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("anchors", C.c_double * 12), ("max_batch", C.c_int32), ("device", C.c_int32)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class Yfv2Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libyfv2 error %d: %s" % (code, msg))
+        self.code = code
+
+
+_PROTOTYPES = {
+    # name: (restype, argtypes)
+    "yfv2_abi_version": (C.c_int, []),
+    "yfv2_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config)]),
+    "yfv2_destroy": (None, [C.c_void_p]),
+    "yfv2_last_error": (C.c_char_p, [C.c_void_p]),
+    "yfv2_load_weights": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_int32]),
+    "yfv2_set_anchors": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "yfv2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),
+    "yfv2_decode": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p]),
+    "yfv2_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_double, C.POINTER(C.c_int32), C.c_int32,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "yfv2_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p]),
+    "yfv2_num_rows": (C.c_int32, [C.c_void_p]),
+    "yfv2_num_stages": (C.c_int32, [C.c_void_p]),
+    "yfv2_stage_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]),
+    "yfv2_profile_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                       C.POINTER(C.c_float), C.c_void_p]),
+    "yfv2_debug_activation": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libyfv2.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: the HIP extension has not been built (run __graft_entry__.build()); "
+                          "yolo_fastestv2_amd has no CPU or PyTorch fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(L, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if L.yfv2_abi_version() != ABI_VERSION:
+        raise ImportError("libyfv2.so ABI %d != binding ABI %d: rebuild" % (L.yfv2_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def last_error(handle=None):
+    msg = lib().yfv2_last_error(handle)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, handle=None):
+    if rc != OK:
+        raise Yfv2Error(rc, last_error(handle))

@@ -1,0 +1,674 @@
+// yfv2_api.hip - host side of libyfv2.so: handle, weight folding/re-layout, the
+// forward launch plan and the extern "C" entry points declared in include/yfv2.h.
+//
+// The forward is a static list of launches ("plan") built once per handle from
+// the model configuration; executing it enqueues the launches on the caller's
+// stream, nothing else.  Reference dataflow followed by the plan (behaviour
+// only): model/backbone/shufflenetv2.py:102-109, model/fpn.py:51-64,
+// model/detector.py:21-47.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/yfv2.h"
+#include "yfv2_internal.h"
+
+namespace {
+
+thread_local std::string g_tls_error;
+
+struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
+
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2 };
+
+struct Step {
+  int kind = 0;
+  int K = 0, mode = 0;        // pw
+  int ksize = 0, stride = 0;  // dw
+  StemArgs stem{};
+  PwArgs pw{};
+  DwArgs dw{};
+  // offsets into the param blob, resolved to pointers after the upload
+  size_t w_off = 0, scale_off = 0, shift_off = 0;
+  int px_per_img = 0;         // pw: pixels per image (P = B * px_per_img)
+  int head0 = -1, head1 = -1; // PW_HEAD: indices into out6
+  std::string name;
+  double flops = 0, bytes = 0;  // algorithmic, per image
+};
+
+struct Buf { float* p = nullptr; size_t per_img = 0; };
+
+}  // namespace
+
+struct yfv2_ctx {
+  yfv2_config cfg{};
+  int device = 0;
+  std::string err;
+  bool weights_loaded = false;
+  int rows = 0;
+  int fh[2] = {0, 0}, fw[2] = {0, 0};
+
+  float* d_params = nullptr;
+  size_t n_params = 0;
+  std::vector<Step> plan;
+
+  // workspace (NHWC fp32), sized for cfg.max_batch
+  Buf a1, s2[2], s3[2], s4[2], t1, t2, t3, f2, f3, ta, tb;
+  Buf logits[6];
+  Buf decoded;
+  int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries)
+  // which buffers hold the stage outputs of the last forward (for debug/parity)
+  float* dbg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t dbg_per_img[6] = {0, 0, 0, 0, 0, 0};
+  int dbg_c[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(yfv2_ctx* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  g_tls_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return fail(h, YFV2_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// weights: reference state_dict -> one device blob of kernel-ready parameters
+// ---------------------------------------------------------------------------
+struct WeightPacker {
+  std::map<std::string, const yfv2_tensor_desc*> byname;
+  std::vector<float> blob;
+  std::string missing;
+
+  const float* get(const std::string& name, int64_t numel) {
+    auto it = byname.find(name);
+    if (it == byname.end() || it->second->data == nullptr) {
+      if (missing.empty()) missing = "missing tensor '" + name + "'";
+      return nullptr;
+    }
+    if (it->second->numel != numel) {
+      if (missing.empty())
+        missing = "tensor '" + name + "' has " + std::to_string(it->second->numel) + " elements, expected " +
+                  std::to_string(numel);
+      return nullptr;
+    }
+    return it->second->data;
+  }
+  size_t reserve(size_t n) {  // 16-byte aligned slots
+    size_t off = (blob.size() + 3) & ~size_t(3);
+    blob.resize(off + n, 0.f);
+    return off;
+  }
+  // eval-mode BatchNorm2d -> y = x*scale + shift  (ATen: alpha = gamma*invstd, beta = bias - mean*alpha)
+  bool bn(const std::string& name, int c, Folded* f) {
+    const float* g = get(name + ".weight", c);
+    const float* b = get(name + ".bias", c);
+    const float* m = get(name + ".running_mean", c);
+    const float* v = get(name + ".running_var", c);
+    if (!g || !b || !m || !v) return false;
+    f->scale = reserve(c);
+    f->shift = reserve(c);
+    for (int i = 0; i < c; ++i) {
+      const float invstd = 1.0f / std::sqrt(v[i] + 1e-5f);
+      const float alpha = g[i] * invstd;
+      blob[f->scale + i] = alpha;
+      blob[f->shift + i] = b[i] - m[i] * alpha;
+    }
+    return true;
+  }
+  // pointwise conv weight (co, ci, 1, 1) is already the [M][K] row-major A operand
+  bool pw(const std::string& conv, const std::string& bnname, int co, int ci, Folded* f) {
+    const float* w = get(conv + ".weight", (int64_t)co * ci);
+    if (!w) return false;
+    f->w = reserve((size_t)co * ci);
+    std::memcpy(&blob[f->w], w, sizeof(float) * co * ci);
+    return bn(bnname, co, f);
+  }
+  // depthwise weight (C,1,k,k) -> [k*k][C] so that a channel quad is one 16-byte load
+  bool dw(const std::string& conv, const std::string& bnname, int c, int k, Folded* f) {
+    const float* w = get(conv + ".weight", (int64_t)c * k * k);
+    if (!w) return false;
+    f->w = reserve((size_t)c * k * k);
+    for (int ch = 0; ch < c; ++ch)
+      for (int t = 0; t < k * k; ++t) blob[f->w + (size_t)t * c + ch] = w[(size_t)ch * k * k + t];
+    return bn(bnname, c, f);
+  }
+  // stem weight (24,3,3,3) -> [27 taps][24 co]
+  bool stem(const std::string& conv, const std::string& bnname, Folded* f) {
+    const float* w = get(conv + ".weight", 24 * 27);
+    if (!w) return false;
+    f->w = reserve(24 * 27);
+    for (int co = 0; co < 24; ++co)
+      for (int t = 0; t < 27; ++t) blob[f->w + (size_t)t * 24 + co] = w[co * 27 + t];
+    return bn(bnname, 24, f);
+  }
+  // biased output convs: rows of several (co_i, 72) matrices stacked; scale = 1, shift = bias
+  bool heads(const std::vector<std::pair<std::string, int>>& parts, int ci, Folded* f) {
+    int total = 0;
+    for (auto& p : parts) total += p.second;
+    f->w = reserve((size_t)total * ci);
+    f->scale = reserve(total);
+    f->shift = reserve(total);
+    int row = 0;
+    for (auto& p : parts) {
+      const float* w = get(p.first + ".weight", (int64_t)p.second * ci);
+      const float* b = get(p.first + ".bias", p.second);
+      if (!w || !b) return false;
+      std::memcpy(&blob[f->w + (size_t)row * ci], w, sizeof(float) * p.second * ci);
+      for (int i = 0; i < p.second; ++i) {
+        blob[f->scale + row + i] = 1.0f;
+        blob[f->shift + row + i] = b[i];
+      }
+      row += p.second;
+    }
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct PlanBuilder {
+  yfv2_ctx* h;
+  WeightPacker& wp;
+  bool ok = true;
+
+  void add_stem(const Buf& out) {
+    Folded f;
+    ok &= wp.stem("backbone.first_conv.0", "backbone.first_conv.1", &f);
+    Step s;
+    s.kind = STEP_STEM;
+    s.stem.out = out.p;
+    s.stem.H = h->cfg.height;
+    s.stem.W = h->cfg.width;
+    const int ph = h->cfg.height / 4;
+    int R = 11;  // pooled rows per band: halo recompute (2R+1)/(2R)
+    while (ph % R) --R;
+    s.stem.R = R;
+    s.w_off = f.w; s.scale_off = f.scale; s.shift_off = f.shift;
+    s.name = "stem conv3x3s2+bn+relu+maxpool3x3s2";
+    const double ch = h->cfg.height / 2.0, cw = h->cfg.width / 2.0;
+    s.flops = 2.0 * ch * cw * 27 * 24;
+    s.bytes = 4.0 * (3.0 * h->cfg.height * h->cfg.width + (ch / 2) * (cw / 2) * 24);
+    h->plan.push_back(s);
+  }
+
+  // generic pointwise launch; bn_name empty => Folded given by caller (heads)
+  Step& add_pw(const std::string& name, int K, int mode, int M, int px, const float* in, int in_stride, int in_off,
+               float* out, int out_stride, int out_off, bool relu, const Folded& f) {
+    Step s;
+    s.kind = STEP_PW;
+    s.K = K; s.mode = mode;
+    s.pw.in = in; s.pw.in2 = nullptr; s.pw.out = out;
+    s.pw.M = M;
+    s.pw.in_stride = in_stride; s.pw.in_off = in_off;
+    s.pw.out_stride = out_stride; s.pw.out_off = out_off;
+    s.pw.relu = relu ? 1 : 0;
+    s.pw.copy = nullptr; s.pw.copy_stride = 0; s.pw.copy_off = 0;
+    s.pw.H = 0; s.pw.W = 0; s.pw.HW = px;
+    s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0;
+    s.px_per_img = px;
+    s.w_off = f.w; s.scale_off = f.scale; s.shift_off = f.shift;
+    s.name = name;
+    s.flops = 2.0 * px * K * M;
+    s.bytes = 4.0 * px * (K + M);
+    h->plan.push_back(s);
+    return h->plan.back();
+  }
+
+  void add_dw(const std::string& name, int k, int stride, int C, int H, int W, const float* in, int in_stride,
+              float* out, int out_stride, bool relu, const Folded& f) {
+    Step s;
+    s.kind = STEP_DW;
+    s.ksize = k; s.stride = stride;
+    s.dw.in = in; s.dw.out = out;
+    s.dw.H = H; s.dw.W = W; s.dw.C = C;
+    s.dw.OH = H / stride; s.dw.OW = W / stride;
+    s.dw.in_stride = in_stride; s.dw.in_off = 0;
+    s.dw.out_stride = out_stride; s.dw.out_off = 0;
+    s.dw.relu = relu ? 1 : 0;
+    s.w_off = f.w; s.scale_off = f.scale; s.shift_off = f.shift;
+    s.name = name;
+    s.flops = 2.0 * s.dw.OH * s.dw.OW * C * k * k;
+    s.bytes = 4.0 * C * ((double)H * W + (double)s.dw.OH * s.dw.OW);
+    h->plan.push_back(s);
+  }
+
+  // ShuffleV2Block stride 2 (shufflenetv2.py:19-44,52-55): out = cat(proj(x), main(x))
+  void block_s2(const std::string& p, int cin, int H, int W, const Buf& x, const Buf& y) {
+    Folded f;
+    const int oh = H / 2, ow = W / 2, co = 2 * cin;
+    ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &f);
+    add_dw(p + ".proj.dw3x3s2+bn", 3, 2, cin, H, W, x.p, cin, h->t3.p, cin, false, f);
+    ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &f);
+    add_pw(p + ".proj.pw+bn+relu", cin, PW_PLAIN, cin, oh * ow, h->t3.p, cin, 0, y.p, co, 0, true, f);
+    ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", cin, cin, &f);
+    add_pw(p + ".main.pw1+bn+relu", cin, PW_PLAIN, cin, H * W, x.p, cin, 0, h->t1.p, cin, 0, true, f);
+    ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", cin, 3, &f);
+    add_dw(p + ".main.dw3x3s2+bn", 3, 2, cin, H, W, h->t1.p, cin, h->t2.p, cin, false, f);
+    ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", cin, cin, &f);
+    add_pw(p + ".main.pw2+bn+relu", cin, PW_PLAIN, cin, oh * ow, h->t2.p, cin, 0, y.p, co, cin, true, f);
+  }
+
+  // ShuffleV2Block stride 1 (shufflenetv2.py:48-51,57-63): even channels pass through,
+  // odd channels -> main; out = cat(pass, main)
+  void block_s1(const std::string& p, int c, int H, int W, const Buf& x, const Buf& y) {
+    Folded f;
+    const int c2 = c / 2;
+    ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", c2, c2, &f);
+    Step& s = add_pw(p + ".shuffle+pass+main.pw1+bn+relu", c2, PW_SHUFFLE, c2, H * W, x.p, c, 0, h->t1.p, c2, 0, true, f);
+    s.pw.copy = y.p; s.pw.copy_stride = c; s.pw.copy_off = 0;
+    s.bytes = 4.0 * H * W * (c + c2 + c2);  // reads both halves, writes pass-through half + pw1 output
+    ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", c2, 3, &f);
+    add_dw(p + ".main.dw3x3+bn", 3, 1, c2, H, W, h->t1.p, c2, h->t2.p, c2, false, f);
+    ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", c2, c2, &f);
+    add_pw(p + ".main.pw2+bn+relu", c2, PW_PLAIN, c2, H * W, h->t2.p, c2, 0, y.p, c, c2, true, f);
+  }
+
+  // DWConvblock (fpn.py:12-25) + the output convs fed by this tower (detector.py:25-31)
+  void tower(const std::string& p, int H, int W, const Buf& s_in, bool is_cls, int scale_idx) {
+    Folded f;
+    const int px = H * W;
+    ok &= wp.dw(p + ".0", p + ".1", 72, 5, &f);
+    add_dw(p + ".dw5x5+bn+relu(a)", 5, 1, 72, H, W, s_in.p, 72, h->ta.p, 72, true, f);
+    ok &= wp.pw(p + ".3", p + ".4", 72, 72, &f);
+    add_pw(p + ".pw+bn(a)", 72, PW_PLAIN, 72, px, h->ta.p, 72, 0, h->tb.p, 72, 0, false, f);
+    ok &= wp.dw(p + ".5", p + ".6", 72, 5, &f);
+    add_dw(p + ".dw5x5+bn+relu(b)", 5, 1, 72, H, W, h->tb.p, 72, h->ta.p, 72, true, f);
+    ok &= wp.pw(p + ".8", p + ".9", 72, 72, &f);
+    add_pw(p + ".pw+bn(b)", 72, PW_PLAIN, 72, px, h->ta.p, 72, 0, h->tb.p, 72, 0, false, f);
+    const int A = h->cfg.anchor_num, nc = h->cfg.classes;
+    if (is_cls) {
+      ok &= wp.heads({{"output_obj_layers", A}, {"output_cls_layers", nc}}, 72, &f);
+      Step& s = add_pw(p + " -> output_obj+output_cls (bias, NCHW)", 72, PW_HEAD, A + nc, px, h->tb.p, 72, 0, nullptr,
+                       0, 0, false, f);
+      s.pw.split = A;
+      s.head0 = scale_idx * 3 + 1;
+      s.head1 = scale_idx * 3 + 2;
+    } else {
+      ok &= wp.heads({{"output_reg_layers", 4 * A}}, 72, &f);
+      Step& s = add_pw(p + " -> output_reg (bias, NCHW)", 72, PW_HEAD, 4 * A, px, h->tb.p, 72, 0, nullptr, 0, 0, false, f);
+      s.pw.split = 4 * A;
+      s.head0 = scale_idx * 3 + 0;
+      s.head1 = -1;
+    }
+  }
+
+  void build() {
+    const int H = h->cfg.height, W = h->cfg.width;
+    add_stem(h->a1);
+    int hh = H / 4, ww = W / 4, cin = 24;
+    Buf* stage_bufs[3] = {h->s2, h->s3, h->s4};
+    const int repeats[3] = {4, 8, 4};
+    const Buf* x = &h->a1;
+    h->dbg[0] = h->a1.p; h->dbg_per_img[0] = h->a1.per_img; h->dbg_c[0] = 24;
+    for (int si = 0; si < 3; ++si) {
+      const int cout = cin * 2;
+      int cur = 0;
+      for (int i = 0; i < repeats[si]; ++i) {
+        const std::string p = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i);
+        const Buf* y = &stage_bufs[si][cur];
+        if (i == 0) {
+          block_s2(p, cin, hh, ww, *x, *y);
+          hh /= 2; ww /= 2;
+        } else {
+          block_s1(p, cout, hh, ww, *x, *y);
+        }
+        x = y;
+        cur ^= 1;
+      }
+      h->dbg[1 + si] = x->p; h->dbg_per_img[1 + si] = x->per_img; h->dbg_c[1 + si] = cout;
+      cin = cout;
+    }
+    const Buf* c2 = nullptr; const Buf* c3 = x;
+    // stage3 output: 8 blocks -> last written buffer index is (8-1)&1 ... recover from dbg
+    Buf c2b; c2b.p = h->dbg[2]; c2b.per_img = h->dbg_per_img[2]; c2 = &c2b;
+    const int h3 = H / 32, w3 = W / 32, h2 = H / 16, w2 = W / 16;
+    Folded f;
+    ok &= wp.pw("fpn.conv1x1_3.0", "fpn.conv1x1_3.1", 72, 192, &f);
+    add_pw("fpn.conv1x1_3 pw192->72+bn+relu", 192, PW_PLAIN, 72, h3 * w3, c3->p, 192, 0, h->f3.p, 72, 0, true, f);
+    ok &= wp.pw("fpn.conv1x1_2.0", "fpn.conv1x1_2.1", 72, 288, &f);
+    {
+      Step& s = add_pw("fpn.conv1x1_2 up2x(C3)+cat(C2)+pw288->72+bn+relu", 288, PW_FPN, 72, h2 * w2, c3->p, 192, 0,
+                       h->f2.p, 72, 0, true, f);
+      s.pw.in2 = c2->p;
+      s.pw.H = h2; s.pw.W = w2;
+      s.bytes = 4.0 * (h3 * w3 * 192.0 + h2 * w2 * 96.0 + h2 * w2 * 72.0);
+    }
+    h->dbg[4] = h->f2.p; h->dbg_per_img[4] = h->f2.per_img; h->dbg_c[4] = 72;
+    h->dbg[5] = h->f3.p; h->dbg_per_img[5] = h->f3.per_img; h->dbg_c[5] = 72;
+    tower("fpn.cls_head_3.block", h3, w3, h->f3, true, 1);
+    tower("fpn.reg_head_3.block", h3, w3, h->f3, false, 1);
+    tower("fpn.cls_head_2.block", h2, w2, h->f2, true, 0);
+    tower("fpn.reg_head_2.block", h2, w2, h->f2, false, 0);
+  }
+};
+
+int alloc_buf(yfv2_ctx* h, Buf* b, size_t per_img) {
+  b->per_img = per_img;
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&b->p), per_img * sizeof(float) * (size_t)h->cfg.max_batch));
+  return YFV2_OK;
+}
+
+void free_buf(Buf* b) {
+  if (b->p) (void)hipFree(b->p);
+  b->p = nullptr;
+}
+
+size_t logit_elems(const yfv2_ctx* h, int i) {
+  const int sc = i / 3, k = i % 3;
+  const int c = k == 0 ? 4 * h->cfg.anchor_num : (k == 1 ? h->cfg.anchor_num : h->cfg.classes);
+  return (size_t)c * h->fh[sc] * h->fw[sc];
+}
+
+int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream_t s, hipEvent_t* ev /*nullable: 2 per step*/) {
+  const float* params = h->d_params;
+  for (size_t i = 0; i < h->plan.size(); ++i) {
+    Step& st = h->plan[i];
+    if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i], s));
+    if (st.kind == STEP_STEM) {
+      StemArgs a = st.stem;
+      a.x = x; a.B = B;
+      a.w = params + st.w_off; a.scale = params + st.scale_off; a.shift = params + st.shift_off;
+      yfv2_launch_stem(a, s);
+    } else if (st.kind == STEP_PW) {
+      PwArgs a = st.pw;
+      a.P = B * st.px_per_img;
+      a.w = params + st.w_off; a.scale = params + st.scale_off; a.shift = params + st.shift_off;
+      if (st.mode == PW_HEAD) {
+        a.nchw0 = out6[st.head0];
+        a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
+      }
+      if (!yfv2_launch_pw(st.K, st.mode, a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no pointwise kernel for step '" + st.name + "'");
+    } else {
+      DwArgs a = st.dw;
+      a.B = B;
+      a.w = params + st.w_off; a.scale = params + st.scale_off; a.shift = params + st.shift_off;
+      if (!yfv2_launch_dw(st.ksize, st.stride, a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no depthwise kernel for step '" + st.name + "'");
+    }
+    if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i + 1], s));
+  }
+  HIP_TRY(h, hipGetLastError());
+  return YFV2_OK;
+}
+
+int check_call(yfv2_ctx* h, int B, bool need_weights) {
+  if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
+  if (B < 1 || B > h->cfg.max_batch)
+    return fail(h, YFV2_ERR_BATCH, "batch " + std::to_string(B) + " outside [1, max_batch=" + std::to_string(h->cfg.max_batch) + "]");
+  if (need_weights && !h->weights_loaded) return fail(h, YFV2_ERR_STATE, "yfv2_load_weights has not been called");
+  return YFV2_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// extern "C" surface
+// ===========================================================================
+extern "C" {
+
+int yfv2_abi_version(void) { return YFV2_ABI_VERSION; }
+
+const char* yfv2_last_error(yfv2_handle h) { return h ? h->err.c_str() : g_tls_error.c_str(); }
+
+int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
+  if (!out || !cfg) return fail(nullptr, YFV2_ERR_ARG, "yfv2_create: null argument");
+  *out = nullptr;
+  if (cfg->anchor_num != 3)
+    return fail(nullptr, YFV2_ERR_CONFIG, "anchor_num must be 3 (the reference decode hard-codes 3 anchors per scale)");
+  if (cfg->classes < 1 || cfg->classes + cfg->anchor_num > 96)
+    return fail(nullptr, YFV2_ERR_CONFIG, "classes must be in [1, 93]");
+  if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32 || cfg->width > 384)
+    return fail(nullptr, YFV2_ERR_CONFIG, "height/width must be multiples of 32 and width <= 384");
+  if (cfg->max_batch < 1) return fail(nullptr, YFV2_ERR_CONFIG, "max_batch must be >= 1");
+  const int rows = 3 * ((cfg->height / 16) * (cfg->width / 16) + (cfg->height / 32) * (cfg->width / 32));
+  if (rows > 2048) return fail(nullptr, YFV2_ERR_CONFIG, "more than 2048 decode rows per image is not supported by the NMS kernel");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, YFV2_ERR_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+    return fail(nullptr, YFV2_ERR_DEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, YFV2_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+
+  yfv2_ctx* h = new yfv2_ctx();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  h->rows = rows;
+  h->fh[0] = cfg->height / 16; h->fw[0] = cfg->width / 16;
+  h->fh[1] = cfg->height / 32; h->fw[1] = cfg->width / 32;
+  DeviceGuard guard(h->device);
+  const size_t H = cfg->height, W = cfg->width;
+  int rc = YFV2_OK;
+  auto A = [&](Buf* b, size_t n) { if (rc == YFV2_OK) rc = alloc_buf(h, b, n); };
+  A(&h->a1, (H / 4) * (W / 4) * 24);
+  for (int i = 0; i < 2; ++i) {
+    A(&h->s2[i], (H / 8) * (W / 8) * 48);
+    A(&h->s3[i], (H / 16) * (W / 16) * 96);
+    A(&h->s4[i], (H / 32) * (W / 32) * 192);
+  }
+  A(&h->t1, (H / 4) * (W / 4) * 24);
+  A(&h->t2, (H / 4) * (W / 4) * 24);
+  A(&h->t3, (H / 4) * (W / 4) * 24);
+  A(&h->f2, (H / 16) * (W / 16) * 72);
+  A(&h->f3, (H / 32) * (W / 32) * 72);
+  A(&h->ta, (H / 16) * (W / 16) * 72);
+  A(&h->tb, (H / 16) * (W / 16) * 72);
+  for (int i = 0; i < 6; ++i) A(&h->logits[i], logit_elems(h, i));
+  A(&h->decoded, (size_t)rows * (5 + cfg->classes));
+  if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 256 * sizeof(int32_t)) != hipSuccess)
+    rc = fail(h, YFV2_ERR_DEVICE, "hipMalloc(class filter) failed");
+  if (rc != YFV2_OK) {
+    g_tls_error = h->err;
+    yfv2_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return YFV2_OK;
+}
+
+void yfv2_destroy(yfv2_handle h) {
+  if (!h) return;
+  DeviceGuard guard(h->device);
+  free_buf(&h->a1);
+  for (int i = 0; i < 2; ++i) { free_buf(&h->s2[i]); free_buf(&h->s3[i]); free_buf(&h->s4[i]); }
+  free_buf(&h->t1); free_buf(&h->t2); free_buf(&h->t3);
+  free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->ta); free_buf(&h->tb);
+  for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
+  free_buf(&h->decoded);
+  if (h->d_classes) (void)hipFree(h->d_classes);
+  if (h->d_params) (void)hipFree(h->d_params);
+  delete h;
+}
+
+int yfv2_load_weights(yfv2_handle h, const yfv2_tensor_desc* tensors, int32_t n) {
+  if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
+  if (!tensors || n <= 0) return fail(h, YFV2_ERR_ARG, "yfv2_load_weights: no tensors");
+  DeviceGuard guard(h->device);
+  WeightPacker wp;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
+  h->plan.clear();
+  PlanBuilder pb{h, wp};
+  pb.build();
+  if (!pb.ok || !wp.missing.empty()) {
+    h->plan.clear();
+    h->weights_loaded = false;
+    return fail(h, YFV2_ERR_WEIGHTS, wp.missing.empty() ? "weight packing failed" : wp.missing);
+  }
+  HIP_TRY(h, hipDeviceSynchronize());  // nothing of ours may still read the old blob
+  if (h->d_params && h->n_params < wp.blob.size()) { (void)hipFree(h->d_params); h->d_params = nullptr; }
+  if (!h->d_params) {
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_params), wp.blob.size() * sizeof(float)));
+    h->n_params = wp.blob.size();
+  }
+  HIP_TRY(h, hipMemcpy(h->d_params, wp.blob.data(), wp.blob.size() * sizeof(float), hipMemcpyHostToDevice));
+  h->weights_loaded = true;
+  return YFV2_OK;
+}
+
+int yfv2_set_anchors(yfv2_handle h, const double anchors[12]) {
+  if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
+  if (!anchors) return fail(h, YFV2_ERR_ARG, "yfv2_set_anchors: null pointer");
+  for (int i = 0; i < 12; ++i) h->cfg.anchors[i] = anchors[i];
+  return YFV2_OK;
+}
+
+int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream) {
+  int rc = check_call(h, B, true);
+  if (rc) return rc;
+  if (!x || !out6) return fail(h, YFV2_ERR_ARG, "yfv2_forward: null pointer");
+  for (int i = 0; i < 6; ++i)
+    if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_forward: null output tensor");
+  DeviceGuard guard(h->device);
+  return run_plan(h, x, B, out6, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int yfv2_decode(yfv2_handle h, const float* const out6[6], int32_t B, float* boxes, void* stream) {
+  int rc = check_call(h, B, false);
+  if (rc) return rc;
+  if (!out6 || !boxes) return fail(h, YFV2_ERR_ARG, "yfv2_decode: null pointer");
+  for (int i = 0; i < 6; ++i)
+    if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_decode: null logit tensor");
+  DeviceGuard guard(h->device);
+  DecodeArgs a{};
+  for (int sc = 0; sc < 2; ++sc) {
+    a.reg[sc] = out6[sc * 3 + 0];
+    a.obj[sc] = out6[sc * 3 + 1];
+    a.cls[sc] = out6[sc * 3 + 2];
+    a.fh[sc] = h->fh[sc];
+    a.fw[sc] = h->fw[sc];
+    // utils.py:332  stride = cfg["height"] / r.shape[0]  (python float -> fp32 scalar multiply)
+    a.stride[sc] = (float)((double)h->cfg.height / (double)h->fh[sc]);
+  }
+  for (int i = 0; i < 12; ++i) a.anchors[i] = h->cfg.anchors[i];
+  a.boxes = boxes;
+  a.B = B;
+  a.classes = h->cfg.classes;
+  a.rows = h->rows;
+  yfv2_launch_decode(a, static_cast<hipStream_t>(stream));
+  HIP_TRY(h, hipGetLastError());
+  return YFV2_OK;
+}
+
+int yfv2_nms(yfv2_handle h, const float* boxes, int32_t B, float conf_thres, double iou_thres, const int32_t* classes,
+             int32_t n_classes, float* dets, int32_t* idx, int32_t* count, void* stream) {
+  int rc = check_call(h, B, false);
+  if (rc) return rc;
+  if (!boxes || !dets || !idx || !count) return fail(h, YFV2_ERR_ARG, "yfv2_nms: null pointer");
+  if (n_classes < 0 || n_classes > 256 || (n_classes > 0 && !classes))
+    return fail(h, YFV2_ERR_ARG, "yfv2_nms: bad class filter");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NmsArgs a{};
+  a.boxes = boxes; a.dets = dets; a.idx = idx; a.count = count;
+  a.classes = nullptr; a.n_classes = 0;
+  if (n_classes > 0) {  // classes is a HOST array (python list in the reference, utils.py:271-272)
+    HIP_TRY(h, hipMemcpyAsync(h->d_classes, classes, sizeof(int32_t) * n_classes, hipMemcpyHostToDevice, s));
+    a.classes = h->d_classes; a.n_classes = n_classes;
+  }
+  a.B = B; a.rows = h->rows; a.nc = h->cfg.classes;
+  a.conf_thres = conf_thres; a.iou_thres = iou_thres;
+  yfv2_launch_nms(a, s);
+  HIP_TRY(h, hipGetLastError());
+  return YFV2_OK;
+}
+
+int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, double iou_thres, float* dets, int32_t* idx,
+                int32_t* count, void* stream) {
+  int rc = check_call(h, B, true);
+  if (rc) return rc;
+  float* out6[6];
+  for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
+  rc = yfv2_forward(h, x, B, out6, stream);
+  if (rc) return rc;
+  rc = yfv2_decode(h, out6, B, h->decoded.p, stream);
+  if (rc) return rc;
+  return yfv2_nms(h, h->decoded.p, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
+}
+
+int32_t yfv2_num_rows(yfv2_handle h) { return h ? h->rows : 0; }
+
+int32_t yfv2_num_stages(yfv2_handle h) { return h ? (int32_t)h->plan.size() : 0; }
+
+int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_cap, double* flops_per_image, double* bytes_per_image) {
+  if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
+  if (i < 0 || i >= (int32_t)h->plan.size()) return fail(h, YFV2_ERR_ARG, "stage index out of range");
+  const Step& s = h->plan[i];
+  if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", s.name.c_str());
+  if (flops_per_image) *flops_per_image = s.flops;
+  if (bytes_per_image) *bytes_per_image = s.bytes;
+  return YFV2_OK;
+}
+
+int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], int32_t iters, float* ms, void* stream) {
+  int rc = check_call(h, B, true);
+  if (rc) return rc;
+  if (!x || !out6 || !ms || iters < 1) return fail(h, YFV2_ERR_ARG, "yfv2_profile_forward: bad argument");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t n = h->plan.size();
+  std::vector<hipEvent_t> ev(2 * n);
+  for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
+  std::vector<double> acc(n, 0.0);
+  for (int it = 0; it < iters && rc == YFV2_OK; ++it) {
+    rc = run_plan(h, x, B, out6, s, ev.data());
+    if (rc) break;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; ++i) {
+      float t = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+      acc[i] += t;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc) return rc;
+  for (size_t i = 0; i < n; ++i) ms[i] = (float)(acc[i] / iters);
+  return YFV2_OK;
+}
+
+int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap) {
+  if (!h || which < 0 || which > 5 || !h->dbg[which] || B < 1 || B > h->cfg.max_batch) {
+    fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: bad argument");
+    return YFV2_ERR_ARG;
+  }
+  DeviceGuard guard(h->device);
+  const int64_t n = (int64_t)h->dbg_per_img[which] * B;
+  if (!host_dst) return n;
+  if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(host_dst, h->dbg[which], (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+    fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");
+    return YFV2_ERR_DEVICE;
+  }
+  return n;
+}
+
+}  // extern "C"

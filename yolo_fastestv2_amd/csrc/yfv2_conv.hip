@@ -1,0 +1,401 @@
+// yfv2_conv.hip - gfx950 (CDNA4, wave64) kernels of the Yolo-FastestV2 forward:
+//   stem_kernel : conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2   (VALU, SGPR weights)
+//   pw_kernel   : every pointwise 1x1 conv (+BN, +ReLU) on v_mfma_f32_16x16x4_f32,
+//                 with channel-shuffle / concat / nearest-upsample / NCHW-head
+//                 folded into its operand loads and stores
+//   dw_kernel   : depthwise 3x3 / 5x5 (+BN, +ReLU), NHWC float4 over channels
+//
+// Reference layers (read for behaviour only): model/backbone/shufflenetv2.py:19-63,
+// 74-80; model/fpn.py:12-25,35-43,51-64; model/detector.py:17-31.
+//
+// Data layout: all internal activations are NHWC fp32 (pixel-major, channels
+// contiguous) so that a 16-lane group reads one pixel's channel quad per lane
+// and stores are 16 B per lane; the API surface stays NCHW (input image and the
+// six logit maps).
+#include "yfv2_internal.h"
+
+// ============================================================================
+// stem: conv3x3 s2 + BN + ReLU + maxpool3x3 s2
+// ============================================================================
+// One workgroup = one band of R pooled rows of one image; thread = one conv
+// column (W/2 <= 192).  The block streams down the conv rows of its band: each
+// thread computes the 24 output channels of its conv pixel with the 648 filter
+// taps held in SGPRs (wave-uniform scalar loads -> v_fmac v, s, v: no LDS or
+// VGPR traffic for weights), writes the BN+ReLU row into a 3-row LDS ring, and
+// every second row the block max-pools the ring into one NHWC output row.  The
+// 24x176x176 conv map (2.97 MB/image) never touches HBM.
+typedef const float __attribute__((address_space(4)))* cfloat_p;
+constexpr int STEM_THREADS = 192;
+constexpr int STEM_CS = 28;  // LDS floats per conv pixel (24 + 4 pad: conflict-free b128 stores)
+
+__global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];  // [3][CW+2][STEM_CS]
+  const int H = a.H, W = a.W, CH = H >> 1, CW = W >> 1, PH = H >> 2, PW = W >> 2;
+  const int RS = (CW + 2) * STEM_CS;
+  const int bands = PH / a.R;
+  const int band = blockIdx.x % bands, b = blockIdx.x / bands;
+  const int py0 = band * a.R;
+  const int tid = threadIdx.x;
+  const int cx = tid;
+  const bool col_ok = cx < CW;
+  // filter taps and BN constants are read through the constant address space so
+  // that hipcc emits wave-uniform s_load (SGPR operands), not per-lane vector loads
+  const cfloat_p wgt = (cfloat_p)(uintptr_t)a.w;
+  const cfloat_p bn_sc = (cfloat_p)(uintptr_t)a.scale;
+  const cfloat_p bn_sh = (cfloat_p)(uintptr_t)a.shift;
+  const float* __restrict__ xb = a.x + (size_t)b * 3 * H * W;
+
+  // zero the two pad columns of all three ring rows once (conv cols -1 and CW;
+  // post-ReLU values are >= 0 so 0 is a neutral element for the max)
+  for (int i = tid; i < 3 * 2 * STEM_CS; i += STEM_THREADS) {
+    int slot = i / (2 * STEM_CS), r = i % (2 * STEM_CS);
+    int col = (r < STEM_CS) ? 0 : (CW + 1);
+    ring[slot * RS + col * STEM_CS + (r % STEM_CS)] = 0.f;
+  }
+
+  const int cy_first = 2 * py0 - 1, cy_last = 2 * py0 + 2 * a.R - 1;
+  for (int cy = cy_first; cy <= cy_last; ++cy) {
+    const int slot = (cy + 3) % 3;
+    float* row = ring + slot * RS;
+    if (col_ok) {
+      f32x4 o[6];
+      if (cy >= 0 && cy < CH) {
+        // 3x3x3 input window of this conv pixel.  With pad 1 / stride 2 only input
+        // row -1 (cy == 0) and input column -1 (cx == 0) can fall outside the image, so
+        // loads are unconditional on clamped addresses and masked by selects (no branches).
+        float v[27];
+        const int ixm = cx > 0 ? 2 * cx - 1 : 0;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * cy - 1 + ky;
+            const bool rok = iy >= 0;
+            const float* rp = xb + ((size_t)ci * H + (rok ? iy : 0)) * W;
+            const float l = rp[ixm];
+            const f32x2 cr = *reinterpret_cast<const f32x2*>(rp + 2 * cx);
+            v[ci * 9 + ky * 3 + 0] = (rok && cx > 0) ? l : 0.f;
+            v[ci * 9 + ky * 3 + 1] = rok ? cr[0] : 0.f;
+            v[ci * 9 + ky * 3 + 2] = rok ? cr[1] : 0.f;
+          }
+        float acc[24];
+#pragma unroll
+        for (int co = 0; co < 24; ++co) acc[co] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const float vt = v[t];
+#pragma unroll
+          for (int co = 0; co < 24; ++co) acc[co] = __builtin_fmaf(vt, wgt[t * 24 + co], acc[co]);
+        }
+#pragma unroll
+        for (int co = 0; co < 24; ++co) {
+          float y = __builtin_fmaf(acc[co], bn_sc[co], bn_sh[co]);
+          o[co >> 2][co & 3] = y > 0.f ? y : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(row + (cx + 1) * STEM_CS + 4 * q) = o[q];
+    }
+    __syncthreads();
+    if ((cy & 1) && cy >= 2 * py0 + 1) {
+      const int py = (cy - 1) >> 1;
+      const float* r0 = ring + ((cy - 2 + 3) % 3) * RS;
+      const float* r1 = ring + ((cy - 1 + 3) % 3) * RS;
+      const float* r2 = row;
+      float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
+      for (int i = tid; i < PW * 6; i += STEM_THREADS) {
+        const int px = i / 6, q = i - px * 6;
+        const int base = (2 * px) * STEM_CS + 4 * q;
+        f32x4 m = *reinterpret_cast<const f32x4*>(r0 + base);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int o = base + dx * STEM_CS;
+          f32x4 u0 = *reinterpret_cast<const f32x4*>(r0 + o);
+          f32x4 u1 = *reinterpret_cast<const f32x4*>(r1 + o);
+          f32x4 u2 = *reinterpret_cast<const f32x4*>(r2 + o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], u0[k]), fmaxf(u1[k], u2[k]));
+        }
+        *reinterpret_cast<f32x4*>(orow + (size_t)i * 4) = m;  // (px*24 + 4q) == 4*i
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
+  const int bands = (a.H / 4) / a.R;
+  const size_t lds = (size_t)3 * (a.W / 2 + 2) * STEM_CS * sizeof(float);
+  hipLaunchKernelGGL(stem_kernel, dim3(a.B * bands), dim3(STEM_THREADS), lds, s, a);
+}
+
+// ============================================================================
+// pointwise 1x1 conv on the fp32 matrix cores
+// ============================================================================
+// GEMM view per wave:  D[co][pixel] = sum_ci W[co][ci] * X[pixel][ci]
+//   A operand = W   (M = output channels, 16 per tile)  - from LDS, staged once per block
+//   B operand = X^T (N = pixels, 16 per tile)           - straight from global NHWC
+// v_mfma_f32_16x16x4_f32 fragment maps (wave64): A lane l holds A[i=l&15][k=l>>4],
+// B lane l holds B[k=l>>4][j=l&15], D lane l reg r holds D[i=4*(l>>4)+r][j=l&15].
+// K order inside a 16-channel chunk is permuted so that every lane fetches its
+// four k-values as one 16-byte load: MFMA step j of chunk s consumes channel
+// 16*s + 4*(l>>4) + j from BOTH operands (any bijection of K is legal as long as
+// A and B agree).  D gives each lane 4 consecutive output channels of one pixel
+// -> one 16-byte NHWC store per tile.
+//
+// Modes fold the reference's data-movement ops into the operand traffic:
+//   PW_SHUFFLE  channel_shuffle (shufflenetv2.py:57-63): B reads the ODD input
+//               channels; the EVEN ones (the pass-through branch) are written
+//               to out[copy_off + j] by the same lanes - shuffle + cat, no copy kernel
+//   PW_FPN      F.interpolate(x2, nearest) + torch.cat (fpn.py:57-58): channels
+//               [0,192) gathered from C3 at (y/2, x/2), [192,288) from C2
+//   PW_HEAD     the three biased output convs (detector.py:17-19,25-31): stores
+//               NCHW logits into two destination tensors split at `split`
+template <int K, int MT, int NT, int MODE>
+__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
+  constexpr int KP = K + 4;  // padded LDS row: (KP/4) odd -> spreads 16-B slots
+  constexpr int K16 = K / 16;
+  constexpr int KT = K % 16;
+  static_assert(KT == 0 || KT == 8, "K must be 16*n or 16*n+8");
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [MT*16][KP]
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < MT * 16 * (K / 4); i += blockDim.x) {
+    const int row = i / (K / 4), c4 = i - row * (K / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.M) v = *reinterpret_cast<const f32x4*>(a.w + (size_t)row * K + c4 * 4);
+    *reinterpret_cast<f32x4*>(wl + row * KP + c4 * 4) = v;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = tid >> 6, nwaves = blockDim.x >> 6;
+
+  f32x4 sc[MT], sh[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * mt + 4 * g + r;
+      sc[mt][r] = co < a.M ? a.scale[co] : 0.f;
+      sh[mt][r] = co < a.M ? a.shift[co] : 0.f;
+    }
+
+  const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
+  for (int st = blockIdx.x * nwaves + wave; st < n_super; st += gridDim.x * nwaves) {
+    const int pix0 = st * (NT * 16);
+    // ---- B fragments: all K channels of this lane's pixel(s), 16 B per load
+    f32x4 bf[NT][K16 > 0 ? K16 : 1];
+    f32x2 bt[NT];
+    int pixv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pix = pix0 + nt * 16 + p;
+      pixv[nt] = pix;
+      const int pc = pix < a.P ? pix : a.P - 1;  // clamp: tail lanes load valid memory, never store
+      if constexpr (MODE == PW_PLAIN || MODE == PW_HEAD) {
+        const float* src = a.in + (size_t)pc * a.in_stride + a.in_off;
+#pragma unroll
+        for (int s = 0; s < K16; ++s) bf[nt][s] = *reinterpret_cast<const f32x4*>(src + 16 * s + 4 * g);
+        if constexpr (KT) bt[nt] = *reinterpret_cast<const f32x2*>(src + 16 * K16 + 2 * g);
+      } else if constexpr (MODE == PW_SHUFFLE) {
+        const float* src = a.in + (size_t)pc * a.in_stride;
+        float* cp = a.copy + (size_t)pc * a.copy_stride + a.copy_off;
+        const bool ok = pix < a.P;
+#pragma unroll
+        for (int s = 0; s < K16; ++s) {
+          const f32x4 q0 = *reinterpret_cast<const f32x4*>(src + 2 * (16 * s + 4 * g));
+          const f32x4 q1 = *reinterpret_cast<const f32x4*>(src + 2 * (16 * s + 4 * g) + 4);
+          bf[nt][s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};
+          if (ok) *reinterpret_cast<f32x4*>(cp + 16 * s + 4 * g) = (f32x4){q0[0], q0[2], q1[0], q1[2]};
+        }
+        if constexpr (KT) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(src + 2 * (16 * K16 + 2 * g));
+          bt[nt] = (f32x2){q[1], q[3]};
+          if (ok) *reinterpret_cast<f32x2*>(cp + 16 * K16 + 2 * g) = (f32x2){q[0], q[2]};
+        }
+      } else {  // PW_FPN: K = 288 = 192 (C3, upsampled) + 96 (C2)
+        static_assert(MODE != PW_FPN || K == 288, "PW_FPN expects K=288");
+        const int hw = a.H * a.W;
+        const int b = pc / hw, rem = pc - b * hw;
+        const int y = rem / a.W, x = rem - y * a.W;
+        const float* s3 = a.in + ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * 192;
+        const float* s2 = a.in2 + (size_t)pc * 96;
+#pragma unroll
+        for (int s = 0; s < 12; ++s) bf[nt][s] = *reinterpret_cast<const f32x4*>(s3 + 16 * s + 4 * g);
+#pragma unroll
+        for (int s = 12; s < K16; ++s) bf[nt][s] = *reinterpret_cast<const f32x4*>(s2 + 16 * (s - 12) + 4 * g);
+      }
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < K16; ++s) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[nt][s][j], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    if constexpr (KT) {  // 8-channel tail: group g owns channels 16*K16 + 2g, +1
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x2 af = *reinterpret_cast<const f32x2*>(wl + (16 * mt + p) * KP + 16 * K16 + 2 * g);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bt[nt][j], acc[mt][nt], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: BN scale/shift (or bias), ReLU, store
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pix = pixv[nt];
+      if (pix >= a.P) continue;
+      if constexpr (MODE == PW_HEAD) {
+        const int b = pix / a.HW, hw = pix - b * a.HW;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * mt + 4 * g + r;
+            if (co < a.M) {
+              const float y = __builtin_fmaf(acc[mt][nt][r], sc[mt][r], sh[mt][r]);
+              if (co < a.split)
+                a.nchw0[((size_t)b * a.split + co) * a.HW + hw] = y;
+              else
+                a.nchw1[((size_t)b * (a.M - a.split) + (co - a.split)) * a.HW + hw] = y;
+            }
+          }
+      } else {
+        float* dst = a.out + (size_t)pix * a.out_stride + a.out_off;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (16 * mt + 4 * g < a.M) {  // M % 4 == 0 for every NHWC destination
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              y[r] = __builtin_fmaf(acc[mt][nt][r], sc[mt][r], sh[mt][r]);
+              if (a.relu) y[r] = y[r] > 0.f ? y[r] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = y;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int K, int MT, int NT, int MODE>
+static void pw_launch(const PwArgs& a, hipStream_t s) {
+  constexpr int THREADS = 256;
+  const size_t lds = (size_t)MT * 16 * (K + 4) * sizeof(float);
+  const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
+  int blocks = (n_super + 3) / 4;
+  // persistent-ish grid: enough blocks to fill 256 CUs a few times over, few
+  // enough that the per-block weight staging (L2 -> LDS) stays amortised
+  const int cap = lds > 64 * 1024 ? 256 : (lds > 32 * 1024 ? 512 : 1024);
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  static bool attr_done = false;  // allow > 64 KiB dynamic LDS where needed
+  if (!attr_done && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE>), dim3(blocks), dim3(THREADS), lds, s, a);
+}
+
+bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
+  const int MT = (a.M + 15) / 16;
+  if (mode == PW_PLAIN) {
+    if (K == 24 && MT == 2) { pw_launch<24, 2, 4, PW_PLAIN>(a, s); return true; }
+    if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_PLAIN>(a, s); return true; }
+    if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_PLAIN>(a, s); return true; }
+    if (K == 72 && MT == 5) { pw_launch<72, 5, 2, PW_PLAIN>(a, s); return true; }
+    if (K == 192 && MT == 5) { pw_launch<192, 5, 2, PW_PLAIN>(a, s); return true; }
+  } else if (mode == PW_SHUFFLE) {
+    if (K == 24 && MT == 2) { pw_launch<24, 2, 4, PW_SHUFFLE>(a, s); return true; }
+    if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_SHUFFLE>(a, s); return true; }
+    if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_SHUFFLE>(a, s); return true; }
+  } else if (mode == PW_FPN) {
+    if (K == 288 && MT == 5) { pw_launch<288, 5, 1, PW_FPN>(a, s); return true; }
+  } else if (mode == PW_HEAD) {
+    if (K == 72 && MT == 1) { pw_launch<72, 1, 4, PW_HEAD>(a, s); return true; }
+    if (K == 72 && MT <= 6) { pw_launch<72, 6, 2, PW_HEAD>(a, s); return true; }
+  }
+  return false;
+}
+
+// ============================================================================
+// depthwise kxk conv + BN (+ReLU), NHWC
+// ============================================================================
+// Thread = (output pixel, channel quad): KS*KS 16-byte loads that are contiguous
+// across the lanes of a pixel (C*4 bytes) and across consecutive pixels, so
+// every wave-level load is a dense run of 1 KiB; the KS-fold re-reads of
+// neighbouring rows are served by L1/L2.  Pure HBM-bound work: no MFMA shape.
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
+  constexpr int PAD = KS / 2;
+  const int C4 = a.C >> 2;
+  const size_t total = (size_t)a.B * a.OH * a.OW * C4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    size_t pix = idx / C4;
+    const int ox = (int)(pix % a.OW);
+    size_t t = pix / a.OW;
+    const int oy = (int)(t % a.OH);
+    const int b = (int)(t / a.OH);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* inb = a.in + (size_t)b * a.H * a.W * a.in_stride + a.in_off + 4 * c4;
+    const float* wp = a.w + 4 * c4;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      const int iy = oy * STRIDE - PAD + ky;
+      if (iy < 0 || iy >= a.H) continue;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int ix = ox * STRIDE - PAD + kx;
+        if (ix < 0 || ix >= a.W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * a.W + ix) * a.in_stride);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + (ky * KS + kx) * a.C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(v[k], w[k], acc[k]);
+      }
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * c4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + 4 * c4);
+    f32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      y[k] = __builtin_fmaf(acc[k], sc[k], sh[k]);
+      if (a.relu) y[k] = y[k] > 0.f ? y[k] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(a.out + pix * a.out_stride + a.out_off + 4 * c4) = y;
+  }
+}
+
+bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s) {
+  const size_t total = (size_t)a.B * a.OH * a.OW * (a.C >> 2);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
+  if (blocks < 1) blocks = 1;
+  if (ksize == 3 && stride == 1) { hipLaunchKernelGGL((dw_kernel<3, 1>), dim3(blocks), dim3(256), 0, s, a); return true; }
+  if (ksize == 3 && stride == 2) { hipLaunchKernelGGL((dw_kernel<3, 2>), dim3(blocks), dim3(256), 0, s, a); return true; }
+  if (ksize == 5 && stride == 1) { hipLaunchKernelGGL((dw_kernel<5, 1>), dim3(blocks), dim3(256), 0, s, a); return true; }
+  return false;
+}

@@ -1,0 +1,92 @@
+// yfv2_internal.h - launch-argument structs shared by the kernel translation
+// units and the host-side plan (yfv2_api.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
+struct StemArgs {
+  const float* x;      // (B,3,H,W)
+  float* out;          // (B,H/4,W/4,24)
+  const float* w;      // [27][24]  (tap = ci*9+ky*3+kx major, co minor)
+  const float* scale;  // [24]
+  const float* shift;  // [24]
+  int B, H, W;
+  int R;               // pooled rows per band (H/4 % R == 0)
+};
+
+// ---- pointwise 1x1 conv on the fp32 MFMA, NHWC
+enum { PW_PLAIN = 0, PW_SHUFFLE = 1, PW_FPN = 2, PW_HEAD = 3 };
+struct PwArgs {
+  const float* in;     // NHWC activations (PW_FPN: C3, coarse map)
+  const float* in2;    // PW_FPN only: C2, fine map
+  float* out;          // NHWC output (unused for PW_HEAD)
+  const float* w;      // [M][K] row major (PyTorch conv weight layout)
+  const float* scale;  // [M]
+  const float* shift;  // [M]
+  int P;               // pixels = B*H*W
+  int M;               // real output channels (<= 16*MT)
+  int in_stride;       // floats per input pixel
+  int in_off;          // first input channel (PW_PLAIN)
+  int out_stride;      // floats per output pixel
+  int out_off;         // first output channel
+  int relu;
+  float* copy;         // PW_SHUFFLE: even input channels (pass-through branch) are copied to
+  int copy_stride;     //   copy[pix*copy_stride + copy_off + j]
+  int copy_off;
+  int H, W;            // PW_FPN: fine map size; PW_HEAD: H*W in HW
+  int HW;
+  float* nchw0;        // PW_HEAD: co <  split -> nchw0[b][co][hw]
+  float* nchw1;        // PW_HEAD: co >= split -> nchw1[b][co-split][hw]
+  int split;
+};
+
+// ---- depthwise kxk conv + BN (+ReLU), NHWC, float4 over channels
+struct DwArgs {
+  const float* in;
+  float* out;
+  const float* w;      // [k*k][C]
+  const float* scale;  // [C]
+  const float* shift;  // [C]
+  int B, H, W, C;      // input size, channels (C % 4 == 0)
+  int OH, OW;
+  int in_stride, in_off;
+  int out_stride, out_off;
+  int relu;
+};
+
+// ---- decode (handel_preds) and NMS
+struct DecodeArgs {
+  const float* reg[2];
+  const float* obj[2];
+  const float* cls[2];
+  float* boxes;        // (B, rows, 5+classes)
+  int B, classes;
+  int fh[2], fw[2];    // feature map sizes
+  float stride[2];     // cfg.height / fh  (fp32, like the reference's python float)
+  double anchors[12];
+  int rows;            // 3*(fh0*fw0 + fh1*fw1)
+};
+
+struct NmsArgs {
+  const float* boxes;  // (B, rows, 5+classes)
+  float* dets;         // (B, 300, 6)
+  int32_t* idx;        // (B, 300)
+  int32_t* count;      // (B)
+  const int32_t* classes;  // optional class filter (device), may be null
+  int n_classes;
+  int B, rows, nc;
+  float conf_thres;
+  double iou_thres;
+};
+
+// launchers (defined next to the kernels)
+void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
+// K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
+bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
+bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
+void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
+void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);

@@ -1,0 +1,236 @@
+// yfv2_post.hip - anchor decode and class-aware NMS for gfx950.
+// Built with -ffp-contract=off: every fp32 operation below must round exactly
+// like the reference's separate torch/numpy ops (no FMA contraction), see
+// SURVEY.md App. B.  Reference behaviour: utils/utils.py:67-74 (xywh2xyxy),
+// :232-296 (non_max_suppression), :298-358 (make_grid, handel_preds) and
+// torchvision.ops.nms (called at :286).
+#include "yfv2_internal.h"
+
+// fp32 sigmoid as ATen's CPU kernel evaluates it: 1 / (1 + exp(-x)), true division
+__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+// ============================================================================
+// decode  (handel_preds)
+// ============================================================================
+// One block = up to 64 consecutive grid cells of one (image, scale).  4 lanes
+// share a cell's 80-way softmax (20 classes each, 4-lane xor-shuffle reduce);
+// lanes 0..2 of the group additionally decode anchor a = lane.  The block
+// assembles its 64 x 3 x 85 output rows in LDS and streams them out as one
+// contiguous, fully coalesced span (rows of consecutive cells are adjacent in
+// the (y, x, anchor) row order).
+constexpr int DEC_CELLS = 64;
+constexpr int DEC_THREADS = 256;
+
+__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int blocks0, int blocks1) {
+  extern __shared__ float stage[];  // [DEC_CELLS][3][5+classes]
+  const int per_img = blocks0 + blocks1;
+  const int b = blockIdx.x / per_img;
+  int blk = blockIdx.x - b * per_img;
+  const int sc = blk >= blocks0 ? 1 : 0;
+  if (sc) blk -= blocks0;
+  const int fh = a.fh[sc], fw = a.fw[sc], hw = fh * fw;
+  const int cell0 = blk * DEC_CELLS;
+  const int ncell = min(DEC_CELLS, hw - cell0);
+  const int nc = a.classes, rowlen = 5 + nc;
+  const int tid = threadIdx.x;
+  const int lc = tid >> 2, part = tid & 3;  // local cell, quarter
+  const int cell = cell0 + lc;
+  const bool ok = lc < ncell;
+  const int cc = ok ? cell : cell0;  // clamp so that shuffles stay convergent
+
+  // ---- class softmax (fp32): exp(x - max) / sum
+  const int per = (nc + 3) >> 2;
+  const int c_lo = part * per, c_hi = min(nc, c_lo + per);
+  const float* cls = a.cls[sc] + (size_t)b * nc * hw + cc;
+  float m = -INFINITY;
+  for (int c = c_lo; c < c_hi; ++c) m = fmaxf(m, cls[(size_t)c * hw]);
+  m = fmaxf(m, __shfl_xor(m, 1));
+  m = fmaxf(m, __shfl_xor(m, 2));
+  float sum = 0.f;
+  float* srow = stage + (size_t)lc * 3 * rowlen;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const float e = expf(__fsub_rn(cls[(size_t)c * hw], m));
+    sum = __fadd_rn(sum, e);
+    if (ok) srow[5 + c] = e;  // normalised below
+  }
+  sum = __fadd_rn(sum, __shfl_xor(sum, 1));
+  sum = __fadd_rn(sum, __shfl_xor(sum, 2));
+  if (ok) {
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float pr = __fdiv_rn(srow[5 + c], sum);
+      srow[5 + c] = pr;
+      srow[rowlen + 5 + c] = pr;  // the 3 anchors share the class scores (utils.py:324-326)
+      srow[2 * rowlen + 5 + c] = pr;
+    }
+    // ---- box + objectness for anchor `part` (App. B steps 2-4)
+    if (part < 3) {
+      const int an = part;
+      const int y = cell / fw, x = cell - y * fw;
+      const float* reg = a.reg[sc] + ((size_t)b * 12 + an * 4) * hw + cell;
+      const float t0 = reg[0], t1 = reg[(size_t)hw], t2 = reg[(size_t)2 * hw], t3 = reg[(size_t)3 * hw];
+      const float ob = a.obj[sc][((size_t)b * 3 + an) * hw + cell];
+      const float st = a.stride[sc];
+      float* o = srow + an * rowlen;
+      o[0] = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t0), 2.0f), 0.5f), (float)x), st);
+      o[1] = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t1), 2.0f), 0.5f), (float)y), st);
+      const float qw = __fmul_rn(sigmoid_f32(t2), 2.0f), qh = __fmul_rn(sigmoid_f32(t3), 2.0f);
+      // fp32 square, then a float64 multiply by the float64 anchor, one rounding to fp32
+      o[2] = (float)((double)__fmul_rn(qw, qw) * a.anchors[(sc * 3 + an) * 2 + 0]);
+      o[3] = (float)((double)__fmul_rn(qh, qh) * a.anchors[(sc * 3 + an) * 2 + 1]);
+      o[4] = sigmoid_f32(ob);
+    }
+  }
+  __syncthreads();
+  const size_t row0 = (size_t)b * a.rows + (sc ? 3 * a.fh[0] * a.fw[0] : 0) + (size_t)cell0 * 3;
+  float* dst = a.boxes + row0 * rowlen;
+  const int n = ncell * 3 * rowlen;
+  for (int i = tid; i < n; i += DEC_THREADS) dst[i] = stage[i];
+}
+
+void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
+  const int b0 = (a.fh[0] * a.fw[0] + DEC_CELLS - 1) / DEC_CELLS;
+  const int b1 = (a.fh[1] * a.fw[1] + DEC_CELLS - 1) / DEC_CELLS;
+  const size_t lds = (size_t)DEC_CELLS * 3 * (5 + a.classes) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(decode_kernel, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
+}
+
+// ============================================================================
+// class-aware greedy NMS  (non_max_suppression + torchvision.ops.nms)
+// ============================================================================
+// One workgroup per image, everything in LDS:
+//   1. filter   obj > ct ; conf = max_j fl32(cls_j*obj) (first max) ; conf > ct ; class filter
+//   2. sort     bitonic sort of 64-bit keys (conf bits << 32 | ~row): descending
+//               conf, ties -> lower row first (stable order of the reference's
+//               filtered list); conf > ct >= 0 so the fp32 bit pattern is monotone
+//   3. prepare  xywh -> xyxy, + cls*4096 offset, area - all in fp32 exactly as
+//               utils.py:67-74,283-285 and torchvision compute them
+//   4. greedy   walk the sorted list; a kept box suppresses later boxes whose
+//               (double)iou > iou_thres; stop after max_det (300) kept boxes
+//               (the reference truncates the full result to 300, same set)
+constexpr int NMS_THREADS = 256;
+constexpr int NMS_CAP = 2048;      // >= rows (1815); power of two for the bitonic network
+constexpr int NMS_MAX_DET = 300;   // utils/utils.py:243 (== YFV2_MAX_DET)
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
+  __shared__ unsigned long long key[NMS_CAP];
+  __shared__ float bx1[NMS_CAP], by1[NMS_CAP], bx2[NMS_CAP], by2[NMS_CAP], area[NMS_CAP];
+  __shared__ unsigned char supp[NMS_CAP];
+  __shared__ unsigned char cls_of_row[NMS_CAP];
+  __shared__ int keep[NMS_MAX_DET];
+  __shared__ int n_cand, n_keep;
+
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int rowlen = 5 + a.nc;
+  const float* img = a.boxes + (size_t)b * a.rows * rowlen;
+  const float ct = a.conf_thres;
+  if (tid == 0) { n_cand = 0; n_keep = 0; }
+  __syncthreads();
+
+  // ---- 1. filter
+  for (int n = tid; n < a.rows; n += NMS_THREADS) {
+    const float* r = img + (size_t)n * rowlen;
+    const float obj = r[4];
+    if (!(obj > ct)) continue;
+    float best = __fmul_rn(r[5], obj);
+    int bj = 0;
+    for (int j = 1; j < a.nc; ++j) {
+      const float pj = __fmul_rn(r[5 + j], obj);
+      if (pj > best) { best = pj; bj = j; }  // strict: first maximal index wins
+    }
+    if (!(best > ct)) continue;
+    if (a.classes) {
+      bool hit = false;
+      for (int k = 0; k < a.n_classes; ++k) hit |= (a.classes[k] == bj);
+      if (!hit) continue;
+    }
+    const int slot = atomicAdd(&n_cand, 1);
+    key[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+    cls_of_row[n] = (unsigned char)bj;
+  }
+  __syncthreads();
+  const int n = n_cand;
+  if (n == 0) {
+    if (tid == 0) a.count[b] = 0;
+    return;
+  }
+
+  // ---- 2. sort (descending) on the next power of two >= n, zero keys pad the end
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = n + tid; i < np2; i += NMS_THREADS) key[i] = 0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += NMS_THREADS) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = key[i], y = key[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { key[i] = y; key[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- 3. per-candidate geometry in sorted order
+  for (int i = tid; i < n; i += NMS_THREADS) {
+    const unsigned row = 0xFFFFFFFFu - (unsigned)(key[i] & 0xFFFFFFFFull);
+    const float* r = img + (size_t)row * rowlen;
+    const float cx = r[0], cy = r[1], hw_ = __fdiv_rn(r[2], 2.0f), hh = __fdiv_rn(r[3], 2.0f);
+    const float c = __fmul_rn((float)cls_of_row[row], 4096.0f);
+    const float x1 = __fadd_rn(__fsub_rn(cx, hw_), c), y1 = __fadd_rn(__fsub_rn(cy, hh), c);
+    const float x2 = __fadd_rn(__fadd_rn(cx, hw_), c), y2 = __fadd_rn(__fadd_rn(cy, hh), c);
+    bx1[i] = x1; by1[i] = y1; bx2[i] = x2; by2[i] = y2;
+    area[i] = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    supp[i] = 0;
+  }
+  __syncthreads();
+
+  // ---- 4. greedy suppression
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    if (supp[i]) continue;  // LDS broadcast; uniform across the block
+    if (tid == 0) keep[kept] = i;
+    ++kept;
+    if (kept == NMS_MAX_DET) break;
+    const float ix1 = bx1[i], iy1 = by1[i], ix2 = bx2[i], iy2 = by2[i], ia = area[i];
+    for (int j = i + 1 + tid; j < n; j += NMS_THREADS) {
+      if (supp[j]) continue;
+      const float xx1 = fmaxf(ix1, bx1[j]), yy1 = fmaxf(iy1, by1[j]);
+      const float xx2 = fminf(ix2, bx2[j]), yy2 = fminf(iy2, by2[j]);
+      const float w = fmaxf(0.0f, __fsub_rn(xx2, xx1)), h = fmaxf(0.0f, __fsub_rn(yy2, yy1));
+      const float inter = __fmul_rn(w, h);
+      const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ia, area[j]), inter));
+      if ((double)ovr > a.iou_thres) supp[j] = 1;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+
+  // ---- output rows: un-offset box, conf, float(cls); idx = decode row
+  for (int k = tid; k < kept; k += NMS_THREADS) {
+    const int i = keep[k];
+    const unsigned long long kk = key[i];
+    const unsigned row = 0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull);
+    const float* r = img + (size_t)row * rowlen;
+    const float cx = r[0], cy = r[1], hw_ = __fdiv_rn(r[2], 2.0f), hh = __fdiv_rn(r[3], 2.0f);
+    float* d = a.dets + ((size_t)b * NMS_MAX_DET + k) * 6;
+    d[0] = __fsub_rn(cx, hw_); d[1] = __fsub_rn(cy, hh);
+    d[2] = __fadd_rn(cx, hw_); d[3] = __fadd_rn(cy, hh);
+    d[4] = __uint_as_float((unsigned)(kk >> 32));
+    d[5] = (float)cls_of_row[row];
+    a.idx[(size_t)b * NMS_MAX_DET + k] = (int)row;
+  }
+  if (tid == 0) a.count[b] = kept;
+}
+
+void yfv2_launch_nms(const NmsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
+}

@@ -1,0 +1,238 @@
+"""Engine: one libyfv2 handle on one GPU.  PyTorch is used for device memory,
+streams and host<->device copies only; every arithmetic op runs in the HIP
+kernels behind the C ABI (include/yfv2.h)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MAX_DET, Config, TensorDesc, check
+
+LOGIT_ORDER = ("reg_2", "obj_2", "cls_2", "reg_3", "obj_3", "cls_3")  # detector.py:47
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """Owns a yfv2 handle.  ``max_batch`` grows on demand (the handle is re-created
+    and the weights re-uploaded)."""
+
+    def __init__(self, device, height=352, width=352, classes=80, anchor_num=3, anchors=None, max_batch=1):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("yolo_fastestv2_amd runs on an MI355X only (got device %s); there is no CPU path" % device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.height, self.width = int(height), int(width)
+        self.classes, self.anchor_num = int(classes), int(anchor_num)
+        self.anchors = [float(a) for a in (anchors if anchors is not None else [0.0] * 12)]
+        if len(self.anchors) != 12:
+            raise ValueError("expected 12 anchor values (6 pairs), got %d" % len(self.anchors))
+        self.max_batch = 0
+        self._h = None
+        self._weights = None  # host copies (name -> contiguous fp32 cpu tensor), kept for re-creation
+        self._create(max_batch)
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def _create(self, max_batch):
+        L = _lib.lib()
+        cfg = Config()
+        cfg.classes, cfg.anchor_num = self.classes, self.anchor_num
+        cfg.height, cfg.width = self.height, self.width
+        for i, a in enumerate(self.anchors):
+            cfg.anchors[i] = a
+        cfg.max_batch = int(max_batch)
+        cfg.device = self.device.index
+        h = C.c_void_p()
+        check(L.yfv2_create(C.byref(h), C.byref(cfg)))
+        self.close()
+        self._h, self.max_batch = h, int(max_batch)
+        self.rows = int(L.yfv2_num_rows(self._h))
+        if self._weights is not None:
+            self._upload()
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().yfv2_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ensure_batch(self, B):
+        if B > self.max_batch:
+            torch.cuda.synchronize(self.device)
+            self._create(max(B, 2 * self.max_batch if self.max_batch < 64 else B))
+
+    # ---- weights --------------------------------------------------------------------------
+    def load_state_dict(self, state):
+        """state: mapping reference-key -> tensor (any device/dtype); integer
+        buffers (num_batches_tracked) are ignored."""
+        host = {}
+        for k, v in state.items():
+            v = torch.as_tensor(v)
+            if not v.is_floating_point():
+                continue
+            host[k] = v.detach().to("cpu", torch.float32).contiguous()
+        self._weights = host
+        self._upload()
+
+    def _upload(self):
+        names = list(self._weights)
+        arr = (TensorDesc * len(names))()
+        for i, k in enumerate(names):
+            t = self._weights[k]
+            arr[i].name = k.encode()
+            arr[i].data = t.data_ptr()
+            arr[i].numel = t.numel()
+        check(_lib.lib().yfv2_load_weights(self._h, arr, len(names)), self._h)
+
+    def set_anchors(self, anchors):
+        anchors = [float(a) for a in anchors]
+        if anchors != self.anchors:
+            if len(anchors) != 12:
+                raise ValueError("expected 12 anchor values (6 pairs), got %d" % len(anchors))
+            self.anchors = anchors
+        check(_lib.lib().yfv2_set_anchors(self._h, (C.c_double * 12)(*self.anchors)), self._h)
+
+    # ---- shapes ---------------------------------------------------------------------------
+    def logit_shapes(self, B):
+        A, nc = self.anchor_num, self.classes
+        h2, w2, h3, w3 = self.height // 16, self.width // 16, self.height // 32, self.width // 32
+        return [(B, 4 * A, h2, w2), (B, A, h2, w2), (B, nc, h2, w2), (B, 4 * A, h3, w3), (B, A, h3, w3), (B, nc, h3, w3)]
+
+    def _check_x(self, x):
+        if x.device != self.device:
+            raise ValueError("input on %s, engine on %s" % (x.device, self.device))
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (3, self.height, self.width):
+            raise ValueError("expected fp32 (B,3,%d,%d), got %s %s" % (self.height, self.width, x.dtype, tuple(x.shape)))
+        return x.contiguous()
+
+    # ---- the hot path ---------------------------------------------------------------------
+    def forward(self, x, out=None):
+        x = self._check_x(x)
+        B = x.shape[0]
+        self.ensure_batch(B)
+        if out is None:
+            out = [torch.empty(s, device=self.device, dtype=torch.float32) for s in self.logit_shapes(B)]
+        ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in out])
+        check(_lib.lib().yfv2_forward(self._h, _ptr(x), B, ptrs, _stream(self.device)), self._h)
+        return tuple(out)
+
+    def decode(self, preds, out=None):
+        preds = [p.contiguous() for p in preds]
+        B = preds[0].shape[0]
+        for p, s in zip(preds, self.logit_shapes(B)):
+            if tuple(p.shape) != s or p.dtype != torch.float32 or p.device != self.device:
+                raise ValueError("logit tensor %s %s on %s, expected fp32 %s on %s" % (p.dtype, tuple(p.shape), p.device, s, self.device))
+        self.ensure_batch(B)
+        if out is None:
+            out = torch.empty((B, self.rows, 5 + self.classes), device=self.device, dtype=torch.float32)
+        ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in preds])
+        check(_lib.lib().yfv2_decode(self._h, ptrs, B, _ptr(out), _stream(self.device)), self._h)
+        return out
+
+    def new_det_buffers(self, B):
+        return (torch.empty((B, MAX_DET, 6), device=self.device, dtype=torch.float32),
+                torch.empty((B, MAX_DET), device=self.device, dtype=torch.int32),
+                torch.empty((B,), device=self.device, dtype=torch.int32))
+
+    def nms(self, boxes, conf_thres, iou_thres, classes=None, out=None):
+        boxes = boxes.contiguous()
+        B = boxes.shape[0]
+        if tuple(boxes.shape[1:]) != (self.rows, 5 + self.classes) or boxes.dtype != torch.float32 or boxes.device != self.device:
+            raise ValueError("decoded tensor %s %s on %s, expected fp32 (B,%d,%d) on %s" % (
+                boxes.dtype, tuple(boxes.shape), boxes.device, self.rows, 5 + self.classes, self.device))
+        self.ensure_batch(B)
+        dets, idx, cnt = out if out is not None else self.new_det_buffers(B)
+        if classes is not None:
+            cl = [int(c) for c in classes]
+            carr, ncl = (C.c_int32 * len(cl))(*cl), len(cl)
+        else:
+            carr, ncl = None, 0
+        check(_lib.lib().yfv2_nms(self._h, _ptr(boxes), B, float(conf_thres), float(iou_thres), carr, ncl, _ptr(dets),
+                                  _ptr(idx), _ptr(cnt), _stream(self.device)), self._h)
+        return dets, idx, cnt
+
+    def detect(self, x, conf_thres, iou_thres, out=None):
+        x = self._check_x(x)
+        B = x.shape[0]
+        self.ensure_batch(B)
+        dets, idx, cnt = out if out is not None else self.new_det_buffers(B)
+        check(_lib.lib().yfv2_detect(self._h, _ptr(x), B, float(conf_thres), float(iou_thres), _ptr(dets), _ptr(idx),
+                                     _ptr(cnt), _stream(self.device)), self._h)
+        return dets, idx, cnt
+
+    # ---- introspection --------------------------------------------------------------------
+    def stages(self):
+        L = _lib.lib()
+        n = L.yfv2_num_stages(self._h)
+        out = []
+        buf = C.create_string_buffer(256)
+        for i in range(n):
+            fl, by = C.c_double(), C.c_double()
+            check(L.yfv2_stage_info(self._h, i, buf, 256, C.byref(fl), C.byref(by)), self._h)
+            out.append({"name": buf.value.decode(), "flops_per_image": fl.value, "bytes_per_image": by.value})
+        return out
+
+    def profile_forward(self, x, iters=5):
+        """Per-launch mean milliseconds (hipEvent pairs on the current stream)."""
+        x = self._check_x(x)
+        B = x.shape[0]
+        self.ensure_batch(B)
+        out = [torch.empty(s, device=self.device, dtype=torch.float32) for s in self.logit_shapes(B)]
+        ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in out])
+        n = _lib.lib().yfv2_num_stages(self._h)
+        ms = (C.c_float * n)()
+        check(_lib.lib().yfv2_profile_forward(self._h, _ptr(x), B, ptrs, int(iters), ms, _stream(self.device)), self._h)
+        return list(ms)
+
+    def debug_activation(self, which, B):
+        """NHWC activation of the last forward: 0 stem+pool, 1 stage2, 2 C2, 3 C3, 4 S2, 5 S3."""
+        L = _lib.lib()
+        n = L.yfv2_debug_activation(self._h, which, B, None, 0)
+        if n < 0:
+            check(int(n), self._h)
+        host = torch.empty(n, dtype=torch.float32)
+        got = L.yfv2_debug_activation(self._h, which, B, C.c_void_p(host.data_ptr()), n)
+        if got < 0:
+            check(int(got), self._h)
+        return host
+
+
+def unpack_detections(dets, idx, cnt):
+    """(B,300,6),(B,300),(B) device tensors -> (list of (n_i,6) CPU tensors, list of (n_i,) CPU index tensors).
+    One D2H copy per tensor (not per image)."""
+    cnt_h = cnt.cpu()
+    dets_h, idx_h = dets.cpu(), idx.cpu()
+    rows, ids = [], []
+    for b in range(cnt_h.shape[0]):
+        n = int(cnt_h[b])
+        rows.append(dets_h[b, :n].clone())
+        ids.append(idx_h[b, :n].to(torch.int64))
+    return rows, ids
+
+
+_engines = {}
+
+
+def get_engine(device, height, width, classes=80, anchor_num=3):
+    """Process-wide engine cache: one handle per (device, H, W, classes)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (str(device), int(height), int(width), int(classes), int(anchor_num))
+    eng = _engines.get(key)
+    if eng is None:
+        eng = Engine(device, height, width, classes, anchor_num)
+        _engines[key] = eng
+    return eng

@@ -1,0 +1,163 @@
+"""Drop-in for the reference's ``model.detector.Detector`` (model/detector.py:8-47).
+
+Same constructor signature, same ``state_dict`` key set (so the reference's
+checkpoints load with ``<All keys matched successfully>``), same forward
+contract: ``(B,3,H,W)`` fp32 in [0,1] -> 6-tuple of raw NCHW logits on the
+input's device.  The arithmetic is NOT torch: ``forward`` hands the input
+pointer to libyfv2's HIP kernels through the C ABI (include/yfv2.h); this module
+only owns the parameters (so ``.to()``, ``.parameters()``, ``load_state_dict``
+behave like the reference module) and the glue.
+
+Out of scope: training.  ``forward`` in ``.train()`` mode raises.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..engine import Engine
+
+STAGE_REPEATS = (4, 8, 4)        # shufflenetv2.py:69
+STAGE_CHANNELS = (24, 48, 96, 192)  # detector.py:11
+OUT_DEPTH = 72                   # detector.py:10
+
+
+def state_spec(classes, anchor_num):
+    """Yield (key, shape, kind) for every entry of the reference state_dict;
+    kind in {"conv", "bn_weight", "bn_bias", "bn_mean", "bn_var", "bn_count", "bias"}.
+    Layer structure per SURVEY.md App. A."""
+    def conv(name, co, ci, k):
+        yield name + ".weight", (co, ci, k, k), "conv"
+
+    def bn(name, c):
+        yield name + ".weight", (c,), "bn_weight"
+        yield name + ".bias", (c,), "bn_bias"
+        yield name + ".running_mean", (c,), "bn_mean"
+        yield name + ".running_var", (c,), "bn_var"
+        yield name + ".num_batches_tracked", (), "bn_count"
+
+    yield from conv("backbone.first_conv.0", STAGE_CHANNELS[0], 3, 3)
+    yield from bn("backbone.first_conv.1", STAGE_CHANNELS[0])
+    cin = STAGE_CHANNELS[0]
+    for si, rep in enumerate(STAGE_REPEATS):
+        cout = STAGE_CHANNELS[si + 1]
+        mid = cout // 2
+        for i in range(rep):
+            p = "backbone.stage%d.%d" % (si + 2, i)
+            inp = cin if i == 0 else cin // 2
+            yield from conv(p + ".branch_main.0", mid, inp, 1)
+            yield from bn(p + ".branch_main.1", mid)
+            yield from conv(p + ".branch_main.3", mid, 1, 3)
+            yield from bn(p + ".branch_main.4", mid)
+            yield from conv(p + ".branch_main.5", cout - inp, mid, 1)
+            yield from bn(p + ".branch_main.6", cout - inp)
+            if i == 0:
+                yield from conv(p + ".branch_proj.0", inp, 1, 3)
+                yield from bn(p + ".branch_proj.1", inp)
+                yield from conv(p + ".branch_proj.2", inp, inp, 1)
+                yield from bn(p + ".branch_proj.3", inp)
+            cin = cout
+    yield from conv("fpn.conv1x1_2.0", OUT_DEPTH, STAGE_CHANNELS[2] + STAGE_CHANNELS[3], 1)
+    yield from bn("fpn.conv1x1_2.1", OUT_DEPTH)
+    yield from conv("fpn.conv1x1_3.0", OUT_DEPTH, STAGE_CHANNELS[3], 1)
+    yield from bn("fpn.conv1x1_3.1", OUT_DEPTH)
+    for head in ("cls_head_2", "reg_head_2", "reg_head_3", "cls_head_3"):
+        p = "fpn.%s.block" % head
+        yield from conv(p + ".0", OUT_DEPTH, 1, 5)
+        yield from bn(p + ".1", OUT_DEPTH)
+        yield from conv(p + ".3", OUT_DEPTH, OUT_DEPTH, 1)
+        yield from bn(p + ".4", OUT_DEPTH)
+        yield from conv(p + ".5", OUT_DEPTH, 1, 5)
+        yield from bn(p + ".6", OUT_DEPTH)
+        yield from conv(p + ".8", OUT_DEPTH, OUT_DEPTH, 1)
+        yield from bn(p + ".9", OUT_DEPTH)
+    for name, co in (("output_reg_layers", 4 * anchor_num), ("output_obj_layers", anchor_num),
+                     ("output_cls_layers", classes)):
+        yield name + ".weight", (co, OUT_DEPTH, 1, 1), "conv"
+        yield name + ".bias", (co,), "bias"
+
+
+class _Node(nn.Module):
+    """Bare container: gives the parameters their reference dotted names."""
+
+
+class Detector(nn.Module):
+    def __init__(self, classes, anchor_num, load_param, export_onnx=False):
+        super().__init__()
+        self.classes, self.anchor_num = int(classes), int(anchor_num)
+        self.export_onnx = export_onnx
+        for key, shape, kind in state_spec(self.classes, self.anchor_num):
+            *path, leaf = key.split(".")
+            node = self
+            for comp in path:
+                nxt = node._modules.get(comp)
+                if nxt is None:
+                    nxt = _Node()
+                    node.add_module(comp, nxt)
+                node = nxt
+            if kind == "conv":
+                t = torch.empty(shape)
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))  # nn.Conv2d default
+                node.register_parameter(leaf, nn.Parameter(t))
+            elif kind == "bias":
+                bound = 1.0 / math.sqrt(OUT_DEPTH)
+                node.register_parameter(leaf, nn.Parameter(torch.empty(shape).uniform_(-bound, bound)))
+            elif kind == "bn_weight":
+                node.register_parameter(leaf, nn.Parameter(torch.ones(shape)))
+            elif kind == "bn_bias":
+                node.register_parameter(leaf, nn.Parameter(torch.zeros(shape)))
+            elif kind == "bn_mean":
+                node.register_buffer(leaf, torch.zeros(shape))
+            elif kind == "bn_var":
+                node.register_buffer(leaf, torch.ones(shape))
+            else:
+                node.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
+        if load_param is False:
+            # shufflenetv2.py:111-114: ImageNet backbone from a CWD-relative path
+            path = "./model/backbone/backbone.pth"
+            print("initialize_weights...")
+            if os.path.exists(path):
+                sd = torch.load(path, map_location="cpu")
+                self.load_state_dict({"backbone." + k: v for k, v in sd.items()}, strict=False)
+            else:
+                print("  (%s not found: backbone keeps its random init)" % path)
+        else:
+            print("load param...")
+        self._engines = {}      # (device, H, W) -> Engine
+        self._synced = {}       # engine key -> weight version token
+
+    # -- weights -> engine -----------------------------------------------------------------
+    def _version_token(self):
+        return tuple((t._version, t.data_ptr()) for t in self.state_dict(keep_vars=True).values())
+
+    def engine_for(self, x):
+        key = (str(x.device), int(x.shape[2]), int(x.shape[3]))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = Engine(x.device, x.shape[2], x.shape[3], self.classes, self.anchor_num, max_batch=int(x.shape[0]))
+            self._engines[key] = eng
+        tok = self._version_token()
+        if self._synced.get(key) != tok:
+            eng.load_state_dict(self.state_dict())
+            self._synced[key] = tok
+        return eng
+
+    # -- forward ---------------------------------------------------------------------------
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("yolo_fastestv2_amd.Detector implements the inference path only; "
+                                      "call .eval() (training is a 'next' row, SURVEY.md 8(f))")
+        if x.device.type != "cuda":
+            raise RuntimeError("yolo_fastestv2_amd.Detector has no CPU path: move the input to the MI355X (.to('cuda'))")
+        eng = self.engine_for(x)
+        out = eng.forward(x.float() if x.dtype != torch.float32 else x)
+        out[0]._yfv2_engine = eng  # lets handel_preds reuse this handle (utils/utils.py)
+        if self.export_onnx:
+            # detector.py:33-44 export layout: post-sigmoid/softmax, NHWC, 12 reg + 3 obj + classes
+            r2, o2, c2, r3, o3, c3 = out
+            print("export onnx ...")
+            return (torch.cat((r2.sigmoid(), o2.sigmoid(), F.softmax(c2, dim=1)), 1).permute(0, 2, 3, 1),
+                    torch.cat((r3.sigmoid(), o3.sigmoid(), F.softmax(c3, dim=1)), 1).permute(0, 2, 3, 1))
+        return out

@@ -1,0 +1,39 @@
+"""Batch-sharded inference across the GPUs of one node.
+
+Images are independent through forward, decode and NMS, so the batch is split
+contiguously over ranks (one process per GPU) with no data-path collective; the
+only exchange is one all-gather of the fixed-size, padded per-image detections
+(count + 300x6 rows + 300 indices = 8.4 KB/image).  ``torch.distributed`` backend
+"nccl" is RCCL on ROCm (xGMI); the same code runs under "gloo" on CPU tensors,
+which is how the N>1 path is tested without GPUs.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous split; the first ``n_items % world_size`` ranks get one extra."""
+    base, rem = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_detections(dets, idx, cnt, group=None):
+    """All-gather equally-sized per-rank results -> (W*B,300,6), (W*B,300), (W*B) on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dets, idx, cnt
+    W = dist.get_world_size(group)
+    out = []
+    for t in (dets, idx, cnt):
+        t = t.contiguous()
+        g = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(g, t, group=group)
+        out.append(g)
+    return tuple(out)
+
+
+def detect_sharded(engine, x_local, conf_thres, iou_thres, group=None, out=None):
+    """This rank's shard through forward+decode+NMS, then the all-gather.
+    Every rank must pass the same local batch size (pad the last shard)."""
+    dets, idx, cnt = engine.detect(x_local, conf_thres, iou_thres, out=out)
+    return gather_detections(dets, idx, cnt, group)

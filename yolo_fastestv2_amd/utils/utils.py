@@ -1,0 +1,94 @@
+"""Drop-ins for the hot-path functions of the reference's ``utils/utils.py``:
+``handel_preds`` (:303-358) and ``non_max_suppression`` (:232-296), same
+signatures and return types, executed by libyfv2's HIP kernels.  Also
+``load_datafile`` (:13-65), the ``.data`` config reader those callers need.
+"""
+import os
+
+import torch
+
+from ..engine import get_engine, unpack_detections
+
+_LIST_KEYS = ("anchors", "steps")
+_STR_KEYS = ("model_name", "val", "train", "names", "pre_weights")
+_INT_KEYS = ("epochs", "batch_size", "classes", "width", "height", "anchor_num", "subdivisions")
+_FLOAT_KEYS = ("learning_rate",)
+
+
+def load_datafile(data_path):
+    """Parse a darknet-style ``.data`` file into the cfg dict the reference uses:
+    ``[section]`` lines and blank lines are skipped, ``key=value`` typed by key."""
+    assert os.path.exists(data_path), "config file %s not found" % data_path
+    cfg = {k: None for k in _LIST_KEYS + _STR_KEYS + _INT_KEYS + _FLOAT_KEYS}
+    with open(data_path, "r") as f:
+        for line in f:
+            if line == "\n" or line[0] == "[":
+                continue
+            key, _, val = line.strip().partition("=")
+            if key in _INT_KEYS:
+                cfg[key] = int(val)
+            elif key in _STR_KEYS:
+                cfg[key] = val
+            elif key in _FLOAT_KEYS:
+                cfg[key] = float(val)
+            elif key in _LIST_KEYS:
+                cfg[key] = [float(v) for v in val.split(",")]
+            else:
+                print("%s: unknown key %r ignored" % (data_path, key))
+    return cfg
+
+
+def handel_preds(preds, cfg, device):
+    """6-tuple of NCHW logits (on the GPU) -> (B, 1815, 5+classes) fp32 **CPU** tensor,
+    exactly the reference's contract (it allocates with torch.zeros(...) on the CPU,
+    utils.py:328).  The GPU copy is kept on the returned tensor (``_yfv2_dev``) so
+    that ``non_max_suppression`` can skip the upload when handed the same object."""
+    preds = list(preds)
+    if len(preds) != 6:
+        raise ValueError("expected the 6-tuple returned by Detector.forward, got %d tensors" % len(preds))
+    p0 = preds[0]
+    if p0.device.type != "cuda":
+        raise RuntimeError("handel_preds: logits must live on the MI355X (no CPU path)")
+    eng = getattr(p0, "_yfv2_engine", None)
+    if eng is None or eng.device != p0.device:
+        eng = get_engine(p0.device, cfg["height"], cfg["width"], preds[2].shape[1], cfg["anchor_num"])
+    eng.set_anchors(cfg["anchors"])
+    dev = eng.decode([p.detach().float() for p in preds])
+    out = dev.cpu()
+    out._yfv2_dev = (dev, eng, out._version)
+    return out
+
+
+def non_max_suppression(prediction, conf_thres=0.3, iou_thres=0.45, classes=None):
+    """(B, rows, 5+classes) -> list of B CPU fp32 tensors (n_i, 6): x1,y1,x2,y2,conf,cls in
+    descending conf; empty images give (0, 6).  No 1 s wall-clock abort (utils.py:245,292-294)."""
+    rows, _ = nms_with_indices(prediction, conf_thres, iou_thres, classes)
+    return rows
+
+
+def nms_with_indices(prediction, conf_thres=0.3, iou_thres=0.45, classes=None):
+    """non_max_suppression that also returns, per image, the index of every
+    survivor in the decode row order (SURVEY.md 8(b) 'survivor indices')."""
+    cached = getattr(prediction, "_yfv2_dev", None)
+    if cached is not None and cached[2] == prediction._version:
+        dev, eng = cached[0], cached[1]
+    else:
+        if not torch.cuda.is_available():
+            raise RuntimeError("non_max_suppression: no MI355X visible (there is no CPU path)")
+        device = prediction.device if prediction.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        dev = prediction.detach().to(device, torch.float32)
+        # rows = 3*(H/16*W/16 + H/32*W/32); the NMS kernel only needs (rows, classes)
+        eng = _engine_for_rows(device, dev.shape[1], dev.shape[2] - 5)
+    dets, idx, cnt = eng.nms(dev, conf_thres, iou_thres, classes)
+    return unpack_detections(dets, idx, cnt)
+
+
+def _engine_for_rows(device, rows, classes):
+    for h in range(32, 2049, 32):  # square inputs first (the reference only ever uses H == W)
+        if 3 * ((h // 16) ** 2 + (h // 32) ** 2) == rows and h <= 384:
+            return get_engine(device, h, h, classes, 3)
+    for h in range(32, 2049, 32):
+        for w in range(32, 385, 32):
+            if 3 * ((h // 16) * (w // 16) + (h // 32) * (w // 32)) == rows:
+                return get_engine(device, h, w, classes, 3)
+    raise ValueError("cannot infer the input size from %d decode rows" % rows)
