@@ -158,20 +158,40 @@ def main():
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             from oracle import yfv2_oracle as oracle
+            # the reference's CPU path is ATen/oneDNN on all host cores; on a 256-thread
+            # box that oversubscribes these tiny convs badly, so probe a few thread counts
+            # on a small batch and time the bounded sample with the fastest one
             ncores = os.cpu_count() or 1
-            torch.set_num_threads(ncores)
+            try:
+                ncores = min(ncores, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                pass
             bs = 64
             xc = x[:bs].cpu()
-            oracle.detect(sd, xc[:8], ANCHORS, 352, a.conf, a.iou)  # warm-up
+            cands = sorted({c for c in (8, 16, 32, 64, 128, ncores) if c <= ncores})
+            best_t, best_rate = cands[0], 0.0
+            for c in cands:
+                torch.set_num_threads(c)
+                oracle.forward(sd, xc[:4])  # warm-up at this thread count
+                t0 = time.perf_counter()
+                oracle.detect(sd, xc[:16], ANCHORS, 352, a.conf, a.iou)
+                el = time.perf_counter() - t0
+                if 16 / el > best_rate:
+                    best_t, best_rate = c, 16 / el
+                if el > 4.0:
+                    break  # larger counts only get slower from here
+            torch.set_num_threads(best_t)
             n_img, t0 = 0, time.perf_counter()
             while True:
                 oracle.detect(sd, xc, ANCHORS, 352, a.conf, a.iou)
                 n_img += bs
                 el = time.perf_counter() - t0
-                if el >= a.cpu_seconds or n_img >= 4096:
+                if el >= a.cpu_seconds or n_img >= 8192:
                     break
             cpu = {"value": round(n_img / el, 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": "%d synthetic images in batches of %d through oracle forward(ATen CPU)+decode+NMS, %.1f s" % (n_img, bs, el)}
+                   "host_threads_available": ncores,
+                   "sample": "%d synthetic images in batches of %d through oracle forward(ATen CPU)+decode+NMS, %.1f s, "
+                             "thread count chosen by a 16-image probe over %s" % (n_img, bs, el, cands)}
 
         out = {
             "metric": "images/sec at 352x352 bs=256 per GPU (forward+decode+NMS)", "value": round(value, 1), "unit": "images/s",

@@ -16,5 +16,5 @@ echo "== bench"
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench_$TAG.log 2>&1; echo "bench rc=$?"; tail -2 $OUT/bench_$TAG.log
 echo "== rocprofv3"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
 ls $OUT/prof_$TAG 2>/dev/null | head; find $OUT/prof_$TAG -name "*kernel_stats*" | head -2 | while read f; do head -25 "$f"; done

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -24,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3 };
 
 struct Step {
   int kind = 0;
@@ -33,6 +34,9 @@ struct Step {
   StemArgs stem{};
   PwArgs pw{};
   DwArgs dw{};
+  BlockS1Args s1{};
+  int c2 = 0;                 // fused s1 block
+  size_t w2_off = 0, sc2_off = 0, sh2_off = 0, wd_off = 0, scd_off = 0, shd_off = 0;
   // offsets into the param blob, resolved to pointers after the upload
   size_t w_off = 0, scale_off = 0, shift_off = 0;
   int px_per_img = 0;         // pw: pixels per image (P = B * px_per_img)
@@ -278,6 +282,28 @@ struct PlanBuilder {
   void block_s1(const std::string& p, int c, int H, int W, const Buf& x, const Buf& y) {
     Folded f;
     const int c2 = c / 2;
+    const char* env = std::getenv("YFV2_FUSED");
+    const bool fused = !(env && env[0] == '0');
+    if (fused && (c2 == 24 || c2 == 48 || c2 == 96)) {
+      Folded f1, fd, f2;
+      ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", c2, c2, &f1);
+      ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", c2, 3, &fd);
+      ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", c2, c2, &f2);
+      Step s;
+      s.kind = STEP_S1;
+      s.c2 = c2;
+      s.s1.in = x.p; s.s1.out = y.p;
+      s.s1.H = H; s.s1.W = W;
+      s.s1.R = yfv2_block_s1_rows(c2, H, W);
+      s.w_off = f1.w; s.scale_off = f1.scale; s.shift_off = f1.shift;
+      s.wd_off = fd.w; s.scd_off = fd.scale; s.shd_off = fd.shift;
+      s.w2_off = f2.w; s.sc2_off = f2.scale; s.sh2_off = f2.shift;
+      s.name = p + " fused s1 block: shuffle+pass | pw1+bn+relu -> dw3x3+bn -> pw2+bn+relu | cat";
+      s.flops = 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
+      s.bytes = 4.0 * H * W * (2.0 * c);  // read c, write c channels per pixel
+      h->plan.push_back(s);
+      return;
+    }
     ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", c2, c2, &f);
     Step& s = add_pw(p + ".shuffle+pass+main.pw1+bn+relu", c2, PW_SHUFFLE, c2, H * W, x.p, c, 0, h->t1.p, c2, 0, true, f);
     s.pw.copy = y.p; s.pw.copy_stride = c; s.pw.copy_off = 0;
@@ -404,6 +430,14 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
       }
       if (!yfv2_launch_pw(st.K, st.mode, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no pointwise kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_S1) {
+      BlockS1Args a = st.s1;
+      a.B = B;
+      a.w1 = params + st.w_off; a.sc1 = params + st.scale_off; a.sh1 = params + st.shift_off;
+      a.wdw = params + st.wd_off; a.scd = params + st.scd_off; a.shd = params + st.shd_off;
+      a.w2 = params + st.w2_off; a.sc2 = params + st.sc2_off; a.sh2 = params + st.sh2_off;
+      if (!yfv2_launch_block_s1(st.c2, a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no fused block kernel for step '" + st.name + "'");
     } else {
       DwArgs a = st.dw;
       a.B = B;

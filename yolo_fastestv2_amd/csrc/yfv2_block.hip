@@ -1,0 +1,276 @@
+// yfv2_block.hip - fused ShuffleV2 stride-1 block for gfx950 (one launch per block
+// instead of three, no intermediate tensor in HBM).
+//
+// Reference block (model/backbone/shufflenetv2.py:19-32,48-51,57-63), c = 2*C2 channels:
+//   pass = x[:, 0::2]                      (even channels, untouched)
+//   y    = x[:, 1::2]                      (odd channels)
+//   y    = ReLU(BN(pw1(y)))   C2 -> C2
+//   y    = BN(dw3x3(y))       pad 1, stride 1
+//   y    = ReLU(BN(pw2(y)))   C2 -> C2
+//   out  = cat(pass, y)
+//
+// Work item = (image, tile of R rows, full width).  Per item, one workgroup:
+//   phase A  pw1 on the fp32 MFMA for the tile rows plus a 1-row halo above and below.
+//            B operand straight from global NHWC (each lane loads 8 consecutive floats,
+//            keeps the odd ones, and - for non-halo rows - stores the even ones to
+//            out[..., 0:C2]: shuffle + pass-through + concat cost no extra pass).
+//            D (+BN+ReLU) goes to an LDS tile T1[(R+2)][(W+2)][C2+4] whose border
+//            (conv zero padding) is zero.
+//   phase B  per 16-pixel tile, each lane computes the depthwise 3x3 (+BN) of ITS pixel
+//            and ITS four channels directly in registers from T1 - exactly the
+//            B-operand fragment v_mfma_f32_16x16x4_f32 wants - and feeds pw2's MFMAs;
+//            D (+BN+ReLU) is stored to out[..., C2:2*C2] as 16-byte NHWC stores.
+// pw1/pw2 filters, the depthwise taps and all BN constants stay in LDS for the
+// lifetime of the (persistent) workgroup.
+//
+// HBM traffic per block: read c*H*W, write c*H*W floats (plus halo re-reads served by
+// L2) instead of 3 reads + 3 writes of activations in the unfused plan.
+#include "yfv2_internal.h"
+
+template <int C2>
+struct S1Cfg {
+  static constexpr int KC = (C2 + 15) / 16;  // 16-channel chunks (also M tiles: M == K == C2)
+  static constexpr int KP = 16 * KC + 4;     // padded LDS row of the [C2][C2] filters
+  static constexpr int CP = C2 + 4;          // floats per T1 pixel
+  static constexpr int W_FL = KC * 16 * KP;  // one filter matrix in LDS
+  static constexpr int DW_FL = 9 * KC * 16;  // depthwise taps [9][KC*16]
+  static constexpr int CST_FL = 6 * KC * 16; // sc1, sh1, scd, shd, sc2, sh2
+  static constexpr bool DWREG = C2 <= 48;    // depthwise taps + BN in registers
+  static constexpr int NTB = C2 <= 48 ? 1 : 2;  // pixel tiles per phase-B pass
+};
+
+template <int C2, int THREADS>
+__global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
+  using Cfg = S1Cfg<C2>;
+  constexpr int KC = Cfg::KC, KP = Cfg::KP, CP = Cfg::CP, NTB = Cfg::NTB;
+  constexpr int NW = THREADS / 64;
+  constexpr int C = 2 * C2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* W1 = lds;
+  float* W2 = W1 + Cfg::W_FL;
+  float* WD = W2 + Cfg::W_FL;
+  float* CS = WD + Cfg::DW_FL;  // [6][KC*16]
+  float* T1 = CS + Cfg::CST_FL;
+  const int H = a.H, W = a.W, R = a.R;
+  const int WP = W + 2;
+  const int t1_fl = (R + 2) * WP * CP + 16;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+
+  // ---- stage filters / constants, zero T1 (its border stays zero for every item)
+  for (int i = tid; i < Cfg::W_FL; i += THREADS) {
+    const int row = i / KP, c = i - row * KP;
+    const bool ok = row < C2 && c < C2;
+    W1[i] = ok ? a.w1[row * C2 + c] : 0.f;
+    W2[i] = ok ? a.w2[row * C2 + c] : 0.f;
+  }
+  for (int i = tid; i < Cfg::DW_FL; i += THREADS) {
+    const int k = i / (KC * 16), c = i - k * (KC * 16);
+    WD[i] = c < C2 ? a.wdw[k * C2 + c] : 0.f;
+  }
+  for (int i = tid; i < KC * 16; i += THREADS) {
+    const bool ok = i < C2;
+    CS[0 * KC * 16 + i] = ok ? a.sc1[i] : 0.f;
+    CS[1 * KC * 16 + i] = ok ? a.sh1[i] : 0.f;
+    CS[2 * KC * 16 + i] = ok ? a.scd[i] : 0.f;
+    CS[3 * KC * 16 + i] = ok ? a.shd[i] : 0.f;
+    CS[4 * KC * 16 + i] = ok ? a.sc2[i] : 0.f;
+    CS[5 * KC * 16 + i] = ok ? a.sh2[i] : 0.f;
+  }
+  for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;
+  __syncthreads();
+
+  // depthwise taps / BN of this lane's channel quads, in registers when they fit
+  f32x4 wk[Cfg::DWREG ? KC : 1][9], dsc[Cfg::DWREG ? KC : 1], dsh[Cfg::DWREG ? KC : 1];
+  if constexpr (Cfg::DWREG) {
+#pragma unroll
+    for (int s = 0; s < KC; ++s) {
+      const int cb = 16 * s + 4 * g;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wk[s][k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
+      dsc[s] = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+      dsh[s] = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+    }
+  }
+
+  const int tiles_per_img = (H + R - 1) / R;
+  const int n_items = a.B * tiles_per_img;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R;
+    const int rows = min(R, H - y0);
+    const size_t img_px = (size_t)b * H * W;
+
+    // ================= phase A: pw1 (+BN+ReLU) over rows y0-1 .. y0+rows, into T1
+    const int npxA = (rows + 2) * W;
+    for (int t = wave; t * 16 < npxA; t += NW) {
+      const int q = 16 * t + p;
+      const bool valid = q < npxA;
+      const int r = q / W, x = q - r * W;
+      const int gy = y0 - 1 + r;
+      const bool inimg = valid && gy >= 0 && gy < H;
+      const bool interior = inimg && r >= 1 && r <= rows;
+      const size_t gp = inimg ? img_px + (size_t)gy * W + x : img_px;  // clamped: always readable
+      const float* src = a.in + gp * C;
+      float* cp = a.out + gp * C;
+      f32x4 bf[KC];
+#pragma unroll
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        if (cb < C2) {
+          const f32x4 q0 = *reinterpret_cast<const f32x4*>(src + 2 * cb);
+          const f32x4 q1 = *reinterpret_cast<const f32x4*>(src + 2 * cb + 4);
+          bf[s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};
+          if (interior) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};
+        } else {
+          bf[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      // one output-channel tile at a time: a single live accumulator keeps the register
+      // footprint flat (the big C2=96 variant must not spill); the dependent MFMA chain is
+      // covered by the second wave on the SIMD
+      float* dst = T1 + (r * WP + x + 1) * CP;
+#pragma unroll(Cfg::KC <= 3 ? Cfg::KC : 1)
+      for (int mt = 0; mt < KC; ++mt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(W1 + (16 * mt + p) * KP + 16 * s + 4 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[s][j], acc, 0, 0, 0);
+        }
+        const int cb = 16 * mt + 4 * g;
+        if (valid && cb < C2) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
+          f32x4 y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
+            y[k] = (inimg && u > 0.f) ? u : 0.f;  // rows outside the image are conv zero padding
+          }
+          *reinterpret_cast<f32x4*>(dst + cb) = y;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
+    const int npxB = rows * W;
+    for (int t0 = wave * NTB; t0 * 16 < npxB; t0 += NW * NTB) {
+      int base[NTB];
+      size_t opx[NTB];
+      bool pv[NTB];
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt) {
+        const int q = 16 * (t0 + nt) + p;
+        pv[nt] = q < npxB;
+        const int qc = pv[nt] ? q : npxB - 1;
+        const int r = qc / W, x = qc - r * W;
+        base[nt] = (r * WP + x) * CP;  // top-left of the 3x3 window in T1 (halo row + zero column included)
+        opx[nt] = img_px + (size_t)(y0 + r) * W + x;
+      }
+      f32x4 acc[KC][NTB];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll(Cfg::DWREG ? Cfg::KC : 1)
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        f32x4 wl[9], lsc, lsh;
+        if constexpr (!Cfg::DWREG) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
+          lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+          lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+        }
+        f32x4 bfr[NTB];
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+          const float* tp = T1 + base[nt] + cb;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP);
+              const f32x4 w = Cfg::DWREG ? wk[Cfg::DWREG ? s : 0][ky * 3 + kx] : wl[ky * 3 + kx];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], w[k], d[k]);
+            }
+          const f32x4 sc = Cfg::DWREG ? dsc[Cfg::DWREG ? s : 0] : lsc;
+          const f32x4 sh = Cfg::DWREG ? dsh[Cfg::DWREG ? s : 0] : lsh;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) bfr[nt][k] = cb < C2 ? __builtin_fmaf(d[k], sc[k], sh[k]) : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + (16 * mt + p) * KP + cb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt) {
+        if (!pv[nt]) continue;
+        float* dst = a.out + opx[nt] * C + C2;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const int cb = 16 * mt + 4 * g;
+          if (cb < C2) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + cb);
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float u = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
+              y[k] = u > 0.f ? u : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
+        }
+      }
+    }
+    __syncthreads();  // T1 is rewritten by the next item's phase A
+  }
+}
+
+template <int C2, int THREADS>
+static void launch_s1(const BlockS1Args& a, int blocks_per_cu, hipStream_t s) {
+  using Cfg = S1Cfg<C2>;
+  const size_t lds = sizeof(float) * (size_t)(2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + (a.R + 2) * (a.W + 2) * Cfg::CP + 16);
+  const int tiles = (a.H + a.R - 1) / a.R;
+  int blocks = a.B * tiles;
+  const int cap = 256 * blocks_per_cu;  // persistent: filters are staged once per workgroup
+  if (blocks > cap) blocks = cap;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1_kernel<C2, THREADS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((block_s1_kernel<C2, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a);
+}
+
+// LDS budget decides the row tile: the whole image when it fits (no halo recompute).
+int yfv2_block_s1_rows(int c2, int H, int W) {
+  const int kc = (c2 + 15) / 16;
+  const long fixed = 2L * kc * 16 * (16 * kc + 4) + 9L * kc * 16 + 6L * kc * 16 + 16;
+  const long budget = (c2 == 24 ? 78 : 158) * 1024 / 4;  // C2=24 (44x44): two workgroups per CU
+  int best = 1;
+  for (int r = 1; r <= H; ++r) {
+    if (H % r) continue;
+    if (fixed + (long)(r + 2) * (W + 2) * (c2 + 4) <= budget) best = r;
+  }
+  return best;
+}
+
+bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
+  if (c2 == 24) { launch_s1<24, 256>(a, 2, s); return true; }
+  if (c2 == 48) { launch_s1<48, 512>(a, 1, s); return true; }
+  if (c2 == 96) { launch_s1<96, 512>(a, 1, s); return true; }
+  return false;
+}

@@ -1,5 +1,5 @@
 // yfv2_conv.hip - gfx950 (CDNA4, wave64) kernels of the Yolo-FastestV2 forward:
-//   stem_kernel : conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2   (VALU, SGPR weights)
+//   stem_kernel : conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2   (implicit GEMM on the fp32 MFMA)
 //   pw_kernel   : every pointwise 1x1 conv (+BN, +ReLU) on v_mfma_f32_16x16x4_f32,
 //                 with channel-shuffle / concat / nearest-upsample / NCHW-head
 //                 folded into its operand loads and stores
@@ -17,16 +17,19 @@
 // ============================================================================
 // stem: conv3x3 s2 + BN + ReLU + maxpool3x3 s2
 // ============================================================================
-// One workgroup = one band of R pooled rows of one image; thread = one conv
-// column (W/2 <= 192).  The block streams down the conv rows of its band: each
-// thread computes the 24 output channels of its conv pixel with the 648 filter
-// taps held in SGPRs (wave-uniform scalar loads -> v_fmac v, s, v: no LDS or
-// VGPR traffic for weights), writes the BN+ReLU row into a 3-row LDS ring, and
-// every second row the block max-pools the ring into one NHWC output row.  The
-// 24x176x176 conv map (2.97 MB/image) never touches HBM.
-typedef const float __attribute__((address_space(4)))* cfloat_p;
-constexpr int STEM_THREADS = 192;
-constexpr int STEM_CS = 28;  // LDS floats per conv pixel (24 + 4 pad: conflict-free b128 stores)
+// One workgroup (4 waves) = one band of R pooled rows of one image.  The block
+// streams down the conv rows of its band; each conv row is cut into 16-pixel
+// tiles that the waves share.  A tile is an implicit GEMM on the fp32 MFMA:
+//   D[co][pixel] = sum_k W[co][k] * patch[k][pixel],  K = 27 taps (padded to 28 =
+//   7 steps of v_mfma_f32_16x16x4_f32), M = 24 channels (2 tiles, 8 rows idle)
+// A (the filter) lives in 14 VGPRs per lane for the whole kernel; B is gathered
+// straight from the NCHW image (lane = pixel, one tap per k-step: stride-2 dwords
+// of one image row, served by L1/L2 - every input byte leaves HBM once).  The
+// BN+ReLU row goes into a 3-row LDS ring and every second row the block
+// max-pools the ring into one NHWC output row, so the 24x176x176 conv map
+// (2.97 MB/image) never touches HBM.
+constexpr int STEM_THREADS = 256;
+constexpr int STEM_CS = 28;  // LDS floats per conv pixel (24 + 4 pad)
 
 __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ring[];  // [3][CW+2][STEM_CS]
@@ -35,69 +38,107 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
   const int bands = PH / a.R;
   const int band = blockIdx.x % bands, b = blockIdx.x / bands;
   const int py0 = band * a.R;
-  const int tid = threadIdx.x;
-  const int cx = tid;
-  const bool col_ok = cx < CW;
-  // filter taps and BN constants are read through the constant address space so
-  // that hipcc emits wave-uniform s_load (SGPR operands), not per-lane vector loads
-  const cfloat_p wgt = (cfloat_p)(uintptr_t)a.w;
-  const cfloat_p bn_sc = (cfloat_p)(uintptr_t)a.scale;
-  const cfloat_p bn_sh = (cfloat_p)(uintptr_t)a.shift;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
   const float* __restrict__ xb = a.x + (size_t)b * 3 * H * W;
+
+  // A fragments: af[mt][ks] = W[co = 16mt + p][k = 4ks + g]   (blob layout [27 taps][24 co])
+  float af[2][7];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+      const int co = 16 * mt + p, k = 4 * ks + g;
+      af[mt][ks] = (co < 24 && k < 27) ? a.w[k * 24 + co] : 0.f;
+    }
+  // BN constants of the D rows this lane owns: co = 16mt + 4g + r
+  f32x4 sc[2], sh[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * mt + 4 * g + r;
+      sc[mt][r] = co < 24 ? a.scale[co] : 0.f;
+      sh[mt][r] = co < 24 ? a.shift[co] : 0.f;
+    }
+  // tap of k-step ks for this lane group: k = 4ks + g -> (ci, ky, kx); k = 27 is the zero pad.
+  // Borders are handled without branches: 32-bit offsets clamped at 0 plus 0/1 multipliers.
+  // With pad 1 / stride 2 only input row -1 (cy == 0, ky == 0) and input col -1 (cx == 0,
+  // kx == 0) fall outside the image.
+  int toff[7];
+  float mtop[7], mleft[7];
+#pragma unroll
+  for (int ks = 0; ks < 7; ++ks) {
+    const int k = 4 * ks + g, kk = k < 27 ? k : 26;  // pad tap reads a valid pixel, its weight is 0
+    const int ci = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
+    toff[ks] = (ci * H + ky) * W + kx;
+    mtop[ks] = ky == 0 ? 0.f : 1.f;
+    mleft[ks] = kx == 0 ? 0.f : 1.f;
+  }
 
   // zero the two pad columns of all three ring rows once (conv cols -1 and CW;
   // post-ReLU values are >= 0 so 0 is a neutral element for the max)
   for (int i = tid; i < 3 * 2 * STEM_CS; i += STEM_THREADS) {
-    int slot = i / (2 * STEM_CS), r = i % (2 * STEM_CS);
-    int col = (r < STEM_CS) ? 0 : (CW + 1);
+    const int slot = i / (2 * STEM_CS), r = i % (2 * STEM_CS);
+    const int col = (r < STEM_CS) ? 0 : (CW + 1);
     ring[slot * RS + col * STEM_CS + (r % STEM_CS)] = 0.f;
   }
 
+  // a wave owns tiles wave, wave+4, wave+8 of every conv row (ntiles <= 12; a tile index past
+  // the row is clamped to the last tile and simply not stored)
+  constexpr int TPW = 3;
+  const int ntiles = CW >> 4;  // W % 32 == 0
+  int cxs[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) cxs[i] = 16 * min(wave + 4 * i, ntiles - 1) + p;
+
+  // gather of one conv row: 21 independent dword loads per lane, issued back to back
+  auto load_row = [&](int cy, float (&dst)[TPW][7]) {
+    const int rorg = (2 * cy - 1) * W - 1;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) dst[i][ks] = xb[max(rorg + 2 * cxs[i] + toff[ks], 0)];
+  };
+
   const int cy_first = 2 * py0 - 1, cy_last = 2 * py0 + 2 * a.R - 1;
+  float cur[TPW][7], nxt[TPW][7];
+  if (cy_first >= 0) load_row(cy_first, cur);
   for (int cy = cy_first; cy <= cy_last; ++cy) {
     const int slot = (cy + 3) % 3;
     float* row = ring + slot * RS;
-    if (col_ok) {
-      f32x4 o[6];
-      if (cy >= 0 && cy < CH) {
-        // 3x3x3 input window of this conv pixel.  With pad 1 / stride 2 only input
-        // row -1 (cy == 0) and input column -1 (cx == 0) can fall outside the image, so
-        // loads are unconditional on clamped addresses and masked by selects (no branches).
-        float v[27];
-        const int ixm = cx > 0 ? 2 * cx - 1 : 0;
+    // software pipeline: the next row's gather is in flight during this row's MFMAs, the
+    // barriers and the pooling (plain global loads survive s_barrier)
+    if (cy + 1 <= cy_last) load_row(cy + 1, nxt);
+    if (cy >= 0) {
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci)
+      for (int i = 0; i < TPW; ++i) {
+        const int cx = cxs[i];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * cy - 1 + ky;
-            const bool rok = iy >= 0;
-            const float* rp = xb + ((size_t)ci * H + (rok ? iy : 0)) * W;
-            const float l = rp[ixm];
-            const f32x2 cr = *reinterpret_cast<const f32x2*>(rp + 2 * cx);
-            v[ci * 9 + ky * 3 + 0] = (rok && cx > 0) ? l : 0.f;
-            v[ci * 9 + ky * 3 + 1] = rok ? cr[0] : 0.f;
-            v[ci * 9 + ky * 3 + 2] = rok ? cr[1] : 0.f;
+        for (int ks = 0; ks < 7; ++ks) {
+          float m = cy == 0 ? mtop[ks] : 1.f;
+          m = cx == 0 ? m * mleft[ks] : m;
+          const float v = cur[i][ks] * m;
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], v, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], v, acc1, 0, 0, 0);
+        }
+        if (wave + 4 * i < ntiles) {  // wave-uniform
+          f32x4 y0, y1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
+            const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
+            y0[r] = u0 > 0.f ? u0 : 0.f;
+            y1[r] = u1 > 0.f ? u1 : 0.f;
           }
-        float acc[24];
-#pragma unroll
-        for (int co = 0; co < 24; ++co) acc[co] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-          const float vt = v[t];
-#pragma unroll
-          for (int co = 0; co < 24; ++co) acc[co] = __builtin_fmaf(vt, wgt[t * 24 + co], acc[co]);
+          float* dst = row + (cx + 1) * STEM_CS + 4 * g;
+          *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
+          if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
         }
-#pragma unroll
-        for (int co = 0; co < 24; ++co) {
-          float y = __builtin_fmaf(acc[co], bn_sc[co], bn_sh[co]);
-          o[co >> 2][co & 3] = y > 0.f ? y : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) o[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(row + (cx + 1) * STEM_CS + 4 * q) = o[q];
+    } else {  // conv row -1: the max-pool's top padding
+      for (int i = tid; i < CW * 6; i += STEM_THREADS)
+        *reinterpret_cast<f32x4*>(row + (i / 6 + 1) * STEM_CS + 4 * (i % 6)) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     if ((cy & 1) && cy >= 2 * py0 + 1) {
@@ -108,21 +149,25 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
       float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
       for (int i = tid; i < PW * 6; i += STEM_THREADS) {
         const int px = i / 6, q = i - px * 6;
-        const int base = (2 * px) * STEM_CS + 4 * q;
+        const int base = (2 * px) * STEM_CS + 4 * q;  // conv col 2px-1 sits at ring col 2px
         f32x4 m = *reinterpret_cast<const f32x4*>(r0 + base);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const int o = base + dx * STEM_CS;
-          f32x4 u0 = *reinterpret_cast<const f32x4*>(r0 + o);
-          f32x4 u1 = *reinterpret_cast<const f32x4*>(r1 + o);
-          f32x4 u2 = *reinterpret_cast<const f32x4*>(r2 + o);
+          const f32x4 u0 = *reinterpret_cast<const f32x4*>(r0 + o);
+          const f32x4 u1 = *reinterpret_cast<const f32x4*>(r1 + o);
+          const f32x4 u2 = *reinterpret_cast<const f32x4*>(r2 + o);
 #pragma unroll
           for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], u0[k]), fmaxf(u1[k], u2[k]));
         }
-        *reinterpret_cast<f32x4*>(orow + (size_t)i * 4) = m;  // (px*24 + 4q) == 4*i
+        *reinterpret_cast<f32x4*>(orow + (size_t)i * 4) = m;  // px*24 + 4q == 4i
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) cur[i][ks] = nxt[i][ks];
   }
 }
 

@@ -58,6 +58,17 @@ struct DwArgs {
   int relu;
 };
 
+// ---- fused ShuffleV2 stride-1 block (yfv2_block.hip)
+struct BlockS1Args {
+  const float* in;   // (B,H,W,2*C2) NHWC
+  float* out;        // (B,H,W,2*C2) NHWC, distinct from in
+  const float* w1; const float* sc1; const float* sh1;   // pw1 [C2][C2] + BN
+  const float* wdw; const float* scd; const float* shd;  // dw3x3 [9][C2] + BN
+  const float* w2; const float* sc2; const float* sh2;   // pw2 [C2][C2] + BN
+  int B, H, W;
+  int R;             // rows per work item (H % R == 0)
+};
+
 // ---- decode (handel_preds) and NMS
 struct DecodeArgs {
   const float* reg[2];
@@ -88,5 +99,7 @@ void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
 // K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
 bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
+int yfv2_block_s1_rows(int c2, int H, int W);
+bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);

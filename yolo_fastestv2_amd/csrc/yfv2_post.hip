@@ -123,35 +123,58 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   __shared__ unsigned char supp[NMS_CAP];
   __shared__ unsigned char cls_of_row[NMS_CAP];
   __shared__ int keep[NMS_MAX_DET];
-  __shared__ int n_cand, n_keep;
+  __shared__ int n_cand, n_keep, n_obj;
 
   const int tid = threadIdx.x, b = blockIdx.x;
   const int rowlen = 5 + a.nc;
   const float* img = a.boxes + (size_t)b * a.rows * rowlen;
   const float ct = a.conf_thres;
-  if (tid == 0) { n_cand = 0; n_keep = 0; }
+  unsigned short* cand_row = reinterpret_cast<unsigned short*>(bx1);  // step 1 only; bx1 is written in step 3
+  if (tid == 0) { n_cand = 0; n_keep = 0; n_obj = 0; }
   __syncthreads();
 
-  // ---- 1. filter
+  // ---- 1. filter.  (a) rows with obj > ct are compacted into cand_row[] (order is
+  // irrelevant: the sort key carries the row).  (b) each 16-lane group takes one such
+  // row: lane l scans classes l, l+16, ... (64-byte coalesced reads), keeps its first
+  // maximum of fl32(cls_j*obj), and a 4-step xor-shuffle picks the group's maximum with
+  // the LOWEST class index among equals (= torch.max's first-index rule, utils.py:267).
   for (int n = tid; n < a.rows; n += NMS_THREADS) {
-    const float* r = img + (size_t)n * rowlen;
-    const float obj = r[4];
-    if (!(obj > ct)) continue;
-    float best = __fmul_rn(r[5], obj);
-    int bj = 0;
-    for (int j = 1; j < a.nc; ++j) {
-      const float pj = __fmul_rn(r[5 + j], obj);
-      if (pj > best) { best = pj; bj = j; }  // strict: first maximal index wins
+    const float obj = img[(size_t)n * rowlen + 4];
+    if (obj > ct) cand_row[atomicAdd(&n_obj, 1)] = (unsigned short)n;
+  }
+  __syncthreads();
+  {
+    const int l16 = tid & 15, grp = tid >> 4, ngrp = NMS_THREADS >> 4;
+    const int nobj = n_obj;
+    for (int q = grp; q < nobj; q += ngrp) {  // uniform within a 16-lane group
+      const int n = cand_row[q];
+      const float* r = img + (size_t)n * rowlen;
+      const float obj = r[4];
+      float best = -INFINITY;
+      int bj = 0x7fffffff;
+      for (int j = l16; j < a.nc; j += 16) {
+        const float pj = __fmul_rn(r[5 + j], obj);
+        if (pj > best) { best = pj; bj = j; }  // strict: first maximal index of this lane
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const float ob = __shfl_xor(best, m, 16);
+        const int oj = __shfl_xor(bj, m, 16);
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+      }
+      if (l16 == 0 && best > ct) {
+        bool hit = true;
+        if (a.classes) {
+          hit = false;
+          for (int k = 0; k < a.n_classes; ++k) hit |= (a.classes[k] == bj);
+        }
+        if (hit) {
+          const int slot = atomicAdd(&n_cand, 1);
+          key[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+          cls_of_row[n] = (unsigned char)bj;
+        }
+      }
     }
-    if (!(best > ct)) continue;
-    if (a.classes) {
-      bool hit = false;
-      for (int k = 0; k < a.n_classes; ++k) hit |= (a.classes[k] == bj);
-      if (!hit) continue;
-    }
-    const int slot = atomicAdd(&n_cand, 1);
-    key[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
-    cls_of_row[n] = (unsigned char)bj;
   }
   __syncthreads();
   const int n = n_cand;
