@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4 };
 
 struct Step {
   int kind = 0;
@@ -35,6 +35,9 @@ struct Step {
   PwArgs pw{};
   DwArgs dw{};
   BlockS1Args s1{};
+  TowerArgs tw{};
+  size_t wh_off = 0, bh_off = 0;  // tower: chained output conv
+  bool has_head = false;
   int c2 = 0;                 // fused s1 block
   size_t w2_off = 0, sc2_off = 0, sh2_off = 0, wd_off = 0, scd_off = 0, shd_off = 0;
   // offsets into the param blob, resolved to pointers after the upload
@@ -315,9 +318,50 @@ struct PlanBuilder {
   }
 
   // DWConvblock (fpn.py:12-25) + the output convs fed by this tower (detector.py:25-31)
+  void tower_half(const std::string& name, int H, int W, const float* in, float* out, const Folded& fd, const Folded& fp,
+                  const Folded* fh, int mh, int split, int head0, int head1) {
+    Step s;
+    s.kind = STEP_TOWER;
+    s.tw.in = in; s.tw.out = out;
+    s.tw.H = H; s.tw.W = W;
+    s.tw.mh = mh; s.tw.split = split;
+    s.tw.R = yfv2_tower_rows(fh ? (mh + 15) / 16 : 0, H, W);
+    s.wd_off = fd.w; s.scd_off = fd.scale; s.shd_off = fd.shift;
+    s.w_off = fp.w; s.scale_off = fp.scale; s.shift_off = fp.shift;
+    s.has_head = fh != nullptr;
+    if (fh) { s.wh_off = fh->w; s.bh_off = fh->shift; }
+    s.head0 = head0; s.head1 = head1;
+    s.name = name;
+    s.flops = 2.0 * H * W * (25.0 * 72 + 72.0 * 72 + (fh ? 72.0 * mh : 0.0));
+    s.bytes = 4.0 * H * W * (72.0 + (fh ? mh : 72.0));
+    h->plan.push_back(s);
+  }
+
   void tower(const std::string& p, int H, int W, const Buf& s_in, bool is_cls, int scale_idx) {
     Folded f;
     const int px = H * W;
+    {
+      const char* env = std::getenv("YFV2_FUSED");
+      if (!(env && env[0] == '0')) {
+        Folded fd1, fp1, fd2, fp2, fh;
+        ok &= wp.dw(p + ".0", p + ".1", 72, 5, &fd1);
+        ok &= wp.pw(p + ".3", p + ".4", 72, 72, &fp1);
+        ok &= wp.dw(p + ".5", p + ".6", 72, 5, &fd2);
+        ok &= wp.pw(p + ".8", p + ".9", 72, 72, &fp2);
+        const int A = h->cfg.anchor_num, nc = h->cfg.classes;
+        tower_half(p + " half a: dw5x5+bn+relu -> pw+bn", H, W, s_in.p, h->ta.p, fd1, fp1, nullptr, 0, 0, -1, -1);
+        if (is_cls) {
+          ok &= wp.heads({{"output_obj_layers", A}, {"output_cls_layers", nc}}, 72, &fh);
+          tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_obj+output_cls (bias, NCHW)", H, W, h->ta.p, nullptr, fd2,
+                     fp2, &fh, A + nc, A, scale_idx * 3 + 1, scale_idx * 3 + 2);
+        } else {
+          ok &= wp.heads({{"output_reg_layers", 4 * A}}, 72, &fh);
+          tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_reg (bias, NCHW)", H, W, h->ta.p, nullptr, fd2, fp2, &fh,
+                     4 * A, 4 * A, scale_idx * 3 + 0, -1);
+        }
+        return;
+      }
+    }
     ok &= wp.dw(p + ".0", p + ".1", 72, 5, &f);
     add_dw(p + ".dw5x5+bn+relu(a)", 5, 1, 72, H, W, s_in.p, 72, h->ta.p, 72, true, f);
     ok &= wp.pw(p + ".3", p + ".4", 72, 72, &f);
@@ -430,6 +474,19 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
       }
       if (!yfv2_launch_pw(st.K, st.mode, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no pointwise kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_TOWER) {
+      TowerArgs a = st.tw;
+      a.B = B;
+      a.wdw = params + st.wd_off; a.scd = params + st.scd_off; a.shd = params + st.shd_off;
+      a.wpw = params + st.w_off; a.scp = params + st.scale_off; a.shp = params + st.shift_off;
+      a.wh = nullptr; a.bh = nullptr; a.nchw0 = nullptr; a.nchw1 = nullptr;
+      if (st.has_head) {
+        a.wh = params + st.wh_off; a.bh = params + st.bh_off;
+        a.nchw0 = out6[st.head0];
+        a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
+      }
+      if (!yfv2_launch_tower(a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S1) {
       BlockS1Args a = st.s1;
       a.B = B;

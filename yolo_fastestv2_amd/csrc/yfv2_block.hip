@@ -274,3 +274,232 @@ bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
   if (c2 == 96) { launch_s1<96, 512>(a, 1, s); return true; }
   return false;
 }
+
+// ============================================================================
+// fused DWConvblock half ("tower half"), 72 channels
+// ============================================================================
+// Reference (model/fpn.py:12-25): DWConvblock = [dw5x5+BN+ReLU -> pw72+BN] x 2, and
+// model/detector.py:25-31 applies a biased 1x1 output conv to the block's result.
+// One launch = one half:   dw5x5 (pad 2) + BN + ReLU  ->  pw 72->72 + BN  [-> output conv + bias]
+//   phase 0  the input tile (R rows + 2 halo rows/cols each side, zero outside the image)
+//            is copied NHWC -> LDS (the 25-fold tap reuse lives in LDS, not L1)
+//   phase 1  per 16-pixel tile pair, each lane computes the depthwise 5x5 of ITS pixel and
+//            ITS 4 channels in registers (= the MFMA B fragment) and runs the pointwise
+//            GEMM; with HEAD the BN'd accumulator tile t IS the B fragment of chunk t of
+//            the output conv (D and B fragments share the lane map), so the chained 1x1
+//            conv starts from registers and writes the NCHW logits directly.
+// Filters, taps and BN constants stay in LDS for the life of the persistent workgroup.
+constexpr int TW_C = 72, TW_KC = 5, TW_KP = 84, TW_CP = 76, TW_NT = 2;
+
+template <int MH /* output-conv M tiles, 0 = no head */>
+__global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
+  constexpr int KC = TW_KC, KP = TW_KP, CP = TW_CP, NT = TW_NT, C = TW_C;
+  constexpr int THREADS = 512, NW = THREADS / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* WP_ = lds;                                 // [80][KP]  pointwise filter
+  float* WH = WP_ + KC * 16 * KP;                   // [MH*16][KP] output conv (HEAD only)
+  float* WD = WH + MH * 16 * KP;                    // [25][80] depthwise taps
+  float* CS = WD + 25 * KC * 16;                    // scd, shd, scp, shp, bias(head): 5 x 96
+  float* TIN = CS + 5 * 96;
+  const int H = a.H, W = a.W, R = a.R;
+  const int WP4 = W + 4;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+
+  for (int i = tid; i < KC * 16 * KP; i += THREADS) {
+    const int row = i / KP, c = i - row * KP;
+    WP_[i] = (row < C && c < C) ? a.wpw[row * C + c] : 0.f;
+  }
+  if constexpr (MH > 0)
+    for (int i = tid; i < MH * 16 * KP; i += THREADS) {
+      const int row = i / KP, c = i - row * KP;
+      WH[i] = (row < a.mh && c < C) ? a.wh[row * C + c] : 0.f;
+    }
+  for (int i = tid; i < 25 * KC * 16; i += THREADS) {
+    const int k = i / (KC * 16), c = i - k * (KC * 16);
+    WD[i] = c < C ? a.wdw[k * C + c] : 0.f;
+  }
+  for (int i = tid; i < 96; i += THREADS) {
+    const bool ok = i < C;
+    CS[0 * 96 + i] = ok ? a.scd[i] : 0.f;
+    CS[1 * 96 + i] = ok ? a.shd[i] : 0.f;
+    CS[2 * 96 + i] = ok ? a.scp[i] : 0.f;
+    CS[3 * 96 + i] = ok ? a.shp[i] : 0.f;
+    CS[4 * 96 + i] = (MH > 0 && i < a.mh) ? a.bh[i] : 0.f;
+  }
+  __syncthreads();
+
+  const int tiles_per_img = (H + R - 1) / R;
+  const int n_items = a.B * tiles_per_img;
+  const int HW = H * W;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R;
+    const int rows = min(R, H - y0);
+    const float* img = a.in + (size_t)b * HW * C;
+
+    // ---- phase 0: stage rows y0-2 .. y0+rows+1, cols -2 .. W+1 (zero outside the image)
+    const int nq = (rows + 4) * WP4 * (C / 4);
+    for (int i = tid; i < nq; i += THREADS) {
+      const int c4 = i % (C / 4);
+      const int px = i / (C / 4);
+      const int r = px / WP4, xx = px - r * WP4;
+      const int gy = y0 - 2 + r, gx = xx - 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(img + ((size_t)gy * W + gx) * C + 4 * c4);
+      *reinterpret_cast<f32x4*>(TIN + px * CP + 4 * c4) = v;
+    }
+    __syncthreads();
+
+    // ---- phase 1
+    const int npx = rows * W;
+    for (int t0 = wave * NT; t0 * 16 < npx; t0 += NW * NT) {
+      int base[NT], opix[NT];
+      bool pv[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = 16 * (t0 + nt) + p;
+        pv[nt] = q < npx;
+        const int qc = pv[nt] ? q : npx - 1;
+        const int r = qc / W, x = qc - r * W;
+        base[nt] = (r * WP4 + x) * CP;  // top-left of the 5x5 window
+        opix[nt] = (y0 + r) * W + x;
+      }
+      f32x4 acc[KC][NT];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        f32x4 d[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) d[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ky = 0; ky < 5; ++ky) {  // one tap row at a time keeps the live LDS loads at 15
+          const float* wrow = WD + ky * 5 * KC * 16 + cb;
+          const float* trow = TIN + ky * WP4 * CP + cb;
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * KC * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(trow + base[nt] + kx * CP);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) d[nt][k] = __builtin_fmaf(v[k], w[k], d[nt][k]);
+            }
+          }
+        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + cb);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + cb);
+        f32x4 bfr[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float u = __builtin_fmaf(d[nt][k], sc[k], sh[k]);  // channels >= 72: sc = sh = 0 -> 0
+            bfr[nt][k] = (cb < C && u > 0.f) ? u : 0.f;
+          }
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + (16 * mt + p) * KP + cb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+      }
+      // pointwise BN (no ReLU: fpn.py:16-17,23-24)
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 2 * 96 + 16 * mt + 4 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 3 * 96 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[mt][nt][k] = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
+      }
+      if constexpr (MH == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (!pv[nt]) continue;
+          float* dst = a.out + ((size_t)b * HW + opix[nt]) * C;
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt)
+            if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
+        }
+      } else {
+        // chained output conv: acc[s] (channels 16s+4g..) is the B fragment of chunk s.  One
+        // output-channel tile at a time (single live accumulator pair, stored immediately).
+#pragma unroll 1
+        for (int m = 0; m < MH; ++m) {
+          f32x4 hacc[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KC; ++s) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(WH + (16 * m + p) * KP + 16 * s + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                hacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], acc[s][nt][j], hacc[nt], 0, 0, 0);
+          }
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 4 * 96 + 16 * m + 4 * g);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (!pv[nt]) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = 16 * m + 4 * g + r;
+              if (co < a.mh) {
+                const float y = hacc[nt][r] + bias[r];
+                if (co < a.split)
+                  a.nchw0[((size_t)b * a.split + co) * HW + opix[nt]] = y;
+                else
+                  a.nchw1[((size_t)b * (a.mh - a.split) + (co - a.split)) * HW + opix[nt]] = y;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // TIN is restaged by the next item
+  }
+}
+
+static size_t tower_lds_floats(int mh_tiles, int R, int W) {
+  return (size_t)TW_KC * 16 * TW_KP + (size_t)mh_tiles * 16 * TW_KP + 25 * TW_KC * 16 + 5 * 96 + (size_t)(R + 4) * (W + 4) * TW_CP + 16;
+}
+
+int yfv2_tower_rows(int mh_tiles, int H, int W) {
+  int best = 1;
+  for (int r = 1; r <= H; ++r)
+    if (tower_lds_floats(mh_tiles, r, W) * 4 <= 158 * 1024) best = r;
+  // prefer an even split of the image rows
+  const int tiles = (H + best - 1) / best;
+  return (H + tiles - 1) / tiles;
+}
+
+template <int MH>
+static void launch_tower(const TowerArgs& a, hipStream_t s) {
+  const size_t lds = tower_lds_floats(MH, a.R, a.W) * sizeof(float);
+  const int tiles = (a.H + a.R - 1) / a.R;
+  int blocks = a.B * tiles;
+  if (blocks > 256) blocks = 256;  // persistent, one workgroup per CU (LDS-limited)
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel<MH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((tower_kernel<MH>), dim3(blocks), dim3(512), lds, s, a);
+}
+
+bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s) {
+  const int mh_tiles = a.wh ? (a.mh + 15) / 16 : 0;
+  if (mh_tiles == 0) { launch_tower<0>(a, s); return true; }
+  if (mh_tiles == 1) { launch_tower<1>(a, s); return true; }
+  if (mh_tiles <= 6) { launch_tower<6>(a, s); return true; }
+  return false;
+}

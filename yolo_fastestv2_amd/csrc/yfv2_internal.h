@@ -69,6 +69,18 @@ struct BlockS1Args {
   int R;             // rows per work item (H % R == 0)
 };
 
+// ---- fused DWConvblock half (yfv2_block.hip): dw5x5+BN+ReLU -> pw72+BN [-> output conv]
+struct TowerArgs {
+  const float* in;   // (B,H,W,72) NHWC
+  float* out;        // (B,H,W,72) NHWC when there is no chained output conv
+  const float* wdw; const float* scd; const float* shd;  // dw5x5 [25][72] + BN (+ReLU)
+  const float* wpw; const float* scp; const float* shp;  // pw [72][72] + BN
+  const float* wh; const float* bh;                      // chained output conv [mh][72] + bias (or null)
+  int mh, split;     // co < split -> nchw0[b][co][hw], else nchw1[b][co-split][hw]
+  float* nchw0; float* nchw1;
+  int B, H, W, R;
+};
+
 // ---- decode (handel_preds) and NMS
 struct DecodeArgs {
   const float* reg[2];
@@ -101,5 +113,7 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
 bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
 int yfv2_block_s1_rows(int c2, int H, int W);
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
+int yfv2_tower_rows(int mh_tiles, int H, int W);
+bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   __shared__ unsigned char supp[NMS_CAP];
   __shared__ unsigned char cls_of_row[NMS_CAP];
   __shared__ int keep[NMS_MAX_DET];
+  __shared__ unsigned long long pmask[4][64];
   __shared__ int n_cand, n_keep, n_obj;
 
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -216,26 +217,57 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   }
   __syncthreads();
 
-  // ---- 4. greedy suppression
-  int kept = 0;
-  for (int i = 0; i < n; ++i) {
-    if (supp[i]) continue;  // LDS broadcast; uniform across the block
-    if (tid == 0) keep[kept] = i;
-    ++kept;
-    if (kept == NMS_MAX_DET) break;
-    const float ix1 = bx1[i], iy1 = by1[i], ix2 = bx2[i], iy2 = by2[i], ia = area[i];
-    for (int j = i + 1 + tid; j < n; j += NMS_THREADS) {
-      if (supp[j]) continue;
-      const float xx1 = fmaxf(ix1, bx1[j]), yy1 = fmaxf(iy1, by1[j]);
-      const float xx2 = fminf(ix2, bx2[j]), yy2 = fminf(iy2, by2[j]);
-      const float w = fmaxf(0.0f, __fsub_rn(xx2, xx1)), h = fmaxf(0.0f, __fsub_rn(yy2, yy1));
-      const float inter = __fmul_rn(w, h);
-      const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ia, area[j]), inter));
-      if ((double)ovr > a.iou_thres) supp[j] = 1;
+  // ---- 4. greedy suppression, one wave width (64 sorted candidates) at a time.
+  // A candidate is kept iff no EARLIER KEPT candidate overlaps it by more than the
+  // threshold (torchvision's loop).  Per chunk:  (a) all 256 threads test the chunk
+  // members against the boxes kept so far (4 threads per member, early exit);  (b) the
+  // same threads build, per member j, the 64-bit mask of earlier chunk members i < j with
+  // iou(i, j) > thr;  (c) wave 0 walks the chunk in order with scalar bit operations -
+  // 3 barriers per 64 candidates instead of one per kept box.  Stops at max_det kept
+  // (the reference truncates the full greedy result to its first 300: same rows).
+  auto overlaps = [&](int i, int j) -> bool {
+    const float xx1 = fmaxf(bx1[i], bx1[j]), yy1 = fmaxf(by1[i], by1[j]);
+    const float xx2 = fminf(bx2[i], bx2[j]), yy2 = fminf(by2[i], by2[j]);
+    const float w = fmaxf(0.0f, __fsub_rn(xx2, xx1)), h = fmaxf(0.0f, __fsub_rn(yy2, yy1));
+    const float inter = __fmul_rn(w, h);
+    const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area[i], area[j]), inter));  // i = kept box
+    return (double)ovr > a.iou_thres;
+  };
+  const int j = tid & 63, q = tid >> 6;  // chunk member, quarter
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int nk = n_keep;  // stable: written only between the barriers below
+    if (nk >= NMS_MAX_DET) break;
+    const int m = min(64, n - c0);
+    unsigned long long bits = 0ull;
+    if (j < m) {
+      const int cj = c0 + j;
+      for (int k = q; k < nk; k += NMS_THREADS / 64)
+        if (overlaps(keep[k], cj)) { supp[cj] = 1; break; }
+      const int i_hi = min(16 * q + 16, j);
+      for (int i = 16 * q; i < i_hi; ++i)
+        if (overlaps(c0 + i, cj)) bits |= 1ull << i;
+    }
+    pmask[q][j] = bits;
+    __syncthreads();
+    if (tid < 64) {
+      const unsigned long long S = pmask[0][tid] | pmask[1][tid] | pmask[2][tid] | pmask[3][tid];
+      const bool alive = tid < m && !supp[c0 + tid];
+      const unsigned long long alive_mask = __ballot(alive);
+      unsigned long long kmask = 0ull;
+      for (int i = 0; i < m; ++i) {  // wave-uniform scalar walk
+        const unsigned long long Si = __shfl(S, i);
+        if (((alive_mask >> i) & 1ull) && !(Si & kmask)) kmask |= 1ull << i;
+      }
+      if ((kmask >> tid) & 1ull) {
+        const int pos = nk + __popcll(kmask & ((1ull << tid) - 1ull));
+        if (pos < NMS_MAX_DET) keep[pos] = c0 + tid;
+      }
+      if (tid == 0) n_keep = min(NMS_MAX_DET, nk + __popcll(kmask));
     }
     __syncthreads();
   }
   __syncthreads();
+  const int kept = n_keep;
 
   // ---- output rows: un-offset box, conf, float(cls); idx = decode row
   for (int k = tid; k < kept; k += NMS_THREADS) {
