@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5 };
 
 struct Step {
   int kind = 0;
@@ -36,6 +36,8 @@ struct Step {
   DwArgs dw{};
   BlockS1Args s1{};
   TowerArgs tw{};
+  BlockS2Args s2{};
+  size_t pj_d[3] = {0, 0, 0}, pj_p[3] = {0, 0, 0};  // s2 block: proj dw / proj pw (w, scale, shift)
   size_t wh_off = 0, bh_off = 0;  // tower: chained output conv
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
@@ -68,6 +70,7 @@ struct yfv2_ctx {
   Buf a1, s2[2], s3[2], s4[2], t1, t2, t3, f2, f3, ta, tb;
   Buf logits[6];
   Buf decoded;
+  Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries)
   // which buffers hold the stage outputs of the last forward (for debug/parity)
   float* dbg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -268,6 +271,31 @@ struct PlanBuilder {
   void block_s2(const std::string& p, int cin, int H, int W, const Buf& x, const Buf& y) {
     Folded f;
     const int oh = H / 2, ow = W / 2, co = 2 * cin;
+    const char* env = std::getenv("YFV2_FUSED");
+    const int rfused = (cin == 24 || cin == 48) ? yfv2_block_s2_rows(cin, H, W) : 0;
+    if (!(env && env[0] == '0') && rfused > 0) {
+      Folded f1, fd, f2, fpd, fpp;
+      ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fpd);
+      ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &fpp);
+      ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", cin, cin, &f1);
+      ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", cin, 3, &fd);
+      ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", cin, cin, &f2);
+      Step s;
+      s.kind = STEP_S2;
+      s.c2 = cin;
+      s.s2.in = x.p; s.s2.out = y.p;
+      s.s2.H = H; s.s2.W = W; s.s2.R = rfused;
+      s.w_off = f1.w; s.scale_off = f1.scale; s.shift_off = f1.shift;
+      s.wd_off = fd.w; s.scd_off = fd.scale; s.shd_off = fd.shift;
+      s.w2_off = f2.w; s.sc2_off = f2.scale; s.sh2_off = f2.shift;
+      s.pj_d[0] = fpd.w; s.pj_d[1] = fpd.scale; s.pj_d[2] = fpd.shift;
+      s.pj_p[0] = fpp.w; s.pj_p[1] = fpp.scale; s.pj_p[2] = fpp.shift;
+      s.name = p + " fused s2 block: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) | cat";
+      s.flops = 2.0 * ((double)H * W * cin * cin + 2.0 * oh * ow * cin * cin + 2.0 * oh * ow * 9 * cin);
+      s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * co);
+      h->plan.push_back(s);
+      return;
+    }
     ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &f);
     add_dw(p + ".proj.dw3x3s2+bn", 3, 2, cin, H, W, x.p, cin, h->t3.p, cin, false, f);
     ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &f);
@@ -474,6 +502,16 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
       }
       if (!yfv2_launch_pw(st.K, st.mode, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no pointwise kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_S2) {
+      BlockS2Args a = st.s2;
+      a.B = B;
+      a.w1 = params + st.w_off; a.sc1 = params + st.scale_off; a.sh1 = params + st.shift_off;
+      a.wdw = params + st.wd_off; a.scd = params + st.scd_off; a.shd = params + st.shd_off;
+      a.w2 = params + st.w2_off; a.sc2 = params + st.sc2_off; a.sh2 = params + st.sh2_off;
+      a.wpd = params + st.pj_d[0]; a.scpd = params + st.pj_d[1]; a.shpd = params + st.pj_d[2];
+      a.wpp = params + st.pj_p[0]; a.scpp = params + st.pj_p[1]; a.shpp = params + st.pj_p[2];
+      if (!yfv2_launch_block_s2(st.c2, a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no fused stride-2 kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_TOWER) {
       TowerArgs a = st.tw;
       a.B = B;
@@ -574,6 +612,7 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   A(&h->tb, (H / 16) * (W / 16) * 72);
   for (int i = 0; i < 6; ++i) A(&h->logits[i], logit_elems(h, i));
   A(&h->decoded, (size_t)rows * (5 + cfg->classes));
+  A(&h->cand, (size_t)rows * 8);
   if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 256 * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, YFV2_ERR_DEVICE, "hipMalloc(class filter) failed");
   if (rc != YFV2_OK) {
@@ -594,6 +633,7 @@ void yfv2_destroy(yfv2_handle h) {
   free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->ta); free_buf(&h->tb);
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
   free_buf(&h->decoded);
+  free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);
   if (h->d_params) (void)hipFree(h->d_params);
   delete h;
@@ -642,10 +682,18 @@ int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6],
   return run_plan(h, x, B, out6, static_cast<hipStream_t>(stream), nullptr);
 }
 
+static int decode_impl(yfv2_handle h, const float* const out6[6], int32_t B, float* boxes, float* cand, void* stream);
+static int nms_impl(yfv2_handle h, const float* boxes, int compact, int32_t B, float conf_thres, double iou_thres,
+                    const int32_t* classes, int32_t n_classes, float* dets, int32_t* idx, int32_t* count, void* stream);
+
 int yfv2_decode(yfv2_handle h, const float* const out6[6], int32_t B, float* boxes, void* stream) {
+  return decode_impl(h, out6, B, boxes, nullptr, stream);
+}
+
+static int decode_impl(yfv2_handle h, const float* const out6[6], int32_t B, float* boxes, float* cand, void* stream) {
   int rc = check_call(h, B, false);
   if (rc) return rc;
-  if (!out6 || !boxes) return fail(h, YFV2_ERR_ARG, "yfv2_decode: null pointer");
+  if (!out6 || (!boxes && !cand)) return fail(h, YFV2_ERR_ARG, "yfv2_decode: null pointer");
   for (int i = 0; i < 6; ++i)
     if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_decode: null logit tensor");
   DeviceGuard guard(h->device);
@@ -661,6 +709,7 @@ int yfv2_decode(yfv2_handle h, const float* const out6[6], int32_t B, float* box
   }
   for (int i = 0; i < 12; ++i) a.anchors[i] = h->cfg.anchors[i];
   a.boxes = boxes;
+  a.cand = cand;
   a.B = B;
   a.classes = h->cfg.classes;
   a.rows = h->rows;
@@ -671,6 +720,11 @@ int yfv2_decode(yfv2_handle h, const float* const out6[6], int32_t B, float* box
 
 int yfv2_nms(yfv2_handle h, const float* boxes, int32_t B, float conf_thres, double iou_thres, const int32_t* classes,
              int32_t n_classes, float* dets, int32_t* idx, int32_t* count, void* stream) {
+  return nms_impl(h, boxes, 0, B, conf_thres, iou_thres, classes, n_classes, dets, idx, count, stream);
+}
+
+static int nms_impl(yfv2_handle h, const float* boxes, int compact, int32_t B, float conf_thres, double iou_thres,
+                    const int32_t* classes, int32_t n_classes, float* dets, int32_t* idx, int32_t* count, void* stream) {
   int rc = check_call(h, B, false);
   if (rc) return rc;
   if (!boxes || !dets || !idx || !count) return fail(h, YFV2_ERR_ARG, "yfv2_nms: null pointer");
@@ -679,7 +733,7 @@ int yfv2_nms(yfv2_handle h, const float* boxes, int32_t B, float conf_thres, dou
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   NmsArgs a{};
-  a.boxes = boxes; a.dets = dets; a.idx = idx; a.count = count;
+  a.boxes = boxes; a.compact = compact; a.dets = dets; a.idx = idx; a.count = count;
   a.classes = nullptr; a.n_classes = 0;
   if (n_classes > 0) {  // classes is a HOST array (python list in the reference, utils.py:271-272)
     HIP_TRY(h, hipMemcpyAsync(h->d_classes, classes, sizeof(int32_t) * n_classes, hipMemcpyHostToDevice, s));
@@ -700,9 +754,10 @@ int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, doub
   for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
   rc = yfv2_forward(h, x, B, out6, stream);
   if (rc) return rc;
-  rc = yfv2_decode(h, out6, B, h->decoded.p, stream);
+  // compact candidate rows instead of the (B,1815,85) tensor: same arithmetic, 10x less traffic
+  rc = decode_impl(h, out6, B, nullptr, h->cand.p, stream);
   if (rc) return rc;
-  return yfv2_nms(h, h->decoded.p, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
+  return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
 }
 
 int32_t yfv2_num_rows(yfv2_handle h) { return h ? h->rows : 0; }

@@ -503,3 +503,252 @@ bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s) {
   if (mh_tiles <= 6) { launch_tower<6>(a, s); return true; }
   return false;
 }
+
+// ============================================================================
+// fused ShuffleV2 stride-2 block (first block of a stage)
+// ============================================================================
+// Reference (model/backbone/shufflenetv2.py:19-44,52-55), input c = CIN channels at HxW:
+//   proj = ReLU(BN(pw(BN(dw3x3 s2(x)))))                       CIN -> CIN at H/2 x W/2
+//   main = ReLU(BN(pw2(BN(dw3x3 s2(ReLU(BN(pw1(x))))))))       CIN -> CIN
+//   out  = cat(proj, main)                                     2*CIN channels
+// Work item = (image, R output rows).  phase A: pw1 (+BN+ReLU) of the 2R+1 input rows the
+// tile's depthwise windows touch -> LDS tile T1 (left zero column, zero top row at the
+// image edge).  phase B: per 16 output pixels each lane forms the stride-2 depthwise
+// (+BN) of its pixel / its 4 channels in registers from T1 = B fragment of pw2.
+// phase C: the proj branch the same way, its depthwise taps read straight from the
+// (L1/L2-hot) input.  One launch replaces five and removes four intermediate tensors.
+template <int CIN>
+struct S2Cfg {
+  static constexpr int KC = (CIN + 15) / 16;
+  static constexpr int KP = 16 * KC + 4;
+  static constexpr int CP = CIN + 4;
+  static constexpr int W_FL = KC * 16 * KP;
+  static constexpr int DW_FL = 9 * KC * 16;
+  static constexpr int NCS = 10;  // sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
+};
+
+template <int CIN, int THREADS>
+__global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
+  using Cfg = S2Cfg<CIN>;
+  constexpr int KC = Cfg::KC, KP = Cfg::KP, CP = Cfg::CP, KS = KC * 16;
+  constexpr int NW = THREADS / 64;
+  constexpr int CO = 2 * CIN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* W1 = lds;
+  float* W2 = W1 + Cfg::W_FL;
+  float* WJ = W2 + Cfg::W_FL;       // proj pointwise
+  float* WD = WJ + Cfg::W_FL;       // main depthwise taps [9][KS]
+  float* WE = WD + Cfg::DW_FL;      // proj depthwise taps [9][KS]
+  float* CS = WE + Cfg::DW_FL;      // [10][KS]
+  float* T1 = CS + Cfg::NCS * KS;
+  const int H = a.H, W = a.W, R = a.R, OH = H >> 1, OW = W >> 1;
+  const int WP = W + 1;
+  const int t1_fl = (2 * R + 1) * WP * CP + 16;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+
+  for (int i = tid; i < Cfg::W_FL; i += THREADS) {
+    const int row = i / KP, c = i - row * KP;
+    const bool ok = row < CIN && c < CIN;
+    W1[i] = ok ? a.w1[row * CIN + c] : 0.f;
+    W2[i] = ok ? a.w2[row * CIN + c] : 0.f;
+    WJ[i] = ok ? a.wpp[row * CIN + c] : 0.f;
+  }
+  for (int i = tid; i < Cfg::DW_FL; i += THREADS) {
+    const int k = i / KS, c = i - k * KS;
+    WD[i] = c < CIN ? a.wdw[k * CIN + c] : 0.f;
+    WE[i] = c < CIN ? a.wpd[k * CIN + c] : 0.f;
+  }
+  for (int i = tid; i < KS; i += THREADS) {
+    const bool ok = i < CIN;
+    CS[0 * KS + i] = ok ? a.sc1[i] : 0.f;  CS[1 * KS + i] = ok ? a.sh1[i] : 0.f;
+    CS[2 * KS + i] = ok ? a.scd[i] : 0.f;  CS[3 * KS + i] = ok ? a.shd[i] : 0.f;
+    CS[4 * KS + i] = ok ? a.sc2[i] : 0.f;  CS[5 * KS + i] = ok ? a.sh2[i] : 0.f;
+    CS[6 * KS + i] = ok ? a.scpd[i] : 0.f; CS[7 * KS + i] = ok ? a.shpd[i] : 0.f;
+    CS[8 * KS + i] = ok ? a.scpp[i] : 0.f; CS[9 * KS + i] = ok ? a.shpp[i] : 0.f;
+  }
+  for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;  // column 0 (input col -1) stays zero
+  __syncthreads();
+
+  const int tiles_per_img = (OH + R - 1) / R;
+  const int n_items = a.B * tiles_per_img;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R;                 // first output row
+    const int rows = min(R, OH - y0);
+    const int iy0 = 2 * y0 - 1;            // first input row of T1
+    const size_t in_px = (size_t)b * H * W;
+    const size_t out_px = (size_t)b * OH * OW;
+
+    // ================= phase A: pw1 (+BN+ReLU) over input rows iy0 .. iy0 + 2*rows
+    const int npxA = (2 * rows + 1) * W;
+    for (int t = wave; t * 16 < npxA; t += NW) {
+      const int q = 16 * t + p;
+      const bool valid = q < npxA;
+      const int r = q / W, x = q - r * W;
+      const int gy = iy0 + r;
+      const bool inimg = valid && gy >= 0 && gy < H;
+      const float* src = a.in + (inimg ? in_px + (size_t)gy * W + x : in_px) * CIN;
+      f32x4 bf[KC];
+#pragma unroll
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        bf[s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      float* dst = T1 + (r * WP + x + 1) * CP;
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(W1 + (16 * mt + p) * KP + 16 * s + 4 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[s][j], acc, 0, 0, 0);
+        }
+        const int cb = 16 * mt + 4 * g;
+        if (valid && cb < CIN) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KS + cb);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KS + cb);
+          f32x4 y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
+            y[k] = (inimg && u > 0.f) ? u : 0.f;  // input row -1 is the depthwise zero padding
+          }
+          *reinterpret_cast<f32x4*>(dst + cb) = y;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= phases B (main) and C (proj): depthwise s2 in registers -> pointwise
+    const int npxB = rows * OW;
+#pragma unroll 1
+    for (int branch = 0; branch < 2; ++branch) {
+      const float* taps = branch == 0 ? WD : WE;
+      const float* wmat = branch == 0 ? W2 : WJ;
+      const float* dsc_p = CS + (branch == 0 ? 2 : 6) * KS;
+      const float* dsh_p = CS + (branch == 0 ? 3 : 7) * KS;
+      const float* psc_p = CS + (branch == 0 ? 4 : 8) * KS;
+      const float* psh_p = CS + (branch == 0 ? 5 : 9) * KS;
+      f32x4 wk[KC][9], dsc[KC], dsh[KC];
+#pragma unroll
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[s][k] = *reinterpret_cast<const f32x4*>(taps + k * KS + cb);
+        dsc[s] = *reinterpret_cast<const f32x4*>(dsc_p + cb);
+        dsh[s] = *reinterpret_cast<const f32x4*>(dsh_p + cb);
+      }
+      for (int t = wave; t * 16 < npxB; t += NW) {
+        const int q = 16 * t + p;
+        const bool pv = q < npxB;
+        const int qc = pv ? q : npxB - 1;
+        const int r = qc / OW, x = qc - r * OW;
+        const int oy = y0 + r;
+        f32x4 bfr[KC];
+        if (branch == 0) {
+          const float* tp = T1 + ((2 * r) * WP + 2 * x) * CP;  // window rows 2r..2r+2, T1 cols 2x..2x+2
+#pragma unroll
+          for (int s = 0; s < KC; ++s) {
+            const int cb = 16 * s + 4 * g;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP + cb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], wk[s][ky * 3 + kx][k], d[k]);
+              }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bfr[s][k] = cb < CIN ? __builtin_fmaf(d[k], dsc[s][k], dsh[s][k]) : 0.f;
+          }
+        } else {
+          // proj: taps from the raw input; only input row -1 / col -1 can be outside (pad 1, stride 2)
+          const int iy = 2 * oy - 1, ix = 2 * x - 1;
+#pragma unroll
+          for (int s = 0; s < KC; ++s) {
+            const int cb = 16 * s + 4 * g;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (cb < CIN) {
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                  const int yy = iy + ky, xx = ix + kx;
+                  const bool ok = yy >= 0 && xx >= 0;
+                  const f32x4 v = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)(ok ? yy : 0) * W + (ok ? xx : 0)) * CIN + cb);
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(ok ? v[k] : 0.f, wk[s][ky * 3 + kx][k], d[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bfr[s][k] = cb < CIN ? __builtin_fmaf(d[k], dsc[s][k], dsh[s][k]) : 0.f;
+          }
+        }
+        float* dst = a.out + (out_px + (size_t)oy * OW + x) * CO + (branch == 0 ? CIN : 0);
+#pragma unroll 1
+        for (int mt = 0; mt < KC; ++mt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KC; ++s) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(wmat + (16 * mt + p) * KP + 16 * s + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[s][j], acc, 0, 0, 0);
+          }
+          const int cb = 16 * mt + 4 * g;
+          if (pv && cb < CIN) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(psc_p + cb);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(psh_p + cb);
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
+              y[k] = u > 0.f ? u : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
+        }
+      }
+    }
+    __syncthreads();  // T1 is rewritten by the next item's phase A
+  }
+}
+
+template <int CIN>
+static size_t s2_lds_floats(int R, int W) {
+  using Cfg = S2Cfg<CIN>;
+  return (size_t)3 * Cfg::W_FL + 2 * Cfg::DW_FL + (size_t)Cfg::NCS * Cfg::KC * 16 + (size_t)(2 * R + 1) * (W + 1) * Cfg::CP + 16;
+}
+
+int yfv2_block_s2_rows(int cin, int H, int W) {
+  const int OH = H / 2;
+  int best = 0;
+  for (int r = 1; r <= OH; ++r) {
+    const size_t fl = cin == 24 ? s2_lds_floats<24>(r, W) : s2_lds_floats<48>(r, W);
+    if (fl * 4 <= 158 * 1024) best = r;
+  }
+  if (best == 0) return 0;
+  const int tiles = (OH + best - 1) / best;
+  return (OH + tiles - 1) / tiles;  // even split
+}
+
+template <int CIN>
+static void launch_s2(const BlockS2Args& a, hipStream_t s) {
+  const size_t lds = s2_lds_floats<CIN>(a.R, a.W) * sizeof(float);
+  const int tiles = (a.H / 2 + a.R - 1) / a.R;
+  int blocks = a.B * tiles;
+  if (blocks > 256) blocks = 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((block_s2_kernel<CIN, 512>), dim3(blocks), dim3(512), lds, s, a);
+}
+
+bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
+  if (cin == 24) { launch_s2<24>(a, s); return true; }
+  if (cin == 48) { launch_s2<48>(a, s); return true; }
+  return false;
+}

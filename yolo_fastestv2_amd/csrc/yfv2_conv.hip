@@ -83,69 +83,85 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
     ring[slot * RS + col * STEM_CS + (r % STEM_CS)] = 0.f;
   }
 
-  // a wave owns tiles wave, wave+4, wave+8 of every conv row (ntiles <= 12; a tile index past
-  // the row is clamped to the last tile and simply not stored)
-  constexpr int TPW = 3;
-  const int ntiles = CW >> 4;  // W % 32 == 0
-  int cxs[TPW];
+  // One iteration = one pooled row py = the two new conv rows 2py and 2py+1 (the third row
+  // of the pooling window, 2py-1, is the previous iteration's last row and is still in the
+  // ring).  The 2*ntiles 16-pixel tiles of the two rows are dealt round-robin to the 4
+  // waves (<= 6 each); a tile index past the end is clamped and simply not stored.
+  constexpr int TPW = 6;
+  const int ntiles = CW >> 4;  // W % 32 == 0, ntiles <= 12
+  int trow[TPW], tcx[TPW];
+  bool tok[TPW];
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) cxs[i] = 16 * min(wave + 4 * i, ntiles - 1) + p;
+  for (int i = 0; i < TPW; ++i) {
+    const int u = wave + 4 * i;
+    tok[i] = u < 2 * ntiles;
+    const int uc = tok[i] ? u : 2 * ntiles - 1;
+    trow[i] = uc / ntiles;
+    tcx[i] = 16 * (uc - trow[i] * ntiles) + p;
+  }
 
-  // gather of one conv row: 21 independent dword loads per lane, issued back to back
-  auto load_row = [&](int cy, float (&dst)[TPW][7]) {
-    const int rorg = (2 * cy - 1) * W - 1;
+  // gather of one tile: 7 dwords per lane (lane = pixel, one tap per k-step)
+  auto load_tile = [&](int cy, int cx, float (&dst)[7]) {
+    const int org = (2 * cy - 1) * W - 1 + 2 * cx;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i)
+    for (int ks = 0; ks < 7; ++ks) dst[ks] = xb[max(org + toff[ks], 0)];
+  };
+  // MFMAs + BN + ReLU of one tile into ring row `row`
+  auto conv_tile = [&](int cy, int cx, const float (&src)[7], float* row, bool store) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 7; ++ks) dst[i][ks] = xb[max(rorg + 2 * cxs[i] + toff[ks], 0)];
+    for (int ks = 0; ks < 7; ++ks) {
+      float m = cy == 0 ? mtop[ks] : 1.f;
+      m = cx == 0 ? m * mleft[ks] : m;
+      const float v = src[ks] * m;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], v, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], v, acc1, 0, 0, 0);
+    }
+    if (store) {
+      f32x4 y0, y1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
+        const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
+        y0[r] = u0 > 0.f ? u0 : 0.f;
+        y1[r] = u1 > 0.f ? u1 : 0.f;
+      }
+      float* dst = row + (cx + 1) * STEM_CS + 4 * g;
+      *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
+      if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
+    }
   };
 
-  const int cy_first = 2 * py0 - 1, cy_last = 2 * py0 + 2 * a.R - 1;
-  float cur[TPW][7], nxt[TPW][7];
-  if (cy_first >= 0) load_row(cy_first, cur);
-  for (int cy = cy_first; cy <= cy_last; ++cy) {
-    const int slot = (cy + 3) % 3;
-    float* row = ring + slot * RS;
-    // software pipeline: the next row's gather is in flight during this row's MFMAs, the
-    // barriers and the pooling (plain global loads survive s_barrier)
-    if (cy + 1 <= cy_last) load_row(cy + 1, nxt);
-    if (cy >= 0) {
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int cx = cxs[i];
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
-          float m = cy == 0 ? mtop[ks] : 1.f;
-          m = cx == 0 ? m * mleft[ks] : m;
-          const float v = cur[i][ks] * m;
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], v, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], v, acc1, 0, 0, 0);
-        }
-        if (wave + 4 * i < ntiles) {  // wave-uniform
-          f32x4 y0, y1;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
-            const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
-            y0[r] = u0 > 0.f ? u0 : 0.f;
-            y1[r] = u1 > 0.f ? u1 : 0.f;
-          }
-          float* dst = row + (cx + 1) * STEM_CS + 4 * g;
-          *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
-          if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
-        }
-      }
-    } else {  // conv row -1: the max-pool's top padding
-      for (int i = tid; i < CW * 6; i += STEM_THREADS)
-        *reinterpret_cast<f32x4*>(row + (i / 6 + 1) * STEM_CS + 4 * (i % 6)) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // prologue: conv row 2*py0-1 (the max-pool's zero padding when py0 == 0) into ring slot 0
+  if (py0 == 0) {
+    for (int i = tid; i < CW * 6; i += STEM_THREADS)
+      *reinterpret_cast<f32x4*>(ring + (i / 6 + 1) * STEM_CS + 4 * (i % 6)) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  } else {
+    for (int t = wave; t < ntiles; t += 4) {
+      float v[7];
+      load_tile(2 * py0 - 1, 16 * t + p, v);
+      conv_tile(2 * py0 - 1, 16 * t + p, v, ring, true);
     }
+  }
+
+  float cur[TPW][7], nxt[TPW][7];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) load_tile(2 * py0 + trow[i], tcx[i], cur[i]);
+  int old = 0;  // ring slot of conv row 2py-1
+  for (int py = py0; py < py0 + a.R; ++py) {
+    float* r0 = ring + old * RS;
+    float* r1 = ring + ((old + 1) % 3) * RS;
+    float* r2 = ring + ((old + 2) % 3) * RS;
+    // software pipeline: the next pooled row's gather flies during this row's MFMAs, the
+    // barriers and the pooling (plain global loads survive s_barrier)
+    if (py + 1 < py0 + a.R) {
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) load_tile(2 * (py + 1) + trow[i], tcx[i], nxt[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) conv_tile(2 * py + trow[i], tcx[i], cur[i], trow[i] ? r2 : r1, tok[i]);
     __syncthreads();
-    if ((cy & 1) && cy >= 2 * py0 + 1) {
-      const int py = (cy - 1) >> 1;
-      const float* r0 = ring + ((cy - 2 + 3) % 3) * RS;
-      const float* r1 = ring + ((cy - 1 + 3) % 3) * RS;
-      const float* r2 = row;
+    {
       float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
       for (int i = tid; i < PW * 6; i += STEM_THREADS) {
         const int px = i / 6, q = i - px * 6;
@@ -164,6 +180,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
       }
     }
     __syncthreads();
+    old = (old + 2) % 3;
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -199,8 +216,8 @@ void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
 //               [0,192) gathered from C3 at (y/2, x/2), [192,288) from C2
 //   PW_HEAD     the three biased output convs (detector.py:17-19,25-31): stores
 //               NCHW logits into two destination tensors split at `split`
-template <int K, int MT, int NT, int MODE>
-__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
+template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
+__global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   constexpr int KP = K + 4;  // padded LDS row: (KP/4) odd -> spreads 16-B slots
   constexpr int K16 = K / 16;
   constexpr int KT = K % 16;
@@ -232,10 +249,62 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
   for (int st = blockIdx.x * nwaves + wave; st < n_super; st += gridDim.x * nwaves) {
     const int pix0 = st * (NT * 16);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int pixv[NT];
+
+    if constexpr (STREAM) {
+      // ---- large K (192 / 288): stream the 16-channel chunks with a one-chunk-ahead
+      // prefetch instead of holding K/4 registers per pixel tile
+      static_assert(!STREAM || (KT == 0 && (MODE == PW_PLAIN || MODE == PW_FPN)), "STREAM: K % 16 == 0, plain/fpn only");
+      const float* src0[NT];
+      const float* src1[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int pix = pix0 + nt * 16 + p;
+        pixv[nt] = pix;
+        const int pc = pix < a.P ? pix : a.P - 1;
+        if constexpr (MODE == PW_FPN) {
+          const int hw = a.H * a.W;
+          const int b = pc / hw, rem = pc - b * hw;
+          const int y = rem / a.W, x = rem - y * a.W;
+          src0[nt] = a.in + ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * 192 + 4 * g;  // chunks 0..11
+          src1[nt] = a.in2 + (size_t)pc * 96 + 4 * g - 16 * 12;                                        // chunks 12..17
+        } else {
+          src0[nt] = a.in + (size_t)pc * a.in_stride + a.in_off + 4 * g;
+          src1[nt] = src0[nt];
+        }
+      }
+      constexpr int SPLIT = MODE == PW_FPN ? 12 : K16;
+      f32x4 bcur[NT], bnxt[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bcur[nt] = *reinterpret_cast<const f32x4*>(src0[nt]);
+#pragma unroll 2
+      for (int s = 0; s < K16; ++s) {
+        if (s + 1 < K16) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            bnxt[nt] = *reinterpret_cast<const f32x4*>((s + 1 < SPLIT ? src0[nt] : src1[nt]) + 16 * (s + 1));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bcur[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
+      }
+    } else {
     // ---- B fragments: all K channels of this lane's pixel(s), 16 B per load
     f32x4 bf[NT][K16 > 0 ? K16 : 1];
     f32x2 bt[NT];
-    int pixv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int pix = pix0 + nt * 16 + p;
@@ -276,12 +345,6 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
       }
     }
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
 #pragma unroll
     for (int s = 0; s < K16; ++s) {
 #pragma unroll
@@ -305,6 +368,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bt[nt][j], acc[mt][nt], 0, 0, 0);
       }
     }
+
+    }  // !STREAM
 
     // ---- epilogue: BN scale/shift (or bias), ReLU, store
 #pragma unroll
@@ -345,12 +410,11 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
   }
 }
 
-template <int K, int MT, int NT, int MODE>
+template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
 static void pw_launch(const PwArgs& a, hipStream_t s) {
-  constexpr int THREADS = 256;
   const size_t lds = (size_t)MT * 16 * (K + 4) * sizeof(float);
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
-  int blocks = (n_super + 3) / 4;
+  int blocks = (n_super + THREADS / 64 - 1) / (THREADS / 64);
   // persistent-ish grid: enough blocks to fill 256 CUs a few times over, few
   // enough that the per-block weight staging (L2 -> LDS) stays amortised
   const int cap = lds > 64 * 1024 ? 256 : (lds > 32 * 1024 ? 512 : 1024);
@@ -358,11 +422,11 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   if (blocks < 1) blocks = 1;
   static bool attr_done = false;  // allow > 64 KiB dynamic LDS where needed
   if (!attr_done && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE>), dim3(blocks), dim3(THREADS), lds, s, a);
+  hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
@@ -372,13 +436,13 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
     if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_PLAIN>(a, s); return true; }
     if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_PLAIN>(a, s); return true; }
     if (K == 72 && MT == 5) { pw_launch<72, 5, 2, PW_PLAIN>(a, s); return true; }
-    if (K == 192 && MT == 5) { pw_launch<192, 5, 2, PW_PLAIN>(a, s); return true; }
+    if (K == 192 && MT == 5) { pw_launch<192, 5, 2, PW_PLAIN, 512, true>(a, s); return true; }
   } else if (mode == PW_SHUFFLE) {
     if (K == 24 && MT == 2) { pw_launch<24, 2, 4, PW_SHUFFLE>(a, s); return true; }
     if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_SHUFFLE>(a, s); return true; }
     if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_SHUFFLE>(a, s); return true; }
   } else if (mode == PW_FPN) {
-    if (K == 288 && MT == 5) { pw_launch<288, 5, 1, PW_FPN>(a, s); return true; }
+    if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }
   } else if (mode == PW_HEAD) {
     if (K == 72 && MT == 1) { pw_launch<72, 1, 4, PW_HEAD>(a, s); return true; }
     if (K == 72 && MT <= 6) { pw_launch<72, 6, 2, PW_HEAD>(a, s); return true; }

@@ -69,6 +69,19 @@ struct BlockS1Args {
   int R;             // rows per work item (H % R == 0)
 };
 
+// ---- fused ShuffleV2 stride-2 block (yfv2_block.hip)
+struct BlockS2Args {
+  const float* in;   // (B,H,W,CIN) NHWC
+  float* out;        // (B,H/2,W/2,2*CIN) NHWC
+  const float* w1; const float* sc1; const float* sh1;      // main pw1 + BN (+ReLU)
+  const float* wdw; const float* scd; const float* shd;     // main dw3x3 s2 + BN
+  const float* w2; const float* sc2; const float* sh2;      // main pw2 + BN (+ReLU)
+  const float* wpd; const float* scpd; const float* shpd;   // proj dw3x3 s2 + BN
+  const float* wpp; const float* scpp; const float* shpp;   // proj pw + BN (+ReLU)
+  int B, H, W;       // input size
+  int R;             // output rows per work item
+};
+
 // ---- fused DWConvblock half (yfv2_block.hip): dw5x5+BN+ReLU -> pw72+BN [-> output conv]
 struct TowerArgs {
   const float* in;   // (B,H,W,72) NHWC
@@ -86,7 +99,8 @@ struct DecodeArgs {
   const float* reg[2];
   const float* obj[2];
   const float* cls[2];
-  float* boxes;        // (B, rows, 5+classes)
+  float* boxes;        // (B, rows, 5+classes), or
+  float* cand;         // (B, rows, 8) compact candidate rows (non-null selects the compact kernel)
   int B, classes;
   int fh[2], fw[2];    // feature map sizes
   float stride[2];     // cfg.height / fh  (fp32, like the reference's python float)
@@ -95,7 +109,8 @@ struct DecodeArgs {
 };
 
 struct NmsArgs {
-  const float* boxes;  // (B, rows, 5+classes)
+  const float* boxes;  // (B, rows, 5+classes), or (B, rows, 8) when compact
+  int compact;
   float* dets;         // (B, 300, 6)
   int32_t* idx;        // (B, 300)
   int32_t* count;      // (B)
@@ -113,6 +128,8 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
 bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
 int yfv2_block_s1_rows(int c2, int H, int W);
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
+int yfv2_block_s2_rows(int cin, int H, int W);
+bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s);
 int yfv2_tower_rows(int mh_tiles, int H, int W);
 bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);

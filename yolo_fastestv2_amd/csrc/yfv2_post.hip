@@ -21,6 +21,7 @@ __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, _
 constexpr int DEC_CELLS = 64;
 constexpr int DEC_THREADS = 256;
 
+template <bool COMPACT>
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int blocks0, int blocks1) {
   extern __shared__ float stage[];  // [DEC_CELLS][3][5+classes]
   const int per_img = blocks0 + blocks1;
@@ -82,9 +83,28 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
   }
   __syncthreads();
   const size_t row0 = (size_t)b * a.rows + (sc ? 3 * a.fh[0] * a.fw[0] : 0) + (size_t)cell0 * 3;
-  float* dst = a.boxes + row0 * rowlen;
-  const int n = ncell * 3 * rowlen;
-  for (int i = tid; i < n; i += DEC_THREADS) dst[i] = stage[i];
+  if constexpr (COMPACT) {
+    // yfv2_detect path: emit only what NMS consumes - box, obj, conf = max_j fl32(cls_j*obj)
+    // (first maximal j, utils.py:261,267) and the class - as one 32-byte row; the 85-wide
+    // tensor (617 KB/image) is never written.  Same arithmetic as nms_kernel's filter.
+    if (ok && part < 3) {
+      const float* o = srow + part * rowlen;
+      const float obj = o[4];
+      float best = __fmul_rn(o[5], obj);
+      int bj = 0;
+      for (int j = 1; j < nc; ++j) {
+        const float pj = __fmul_rn(o[5 + j], obj);
+        if (pj > best) { best = pj; bj = j; }
+      }
+      float* d = a.cand + (row0 + (size_t)lc * 3 + part) * 8;
+      *reinterpret_cast<f32x4*>(d) = (f32x4){o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(d + 4) = (f32x4){obj, best, (float)bj, 0.f};
+    }
+  } else {
+    float* dst = a.boxes + row0 * rowlen;
+    const int n = ncell * 3 * rowlen;
+    for (int i = tid; i < n; i += DEC_THREADS) dst[i] = stage[i];
+  }
 }
 
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
@@ -93,11 +113,14 @@ void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
   const size_t lds = (size_t)DEC_CELLS * 3 * (5 + a.classes) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(decode_kernel, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
+  if (a.cand)
+    hipLaunchKernelGGL(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
+  else
+    hipLaunchKernelGGL(decode_kernel<false>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
 }
 
 // ============================================================================
@@ -117,6 +140,7 @@ constexpr int NMS_THREADS = 256;
 constexpr int NMS_CAP = 2048;      // >= rows (1815); power of two for the bitonic network
 constexpr int NMS_MAX_DET = 300;   // utils/utils.py:243 (== YFV2_MAX_DET)
 
+template <bool COMPACT>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   __shared__ unsigned long long key[NMS_CAP];
   __shared__ float bx1[NMS_CAP], by1[NMS_CAP], bx2[NMS_CAP], by2[NMS_CAP], area[NMS_CAP];
@@ -127,7 +151,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   __shared__ int n_cand, n_keep, n_obj;
 
   const int tid = threadIdx.x, b = blockIdx.x;
-  const int rowlen = 5 + a.nc;
+  const int rowlen = COMPACT ? 8 : 5 + a.nc;  // COMPACT rows: cx,cy,w,h,obj,conf,cls,0 (decode_kernel<true>)
   const float* img = a.boxes + (size_t)b * a.rows * rowlen;
   const float ct = a.conf_thres;
   unsigned short* cand_row = reinterpret_cast<unsigned short*>(bx1);  // step 1 only; bx1 is written in step 3
@@ -139,40 +163,51 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   // row: lane l scans classes l, l+16, ... (64-byte coalesced reads), keeps its first
   // maximum of fl32(cls_j*obj), and a 4-step xor-shuffle picks the group's maximum with
   // the LOWEST class index among equals (= torch.max's first-index rule, utils.py:267).
+  if constexpr (COMPACT) {
+    for (int n = tid; n < a.rows; n += NMS_THREADS) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(img + (size_t)n * 8 + 4);  // obj, conf, cls
+      if (t[0] > ct && t[1] > ct) {
+        const int slot = atomicAdd(&n_cand, 1);
+        key[slot] = ((unsigned long long)__float_as_uint(t[1]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+        cls_of_row[n] = (unsigned char)(int)t[2];
+      }
+    }
+  } else {
   for (int n = tid; n < a.rows; n += NMS_THREADS) {
-    const float obj = img[(size_t)n * rowlen + 4];
-    if (obj > ct) cand_row[atomicAdd(&n_obj, 1)] = (unsigned short)n;
-  }
-  __syncthreads();
-  {
-    const int l16 = tid & 15, grp = tid >> 4, ngrp = NMS_THREADS >> 4;
-    const int nobj = n_obj;
-    for (int q = grp; q < nobj; q += ngrp) {  // uniform within a 16-lane group
-      const int n = cand_row[q];
-      const float* r = img + (size_t)n * rowlen;
-      const float obj = r[4];
-      float best = -INFINITY;
-      int bj = 0x7fffffff;
-      for (int j = l16; j < a.nc; j += 16) {
-        const float pj = __fmul_rn(r[5 + j], obj);
-        if (pj > best) { best = pj; bj = j; }  // strict: first maximal index of this lane
-      }
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) {
-        const float ob = __shfl_xor(best, m, 16);
-        const int oj = __shfl_xor(bj, m, 16);
-        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
-      }
-      if (l16 == 0 && best > ct) {
-        bool hit = true;
-        if (a.classes) {
-          hit = false;
-          for (int k = 0; k < a.n_classes; ++k) hit |= (a.classes[k] == bj);
+      const float obj = img[(size_t)n * rowlen + 4];
+      if (obj > ct) cand_row[atomicAdd(&n_obj, 1)] = (unsigned short)n;
+    }
+    __syncthreads();
+    {
+      const int l16 = tid & 15, grp = tid >> 4, ngrp = NMS_THREADS >> 4;
+      const int nobj = n_obj;
+      for (int q = grp; q < nobj; q += ngrp) {  // uniform within a 16-lane group
+        const int n = cand_row[q];
+        const float* r = img + (size_t)n * rowlen;
+        const float obj = r[4];
+        float best = -INFINITY;
+        int bj = 0x7fffffff;
+        for (int j = l16; j < a.nc; j += 16) {
+          const float pj = __fmul_rn(r[5 + j], obj);
+          if (pj > best) { best = pj; bj = j; }  // strict: first maximal index of this lane
         }
-        if (hit) {
-          const int slot = atomicAdd(&n_cand, 1);
-          key[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
-          cls_of_row[n] = (unsigned char)bj;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          const float ob = __shfl_xor(best, m, 16);
+          const int oj = __shfl_xor(bj, m, 16);
+          if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        if (l16 == 0 && best > ct) {
+          bool hit = true;
+          if (a.classes) {
+            hit = false;
+            for (int k = 0; k < a.n_classes; ++k) hit |= (a.classes[k] == bj);
+          }
+          if (hit) {
+            const int slot = atomicAdd(&n_cand, 1);
+            key[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+            cls_of_row[n] = (unsigned char)bj;
+          }
         }
       }
     }
@@ -287,5 +322,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
 }
 
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
+  if (a.compact)
+    hipLaunchKernelGGL(nms_kernel<true>, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL(nms_kernel<false>, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
 }
