@@ -121,6 +121,7 @@ def main():
     dt_f = timed(lambda: eng.forward(x, out=logit_bufs), a.steps, sync, barrier)
     fwd_img_s = world * a.batch * a.steps / dt_f
 
+    cnt_h = det_bufs[2].float().cpu()
     out = None
     if rank == 0:
         # ---- roofline of the dominant launch (hipEvents on the launch stream) -------------
@@ -204,6 +205,7 @@ def main():
                        "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
             "roofline": roof, "cpu_baseline": cpu,
+            "detections_per_image": {"mean": round(float(cnt_h.mean()), 1), "max": int(cnt_h.max())},
             "forward_launches": len(kern), "forward_sum_of_launch_ms": round(tot_ms, 4), "kernel_groups": groups,
         }
         print(json.dumps(out), flush=True)

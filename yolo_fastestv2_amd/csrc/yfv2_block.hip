@@ -79,19 +79,6 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;
   __syncthreads();
 
-  // depthwise taps / BN of this lane's channel quads, in registers when they fit
-  f32x4 wk[Cfg::DWREG ? KC : 1][9], dsc[Cfg::DWREG ? KC : 1], dsh[Cfg::DWREG ? KC : 1];
-  if constexpr (Cfg::DWREG) {
-#pragma unroll
-    for (int s = 0; s < KC; ++s) {
-      const int cb = 16 * s + 4 * g;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) wk[s][k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-      dsc[s] = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-      dsh[s] = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-    }
-  }
-
   const int tiles_per_img = (H + R - 1) / R;
   const int n_items = a.B * tiles_per_img;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -101,29 +88,55 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
     const size_t img_px = (size_t)b * H * W;
 
     // ================= phase A: pw1 (+BN+ReLU) over rows y0-1 .. y0+rows, into T1
+    // One-tile-ahead software pipeline: the raw loads of the wave's next tile are issued
+    // before the current tile's MFMAs so HBM/L2 latency overlaps compute.
     const int npxA = (rows + 2) * W;
-    for (int t = wave; t * 16 < npxA; t += NW) {
+    auto tile_geom = [&](int t, bool& valid, bool& inimg, bool& interior, int& r, int& x, size_t& gp) {
       const int q = 16 * t + p;
-      const bool valid = q < npxA;
-      const int r = q / W, x = q - r * W;
+      valid = q < npxA;
+      r = q / W;
+      x = q - r * W;
       const int gy = y0 - 1 + r;
-      const bool inimg = valid && gy >= 0 && gy < H;
-      const bool interior = inimg && r >= 1 && r <= rows;
-      const size_t gp = inimg ? img_px + (size_t)gy * W + x : img_px;  // clamped: always readable
+      inimg = valid && gy >= 0 && gy < H;
+      interior = inimg && r >= 1 && r <= rows;
+      gp = inimg ? img_px + (size_t)gy * W + x : img_px;  // clamped: always readable
+    };
+    auto load_raw = [&](size_t gp, f32x4 (&raw)[KC][2]) {
       const float* src = a.in + gp * C;
+#pragma unroll
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        if (cb < C2) {
+          raw[s][0] = *reinterpret_cast<const f32x4*>(src + 2 * cb);
+          raw[s][1] = *reinterpret_cast<const f32x4*>(src + 2 * cb + 4);
+        } else {
+          raw[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          raw[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    };
+    f32x4 rcur[KC][2], rnxt[KC][2];
+    if (wave * 16 < npxA) {
+      bool v_, i_, n_; int r_, x_; size_t gp_;
+      tile_geom(wave, v_, i_, n_, r_, x_, gp_);
+      load_raw(gp_, rcur);
+    }
+    for (int t = wave; t * 16 < npxA; t += NW) {
+      bool valid, inimg, interior; int r, x; size_t gp;
+      tile_geom(t, valid, inimg, interior, r, x, gp);
+      if ((t + NW) * 16 < npxA) {
+        bool v_, i_, n_; int r_, x_; size_t gp_;
+        tile_geom(t + NW, v_, i_, n_, r_, x_, gp_);
+        load_raw(gp_, rnxt);
+      }
       float* cp = a.out + gp * C;
       f32x4 bf[KC];
 #pragma unroll
       for (int s = 0; s < KC; ++s) {
         const int cb = 16 * s + 4 * g;
-        if (cb < C2) {
-          const f32x4 q0 = *reinterpret_cast<const f32x4*>(src + 2 * cb);
-          const f32x4 q1 = *reinterpret_cast<const f32x4*>(src + 2 * cb + 4);
-          bf[s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};
-          if (interior) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};
-        } else {
-          bf[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        const f32x4 q0 = rcur[s][0], q1 = rcur[s][1];
+        bf[s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};  // odd channels -> main branch (zero for cb >= C2)
+        if (interior && cb < C2) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};  // even -> pass-through
       }
       // one output-channel tile at a time: a single live accumulator keeps the register
       // footprint flat (the big C2=96 variant must not spill); the dependent MFMA chain is
@@ -151,85 +164,151 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
           *reinterpret_cast<f32x4*>(dst + cb) = y;
         }
       }
+#pragma unroll
+      for (int s = 0; s < KC; ++s) { rcur[s][0] = rnxt[s][0]; rcur[s][1] = rnxt[s][1]; }
     }
     __syncthreads();
 
     // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
-    const int npxB = rows * W;
-    for (int t0 = wave * NTB; t0 * 16 < npxB; t0 += NW * NTB) {
-      int base[NTB];
-      size_t opx[NTB];
-      bool pv[NTB];
-#pragma unroll
-      for (int nt = 0; nt < NTB; ++nt) {
-        const int q = 16 * (t0 + nt) + p;
-        pv[nt] = q < npxB;
-        const int qc = pv[nt] ? q : npxB - 1;
-        const int r = qc / W, x = qc - r * W;
-        base[nt] = (r * WP + x) * CP;  // top-left of the 3x3 window in T1 (halo row + zero column included)
-        opx[nt] = img_px + (size_t)(y0 + r) * W + x;
-      }
-      f32x4 acc[KC][NTB];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTB; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll(Cfg::DWREG ? Cfg::KC : 1)
+    // (re)loaded per item so that they are not live across phase A
+    // depthwise taps / BN of this lane's channel quads, in registers when they fit
+    f32x4 wk[Cfg::DWREG ? KC : 1][9], dsc[Cfg::DWREG ? KC : 1], dsh[Cfg::DWREG ? KC : 1];
+    if constexpr (Cfg::DWREG) {
+  #pragma unroll
       for (int s = 0; s < KC; ++s) {
         const int cb = 16 * s + 4 * g;
-        f32x4 wl[9], lsc, lsh;
-        if constexpr (!Cfg::DWREG) {
+  #pragma unroll
+        for (int k = 0; k < 9; ++k) wk[s][k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
+        dsc[s] = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+        dsh[s] = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+      }
+    }
+    const int npxB = rows * W;
+    if constexpr (Cfg::DWREG) {
+      // small C2: all depthwise fragments of the tile first (taps in registers), then one
+      // output-channel tile at a time with a single live accumulator
+      for (int t = wave; t * 16 < npxB; t += NW) {
+        const int q = 16 * t + p;
+        const bool pvv = q < npxB;
+        const int qc = pvv ? q : npxB - 1;
+        const int r = qc / W, x = qc - r * W;
+        const float* tp = T1 + (r * WP + x) * CP;  // top-left of the 3x3 window (halo row + zero column included)
+        f32x4 bfr[KC];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-          lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-          lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-        }
-        f32x4 bfr[NTB];
-#pragma unroll
-        for (int nt = 0; nt < NTB; ++nt) {
+        for (int s = 0; s < KC; ++s) {
+          const int cb = 16 * s + 4 * g;
           f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          const float* tp = T1 + base[nt] + cb;
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP);
-              const f32x4 w = Cfg::DWREG ? wk[Cfg::DWREG ? s : 0][ky * 3 + kx] : wl[ky * 3 + kx];
+              const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP + cb);
 #pragma unroll
-              for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], w[k], d[k]);
+              for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], wk[s][ky * 3 + kx][k], d[k]);
             }
-          const f32x4 sc = Cfg::DWREG ? dsc[Cfg::DWREG ? s : 0] : lsc;
-          const f32x4 sh = Cfg::DWREG ? dsh[Cfg::DWREG ? s : 0] : lsh;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) bfr[nt][k] = cb < C2 ? __builtin_fmaf(d[k], sc[k], sh[k]) : 0.f;
+          for (int k = 0; k < 4; ++k) bfr[s][k] = cb < C2 ? __builtin_fmaf(d[k], dsc[s][k], dsh[s][k]) : 0.f;
         }
-#pragma unroll
+        float* dst = a.out + (img_px + (size_t)(y0 + r) * W + x) * C + C2;
+#pragma unroll 1
         for (int mt = 0; mt < KC; ++mt) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + (16 * mt + p) * KP + cb);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int s = 0; s < KC; ++s) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + (16 * mt + p) * KP + 16 * s + 4 * g);
 #pragma unroll
-            for (int nt = 0; nt < NTB; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < NTB; ++nt) {
-        if (!pv[nt]) continue;
-        float* dst = a.out + opx[nt] * C + C2;
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[s][j], acc, 0, 0, 0);
+          }
           const int cb = 16 * mt + 4 * g;
-          if (cb < C2) {
+          if (pvv && cb < C2) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + cb);
             f32x4 y;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float u = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
+              const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
               y[k] = u > 0.f ? u : 0.f;
             }
             *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
+        }
+      }
+    } else {
+      for (int t0 = wave * NTB; t0 * 16 < npxB; t0 += NW * NTB) {
+        int base[NTB];
+        size_t opx[NTB];
+        bool pv[NTB];
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) {
+          const int q = 16 * (t0 + nt) + p;
+          pv[nt] = q < npxB;
+          const int qc = pv[nt] ? q : npxB - 1;
+          const int r = qc / W, x = qc - r * W;
+          base[nt] = (r * WP + x) * CP;  // top-left of the 3x3 window in T1 (halo row + zero column included)
+          opx[nt] = img_px + (size_t)(y0 + r) * W + x;
+        }
+        f32x4 acc[KC][NTB];
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTB; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll(Cfg::DWREG ? Cfg::KC : 1)
+        for (int s = 0; s < KC; ++s) {
+          const int cb = 16 * s + 4 * g;
+          f32x4 wl[9], lsc, lsh;
+          if constexpr (!Cfg::DWREG) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
+            lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+            lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+          }
+          f32x4 bfr[NTB];
+#pragma unroll
+          for (int nt = 0; nt < NTB; ++nt) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            const float* tp = T1 + base[nt] + cb;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP);
+                const f32x4 w = Cfg::DWREG ? wk[Cfg::DWREG ? s : 0][ky * 3 + kx] : wl[ky * 3 + kx];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], w[k], d[k]);
+              }
+            const f32x4 sc = Cfg::DWREG ? dsc[Cfg::DWREG ? s : 0] : lsc;
+            const f32x4 sh = Cfg::DWREG ? dsh[Cfg::DWREG ? s : 0] : lsh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bfr[nt][k] = cb < C2 ? __builtin_fmaf(d[k], sc[k], sh[k]) : 0.f;
+          }
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + (16 * mt + p) * KP + cb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int nt = 0; nt < NTB; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) {
+          if (!pv[nt]) continue;
+          float* dst = a.out + opx[nt] * C + C2;
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) {
+            const int cb = 16 * mt + 4 * g;
+            if (cb < C2) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
+              const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + cb);
+              f32x4 y;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float u = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
+                y[k] = u > 0.f ? u : 0.f;
+              }
+              *reinterpret_cast<f32x4*>(dst + cb) = y;
+            }
           }
         }
       }
@@ -580,19 +659,38 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     const size_t out_px = (size_t)b * OH * OW;
 
     // ================= phase A: pw1 (+BN+ReLU) over input rows iy0 .. iy0 + 2*rows
+    // (one-tile-ahead software pipeline on the global loads, as in the stride-1 block)
     const int npxA = (2 * rows + 1) * W;
-    for (int t = wave; t * 16 < npxA; t += NW) {
+    auto geomA = [&](int t, bool& valid, bool& inimg, int& r, int& x, size_t& gp) {
       const int q = 16 * t + p;
-      const bool valid = q < npxA;
-      const int r = q / W, x = q - r * W;
+      valid = q < npxA;
+      r = q / W;
+      x = q - r * W;
       const int gy = iy0 + r;
-      const bool inimg = valid && gy >= 0 && gy < H;
-      const float* src = a.in + (inimg ? in_px + (size_t)gy * W + x : in_px) * CIN;
-      f32x4 bf[KC];
+      inimg = valid && gy >= 0 && gy < H;
+      gp = inimg ? in_px + (size_t)gy * W + x : in_px;
+    };
+    auto loadA = [&](size_t gp, f32x4 (&raw)[KC]) {
+      const float* src = a.in + gp * CIN;
 #pragma unroll
       for (int s = 0; s < KC; ++s) {
         const int cb = 16 * s + 4 * g;
-        bf[s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        raw[s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    f32x4 bf[KC], bn[KC];
+    if (wave * 16 < npxA) {
+      bool v_, i_; int r_, x_; size_t gp_;
+      geomA(wave, v_, i_, r_, x_, gp_);
+      loadA(gp_, bf);
+    }
+    for (int t = wave; t * 16 < npxA; t += NW) {
+      bool valid, inimg; int r, x; size_t gp;
+      geomA(t, valid, inimg, r, x, gp);
+      if ((t + NW) * 16 < npxA) {
+        bool v_, i_; int r_, x_; size_t gp_;
+        geomA(t + NW, v_, i_, r_, x_, gp_);
+        loadA(gp_, bn);
       }
       float* dst = T1 + (r * WP + x + 1) * CP;
 #pragma unroll
@@ -617,6 +715,8 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
           *reinterpret_cast<f32x4*>(dst + cb) = y;
         }
       }
+#pragma unroll
+      for (int s = 0; s < KC; ++s) bf[s] = bn[s];
     }
     __syncthreads();
 

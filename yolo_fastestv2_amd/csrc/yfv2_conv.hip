@@ -17,23 +17,32 @@
 // ============================================================================
 // stem: conv3x3 s2 + BN + ReLU + maxpool3x3 s2
 // ============================================================================
-// One workgroup (4 waves) = one band of R pooled rows of one image.  The block
-// streams down the conv rows of its band; each conv row is cut into 16-pixel
-// tiles that the waves share.  A tile is an implicit GEMM on the fp32 MFMA:
-//   D[co][pixel] = sum_k W[co][k] * patch[k][pixel],  K = 27 taps (padded to 28 =
-//   7 steps of v_mfma_f32_16x16x4_f32), M = 24 channels (2 tiles, 8 rows idle)
-// A (the filter) lives in 14 VGPRs per lane for the whole kernel; B is gathered
-// straight from the NCHW image (lane = pixel, one tap per k-step: stride-2 dwords
-// of one image row, served by L1/L2 - every input byte leaves HBM once).  The
-// BN+ReLU row goes into a 3-row LDS ring and every second row the block
-// max-pools the ring into one NHWC output row, so the 24x176x176 conv map
-// (2.97 MB/image) never touches HBM.
+// One workgroup (4 waves) = one band of R pooled rows of one image, streamed top to
+// bottom one pooled row (= two conv rows = four new input rows) per iteration:
+//   stage   the 4 new input rows x 3 channels are copied NCHW -> LDS input ring with
+//           coalesced 16-byte loads that were issued one iteration earlier (register
+//           prefetch); the image border is plain zero padding in LDS (row -1, column -1)
+//   conv    each 16-pixel tile of the two conv rows is an implicit GEMM on the fp32 MFMA:
+//             D[co][pixel] = sum_k W[co][k] * patch[k][pixel],  K = 27 taps (padded to 28 =
+//             7 steps of v_mfma_f32_16x16x4_f32), M = 24 channels (2 tiles, 8 rows idle)
+//           A (the filter) lives in 14 VGPRs per lane for the whole kernel; B is gathered
+//           from the LDS input ring (lane = pixel, one tap per k-step).  A direct global
+//           gather of these stride-2 dwords is bound by the texture-address rate (measured
+//           320 us/launch), LDS serves them at 2-way bank conflicts.
+//   pool    BN+ReLU rows sit in a 3-row LDS conv ring; the block max-pools the ring into one
+//           NHWC output row, so the 24x176x176 conv map (2.97 MB/image) never touches HBM.
 constexpr int STEM_THREADS = 256;
-constexpr int STEM_CS = 28;  // LDS floats per conv pixel (24 + 4 pad)
+constexpr int STEM_CS = 24;    // conv-ring floats per conv pixel
+constexpr int STEM_IOFF = 4;   // input-ring column of image column 0 (column 3 = x = -1 = zero)
+constexpr int STEM_NPRE = 5;   // staged float4 per thread per iteration: ceil(4*3*(W/4)/256), W <= 384
 
 __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float ring[];  // [3][CW+2][STEM_CS]
-  const int H = a.H, W = a.W, CH = H >> 1, CW = W >> 1, PH = H >> 2, PW = W >> 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = a.H, W = a.W, CW = W >> 1, PH = H >> 2, PW = W >> 2, W4 = W >> 2;
+  const int WI = W + 8;                 // input-ring row: 4 pad | W data | 4 pad
+  const int SR = 3 * WI;                // one input row, 3 channels
+  float* iring = lds;                   // [5 rows][3][WI]
+  float* ring = lds + 5 * SR;           // conv ring [3][CW+2][STEM_CS]
   const int RS = (CW + 2) * STEM_CS;
   const int bands = PH / a.R;
   const int band = blockIdx.x % bands, b = blockIdx.x / bands;
@@ -60,62 +69,54 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
       sc[mt][r] = co < 24 ? a.scale[co] : 0.f;
       sh[mt][r] = co < 24 ? a.shift[co] : 0.f;
     }
-  // tap of k-step ks for this lane group: k = 4ks + g -> (ci, ky, kx); k = 27 is the zero pad.
-  // Borders are handled without branches: 32-bit offsets clamped at 0 plus 0/1 multipliers.
-  // With pad 1 / stride 2 only input row -1 (cy == 0, ky == 0) and input col -1 (cx == 0,
-  // kx == 0) fall outside the image.
-  int toff[7];
-  float mtop[7], mleft[7];
+  // tap of k-step ks for this lane group: k = 4ks + g -> (ci, ky, kx); k = 27 is the zero-weight pad
+  int tky[7], tofs[7];
 #pragma unroll
   for (int ks = 0; ks < 7; ++ks) {
-    const int k = 4 * ks + g, kk = k < 27 ? k : 26;  // pad tap reads a valid pixel, its weight is 0
+    const int k = 4 * ks + g, kk = k < 27 ? k : 26;
     const int ci = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
-    toff[ks] = (ci * H + ky) * W + kx;
-    mtop[ks] = ky == 0 ? 0.f : 1.f;
-    mleft[ks] = kx == 0 ? 0.f : 1.f;
+    tky[ks] = ky;
+    tofs[ks] = ci * WI + kx + STEM_IOFF - 1;  // + 2*cx + slot(row) * SR
   }
 
-  // zero the two pad columns of all three ring rows once (conv cols -1 and CW;
-  // post-ReLU values are >= 0 so 0 is a neutral element for the max)
-  for (int i = tid; i < 3 * 2 * STEM_CS; i += STEM_THREADS) {
-    const int slot = i / (2 * STEM_CS), r = i % (2 * STEM_CS);
-    const int col = (r < STEM_CS) ? 0 : (CW + 1);
-    ring[slot * RS + col * STEM_CS + (r % STEM_CS)] = 0.f;
-  }
+  // zero both rings once: input pad columns and conv-ring pad columns stay zero forever
+  for (int i = tid; i < 5 * SR + 3 * RS; i += STEM_THREADS) lds[i] = 0.f;
 
-  // One iteration = one pooled row py = the two new conv rows 2py and 2py+1 (the third row
-  // of the pooling window, 2py-1, is the previous iteration's last row and is still in the
-  // ring).  The 2*ntiles 16-pixel tiles of the two rows are dealt round-robin to the 4
-  // waves (<= 6 each); a tile index past the end is clamped and simply not stored.
-  constexpr int TPW = 6;
-  const int ntiles = CW >> 4;  // W % 32 == 0, ntiles <= 12
-  int trow[TPW], tcx[TPW];
-  bool tok[TPW];
+  // ---- staging of input rows [iy_first, iy_first + nrows) into the input ring
+  const int per_row = 3 * W4;
+  auto stage_load = [&](int iy_first, int nrows, f32x4 (&pre)[STEM_NPRE]) {
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int u = wave + 4 * i;
-    tok[i] = u < 2 * ntiles;
-    const int uc = tok[i] ? u : 2 * ntiles - 1;
-    trow[i] = uc / ntiles;
-    tcx[i] = 16 * (uc - trow[i] * ntiles) + p;
-  }
-
-  // gather of one tile: 7 dwords per lane (lane = pixel, one tap per k-step)
-  auto load_tile = [&](int cy, int cx, float (&dst)[7]) {
-    const int org = (2 * cy - 1) * W - 1 + 2 * cx;
-#pragma unroll
-    for (int ks = 0; ks < 7; ++ks) dst[ks] = xb[max(org + toff[ks], 0)];
+    for (int j = 0; j < STEM_NPRE; ++j) {
+      const int i = tid + j * STEM_THREADS;
+      const int k = i / per_row, rem = i - k * per_row;
+      const int ci = rem / W4, c4 = rem - ci * W4;
+      const int iy = iy_first + k;
+      pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (k < nrows && iy >= 0 && iy < H) pre[j] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ci * H + iy) * W + 4 * c4);
+    }
   };
-  // MFMAs + BN + ReLU of one tile into ring row `row`
-  auto conv_tile = [&](int cy, int cx, const float (&src)[7], float* row, bool store) {
+  auto stage_store = [&](int iy_first, int nrows, const f32x4 (&pre)[STEM_NPRE]) {
+#pragma unroll
+    for (int j = 0; j < STEM_NPRE; ++j) {
+      const int i = tid + j * STEM_THREADS;
+      const int k = i / per_row, rem = i - k * per_row;
+      const int ci = rem / W4, c4 = rem - ci * W4;
+      const int iy = iy_first + k;
+      if (k < nrows) *reinterpret_cast<f32x4*>(iring + ((iy + 5) % 5) * SR + ci * WI + STEM_IOFF + 4 * c4) = pre[j];
+    }
+  };
+  // ---- one 16-pixel conv tile: gather from the input ring, 14 MFMAs, BN + ReLU, store to conv ring
+  auto conv_tile = [&](int cy, int cx, float* row, bool store) {
+    const int r0 = 2 * cy - 1 + 5;  // input row of ky = 0, biased so that % is on a non-negative value
+    const int s0 = (r0 % 5) * SR, s1 = ((r0 + 1) % 5) * SR, s2 = ((r0 + 2) % 5) * SR;
+    float bv[7];
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) bv[ks] = iring[(tky[ks] == 0 ? s0 : (tky[ks] == 1 ? s1 : s2)) + tofs[ks] + 2 * cx];
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 7; ++ks) {
-      float m = cy == 0 ? mtop[ks] : 1.f;
-      m = cx == 0 ? m * mleft[ks] : m;
-      const float v = src[ks] * m;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], v, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], v, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], bv[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], bv[ks], acc1, 0, 0, 0);
     }
     if (store) {
       f32x4 y0, y1;
@@ -132,65 +133,60 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
     }
   };
 
-  // prologue: conv row 2*py0-1 (the max-pool's zero padding when py0 == 0) into ring slot 0
-  if (py0 == 0) {
-    for (int i = tid; i < CW * 6; i += STEM_THREADS)
-      *reinterpret_cast<f32x4*>(ring + (i / 6 + 1) * STEM_CS + 4 * (i % 6)) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  } else {
-    for (int t = wave; t < ntiles; t += 4) {
-      float v[7];
-      load_tile(2 * py0 - 1, 16 * t + p, v);
-      conv_tile(2 * py0 - 1, 16 * t + p, v, ring, true);
-    }
-  }
+  const int ntiles = CW >> 4;  // W % 32 == 0, ntiles <= 12
+  f32x4 pre[STEM_NPRE];
+  // prologue: conv row 2*py0-1 needs input rows 4*py0-3 .. 4*py0-1 (zeros above the image)
+  stage_load(4 * py0 - 3, 3, pre);
+  __syncthreads();  // ring zero-fill complete
+  stage_store(4 * py0 - 3, 3, pre);
+  stage_load(4 * py0, 4, pre);  // first iteration's rows: in flight during the prologue conv
+  __syncthreads();
+  if (py0 > 0)  // for py0 == 0 conv row -1 is the max-pool padding: ring slot 0 stays zero
+    for (int t = wave; t < ntiles; t += 4) conv_tile(2 * py0 - 1, 16 * t + p, ring, true);
 
-  float cur[TPW][7], nxt[TPW][7];
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) load_tile(2 * py0 + trow[i], tcx[i], cur[i]);
-  int old = 0;  // ring slot of conv row 2py-1
+  int old = 0;  // conv-ring slot of conv row 2py-1
   for (int py = py0; py < py0 + a.R; ++py) {
     float* r0 = ring + old * RS;
     float* r1 = ring + ((old + 1) % 3) * RS;
     float* r2 = ring + ((old + 2) % 3) * RS;
-    // software pipeline: the next pooled row's gather flies during this row's MFMAs, the
-    // barriers and the pooling (plain global loads survive s_barrier)
-    if (py + 1 < py0 + a.R) {
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) load_tile(2 * (py + 1) + trow[i], tcx[i], nxt[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) conv_tile(2 * py + trow[i], tcx[i], cur[i], trow[i] ? r2 : r1, tok[i]);
+    __syncthreads();  // previous conv phase has finished reading the input ring / pooling the conv ring
+    stage_store(4 * py, 4, pre);
+    if (py + 1 < py0 + a.R) stage_load(4 * (py + 1), 4, pre);  // flies during conv + pool
     __syncthreads();
-    {
-      float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
-      for (int i = tid; i < PW * 6; i += STEM_THREADS) {
-        const int px = i / 6, q = i - px * 6;
-        const int base = (2 * px) * STEM_CS + 4 * q;  // conv col 2px-1 sits at ring col 2px
-        f32x4 m = *reinterpret_cast<const f32x4*>(r0 + base);
+    // the 2*ntiles tiles of conv rows 2py, 2py+1 are dealt round-robin to the 4 waves
+    for (int u = wave; u < 2 * ntiles; u += 4) {
+      const int rr = u >= ntiles ? 1 : 0;
+      conv_tile(2 * py + rr, 16 * (u - rr * ntiles) + p, rr ? r2 : r1, true);
+    }
+    __syncthreads();
+    float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
+    for (int i = tid; i < PW * 6; i += STEM_THREADS) {
+      const int px = i / 6, q = i - px * 6;
+      const int base = (2 * px) * STEM_CS + 4 * q;  // conv col 2px-1 sits at ring col 2px
+      f32x4 m = *reinterpret_cast<const f32x4*>(r0 + base);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int o = base + dx * STEM_CS;
-          const f32x4 u0 = *reinterpret_cast<const f32x4*>(r0 + o);
-          const f32x4 u1 = *reinterpret_cast<const f32x4*>(r1 + o);
-          const f32x4 u2 = *reinterpret_cast<const f32x4*>(r2 + o);
+      for (int dx = 0; dx < 3; ++dx) {
+        const int o = base + dx * STEM_CS;
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(r0 + o);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(r1 + o);
+        const f32x4 u2 = *reinterpret_cast<const f32x4*>(r2 + o);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], u0[k]), fmaxf(u1[k], u2[k]));
-        }
-        *reinterpret_cast<f32x4*>(orow + (size_t)i * 4) = m;  // px*24 + 4q == 4i
+        for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], u0[k]), fmaxf(u1[k], u2[k]));
       }
+      *reinterpret_cast<f32x4*>(orow + (size_t)i * 4) = m;  // px*24 + 4q == 4i
     }
-    __syncthreads();
     old = (old + 2) % 3;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 7; ++ks) cur[i][ks] = nxt[i][ks];
   }
 }
 
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
   const int bands = (a.H / 4) / a.R;
-  const size_t lds = (size_t)3 * (a.W / 2 + 2) * STEM_CS * sizeof(float);
+  const size_t lds = sizeof(float) * ((size_t)5 * 3 * (a.W + 8) + (size_t)3 * (a.W / 2 + 2) * STEM_CS);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
   hipLaunchKernelGGL(stem_kernel, dim3(a.B * bands), dim3(STEM_THREADS), lds, s, a);
 }
 
