@@ -44,6 +44,7 @@ struct Step {
   size_t w2_off = 0, sc2_off = 0, sh2_off = 0, wd_off = 0, scd_off = 0, shd_off = 0;
   // offsets into the param blob, resolved to pointers after the upload
   size_t w_off = 0, scale_off = 0, shift_off = 0;
+  size_t img_off = 0;         // host-packed LDS image of this launch
   int px_per_img = 0;         // pw: pixels per image (P = B * px_per_img)
   int head0 = -1, head1 = -1; // PW_HEAD: indices into out6
   std::string name;
@@ -196,6 +197,89 @@ struct WeightPacker {
     }
     return true;
   }
+
+  // ---- LDS images: the exact, zero-padded block of floats a kernel copies into LDS (or its
+  // registers) in its prologue.  Built from the arrays packed above.
+  static void push_matrix(std::vector<float>& im, const float* w, int M, int K, int rows, int KP) {
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < KP; ++c) im.push_back((r < M && c < K) ? w[(size_t)r * K + c] : 0.f);
+  }
+  static void push_rows(std::vector<float>& im, const float* w, int nrows, int C, int KS) {  // [nrows][C] -> [nrows][KS]
+    for (int r = 0; r < nrows; ++r)
+      for (int c = 0; c < KS; ++c) im.push_back(c < C ? w[(size_t)r * C + c] : 0.f);
+  }
+  static void push_vec(std::vector<float>& im, const float* v, int n, int padded) {
+    for (int i = 0; i < padded; ++i) im.push_back((v && i < n) ? v[i] : 0.f);
+  }
+  size_t put(const std::vector<float>& im) {
+    const size_t off = reserve(im.size());
+    std::memcpy(&blob[off], im.data(), sizeof(float) * im.size());
+    return off;
+  }
+  // pw_kernel: filter [MT*16][K+4], scale[MT*16], shift[MT*16]
+  size_t image_pw(const Folded& f, int M, int K) {
+    const int rows = ((M + 15) / 16) * 16, KP = K + 4;
+    std::vector<float> im;
+    push_matrix(im, &blob[f.w], M, K, rows, KP);
+    push_vec(im, &blob[f.scale], M, rows);
+    push_vec(im, &blob[f.shift], M, rows);
+    return put(im);
+  }
+  // block_s1_kernel<C2>: W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2
+  size_t image_s1(const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
+    const int KC = (c2 + 15) / 16, KS = 16 * KC, KP = KS + 4;
+    std::vector<float> im;
+    push_matrix(im, &blob[f1.w], c2, c2, KS, KP);
+    push_matrix(im, &blob[f2.w], c2, c2, KS, KP);
+    push_rows(im, &blob[fd.w], 9, c2, KS);
+    for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], c2, KS); push_vec(im, &blob[f->shift], c2, KS); }
+    return put(im);
+  }
+  // block_s2_kernel<CIN>: W1 | W2 | Wproj | main dw taps | proj dw taps | sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
+  size_t image_s2(const Folded& f1, const Folded& fd, const Folded& f2, const Folded& fpd, const Folded& fpp, int cin) {
+    const int KC = (cin + 15) / 16, KS = 16 * KC, KP = KS + 4;
+    std::vector<float> im;
+    push_matrix(im, &blob[f1.w], cin, cin, KS, KP);
+    push_matrix(im, &blob[f2.w], cin, cin, KS, KP);
+    push_matrix(im, &blob[fpp.w], cin, cin, KS, KP);
+    push_rows(im, &blob[fd.w], 9, cin, KS);
+    push_rows(im, &blob[fpd.w], 9, cin, KS);
+    for (const Folded* f : {&f1, &fd, &f2, &fpd, &fpp}) { push_vec(im, &blob[f->scale], cin, KS); push_vec(im, &blob[f->shift], cin, KS); }
+    return put(im);
+  }
+  // tower kernels: pw [80][84] | output conv [mh16][84] | dw taps [25][80] | scd shd scp shp bias [5][96]
+  size_t image_tower(const Folded& fd, const Folded& fp, const Folded* fh, int mh) {
+    std::vector<float> im;
+    push_matrix(im, &blob[fp.w], 72, 72, 80, 84);
+    const int mh16 = fh ? ((mh + 15) / 16 <= 1 ? 16 : 96) : 0;  // kernels are instantiated for 1 or 6 output tiles
+    if (fh) push_matrix(im, &blob[fh->w], mh, 72, mh16, 84);
+    push_rows(im, &blob[fd.w], 25, 72, 80);
+    push_vec(im, &blob[fd.scale], 72, 96); push_vec(im, &blob[fd.shift], 72, 96);
+    push_vec(im, &blob[fp.scale], 72, 96); push_vec(im, &blob[fp.shift], 72, 96);
+    push_vec(im, fh ? &blob[fh->shift] : nullptr, mh, 96);
+    return put(im);
+  }
+  // stem_kernel: lane-major fragments [64][32]: af[2][7] (+2 pad), sc[2][4], sh[2][4]
+  size_t image_stem(const Folded& f) {
+    std::vector<float> im(64 * 32, 0.f);
+    const float* w = &blob[f.w];  // [27 taps][24 co]
+    for (int lane = 0; lane < 64; ++lane) {
+      const int p = lane & 15, g = lane >> 4;
+      float* d = &im[(size_t)lane * 32];
+      for (int mt = 0; mt < 2; ++mt)
+        for (int ks = 0; ks < 7; ++ks) {
+          const int co = 16 * mt + p, k = 4 * ks + g;
+          d[mt * 8 + ks] = (co < 24 && k < 27) ? w[k * 24 + co] : 0.f;
+        }
+      for (int mt = 0; mt < 2; ++mt)
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * mt + 4 * g + r;
+          d[16 + mt * 4 + r] = co < 24 ? blob[f.scale + co] : 0.f;
+          d[24 + mt * 4 + r] = co < 24 ? blob[f.shift + co] : 0.f;
+        }
+    }
+    return put(im);
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -218,7 +302,7 @@ struct PlanBuilder {
     int R = 11;  // pooled rows per band: halo recompute (2R+1)/(2R)
     while (ph % R) --R;
     s.stem.R = R;
-    s.w_off = f.w; s.scale_off = f.scale; s.shift_off = f.shift;
+    s.img_off = wp.image_stem(f);
     s.name = "stem conv3x3s2+bn+relu+maxpool3x3s2";
     const double ch = h->cfg.height / 2.0, cw = h->cfg.width / 2.0;
     s.flops = 2.0 * ch * cw * 27 * 24;
@@ -241,7 +325,7 @@ struct PlanBuilder {
     s.pw.H = 0; s.pw.W = 0; s.pw.HW = px;
     s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0;
     s.px_per_img = px;
-    s.w_off = f.w; s.scale_off = f.scale; s.shift_off = f.shift;
+    s.img_off = wp.image_pw(f, M, K);
     s.name = name;
     s.flops = 2.0 * px * K * M;
     s.bytes = 4.0 * px * (K + M);
@@ -285,11 +369,7 @@ struct PlanBuilder {
       s.c2 = cin;
       s.s2.in = x.p; s.s2.out = y.p;
       s.s2.H = H; s.s2.W = W; s.s2.R = rfused;
-      s.w_off = f1.w; s.scale_off = f1.scale; s.shift_off = f1.shift;
-      s.wd_off = fd.w; s.scd_off = fd.scale; s.shd_off = fd.shift;
-      s.w2_off = f2.w; s.sc2_off = f2.scale; s.sh2_off = f2.shift;
-      s.pj_d[0] = fpd.w; s.pj_d[1] = fpd.scale; s.pj_d[2] = fpd.shift;
-      s.pj_p[0] = fpp.w; s.pj_p[1] = fpp.scale; s.pj_p[2] = fpp.shift;
+      s.img_off = wp.image_s2(f1, fd, f2, fpd, fpp, cin);
       s.name = p + " fused s2 block: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) | cat";
       s.flops = 2.0 * ((double)H * W * cin * cin + 2.0 * oh * ow * cin * cin + 2.0 * oh * ow * 9 * cin);
       s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * co);
@@ -326,9 +406,7 @@ struct PlanBuilder {
       s.s1.in = x.p; s.s1.out = y.p;
       s.s1.H = H; s.s1.W = W;
       s.s1.R = yfv2_block_s1_rows(c2, H, W);
-      s.w_off = f1.w; s.scale_off = f1.scale; s.shift_off = f1.shift;
-      s.wd_off = fd.w; s.scd_off = fd.scale; s.shd_off = fd.shift;
-      s.w2_off = f2.w; s.sc2_off = f2.scale; s.sh2_off = f2.shift;
+      s.img_off = wp.image_s1(f1, fd, f2, c2);
       s.name = p + " fused s1 block: shuffle+pass | pw1+bn+relu -> dw3x3+bn -> pw2+bn+relu | cat";
       s.flops = 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
       s.bytes = 4.0 * H * W * (2.0 * c);  // read c, write c channels per pixel
@@ -354,10 +432,8 @@ struct PlanBuilder {
     s.tw.H = H; s.tw.W = W;
     s.tw.mh = mh; s.tw.split = split;
     s.tw.R = yfv2_tower_rows(fh ? (mh + 15) / 16 : 0, H, W);
-    s.wd_off = fd.w; s.scd_off = fd.scale; s.shd_off = fd.shift;
-    s.w_off = fp.w; s.scale_off = fp.scale; s.shift_off = fp.shift;
+    s.img_off = wp.image_tower(fd, fp, fh, mh);
     s.has_head = fh != nullptr;
-    if (fh) { s.wh_off = fh->w; s.bh_off = fh->shift; }
     s.head0 = head0; s.head1 = head1;
     s.name = name;
     s.flops = 2.0 * H * W * (25.0 * 72 + 72.0 * 72 + (fh ? 72.0 * mh : 0.0));
@@ -490,12 +566,12 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
     if (st.kind == STEP_STEM) {
       StemArgs a = st.stem;
       a.x = x; a.B = B;
-      a.w = params + st.w_off; a.scale = params + st.scale_off; a.shift = params + st.shift_off;
+      a.img = params + st.img_off;
       yfv2_launch_stem(a, s);
     } else if (st.kind == STEP_PW) {
       PwArgs a = st.pw;
       a.P = B * st.px_per_img;
-      a.w = params + st.w_off; a.scale = params + st.scale_off; a.shift = params + st.shift_off;
+      a.img = params + st.img_off;
       if (st.mode == PW_HEAD) {
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
@@ -505,32 +581,26 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
     } else if (st.kind == STEP_S2) {
       BlockS2Args a = st.s2;
       a.B = B;
-      a.w1 = params + st.w_off; a.sc1 = params + st.scale_off; a.sh1 = params + st.shift_off;
-      a.wdw = params + st.wd_off; a.scd = params + st.scd_off; a.shd = params + st.shd_off;
-      a.w2 = params + st.w2_off; a.sc2 = params + st.sc2_off; a.sh2 = params + st.sh2_off;
-      a.wpd = params + st.pj_d[0]; a.scpd = params + st.pj_d[1]; a.shpd = params + st.pj_d[2];
-      a.wpp = params + st.pj_p[0]; a.scpp = params + st.pj_p[1]; a.shpp = params + st.pj_p[2];
+      a.img = params + st.img_off;
       if (!yfv2_launch_block_s2(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused stride-2 kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_TOWER) {
       TowerArgs a = st.tw;
       a.B = B;
-      a.wdw = params + st.wd_off; a.scd = params + st.scd_off; a.shd = params + st.shd_off;
-      a.wpw = params + st.w_off; a.scp = params + st.scale_off; a.shp = params + st.shift_off;
-      a.wh = nullptr; a.bh = nullptr; a.nchw0 = nullptr; a.nchw1 = nullptr;
+      a.img = params + st.img_off;
+      a.has_head = st.has_head ? 1 : 0;
+      a.nchw0 = nullptr; a.nchw1 = nullptr;
       if (st.has_head) {
-        a.wh = params + st.wh_off; a.bh = params + st.bh_off;
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
       }
-      if (!yfv2_launch_tower(a, s))
+      static const bool tower_v1 = [] { const char* e = std::getenv("YFV2_TOWER"); return e && e[0] == '1'; }();
+      if (!(!tower_v1 && yfv2_launch_tower2(a, s)) && !yfv2_launch_tower(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S1) {
       BlockS1Args a = st.s1;
       a.B = B;
-      a.w1 = params + st.w_off; a.sc1 = params + st.scale_off; a.sh1 = params + st.shift_off;
-      a.wdw = params + st.wd_off; a.scd = params + st.scd_off; a.shd = params + st.shd_off;
-      a.w2 = params + st.w2_off; a.sc2 = params + st.sc2_off; a.sh2 = params + st.sh2_off;
+      a.img = params + st.img_off;
       if (!yfv2_launch_block_s1(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused block kernel for step '" + st.name + "'");
     } else {

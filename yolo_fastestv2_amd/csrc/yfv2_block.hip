@@ -56,26 +56,14 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   const int t1_fl = (R + 2) * WP * CP + 16;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
 
-  // ---- stage filters / constants, zero T1 (its border stays zero for every item)
-  for (int i = tid; i < Cfg::W_FL; i += THREADS) {
-    const int row = i / KP, c = i - row * KP;
-    const bool ok = row < C2 && c < C2;
-    W1[i] = ok ? a.w1[row * C2 + c] : 0.f;
-    W2[i] = ok ? a.w2[row * C2 + c] : 0.f;
+  // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
+  // yfv2_load_weights) is one straight coalesced 16-byte copy
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i = tid; i < (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4; i += THREADS) dst[i] = src[i];
   }
-  for (int i = tid; i < Cfg::DW_FL; i += THREADS) {
-    const int k = i / (KC * 16), c = i - k * (KC * 16);
-    WD[i] = c < C2 ? a.wdw[k * C2 + c] : 0.f;
-  }
-  for (int i = tid; i < KC * 16; i += THREADS) {
-    const bool ok = i < C2;
-    CS[0 * KC * 16 + i] = ok ? a.sc1[i] : 0.f;
-    CS[1 * KC * 16 + i] = ok ? a.sh1[i] : 0.f;
-    CS[2 * KC * 16 + i] = ok ? a.scd[i] : 0.f;
-    CS[3 * KC * 16 + i] = ok ? a.shd[i] : 0.f;
-    CS[4 * KC * 16 + i] = ok ? a.sc2[i] : 0.f;
-    CS[5 * KC * 16 + i] = ok ? a.sh2[i] : 0.f;
-  }
+  // T1's border stays zero for every item
   for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;
   __syncthreads();
 
@@ -384,26 +372,12 @@ __global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
   const int WP4 = W + 4;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
 
-  for (int i = tid; i < KC * 16 * KP; i += THREADS) {
-    const int row = i / KP, c = i - row * KP;
-    WP_[i] = (row < C && c < C) ? a.wpw[row * C + c] : 0.f;
-  }
-  if constexpr (MH > 0)
-    for (int i = tid; i < MH * 16 * KP; i += THREADS) {
-      const int row = i / KP, c = i - row * KP;
-      WH[i] = (row < a.mh && c < C) ? a.wh[row * C + c] : 0.f;
-    }
-  for (int i = tid; i < 25 * KC * 16; i += THREADS) {
-    const int k = i / (KC * 16), c = i - k * (KC * 16);
-    WD[i] = c < C ? a.wdw[k * C + c] : 0.f;
-  }
-  for (int i = tid; i < 96; i += THREADS) {
-    const bool ok = i < C;
-    CS[0 * 96 + i] = ok ? a.scd[i] : 0.f;
-    CS[1 * 96 + i] = ok ? a.shd[i] : 0.f;
-    CS[2 * 96 + i] = ok ? a.scp[i] : 0.f;
-    CS[3 * 96 + i] = ok ? a.shp[i] : 0.f;
-    CS[4 * 96 + i] = (MH > 0 && i < a.mh) ? a.bh[i] : 0.f;
+  // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
+  // yfv2_load_weights) is one straight coalesced 16-byte copy
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i = tid; i < (KC * 16 * KP + MH * 16 * KP + 25 * KC * 16 + 5 * 96) / 4; i += THREADS) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -576,7 +550,7 @@ static void launch_tower(const TowerArgs& a, hipStream_t s) {
 }
 
 bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s) {
-  const int mh_tiles = a.wh ? (a.mh + 15) / 16 : 0;
+  const int mh_tiles = a.has_head ? (a.mh + 15) / 16 : 0;
   if (mh_tiles == 0) { launch_tower<0>(a, s); return true; }
   if (mh_tiles == 1) { launch_tower<1>(a, s); return true; }
   if (mh_tiles <= 6) { launch_tower<6>(a, s); return true; }
@@ -625,25 +599,12 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   const int t1_fl = (2 * R + 1) * WP * CP + 16;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
 
-  for (int i = tid; i < Cfg::W_FL; i += THREADS) {
-    const int row = i / KP, c = i - row * KP;
-    const bool ok = row < CIN && c < CIN;
-    W1[i] = ok ? a.w1[row * CIN + c] : 0.f;
-    W2[i] = ok ? a.w2[row * CIN + c] : 0.f;
-    WJ[i] = ok ? a.wpp[row * CIN + c] : 0.f;
-  }
-  for (int i = tid; i < Cfg::DW_FL; i += THREADS) {
-    const int k = i / KS, c = i - k * KS;
-    WD[i] = c < CIN ? a.wdw[k * CIN + c] : 0.f;
-    WE[i] = c < CIN ? a.wpd[k * CIN + c] : 0.f;
-  }
-  for (int i = tid; i < KS; i += THREADS) {
-    const bool ok = i < CIN;
-    CS[0 * KS + i] = ok ? a.sc1[i] : 0.f;  CS[1 * KS + i] = ok ? a.sh1[i] : 0.f;
-    CS[2 * KS + i] = ok ? a.scd[i] : 0.f;  CS[3 * KS + i] = ok ? a.shd[i] : 0.f;
-    CS[4 * KS + i] = ok ? a.sc2[i] : 0.f;  CS[5 * KS + i] = ok ? a.sh2[i] : 0.f;
-    CS[6 * KS + i] = ok ? a.scpd[i] : 0.f; CS[7 * KS + i] = ok ? a.shpd[i] : 0.f;
-    CS[8 * KS + i] = ok ? a.scpp[i] : 0.f; CS[9 * KS + i] = ok ? a.shpp[i] : 0.f;
+  // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
+  // yfv2_load_weights) is one straight coalesced 16-byte copy
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i = tid; i < (3 * Cfg::W_FL + 2 * Cfg::DW_FL + Cfg::NCS * KS) / 4; i += THREADS) dst[i] = src[i];
   }
   for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;  // column 0 (input col -1) stays zero
   __syncthreads();
@@ -850,5 +811,216 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
   if (cin == 24) { launch_s2<24>(a, s); return true; }
   if (cin == 48) { launch_s2<48>(a, s); return true; }
+  return false;
+}
+
+// ============================================================================
+// tower half, version 2: one image per workgroup, channel-chunk loop outermost
+// ============================================================================
+// Same math as tower_kernel above.  A wave owns NT fixed 16-pixel tiles of the image and
+// keeps their pointwise accumulators in registers while the workgroup walks the five
+// 16-channel chunks: per chunk only that channel slice of the (zero-haloed) input image
+// is in LDS (26x26x16 floats at 22x22 instead of a 10-row x 72-channel tile), staged with a
+// one-chunk-ahead register prefetch.  No halo re-staging, every wave busy, and the
+// accumulators never leave registers until the (chained) output conv is done.
+constexpr int TW2_PS = 20;  // LDS floats per staged pixel (16 channels + 4 pad)
+
+template <int MH, int THREADS, int NT, int NPF>
+__global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
+  constexpr int KC = TW_KC, KP = TW_KP, C = TW_C, PS = TW2_PS;
+  constexpr int NW = THREADS / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* WP_ = lds;
+  float* WH = WP_ + KC * 16 * KP;
+  float* WD = WH + MH * 16 * KP;
+  float* CS = WD + 25 * KC * 16;
+  float* TIN = CS + 5 * 96;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int WP4 = W + 4;
+  const int tin_fl = (H + 4) * WP4 * PS + 16;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+
+  // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
+  // yfv2_load_weights) is one straight coalesced 16-byte copy
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i = tid; i < (KC * 16 * KP + MH * 16 * KP + 25 * KC * 16 + 5 * 96) / 4; i += THREADS) dst[i] = src[i];
+  }
+  for (int i = tid; i < tin_fl; i += THREADS) TIN[i] = 0.f;  // the 2-pixel halo stays zero
+  __syncthreads();
+
+  // this wave's pixel tiles (fixed for every image)
+  int base[NT], opix[NT];
+  bool pv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int q = 16 * (wave * NT + nt) + p;
+    pv[nt] = q < HW;
+    const int qc = pv[nt] ? q : HW - 1;
+    const int r = qc / W, x = qc - r * W;
+    base[nt] = (r * WP4 + x) * PS;  // top-left of the 5x5 window
+    opix[nt] = qc;
+  }
+  // staging slots of this thread: float4 i -> (pixel, quad) of the chunk slice
+  int s_src[NPF], s_dst[NPF];
+#pragma unroll
+  for (int j = 0; j < NPF; ++j) {
+    const int i = tid + j * THREADS;
+    const int px = i >> 2, c4 = i & 3;
+    const bool ok = px < HW;
+    const int y = ok ? px / W : 0, x = ok ? px - y * W : 0;
+    s_src[j] = ok ? px * C + 4 * c4 : -1;
+    s_dst[j] = ((y + 2) * WP4 + x + 2) * PS + 4 * c4;
+  }
+  auto stage_load = [&](const float* img, int s, f32x4 (&pre)[NPF]) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (s_src[j] >= 0 && 16 * s + 4 * (int)((tid + j * THREADS) & 3) < C)
+        pre[j] = *reinterpret_cast<const f32x4*>(img + s_src[j] + 16 * s);
+    }
+  };
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float* img = a.in + (size_t)b * HW * C;
+    f32x4 acc[KC][NT];
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 pre[NPF];
+    stage_load(img, 0, pre);
+#pragma unroll 1
+    for (int s = 0; s < KC; ++s) {
+      __syncthreads();  // the previous chunk's (or image's) readers are done with TIN
+#pragma unroll
+      for (int j = 0; j < NPF; ++j)
+        if (s_src[j] >= 0) *reinterpret_cast<f32x4*>(TIN + s_dst[j]) = pre[j];
+      if (s + 1 < KC) stage_load(img, s + 1, pre);  // flies during this chunk's compute
+      __syncthreads();
+      const int cb = 16 * s + 4 * g;
+      f32x4 d[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) d[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ky = 0; ky < 5; ++ky) {
+        const float* wrow = WD + ky * 5 * KC * 16 + cb;
+        const float* trow = TIN + ky * WP4 * PS + 4 * g;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * KC * 16);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(trow + base[nt] + kx * PS);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[nt][k] = __builtin_fmaf(v[k], w[k], d[nt][k]);
+          }
+        }
+      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + cb);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + cb);
+      f32x4 bfr[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = __builtin_fmaf(d[nt][k], sc[k], sh[k]);  // channels >= 72: sc = sh = 0 -> 0
+          bfr[nt][k] = (cb < C && u > 0.f) ? u : 0.f;
+        }
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + (16 * mt + p) * KP + cb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    // pointwise BN (no ReLU: fpn.py:16-17,23-24)
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 2 * 96 + 16 * mt + 4 * g);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 3 * 96 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[mt][nt][k] = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
+    }
+    if constexpr (MH == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (!pv[nt]) continue;
+        float* dst = a.out + ((size_t)b * HW + opix[nt]) * C;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt)
+          if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
+      }
+    } else {
+#pragma unroll 1
+      for (int m = 0; m < MH; ++m) {
+        f32x4 hacc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(WH + (16 * m + p) * KP + 16 * s + 4 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              hacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], acc[s][nt][j], hacc[nt], 0, 0, 0);
+        }
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 4 * 96 + 16 * m + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (!pv[nt]) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * m + 4 * g + r;
+            if (co < a.mh) {
+              const float y = hacc[nt][r] + bias[r];
+              if (co < a.split)
+                a.nchw0[((size_t)b * a.split + co) * HW + opix[nt]] = y;
+              else
+                a.nchw1[((size_t)b * (a.mh - a.split) + (co - a.split)) * HW + opix[nt]] = y;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MH, int THREADS, int NT, int NPF>
+static void launch_tower2(const TowerArgs& a, hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)TW_KC * 16 * TW_KP + (size_t)MH * 16 * TW_KP + 25 * TW_KC * 16 + 5 * 96 +
+                                      (size_t)(a.H + 4) * (a.W + 4) * TW2_PS + 16);
+  int blocks = a.B < 256 ? a.B : 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF>), dim3(blocks), dim3(THREADS), lds, s, a);
+}
+
+// whole-image variant: needs H*W <= 16 * NT * waves and the staged slice to fit the thread grid
+bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s) {
+  const int mh_tiles = a.has_head ? (a.mh + 15) / 16 : 0;
+  const int hw = a.H * a.W;
+  if (hw <= 16 * 4 * 8 && hw * 4 <= 4 * 512) {           // up to 22x22: 512 threads, 4 tiles per wave
+    if (hw > 16 * 1 * 8) {
+      if (mh_tiles == 0) { launch_tower2<0, 512, 4, 4>(a, s); return true; }
+      if (mh_tiles == 1) { launch_tower2<1, 512, 4, 4>(a, s); return true; }
+      if (mh_tiles <= 6) { launch_tower2<6, 512, 4, 4>(a, s); return true; }
+    } else {                                              // up to 11x11: 512 threads, 1 tile per wave
+      if (mh_tiles == 0) { launch_tower2<0, 512, 1, 1>(a, s); return true; }
+      if (mh_tiles == 1) { launch_tower2<1, 512, 1, 1>(a, s); return true; }
+      if (mh_tiles <= 6) { launch_tower2<6, 512, 1, 1>(a, s); return true; }
+    }
+  }
   return false;
 }

@@ -50,25 +50,20 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
   const float* __restrict__ xb = a.x + (size_t)b * 3 * H * W;
 
-  // A fragments: af[mt][ks] = W[co = 16mt + p][k = 4ks + g]   (blob layout [27 taps][24 co])
+  // A fragments af[mt][ks] = W[co = 16mt + p][k = 4ks + g] and the BN constants of the D rows
+  // this lane owns (co = 16mt + 4g + r), pre-packed lane-major on the host: 8 independent
+  // 16-byte loads instead of 30 guarded scalar ones
   float af[2][7];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int ks = 0; ks < 7; ++ks) {
-      const int co = 16 * mt + p, k = 4 * ks + g;
-      af[mt][ks] = (co < 24 && k < 27) ? a.w[k * 24 + co] : 0.f;
-    }
-  // BN constants of the D rows this lane owns: co = 16mt + 4g + r
   f32x4 sc[2], sh[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = 16 * mt + 4 * g + r;
-      sc[mt][r] = co < 24 ? a.scale[co] : 0.f;
-      sh[mt][r] = co < 24 ? a.shift[co] : 0.f;
-    }
+  {
+    const f32x4* im = reinterpret_cast<const f32x4*>(a.img + lane * 32);
+    const f32x4 q0 = im[0], q1 = im[1], q2 = im[2], q3 = im[3];
+    af[0][0] = q0[0]; af[0][1] = q0[1]; af[0][2] = q0[2]; af[0][3] = q0[3];
+    af[0][4] = q1[0]; af[0][5] = q1[1]; af[0][6] = q1[2];
+    af[1][0] = q2[0]; af[1][1] = q2[1]; af[1][2] = q2[2]; af[1][3] = q2[3];
+    af[1][4] = q3[0]; af[1][5] = q3[1]; af[1][6] = q3[2];
+    sc[0] = im[4]; sc[1] = im[5]; sh[0] = im[6]; sh[1] = im[7];
+  }
   // tap of k-step ks for this lane group: k = 4ks + g -> (ci, ky, kx); k = 27 is the zero-weight pad
   int tky[7], tofs[7];
 #pragma unroll
@@ -221,26 +216,22 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [MT*16][KP]
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < MT * 16 * (K / 4); i += blockDim.x) {
-    const int row = i / (K / 4), c4 = i - row * (K / 4);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < a.M) v = *reinterpret_cast<const f32x4*>(a.w + (size_t)row * K + c4 * 4);
-    *reinterpret_cast<f32x4*>(wl + row * KP + c4 * 4) = v;
+  {  // prologue: host-packed LDS image of the filter ([MT*16][K+4], zero padded): one coalesced copy
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(wl);
+    for (int i = tid; i < MT * 16 * KP / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
 
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wave = tid >> 6, nwaves = blockDim.x >> 6;
 
-  f32x4 sc[MT], sh[MT];
+  f32x4 sc[MT], sh[MT];  // padded to MT*16 on the host: unconditional 16-byte loads
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = 16 * mt + 4 * g + r;
-      sc[mt][r] = co < a.M ? a.scale[co] : 0.f;
-      sh[mt][r] = co < a.M ? a.shift[co] : 0.f;
-    }
+  for (int mt = 0; mt < MT; ++mt) {
+    sc[mt] = *reinterpret_cast<const f32x4*>(a.img + MT * 16 * KP + 16 * mt + 4 * g);
+    sh[mt] = *reinterpret_cast<const f32x4*>(a.img + MT * 16 * KP + MT * 16 + 16 * mt + 4 * g);
+  }
 
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
   for (int st = blockIdx.x * nwaves + wave; st < n_super; st += gridDim.x * nwaves) {

@@ -11,9 +11,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct StemArgs {
   const float* x;      // (B,3,H,W)
   float* out;          // (B,H/4,W/4,24)
-  const float* w;      // [27][24]  (tap = ci*9+ky*3+kx major, co minor)
-  const float* scale;  // [24]
-  const float* shift;  // [24]
+  const float* img;    // lane-major fragment image [64 lanes][32]: af[2][7] (+2 pad), sc[2][4], sh[2][4]
   int B, H, W;
   int R;               // pooled rows per band (H/4 % R == 0)
 };
@@ -24,9 +22,7 @@ struct PwArgs {
   const float* in;     // NHWC activations (PW_FPN: C3, coarse map)
   const float* in2;    // PW_FPN only: C2, fine map
   float* out;          // NHWC output (unused for PW_HEAD)
-  const float* w;      // [M][K] row major (PyTorch conv weight layout)
-  const float* scale;  // [M]
-  const float* shift;  // [M]
+  const float* img;    // LDS image: filter [MT*16][K+4] (zero padded), then scale[MT*16], shift[MT*16]
   int P;               // pixels = B*H*W
   int M;               // real output channels (<= 16*MT)
   int in_stride;       // floats per input pixel
@@ -62,9 +58,7 @@ struct DwArgs {
 struct BlockS1Args {
   const float* in;   // (B,H,W,2*C2) NHWC
   float* out;        // (B,H,W,2*C2) NHWC, distinct from in
-  const float* w1; const float* sc1; const float* sh1;   // pw1 [C2][C2] + BN
-  const float* wdw; const float* scd; const float* shd;  // dw3x3 [9][C2] + BN
-  const float* w2; const float* sc2; const float* sh2;   // pw2 [C2][C2] + BN
+  const float* img;  // LDS image (host-packed): W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2 [6][KS]
   int B, H, W;
   int R;             // rows per work item (H % R == 0)
 };
@@ -73,11 +67,7 @@ struct BlockS1Args {
 struct BlockS2Args {
   const float* in;   // (B,H,W,CIN) NHWC
   float* out;        // (B,H/2,W/2,2*CIN) NHWC
-  const float* w1; const float* sc1; const float* sh1;      // main pw1 + BN (+ReLU)
-  const float* wdw; const float* scd; const float* shd;     // main dw3x3 s2 + BN
-  const float* w2; const float* sc2; const float* sh2;      // main pw2 + BN (+ReLU)
-  const float* wpd; const float* scpd; const float* shpd;   // proj dw3x3 s2 + BN
-  const float* wpp; const float* scpp; const float* shpp;   // proj pw + BN (+ReLU)
+  const float* img;  // LDS image: W1 | W2 | Wproj | main dw taps | proj dw taps | 10 BN vectors [10][KS]
   int B, H, W;       // input size
   int R;             // output rows per work item
 };
@@ -86,9 +76,8 @@ struct BlockS2Args {
 struct TowerArgs {
   const float* in;   // (B,H,W,72) NHWC
   float* out;        // (B,H,W,72) NHWC when there is no chained output conv
-  const float* wdw; const float* scd; const float* shd;  // dw5x5 [25][72] + BN (+ReLU)
-  const float* wpw; const float* scp; const float* shp;  // pw [72][72] + BN
-  const float* wh; const float* bh;                      // chained output conv [mh][72] + bias (or null)
+  const float* img;  // LDS image: pw [80][84] | output conv [mh16][84] (if any) | dw taps [25][80] | scd shd scp shp bias [5][96]
+  int has_head;      // chained output conv present
   int mh, split;     // co < split -> nchw0[b][co][hw], else nchw1[b][co-split][hw]
   float* nchw0; float* nchw1;
   int B, H, W, R;
@@ -132,5 +121,6 @@ int yfv2_block_s2_rows(int cin, int H, int W);
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s);
 int yfv2_tower_rows(int mh_tiles, int H, int W);
 bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s);
+bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s);  // whole-image variant (<= 22x22)
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);
