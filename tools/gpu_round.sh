@@ -14,6 +14,8 @@ echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke_$TAG.log
 echo "== bench"
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench_$TAG.log 2>&1; echo "bench rc=$?"; tail -2 $OUT/bench_$TAG.log
+echo "== scale probe"
+timeout 300 python tools/scale_probe.py > $OUT/scale_$TAG.log 2>&1; echo "probe rc=$?"
 echo "== rocprofv3"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"

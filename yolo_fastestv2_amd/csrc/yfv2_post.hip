@@ -39,20 +39,34 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
   const bool ok = lc < ncell;
   const int cc = ok ? cell : cell0;  // clamp so that shuffles stay convergent
 
-  // ---- class softmax (fp32): exp(x - max) / sum
+  // ---- class softmax (fp32): exp(x - max) / sum.  The lane's logits are fetched with one
+  // batch of independent loads (fixed trip count, masked) instead of a load per loop turn.
+  constexpr int MAXPER = 24;  // >= ceil(classes / 4), classes <= 93
   const int per = (nc + 3) >> 2;
   const int c_lo = part * per, c_hi = min(nc, c_lo + per);
   const float* cls = a.cls[sc] + (size_t)b * nc * hw + cc;
+  float lv[MAXPER];
+#pragma unroll
+  for (int i = 0; i < MAXPER; ++i) {
+    const int c = c_lo + i;
+    lv[i] = cls[(size_t)(c < c_hi ? c : c_lo) * hw];
+  }
   float m = -INFINITY;
-  for (int c = c_lo; c < c_hi; ++c) m = fmaxf(m, cls[(size_t)c * hw]);
+#pragma unroll
+  for (int i = 0; i < MAXPER; ++i)
+    if (c_lo + i < c_hi) m = fmaxf(m, lv[i]);
   m = fmaxf(m, __shfl_xor(m, 1));
   m = fmaxf(m, __shfl_xor(m, 2));
   float sum = 0.f;
   float* srow = stage + (size_t)lc * 3 * rowlen;
-  for (int c = c_lo; c < c_hi; ++c) {
-    const float e = expf(__fsub_rn(cls[(size_t)c * hw], m));
-    sum = __fadd_rn(sum, e);
-    if (ok) srow[5 + c] = e;  // normalised below
+#pragma unroll
+  for (int i = 0; i < MAXPER; ++i) {
+    const int c = c_lo + i;
+    if (c < c_hi) {
+      const float e = expf(__fsub_rn(lv[i], m));
+      sum = __fadd_rn(sum, e);
+      if (ok) srow[5 + c] = e;  // normalised below
+    }
   }
   sum = __fadd_rn(sum, __shfl_xor(sum, 1));
   sum = __fadd_rn(sum, __shfl_xor(sum, 2));
