@@ -73,6 +73,7 @@ struct yfv2_ctx {
   Buf decoded;
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries)
+  long long* d_trace = nullptr;  // YFV2_TRACE=1: cycle stamps of the last fused s1 launch (debug)
   // which buffers hold the stage outputs of the last forward (for debug/parity)
   float* dbg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t dbg_per_img[6] = {0, 0, 0, 0, 0, 0};
@@ -601,6 +602,7 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
       BlockS1Args a = st.s1;
       a.B = B;
       a.img = params + st.img_off;
+      a.trace = h->d_trace;
       if (!yfv2_launch_block_s1(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused block kernel for step '" + st.name + "'");
     } else {
@@ -690,6 +692,8 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     yfv2_destroy(h);
     return rc;
   }
+  if (const char* tr = std::getenv("YFV2_TRACE"))
+    if (tr[0] == '1') (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 64 * sizeof(long long));
   *out = h;
   return YFV2_OK;
 }
@@ -871,6 +875,11 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
 }
 
 int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap) {
+  if (h && which == 100 && h->d_trace && host_dst && cap >= 16) {  // debug: 8 cycle stamps as int64 in 16 floats
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host_dst, h->d_trace, 8 * sizeof(long long), hipMemcpyDeviceToHost);
+    return 16;
+  }
   if (!h || which < 0 || which > 5 || !h->dbg[which] || B < 1 || B > h->cfg.max_batch) {
     fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: bad argument");
     return YFV2_ERR_ARG;

@@ -39,6 +39,8 @@ struct S1Cfg {
   static constexpr int NTB = C2 <= 48 ? 1 : 2;  // pixel tiles per phase-B pass
 };
 
+#define YFV2_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
+
 template <int C2, int THREADS>
 __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   using Cfg = S1Cfg<C2>;
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   const int WP = W + 2;
   const int t1_fl = (R + 2) * WP * CP + 16;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  YFV2_STAMP(0);
 
   // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
   // yfv2_load_weights) is one straight coalesced 16-byte copy
@@ -63,9 +66,11 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     for (int i = tid; i < (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4; i += THREADS) dst[i] = src[i];
   }
+  YFV2_STAMP(1);  // image copy issued
   // T1's border stays zero for every item
   for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;
   __syncthreads();
+  YFV2_STAMP(2);  // prologue done
 
   const int tiles_per_img = (H + R - 1) / R;
   const int n_items = a.B * tiles_per_img;
@@ -155,7 +160,9 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
 #pragma unroll
       for (int s = 0; s < KC; ++s) { rcur[s][0] = rnxt[s][0]; rcur[s][1] = rnxt[s][1]; }
     }
+    YFV2_STAMP(3);  // this wave's phase A done
     __syncthreads();
+    YFV2_STAMP(4);  // phase A done (all waves)
 
     // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
     // (re)loaded per item so that they are not live across phase A
@@ -301,7 +308,9 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
         }
       }
     }
+    YFV2_STAMP(5);  // this wave's phase B done
     __syncthreads();  // T1 is rewritten by the next item's phase A
+    YFV2_STAMP(6);
   }
 }
 

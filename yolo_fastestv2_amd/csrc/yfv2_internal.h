@@ -59,6 +59,7 @@ struct BlockS1Args {
   const float* in;   // (B,H,W,2*C2) NHWC
   float* out;        // (B,H,W,2*C2) NHWC, distinct from in
   const float* img;  // LDS image (host-packed): W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2 [6][KS]
+  long long* trace;  // debug: workgroup 0 / thread 0 writes s_memtime stamps at phase boundaries (or null)
   int B, H, W;
   int R;             // rows per work item (H % R == 0)
 };
