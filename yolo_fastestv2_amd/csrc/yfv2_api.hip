@@ -205,6 +205,16 @@ struct WeightPacker {
     for (int r = 0; r < rows; ++r)
       for (int c = 0; c < KP; ++c) im.push_back((r < M && c < K) ? w[(size_t)r * K + c] : 0.f);
   }
+  // fragment-major filter: frag (mt, s), lane l -> W[16mt + (l&15)][16s + 4(l>>4) .. +3]  (zero outside M x K)
+  static void push_frag(std::vector<float>& im, const float* w, int M, int K, int MT, int KC) {
+    for (int mt = 0; mt < MT; ++mt)
+      for (int s = 0; s < KC; ++s)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 4; ++j) {
+            const int r = 16 * mt + (l & 15), c = 16 * s + 4 * (l >> 4) + j;
+            im.push_back((r < M && c < K) ? w[(size_t)r * K + c] : 0.f);
+          }
+  }
   static void push_rows(std::vector<float>& im, const float* w, int nrows, int C, int KS) {  // [nrows][C] -> [nrows][KS]
     for (int r = 0; r < nrows; ++r)
       for (int c = 0; c < KS; ++c) im.push_back(c < C ? w[(size_t)r * C + c] : 0.f);
@@ -228,21 +238,21 @@ struct WeightPacker {
   }
   // block_s1_kernel<C2>: W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2
   size_t image_s1(const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
-    const int KC = (c2 + 15) / 16, KS = 16 * KC, KP = KS + 4;
+    const int KC = (c2 + 15) / 16, KS = 16 * KC;
     std::vector<float> im;
-    push_matrix(im, &blob[f1.w], c2, c2, KS, KP);
-    push_matrix(im, &blob[f2.w], c2, c2, KS, KP);
+    push_frag(im, &blob[f1.w], c2, c2, KC, KC);
+    push_frag(im, &blob[f2.w], c2, c2, KC, KC);
     push_rows(im, &blob[fd.w], 9, c2, KS);
     for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], c2, KS); push_vec(im, &blob[f->shift], c2, KS); }
     return put(im);
   }
   // block_s2_kernel<CIN>: W1 | W2 | Wproj | main dw taps | proj dw taps | sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
   size_t image_s2(const Folded& f1, const Folded& fd, const Folded& f2, const Folded& fpd, const Folded& fpp, int cin) {
-    const int KC = (cin + 15) / 16, KS = 16 * KC, KP = KS + 4;
+    const int KC = (cin + 15) / 16, KS = 16 * KC;
     std::vector<float> im;
-    push_matrix(im, &blob[f1.w], cin, cin, KS, KP);
-    push_matrix(im, &blob[f2.w], cin, cin, KS, KP);
-    push_matrix(im, &blob[fpp.w], cin, cin, KS, KP);
+    push_frag(im, &blob[f1.w], cin, cin, KC, KC);
+    push_frag(im, &blob[f2.w], cin, cin, KC, KC);
+    push_frag(im, &blob[fpp.w], cin, cin, KC, KC);
     push_rows(im, &blob[fd.w], 9, cin, KS);
     push_rows(im, &blob[fpd.w], 9, cin, KS);
     for (const Folded* f : {&f1, &fd, &f2, &fpd, &fpp}) { push_vec(im, &blob[f->scale], cin, KS); push_vec(im, &blob[f->shift], cin, KS); }
@@ -251,9 +261,9 @@ struct WeightPacker {
   // tower kernels: pw [80][84] | output conv [mh16][84] | dw taps [25][80] | scd shd scp shp bias [5][96]
   size_t image_tower(const Folded& fd, const Folded& fp, const Folded* fh, int mh) {
     std::vector<float> im;
-    push_matrix(im, &blob[fp.w], 72, 72, 80, 84);
-    const int mh16 = fh ? ((mh + 15) / 16 <= 1 ? 16 : 96) : 0;  // kernels are instantiated for 1 or 6 output tiles
-    if (fh) push_matrix(im, &blob[fh->w], mh, 72, mh16, 84);
+    push_frag(im, &blob[fp.w], 72, 72, 5, 5);
+    const int mh_tiles = fh ? ((mh + 15) / 16 <= 1 ? 1 : 6) : 0;  // kernels are instantiated for 1 or 6 output tiles
+    if (fh) push_frag(im, &blob[fh->w], mh, 72, mh_tiles, 5);
     push_rows(im, &blob[fd.w], 25, 72, 80);
     push_vec(im, &blob[fd.scale], 72, 96); push_vec(im, &blob[fd.shift], 72, 96);
     push_vec(im, &blob[fp.scale], 72, 96); push_vec(im, &blob[fp.shift], 72, 96);

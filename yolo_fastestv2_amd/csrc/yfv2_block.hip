@@ -30,13 +30,15 @@
 template <int C2>
 struct S1Cfg {
   static constexpr int KC = (C2 + 15) / 16;  // 16-channel chunks (also M tiles: M == K == C2)
-  static constexpr int KP = 16 * KC + 4;     // padded LDS row of the [C2][C2] filters
   static constexpr int CP = C2 + 4;          // floats per T1 pixel
-  static constexpr int W_FL = KC * 16 * KP;  // one filter matrix in LDS
+  // filters live in LDS fragment-major: Wf[(mt*KC + s)*64 + lane] (float4) =
+  // W[16mt + (lane&15)][16s + 4(lane>>4) ..+3]: the 64 lanes of an A-fragment read touch 64
+  // consecutive 16-byte slots - bank-conflict free by construction, no padding
+  static constexpr int W_FL = KC * KC * 256;  // one filter matrix in LDS
   static constexpr int DW_FL = 9 * KC * 16;  // depthwise taps [9][KC*16]
   static constexpr int CST_FL = 6 * KC * 16; // sc1, sh1, scd, shd, sc2, sh2
   static constexpr bool DWREG = C2 <= 48;    // depthwise taps + BN in registers
-  static constexpr int NTB = C2 <= 48 ? 1 : 2;  // pixel tiles per phase-B pass
+  static constexpr int NTB = 1;              // pixel tiles per phase-B pass (all waves busy on small maps)
 };
 
 #define YFV2_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -44,7 +46,7 @@ struct S1Cfg {
 template <int C2, int THREADS>
 __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   using Cfg = S1Cfg<C2>;
-  constexpr int KC = Cfg::KC, KP = Cfg::KP, CP = Cfg::CP, NTB = Cfg::NTB;
+  constexpr int KC = Cfg::KC, CP = Cfg::CP, NTB = Cfg::NTB;
   constexpr int NW = THREADS / 64;
   constexpr int C = 2 * C2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -64,11 +66,17 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    for (int i = tid; i < (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4; i += THREADS) dst[i] = src[i];
+    constexpr int N4 = (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4;
+    int i = tid;
+    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
+      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
+      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
+    }
+    for (; i < N4; i += THREADS) dst[i] = src[i];
   }
   YFV2_STAMP(1);  // image copy issued
   // T1's border stays zero for every item
-  for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;
+  for (int i = tid; i < t1_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   YFV2_STAMP(2);  // prologue done
 
@@ -131,30 +139,39 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
         bf[s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};  // odd channels -> main branch (zero for cb >= C2)
         if (interior && cb < C2) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};  // even -> pass-through
       }
-      // one output-channel tile at a time: a single live accumulator keeps the register
-      // footprint flat (the big C2=96 variant must not spill); the dependent MFMA chain is
-      // covered by the second wave on the SIMD
+      // two output-channel tiles at a time: two independent accumulators alternate on the
+      // MFMA pipe (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, the pipe issues every 32)
+      // while the register footprint stays flat for the big C2=96 variant
       float* dst = T1 + (r * WP + x + 1) * CP;
-#pragma unroll(Cfg::KC <= 3 ? Cfg::KC : 1)
-      for (int mt = 0; mt < KC; ++mt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll(Cfg::KC <= 3 ? 2 : 1)
+      for (int mt = 0; mt < KC; mt += 2) {
+        const bool two = mt + 1 < KC;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(W1 + (16 * mt + p) * KP + 16 * s + 4 * g);
+          const f32x4 af0 = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+          const f32x4 af1 = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[s][j], acc, 0, 0, 0);
-        }
-        const int cb = 16 * mt + 4 * g;
-        if (valid && cb < C2) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
-          f32x4 y;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
-            y[k] = (inimg && u > 0.f) ? u : 0.f;  // rows outside the image are conv zero padding
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[j], bf[s][j], acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[j], bf[s][j], acc1, 0, 0, 0);
           }
-          *reinterpret_cast<f32x4*>(dst + cb) = y;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int cb = 16 * (mt + h) + 4 * g;
+          if (valid && cb < C2 && (h == 0 || two)) {
+            const f32x4 acc = h ? acc1 : acc0;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
+              y[k] = (inimg && u > 0.f) ? u : 0.f;  // rows outside the image are conv zero padding
+            }
+            *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
         }
       }
 #pragma unroll
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < KC; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + (16 * mt + p) * KP + 16 * s + 4 * g);
+            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[s][j], acc, 0, 0, 0);
           }
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
           }
 #pragma unroll
           for (int mt = 0; mt < KC; ++mt) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + (16 * mt + p) * KP + cb);
+            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -334,7 +351,7 @@ static void launch_s1(const BlockS1Args& a, int blocks_per_cu, hipStream_t s) {
 // LDS budget decides the row tile: the whole image when it fits (no halo recompute).
 int yfv2_block_s1_rows(int c2, int H, int W) {
   const int kc = (c2 + 15) / 16;
-  const long fixed = 2L * kc * 16 * (16 * kc + 4) + 9L * kc * 16 + 6L * kc * 16 + 16;
+  const long fixed = 2L * kc * kc * 256 + 9L * kc * 16 + 6L * kc * 16 + 16;
   const long budget = (c2 == 24 ? 78 : 158) * 1024 / 4;  // C2=24 (44x44): two workgroups per CU
   int best = 1;
   for (int r = 1; r <= H; ++r) {
@@ -365,16 +382,18 @@ bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
 //            the output conv (D and B fragments share the lane map), so the chained 1x1
 //            conv starts from registers and writes the NCHW logits directly.
 // Filters, taps and BN constants stay in LDS for the life of the persistent workgroup.
-constexpr int TW_C = 72, TW_KC = 5, TW_KP = 84, TW_CP = 76, TW_NT = 2;
+constexpr int TW_C = 72, TW_KC = 5, TW_CP = 76, TW_NT = 2;
+constexpr int TW_WP_FL = TW_KC * TW_KC * 256;   // pointwise filter, fragment-major
+constexpr int TW_WH_FL = TW_KC * 256;           // per output-conv M tile
 
 template <int MH /* output-conv M tiles, 0 = no head */>
 __global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
-  constexpr int KC = TW_KC, KP = TW_KP, CP = TW_CP, NT = TW_NT, C = TW_C;
+  constexpr int KC = TW_KC, CP = TW_CP, NT = TW_NT, C = TW_C;
   constexpr int THREADS = 512, NW = THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* WP_ = lds;                                 // [80][KP]  pointwise filter
-  float* WH = WP_ + KC * 16 * KP;                   // [MH*16][KP] output conv (HEAD only)
-  float* WD = WH + MH * 16 * KP;                    // [25][80] depthwise taps
+  float* WH = WP_ + TW_WP_FL;                       // output conv, MH tiles (HEAD only)
+  float* WD = WH + MH * TW_WH_FL;                   // [25][80] depthwise taps
   float* CS = WD + 25 * KC * 16;                    // scd, shd, scp, shp, bias(head): 5 x 96
   float* TIN = CS + 5 * 96;
   const int H = a.H, W = a.W, R = a.R;
@@ -386,7 +405,13 @@ __global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    for (int i = tid; i < (KC * 16 * KP + MH * 16 * KP + 25 * KC * 16 + 5 * 96) / 4; i += THREADS) dst[i] = src[i];
+    constexpr int N4 = (TW_WP_FL + MH * TW_WH_FL + 25 * KC * 16 + 5 * 96) / 4;
+    int i = tid;
+    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
+      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
+      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
+    }
+    for (; i < N4; i += THREADS) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -464,7 +489,7 @@ __global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
           }
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + (16 * mt + p) * KP + cb);
+          const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -501,7 +526,7 @@ __global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
           for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < KC; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(WH + (16 * m + p) * KP + 16 * s + 4 * g);
+            const f32x4 af = *reinterpret_cast<const f32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -532,7 +557,7 @@ __global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
 }
 
 static size_t tower_lds_floats(int mh_tiles, int R, int W) {
-  return (size_t)TW_KC * 16 * TW_KP + (size_t)mh_tiles * 16 * TW_KP + 25 * TW_KC * 16 + 5 * 96 + (size_t)(R + 4) * (W + 4) * TW_CP + 16;
+  return (size_t)TW_WP_FL + (size_t)mh_tiles * TW_WH_FL + 25 * TW_KC * 16 + 5 * 96 + (size_t)(R + 4) * (W + 4) * TW_CP + 16;
 }
 
 int yfv2_tower_rows(int mh_tiles, int H, int W) {
@@ -582,9 +607,8 @@ bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s) {
 template <int CIN>
 struct S2Cfg {
   static constexpr int KC = (CIN + 15) / 16;
-  static constexpr int KP = 16 * KC + 4;
   static constexpr int CP = CIN + 4;
-  static constexpr int W_FL = KC * 16 * KP;
+  static constexpr int W_FL = KC * KC * 256;  // fragment-major filter (see S1Cfg)
   static constexpr int DW_FL = 9 * KC * 16;
   static constexpr int NCS = 10;  // sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
 };
@@ -592,7 +616,7 @@ struct S2Cfg {
 template <int CIN, int THREADS>
 __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   using Cfg = S2Cfg<CIN>;
-  constexpr int KC = Cfg::KC, KP = Cfg::KP, CP = Cfg::CP, KS = KC * 16;
+  constexpr int KC = Cfg::KC, CP = Cfg::CP, KS = KC * 16;
   constexpr int NW = THREADS / 64;
   constexpr int CO = 2 * CIN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -613,9 +637,15 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    for (int i = tid; i < (3 * Cfg::W_FL + 2 * Cfg::DW_FL + Cfg::NCS * KS) / 4; i += THREADS) dst[i] = src[i];
+    constexpr int N4 = (3 * Cfg::W_FL + 2 * Cfg::DW_FL + Cfg::NCS * KS) / 4;
+    int i = tid;
+    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
+      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
+      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
+    }
+    for (; i < N4; i += THREADS) dst[i] = src[i];
   }
-  for (int i = tid; i < t1_fl; i += THREADS) T1[i] = 0.f;  // column 0 (input col -1) stays zero
+  for (int i = tid; i < t1_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // column 0 (input col -1) stays zero
   __syncthreads();
 
   const int tiles_per_img = (OH + R - 1) / R;
@@ -668,7 +698,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(W1 + (16 * mt + p) * KP + 16 * s + 4 * g);
+          const f32x4 af = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[s][j], acc, 0, 0, 0);
         }
@@ -762,7 +792,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < KC; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(wmat + (16 * mt + p) * KP + 16 * s + 4 * g);
+            const f32x4 af = *reinterpret_cast<const f32x4*>(wmat + ((mt * KC + s) * 64 + lane) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[s][j], acc, 0, 0, 0);
           }
@@ -836,12 +866,12 @@ constexpr int TW2_PS = 20;  // LDS floats per staged pixel (16 channels + 4 pad)
 
 template <int MH, int THREADS, int NT, int NPF>
 __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
-  constexpr int KC = TW_KC, KP = TW_KP, C = TW_C, PS = TW2_PS;
+  constexpr int KC = TW_KC, C = TW_C, PS = TW2_PS;
   constexpr int NW = THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* WP_ = lds;
-  float* WH = WP_ + KC * 16 * KP;
-  float* WD = WH + MH * 16 * KP;
+  float* WH = WP_ + TW_WP_FL;
+  float* WD = WH + MH * TW_WH_FL;
   float* CS = WD + 25 * KC * 16;
   float* TIN = CS + 5 * 96;
   const int H = a.H, W = a.W, HW = H * W;
@@ -854,9 +884,15 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    for (int i = tid; i < (KC * 16 * KP + MH * 16 * KP + 25 * KC * 16 + 5 * 96) / 4; i += THREADS) dst[i] = src[i];
+    constexpr int N4 = (TW_WP_FL + MH * TW_WH_FL + 25 * KC * 16 + 5 * 96) / 4;
+    int i = tid;
+    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
+      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
+      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
+    }
+    for (; i < N4; i += THREADS) dst[i] = src[i];
   }
-  for (int i = tid; i < tin_fl; i += THREADS) TIN[i] = 0.f;  // the 2-pixel halo stays zero
+  for (int i = tid; i < tin_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(TIN)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the 2-pixel halo stays zero
   __syncthreads();
 
   // this wave's pixel tiles (fixed for every image)
@@ -939,7 +975,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
         }
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
-        const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + (16 * mt + p) * KP + cb);
+        const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -974,7 +1010,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
         for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(WH + (16 * m + p) * KP + 16 * s + 4 * g);
+          const f32x4 af = *reinterpret_cast<const f32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1004,7 +1040,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 
 template <int MH, int THREADS, int NT, int NPF>
 static void launch_tower2(const TowerArgs& a, hipStream_t s) {
-  const size_t lds = sizeof(float) * ((size_t)TW_KC * 16 * TW_KP + (size_t)MH * 16 * TW_KP + 25 * TW_KC * 16 + 5 * 96 +
+  const size_t lds = sizeof(float) * ((size_t)TW_WP_FL + (size_t)MH * TW_WH_FL + 25 * TW_KC * 16 + 5 * 96 +
                                       (size_t)(a.H + 4) * (a.W + 4) * TW2_PS + 16);
   int blocks = a.B < 256 ? a.B : 256;
   static bool attr_done = false;
