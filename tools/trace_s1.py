@@ -15,8 +15,9 @@ for B in (16, 256):
     for _ in range(3):
         eng.forward(x)
     torch.cuda.synchronize()
-    buf = torch.zeros(16, dtype=torch.float32)
-    _lib.lib().yfv2_debug_activation(eng._h, 100, B, C.c_void_p(buf.data_ptr()), 16)
-    st = buf.view(torch.int64)[:7].tolist()
+    buf = torch.zeros(64, dtype=torch.float32)
+    _lib.lib().yfv2_debug_activation(eng._h, 100, B, C.c_void_p(buf.data_ptr()), 64)
+    st = buf.view(torch.int64).tolist()
     d = [st[i] - st[0] for i in range(7)]
+    print("   tile stamps (entry, frags+stores, mfma+epilogue done, next raw arrived):", [st[i] - st[0] for i in range(8, 16)])
     print("B=%d stamps (cycles since entry): copy_issued=%d prologue_done=%d waveA=%d phaseA=%d waveB=%d end=%d" % (B, d[1], d[2], d[3], d[4], d[5], d[6]))

@@ -885,10 +885,10 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
 }
 
 int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap) {
-  if (h && which == 100 && h->d_trace && host_dst && cap >= 16) {  // debug: 8 cycle stamps as int64 in 16 floats
+  if (h && which == 100 && h->d_trace && host_dst && cap >= 64) {  // debug: 32 cycle stamps as int64 in 64 floats
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host_dst, h->d_trace, 8 * sizeof(long long), hipMemcpyDeviceToHost);
-    return 16;
+    (void)hipMemcpy(host_dst, h->d_trace, 32 * sizeof(long long), hipMemcpyDeviceToHost);
+    return 64;
   }
   if (!h || which < 0 || which > 5 || !h->dbg[which] || B < 1 || B > h->cfg.max_batch) {
     fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: bad argument");

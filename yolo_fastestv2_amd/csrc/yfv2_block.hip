@@ -122,8 +122,10 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
       tile_geom(wave, v_, i_, n_, r_, x_, gp_);
       load_raw(gp_, rcur);
     }
-    for (int t = wave; t * 16 < npxA; t += NW) {
+    int titer = 0;
+    for (int t = wave; t * 16 < npxA; t += NW, ++titer) {
       bool valid, inimg, interior; int r, x; size_t gp;
+      YFV2_STAMP(8 + 4 * titer);  // tile loop entry
       tile_geom(t, valid, inimg, interior, r, x, gp);
       if ((t + NW) * 16 < npxA) {
         bool v_, i_, n_; int r_, x_; size_t gp_;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
         bf[s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};  // odd channels -> main branch (zero for cb >= C2)
         if (interior && cb < C2) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};  // even -> pass-through
       }
+      YFV2_STAMP(9 + 4 * titer);  // loads of the next tile issued, B fragments formed, pass-through stored
       // two output-channel tiles at a time: two independent accumulators alternate on the
       // MFMA pipe (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, the pipe issues every 32)
       // while the register footprint stays flat for the big C2=96 variant
@@ -174,8 +177,10 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
           }
         }
       }
+      YFV2_STAMP(10 + 4 * titer);  // MFMAs + epilogue of this tile done
 #pragma unroll
       for (int s = 0; s < KC; ++s) { rcur[s][0] = rnxt[s][0]; rcur[s][1] = rnxt[s][1]; }
+      YFV2_STAMP(11 + 4 * titer);  // next tile's raw data has arrived
     }
     YFV2_STAMP(3);  // this wave's phase A done
     __syncthreads();
