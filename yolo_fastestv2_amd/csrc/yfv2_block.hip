@@ -61,6 +61,34 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
   YFV2_STAMP(0);
 
+  // The first work unit's activations do not depend on the LDS prologue: issue their loads
+  // first so that their HBM/L2 latency overlaps the filter copy and the T1 zero fill.
+  const int tiles_per_img = (H + R - 1) / R;
+  const int n_items = a.B * tiles_per_img;
+  f32x4 rcur[KC][2];
+  bool first_item = true;
+  if ((int)blockIdx.x < n_items) {
+    const int b0 = blockIdx.x / tiles_per_img, ti0 = blockIdx.x - b0 * tiles_per_img;
+    const int fy0 = ti0 * R, frows = min(R, H - fy0);
+    const int fn = (frows + 2) * W;
+    const int ft = wave / ((KC + 1) / 2);
+    const int q = 16 * ft + p;
+    const int r = q / W, x = q - r * W, gy = fy0 - 1 + r;
+    const bool inimg = q < fn && gy >= 0 && gy < H;
+    const size_t gp = (size_t)b0 * H * W + (inimg ? (size_t)gy * W + x : 0);
+    const float* src = a.in + gp * C;
+#pragma unroll
+    for (int s = 0; s < KC; ++s) {
+      const int cb = 16 * s + 4 * g;
+      rcur[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      rcur[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (cb < C2) {
+        rcur[s][0] = *reinterpret_cast<const f32x4*>(src + 2 * cb);
+        rcur[s][1] = *reinterpret_cast<const f32x4*>(src + 2 * cb + 4);
+      }
+    }
+  }
+
   // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
   // yfv2_load_weights) is one straight coalesced 16-byte copy
   {
@@ -80,8 +108,6 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   __syncthreads();
   YFV2_STAMP(2);  // prologue done
 
-  const int tiles_per_img = (H + R - 1) / R;
-  const int n_items = a.B * tiles_per_img;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R;
@@ -89,9 +115,15 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
     const size_t img_px = (size_t)b * H * W;
 
     // ================= phase A: pw1 (+BN+ReLU) over rows y0-1 .. y0+rows, into T1
-    // One-tile-ahead software pipeline: the raw loads of the wave's next tile are issued
-    // before the current tile's MFMAs so HBM/L2 latency overlaps compute.
+    // Work unit = (16-pixel tile, pair of output-channel tiles): on the small maps one image
+    // has only 9..36 pixel tiles for 8 waves, so whole tiles leave most waves idle in the last
+    // round; (tile x channel-pair) units balance to within one short unit.  Two independent
+    // accumulators alternate on the MFMA pipe (a dependent v_mfma_f32_16x16x4_f32 needs 40
+    // cycles, the pipe issues every 32).  The unit that owns channel pair 0 also forwards the
+    // pass-through (even) channels.  Raw loads run one unit ahead.
+    constexpr int NPAIR = (KC + 1) / 2;
     const int npxA = (rows + 2) * W;
+    const int ntA = (npxA + 15) / 16;
     auto tile_geom = [&](int t, bool& valid, bool& inimg, bool& interior, int& r, int& x, size_t& gp) {
       const int q = 16 * t + p;
       valid = q < npxA;
@@ -116,20 +148,22 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
         }
       }
     };
-    f32x4 rcur[KC][2], rnxt[KC][2];
-    if (wave * 16 < npxA) {
-      bool v_, i_, n_; int r_, x_; size_t gp_;
-      tile_geom(wave, v_, i_, n_, r_, x_, gp_);
-      load_raw(gp_, rcur);
-    }
-    int titer = 0;
-    for (int t = wave; t * 16 < npxA; t += NW, ++titer) {
-      bool valid, inimg, interior; int r, x; size_t gp;
-      YFV2_STAMP(8 + 4 * titer);  // tile loop entry
-      tile_geom(t, valid, inimg, interior, r, x, gp);
-      if ((t + NW) * 16 < npxA) {
+    f32x4 rnxt[KC][2];
+    if (!first_item) {  // the first item's first unit was loaded before the prologue
+      if (wave < ntA * NPAIR) {
         bool v_, i_, n_; int r_, x_; size_t gp_;
-        tile_geom(t + NW, v_, i_, n_, r_, x_, gp_);
+        tile_geom(wave / NPAIR, v_, i_, n_, r_, x_, gp_);
+        load_raw(gp_, rcur);
+      }
+    }
+    first_item = false;
+    for (int u = wave; u < ntA * NPAIR; u += NW) {
+      const int t = u / NPAIR, mt = 2 * (u - t * NPAIR);
+      bool valid, inimg, interior; int r, x; size_t gp;
+      tile_geom(t, valid, inimg, interior, r, x, gp);
+      if (u + NW < ntA * NPAIR) {
+        bool v_, i_, n_; int r_, x_; size_t gp_;
+        tile_geom((u + NW) / NPAIR, v_, i_, n_, r_, x_, gp_);
         load_raw(gp_, rnxt);
       }
       float* cp = a.out + gp * C;
@@ -139,48 +173,39 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
         const int cb = 16 * s + 4 * g;
         const f32x4 q0 = rcur[s][0], q1 = rcur[s][1];
         bf[s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};  // odd channels -> main branch (zero for cb >= C2)
-        if (interior && cb < C2) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};  // even -> pass-through
+        if (mt == 0 && interior && cb < C2) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};  // even -> pass-through
       }
-      YFV2_STAMP(9 + 4 * titer);  // loads of the next tile issued, B fragments formed, pass-through stored
-      // two output-channel tiles at a time: two independent accumulators alternate on the
-      // MFMA pipe (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, the pipe issues every 32)
-      // while the register footprint stays flat for the big C2=96 variant
       float* dst = T1 + (r * WP + x + 1) * CP;
-#pragma unroll(Cfg::KC <= 3 ? 2 : 1)
-      for (int mt = 0; mt < KC; mt += 2) {
-        const bool two = mt + 1 < KC;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const bool two = mt + 1 < KC;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          const f32x4 af0 = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-          const f32x4 af1 = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
+      for (int s = 0; s < KC; ++s) {
+        const f32x4 af0 = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+        const f32x4 af1 = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[j], bf[s][j], acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[j], bf[s][j], acc1, 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int cb = 16 * (mt + h) + 4 * g;
-          if (valid && cb < C2 && (h == 0 || two)) {
-            const f32x4 acc = h ? acc1 : acc0;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
-            f32x4 y;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
-              y[k] = (inimg && u > 0.f) ? u : 0.f;  // rows outside the image are conv zero padding
-            }
-            *reinterpret_cast<f32x4*>(dst + cb) = y;
-          }
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[j], bf[s][j], acc0, 0, 0, 0);
+          if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[j], bf[s][j], acc1, 0, 0, 0);  // wave-uniform
         }
       }
-      YFV2_STAMP(10 + 4 * titer);  // MFMAs + epilogue of this tile done
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cb = 16 * (mt + h) + 4 * g;
+        if (valid && cb < C2 && (h == 0 || two)) {
+          const f32x4 acc = h ? acc1 : acc0;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
+          f32x4 y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float uu = __builtin_fmaf(acc[k], sc[k], sh[k]);
+            y[k] = (inimg && uu > 0.f) ? uu : 0.f;  // rows outside the image are conv zero padding
+          }
+          *reinterpret_cast<f32x4*>(dst + cb) = y;
+        }
+      }
 #pragma unroll
       for (int s = 0; s < KC; ++s) { rcur[s][0] = rnxt[s][0]; rcur[s][1] = rnxt[s][1]; }
-      YFV2_STAMP(11 + 4 * titer);  // next tile's raw data has arrived
     }
     YFV2_STAMP(3);  // this wave's phase A done
     __syncthreads();

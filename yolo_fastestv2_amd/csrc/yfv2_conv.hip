@@ -33,20 +33,35 @@
 //           NHWC output row, so the 24x176x176 conv map (2.97 MB/image) never touches HBM.
 constexpr int STEM_THREADS = 256;
 constexpr int STEM_CS = 24;    // conv-ring floats per conv pixel
-constexpr int STEM_IOFF = 4;   // input-ring column of image column 0 (column 3 = x = -1 = zero)
-constexpr int STEM_NPRE = 5;   // staged float4 per thread per iteration: ceil(4*3*(W/4)/256), W <= 384
+constexpr int STEM_IOFF = 4;   // input-ring column of staged column 0
+constexpr int STEM_NPRE = 3;   // staged float4 per thread per iteration: ceil(4*3*SW4/256)
 
+// Column split: every band is cut into two overlapping column halves of th = ceil(ntiles/2)
+// 16-column conv tiles (352 wide: tiles 0..5 and 5..10, one tile recomputed).  A half needs
+// only 40 KB of LDS, so four workgroups share a CU and hide each other's barriers and
+// pooling, and its 2*th tiles per iteration deal out evenly to the 4 waves.
 __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int H = a.H, W = a.W, CW = W >> 1, PH = H >> 2, PW = W >> 2, W4 = W >> 2;
-  const int WI = W + 8;                 // input-ring row: 4 pad | W data | 4 pad
-  const int SR = 3 * WI;                // one input row, 3 channels
-  float* iring = lds;                   // [5 rows][3][WI]
-  float* ring = lds + 5 * SR;           // conv ring [3][CW+2][STEM_CS]
-  const int RS = (CW + 2) * STEM_CS;
+  const int H = a.H, W = a.W, CW = W >> 1, PH = H >> 2, PW = W >> 2;
+  const int ntiles = CW >> 4;            // W % 32 == 0, ntiles <= 12
+  const int th = (ntiles + 1) >> 1;      // tiles per half
+  const int SW = 32 * th + 4;            // staged input columns per row (multiple of 4)
+  const int SW4 = SW >> 2;
+  const int WI = SW + 8;                 // input-ring row: 4 pad | SW data | 4 pad
+  const int SR = 3 * WI;                 // one input row, 3 channels
+  const int RC = 16 * th + 2;            // conv-ring columns: 1 pad | 16*th | 1 pad
+  float* iring = lds;                    // [5 rows][3][WI]
+  float* ring = lds + 5 * SR;            // conv ring [3][RC][STEM_CS]
+  const int RS = RC * STEM_CS;
   const int bands = PH / a.R;
-  const int band = blockIdx.x % bands, b = blockIdx.x / bands;
+  const int half = blockIdx.x & 1;
+  const int bb = blockIdx.x >> 1;
+  const int band = bb % bands, b = bb / bands;
   const int py0 = band * a.R;
+  const int c0 = half ? 16 * (ntiles - th) : 0;    // first conv column of this half
+  const int sx0 = half ? 2 * c0 - 4 : 0;           // first staged input column (multiple of 4)
+  const int px_lo = half ? 8 * th : 0;             // pooled columns written by this half
+  const int px_hi = half ? PW : min(PW, 8 * th);
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
   const float* __restrict__ xb = a.x + (size_t)b * 3 * H * W;
 
@@ -71,23 +86,23 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
     const int k = 4 * ks + g, kk = k < 27 ? k : 26;
     const int ci = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
     tky[ks] = ky;
-    tofs[ks] = ci * WI + kx + STEM_IOFF - 1;  // + 2*cx + slot(row) * SR
+    tofs[ks] = ci * WI + kx + STEM_IOFF - 1 - sx0;  // + 2*cx + slot(row) * SR   (input col 2cx-1+kx)
   }
 
-  // zero both rings once: input pad columns and conv-ring pad columns stay zero forever
-  for (int i = tid; i < 5 * SR + 3 * RS; i += STEM_THREADS) lds[i] = 0.f;
+  // zero both rings once: pad columns (image border / conv-ring border) stay zero forever
+  for (int i = tid; i < (5 * SR + 3 * RS) / 4; i += STEM_THREADS) reinterpret_cast<f32x4*>(lds)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging of input rows [iy_first, iy_first + nrows) into the input ring
-  const int per_row = 3 * W4;
+  // ---- staging of input rows [iy_first, iy_first + nrows) x columns [sx0, sx0 + SW) into the input ring
+  const int per_row = 3 * SW4;
   auto stage_load = [&](int iy_first, int nrows, f32x4 (&pre)[STEM_NPRE]) {
 #pragma unroll
     for (int j = 0; j < STEM_NPRE; ++j) {
       const int i = tid + j * STEM_THREADS;
       const int k = i / per_row, rem = i - k * per_row;
-      const int ci = rem / W4, c4 = rem - ci * W4;
-      const int iy = iy_first + k;
+      const int ci = rem / SW4, c4 = rem - ci * SW4;
+      const int iy = iy_first + k, ix = sx0 + 4 * c4;
       pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (k < nrows && iy >= 0 && iy < H) pre[j] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ci * H + iy) * W + 4 * c4);
+      if (k < nrows && iy >= 0 && iy < H && ix < W) pre[j] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ci * H + iy) * W + ix);
     }
   };
   auto stage_store = [&](int iy_first, int nrows, const f32x4 (&pre)[STEM_NPRE]) {
@@ -95,13 +110,13 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
     for (int j = 0; j < STEM_NPRE; ++j) {
       const int i = tid + j * STEM_THREADS;
       const int k = i / per_row, rem = i - k * per_row;
-      const int ci = rem / W4, c4 = rem - ci * W4;
+      const int ci = rem / SW4, c4 = rem - ci * SW4;
       const int iy = iy_first + k;
       if (k < nrows) *reinterpret_cast<f32x4*>(iring + ((iy + 5) % 5) * SR + ci * WI + STEM_IOFF + 4 * c4) = pre[j];
     }
   };
   // ---- one 16-pixel conv tile: gather from the input ring, 14 MFMAs, BN + ReLU, store to conv ring
-  auto conv_tile = [&](int cy, int cx, float* row, bool store) {
+  auto conv_tile = [&](int cy, int cx, float* row) {
     const int r0 = 2 * cy - 1 + 5;  // input row of ky = 0, biased so that % is on a non-negative value
     const int s0 = (r0 % 5) * SR, s1 = ((r0 + 1) % 5) * SR, s2 = ((r0 + 2) % 5) * SR;
     float bv[7];
@@ -113,22 +128,19 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], bv[ks], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], bv[ks], acc1, 0, 0, 0);
     }
-    if (store) {
-      f32x4 y0, y1;
+    f32x4 y0, y1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
-        const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
-        y0[r] = u0 > 0.f ? u0 : 0.f;
-        y1[r] = u1 > 0.f ? u1 : 0.f;
-      }
-      float* dst = row + (cx + 1) * STEM_CS + 4 * g;
-      *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
-      if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
+    for (int r = 0; r < 4; ++r) {
+      const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
+      const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
+      y0[r] = u0 > 0.f ? u0 : 0.f;
+      y1[r] = u1 > 0.f ? u1 : 0.f;
     }
+    float* dst = row + (cx - c0 + 1) * STEM_CS + 4 * g;
+    *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
+    if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
   };
 
-  const int ntiles = CW >> 4;  // W % 32 == 0, ntiles <= 12
   f32x4 pre[STEM_NPRE];
   // prologue: conv row 2*py0-1 needs input rows 4*py0-3 .. 4*py0-1 (zeros above the image)
   stage_load(4 * py0 - 3, 3, pre);
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
   stage_load(4 * py0, 4, pre);  // first iteration's rows: in flight during the prologue conv
   __syncthreads();
   if (py0 > 0)  // for py0 == 0 conv row -1 is the max-pool padding: ring slot 0 stays zero
-    for (int t = wave; t < ntiles; t += 4) conv_tile(2 * py0 - 1, 16 * t + p, ring, true);
+    for (int t = wave; t < th; t += 4) conv_tile(2 * py0 - 1, c0 + 16 * t + p, ring);
 
   int old = 0;  // conv-ring slot of conv row 2py-1
   for (int py = py0; py < py0 + a.R; ++py) {
@@ -148,16 +160,16 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
     stage_store(4 * py, 4, pre);
     if (py + 1 < py0 + a.R) stage_load(4 * (py + 1), 4, pre);  // flies during conv + pool
     __syncthreads();
-    // the 2*ntiles tiles of conv rows 2py, 2py+1 are dealt round-robin to the 4 waves
-    for (int u = wave; u < 2 * ntiles; u += 4) {
-      const int rr = u >= ntiles ? 1 : 0;
-      conv_tile(2 * py + rr, 16 * (u - rr * ntiles) + p, rr ? r2 : r1, true);
+    // the 2*th tiles of conv rows 2py, 2py+1 are dealt round-robin to the 4 waves
+    for (int u = wave; u < 2 * th; u += 4) {
+      const int rr = u >= th ? 1 : 0;
+      conv_tile(2 * py + rr, c0 + 16 * (u - rr * th) + p, rr ? r2 : r1);
     }
     __syncthreads();
     float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
-    for (int i = tid; i < PW * 6; i += STEM_THREADS) {
-      const int px = i / 6, q = i - px * 6;
-      const int base = (2 * px) * STEM_CS + 4 * q;  // conv col 2px-1 sits at ring col 2px
+    for (int i = tid; i < (px_hi - px_lo) * 6; i += STEM_THREADS) {
+      const int px = px_lo + i / 6, q = i % 6;
+      const int base = (2 * px - c0) * STEM_CS + 4 * q;  // conv col 2px-1 sits at ring col 2px-c0
       f32x4 m = *reinterpret_cast<const f32x4*>(r0 + base);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], u0[k]), fmaxf(u1[k], u2[k]));
       }
-      *reinterpret_cast<f32x4*>(orow + (size_t)i * 4) = m;  // px*24 + 4q == 4i
+      *reinterpret_cast<f32x4*>(orow + (size_t)px * 24 + 4 * q) = m;
     }
     old = (old + 2) % 3;
   }
@@ -176,13 +188,9 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
 
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
   const int bands = (a.H / 4) / a.R;
-  const size_t lds = sizeof(float) * ((size_t)5 * 3 * (a.W + 8) + (size_t)3 * (a.W / 2 + 2) * STEM_CS);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(stem_kernel, dim3(a.B * bands), dim3(STEM_THREADS), lds, s, a);
+  const int ntiles = (a.W / 2) / 16, th = (ntiles + 1) / 2;
+  const size_t lds = sizeof(float) * ((size_t)5 * 3 * (32 * th + 4 + 8) + (size_t)3 * (16 * th + 2) * STEM_CS);
+  hipLaunchKernelGGL(stem_kernel, dim3(a.B * bands * 2), dim3(STEM_THREADS), lds, s, a);
 }
 
 // ============================================================================
