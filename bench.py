@@ -76,12 +76,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_launcher:  # under torch.distributed.run even N=1 goes through RCCL (exercises the N>1 code path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    use_dist = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def sync():
@@ -103,14 +106,14 @@ def main():
 
     def step():
         d, i, c = eng.detect(x, a.conf, a.iou, out=det_bufs)
-        if world > 1:
-            yfv2.gather_detections(d, i, c)
+        if use_dist:
+            yfv2.gather_detections(d, i, c, force=True)
 
     for _ in range(a.warmup):
         step()
     dt = timed(step, a.steps, sync, barrier)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     value = world * a.batch * a.steps / dt
@@ -201,7 +204,7 @@ def main():
             "config": {"workload": "batch %d/GPU synthetic 352x352x3 fp32 (torch.rand), seeded random-init weights, "
                                    "Detector forward + anchor decode + class-aware NMS(conf %.2f, iou %.2f)%s; BASELINE.json "
                                    "configs[1] (forward only) is the subset reported in forward_only_img_s"
-                                   % (a.batch, a.conf, a.iou, " + RCCL all-gather of padded detections" if world > 1 else ""),
+                                   % (a.batch, a.conf, a.iou, " + RCCL all-gather of padded detections" if use_dist else ""),
                        "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
             "roofline": roof, "cpu_baseline": cpu,
@@ -210,7 +213,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     barrier()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

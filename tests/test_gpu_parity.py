@@ -268,3 +268,21 @@ def test_errors_are_loud(yfv2, model, dev):
     model.eval()
     with pytest.raises(yfv2.Yfv2Error):
         yfv2.Engine(dev, 352, 352, 80, 3, max_batch=1).forward(torch.rand(1, 3, 352, 352, device=dev))  # no weights
+
+
+def test_bench_under_torchrun_single_rank_uses_rccl(dev):
+    """N>1 code path on the one GPU we have: bench.py under torch.distributed.run with one rank
+    initialises the nccl (= RCCL) process group and runs the all-gather inside the timed step."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "32", "--no-cpu-baseline", "--profile-iters", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["value"] > 0 and "RCCL all-gather" in j["config"]["workload"]
+    assert j["roofline"]["frac"] > 0 and j["unit"] == "images/s"

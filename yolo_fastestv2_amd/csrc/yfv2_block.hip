@@ -37,7 +37,7 @@ struct S1Cfg {
   static constexpr int W_FL = KC * KC * 256;  // one filter matrix in LDS
   static constexpr int DW_FL = 9 * KC * 16;  // depthwise taps [9][KC*16]
   static constexpr int CST_FL = 6 * KC * 16; // sc1, sh1, scd, shd, sc2, sh2
-  static constexpr bool DWREG = C2 <= 48;    // depthwise taps + BN in registers
+  static constexpr bool DWREG = C2 <= 24;    // depthwise taps + BN in registers (KC = 2: 72 VGPRs)
   static constexpr int NTB = 1;              // pixel tiles per phase-B pass (all waves busy on small maps)
 };
 
@@ -178,16 +178,22 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
       float* dst = T1 + (r * WP + x + 1) * CP;
       const bool two = mt + 1 < KC;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // all A fragments of the unit are fetched into distinct registers first (left to itself
+      // hipcc reuses one register quad: ds_read -> lgkmcnt(0) -> 4 dependent MFMAs per step)
+      f32x4 afa[KC], afb[KC];
 #pragma unroll
       for (int s = 0; s < KC; ++s) {
-        const f32x4 af0 = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-        const f32x4 af1 = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
+        afa[s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+        afb[s] = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < KC; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[j], bf[s][j], acc0, 0, 0, 0);
-          if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[j], bf[s][j], acc1, 0, 0, 0);  // wave-uniform
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[s][j], bf[s][j], acc0, 0, 0, 0);
+          if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afb[s][j], bf[s][j], acc1, 0, 0, 0);  // wave-uniform
         }
-      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int cb = 16 * (mt + h) + 4 * g;
@@ -235,32 +241,43 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
         const int qc = pvv ? q : npxB - 1;
         const int r = qc / W, x = qc - r * W;
         const float* tp = T1 + (r * WP + x) * CP;  // top-left of the 3x3 window (halo row + zero column included)
+        // window taps and all A fragments are fetched up front, then the FMAs / MFMAs run
+        // back to back with KC independent accumulators
+        f32x4 win[KC][9], af[KC][KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
+#pragma unroll
+          for (int k = 0; k < 9; ++k) win[s][k] = *reinterpret_cast<const f32x4*>(tp + ((k / 3) * WP + (k % 3)) * CP + 16 * s + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt)
+#pragma unroll
+          for (int s = 0; s < KC; ++s) af[mt][s] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 bfr[KC];
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
           const int cb = 16 * s + 4 * g;
           f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
+          for (int k = 0; k < 9; ++k)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP + cb);
+            for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[s][k][c], wk[s][k][c], d[c]);
 #pragma unroll
-              for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], wk[s][ky * 3 + kx][k], d[k]);
-            }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) bfr[s][k] = cb < C2 ? __builtin_fmaf(d[k], dsc[s][k], dsh[s][k]) : 0.f;
+          for (int c = 0; c < 4; ++c) bfr[s][c] = cb < C2 ? __builtin_fmaf(d[c], dsc[s][c], dsh[s][c]) : 0.f;
         }
+        f32x4 acc[KC];
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < KC; ++mt)
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][s][j], bfr[s][j], acc[mt], 0, 0, 0);
         float* dst = a.out + (img_px + (size_t)(y0 + r) * W + x) * C + C2;
-#pragma unroll 1
+#pragma unroll
         for (int mt = 0; mt < KC; ++mt) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < KC; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[s][j], acc, 0, 0, 0);
-          }
           const int cb = 16 * mt + 4 * g;
           if (pvv && cb < C2) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
             f32x4 y;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
+              const float u = __builtin_fmaf(acc[mt][k], sc[k], sh[k]);
               y[k] = u > 0.f ? u : 0.f;
             }
             *reinterpret_cast<f32x4*>(dst + cb) = y;
@@ -297,41 +314,39 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
 #pragma unroll(Cfg::DWREG ? Cfg::KC : 1)
         for (int s = 0; s < KC; ++s) {
           const int cb = 16 * s + 4 * g;
-          f32x4 wl[9], lsc, lsh;
-          if constexpr (!Cfg::DWREG) {
+          // everything this chunk needs from LDS - 9 taps, BN, the 3x3 window of each pixel tile
+          // and the KC filter fragments - is fetched into distinct registers first, then the FMAs
+          // and MFMAs (KC independent accumulators per tile) run back to back
+          f32x4 wl[9], lsc, lsh, win[NTB][9], af[KC];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-            lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-            lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-          }
+          for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
+          lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+          lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+#pragma unroll
+          for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) win[nt][k] = *reinterpret_cast<const f32x4*>(T1 + base[nt] + cb + ((k / 3) * WP + (k % 3)) * CP);
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
+          __builtin_amdgcn_sched_barrier(0);
           f32x4 bfr[NTB];
 #pragma unroll
           for (int nt = 0; nt < NTB; ++nt) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            const float* tp = T1 + base[nt] + cb;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-              for (int kx = 0; kx < 3; ++kx) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP);
-                const f32x4 w = Cfg::DWREG ? wk[Cfg::DWREG ? s : 0][ky * 3 + kx] : wl[ky * 3 + kx];
+              for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[nt][k][c], wl[k][c], d[c]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], w[k], d[k]);
-              }
-            const f32x4 sc = Cfg::DWREG ? dsc[Cfg::DWREG ? s : 0] : lsc;
-            const f32x4 sh = Cfg::DWREG ? dsh[Cfg::DWREG ? s : 0] : lsh;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bfr[nt][k] = cb < C2 ? __builtin_fmaf(d[k], sc[k], sh[k]) : 0.f;
+            for (int c = 0; c < 4; ++c) bfr[nt][c] = cb < C2 ? __builtin_fmaf(d[c], lsc[c], lsh[c]) : 0.f;
           }
 #pragma unroll
-          for (int mt = 0; mt < KC; ++mt) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int mt = 0; mt < KC; ++mt)
 #pragma unroll
               for (int nt = 0; nt < NTB; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
-          }
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
         }
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt) {
@@ -723,15 +738,25 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         loadA(gp_, bn);
       }
       float* dst = T1 + (r * WP + x + 1) * CP;
+      // all filter fragments first (distinct registers), then KC independent MFMA chains interleaved
+      f32x4 afA[KC][KC], accA[KC];
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+        for (int s = 0; s < KC; ++s) afA[mt][s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[s][j], acc, 0, 0, 0);
-        }
+      for (int s = 0; s < KC; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt)
+            accA[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afA[mt][s][j], bf[s][j], accA[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const f32x4 acc = accA[mt];
         const int cb = 16 * mt + 4 * g;
         if (valid && cb < CIN) {
           const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KS + cb);
@@ -781,15 +806,15 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
 #pragma unroll
           for (int s = 0; s < KC; ++s) {
             const int cb = 16 * s + 4 * g;
+            f32x4 win[9];  // the chunk's 9 window taps in flight together, then the FMAs
+#pragma unroll
+            for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(tp + ((k / 3) * WP + (k % 3)) * CP + cb);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-              for (int kx = 0; kx < 3; ++kx) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tp + (ky * WP + kx) * CP + cb);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(v[k], wk[s][ky * 3 + kx][k], d[k]);
-              }
+              for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wk[s][k][c], d[c]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) bfr[s][k] = cb < CIN ? __builtin_fmaf(d[k], dsc[s][k], dsh[s][k]) : 0.f;
           }
@@ -817,15 +842,24 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
           }
         }
         float* dst = a.out + (out_px + (size_t)oy * OW + x) * CO + (branch == 0 ? CIN : 0);
-#pragma unroll 1
+        f32x4 afB[KC][KC], accB[KC];
+#pragma unroll
         for (int mt = 0; mt < KC; ++mt) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          accB[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < KC; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(wmat + ((mt * KC + s) * 64 + lane) * 4);
+          for (int s = 0; s < KC; ++s) afB[mt][s] = *reinterpret_cast<const f32x4*>(wmat + ((mt * KC + s) * 64 + lane) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[s][j], acc, 0, 0, 0);
-          }
+        for (int s = 0; s < KC; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < KC; ++mt)
+              accB[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afB[mt][s][j], bfr[s][j], accB[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const f32x4 acc = accB[mt];
           const int cb = 16 * mt + 4 * g;
           if (pv && cb < CIN) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(psc_p + cb);
@@ -1003,15 +1037,17 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
           const float u = __builtin_fmaf(d[nt][k], sc[k], sh[k]);  // channels >= 72: sc = sh = 0 -> 0
           bfr[nt][k] = (cb < C && u > 0.f) ? u : 0.f;
         }
+      f32x4 afP[KC];
 #pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
+      for (int mt = 0; mt < KC; ++mt) afP[mt] = *reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
-      }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afP[mt][j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
     }
     // pointwise BN (no ReLU: fpn.py:16-17,23-24)
 #pragma unroll
@@ -1038,15 +1074,17 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
         f32x4 hacc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 afH[KC];
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
+        for (int s = 0; s < KC; ++s) afH[s] = *reinterpret_cast<const f32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              hacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], acc[s][nt][j], hacc[nt], 0, 0, 0);
-        }
+              hacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afH[s][j], acc[s][nt][j], hacc[nt], 0, 0, 0);
         const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 4 * 96 + 16 * m + 4 * g);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

@@ -304,7 +304,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
       const unsigned long long alive_mask = __ballot(alive);
       unsigned long long kmask = 0ull;
       for (int i = 0; i < m; ++i) {  // wave-uniform scalar walk
-        const unsigned long long Si = __shfl(S, i);
+        // wave-uniform lane index -> v_readlane (SGPR result), not a ds_bpermute round trip
+        const unsigned long long Si = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(S >> 32), i) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(S & 0xFFFFFFFFull), i);
         if (((alive_mask >> i) & 1ull) && !(Si & kmask)) kmask |= 1ull << i;
       }
       if ((kmask >> tid) & 1ull) {

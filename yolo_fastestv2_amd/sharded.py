@@ -18,9 +18,10 @@ def shard_range(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_detections(dets, idx, cnt, group=None):
-    """All-gather equally-sized per-rank results -> (W*B,300,6), (W*B,300), (W*B) on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def gather_detections(dets, idx, cnt, group=None, force=False):
+    """All-gather equally-sized per-rank results -> (W*B,300,6), (W*B,300), (W*B) on every rank.
+    With one rank the collective is skipped unless ``force`` (used to exercise RCCL at N=1)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return dets, idx, cnt
     W = dist.get_world_size(group)
     out = []
