@@ -40,7 +40,7 @@ constexpr int STEM_NPRE = 3;   // staged float4 per thread per iteration: ceil(4
 // 16-column conv tiles (352 wide: tiles 0..5 and 5..10, one tile recomputed).  A half needs
 // only 40 KB of LDS, so four workgroups share a CU and hide each other's barriers and
 // pooling, and its 2*th tiles per iteration deal out evenly to the 4 waves.
-__global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
+__global__ __launch_bounds__(STEM_THREADS, 4) void stem_kernel(StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int H = a.H, W = a.W, CW = W >> 1, PH = H >> 2, PW = W >> 2;
   const int ntiles = CW >> 4;            // W % 32 == 0, ntiles <= 12
@@ -160,10 +160,50 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_kernel(StemArgs a) {
     stage_store(4 * py, 4, pre);
     if (py + 1 < py0 + a.R) stage_load(4 * (py + 1), 4, pre);  // flies during conv + pool
     __syncthreads();
-    // the 2*th tiles of conv rows 2py, 2py+1 are dealt round-robin to the 4 waves
-    for (int u = wave; u < 2 * th; u += 4) {
-      const int rr = u >= th ? 1 : 0;
-      conv_tile(2 * py + rr, c0 + 16 * (u - rr * th) + p, rr ? r2 : r1);
+    // the 2*th (<= 12) tiles of conv rows 2py, 2py+1 are dealt round-robin to the 4 waves: all
+    // gathers of the wave's (<= 3) tiles are issued first, then the MFMAs run back to back
+    {
+      constexpr int TPW = 3;
+      float bvs[TPW][7];
+      int tcx[TPW];
+      float* trow[TPW];
+      bool tok[TPW];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int u = wave + 4 * i;
+        tok[i] = u < 2 * th;
+        const int uc = tok[i] ? u : 0;
+        const int rr = uc >= th ? 1 : 0;
+        const int cy = 2 * py + rr;
+        tcx[i] = c0 + 16 * (uc - rr * th) + p;
+        trow[i] = rr ? r2 : r1;
+        const int rb = 2 * cy - 1 + 5;
+        const int s0 = (rb % 5) * SR, s1 = ((rb + 1) % 5) * SR, s2 = ((rb + 2) % 5) * SR;
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) bvs[i][ks] = iring[(tky[ks] == 0 ? s0 : (tky[ks] == 1 ? s1 : s2)) + tofs[ks] + 2 * tcx[i]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        if (!tok[i]) continue;  // wave-uniform
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], bvs[i][ks], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], bvs[i][ks], acc1, 0, 0, 0);
+        }
+        f32x4 y0, y1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
+          const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
+          y0[r] = u0 > 0.f ? u0 : 0.f;
+          y1[r] = u1 > 0.f ? u1 : 0.f;
+        }
+        float* dst = trow[i] + (tcx[i] - c0 + 1) * STEM_CS + 4 * g;
+        *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
+        if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
+      }
     }
     __syncthreads();
     float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
@@ -284,15 +324,19 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
           for (int nt = 0; nt < NT; ++nt)
             bnxt[nt] = *reinterpret_cast<const f32x4*>((s + 1 < SPLIT ? src0[nt] : src1[nt]) + 16 * (s + 1));
         }
+        // all MT filter fragments of the chunk first (distinct registers), then MT*NT independent
+        // MFMA chains interleaved - no LDS wait between MFMAs
+        f32x4 afs[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+        for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bcur[nt][j], acc[mt][nt], 0, 0, 0);
-        }
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afs[mt][j], bcur[nt][j], acc[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
       }
@@ -342,15 +386,17 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 
 #pragma unroll
     for (int s = 0; s < K16; ++s) {
+      f32x4 afs[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 af = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+      for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[nt][s][j], acc[mt][nt], 0, 0, 0);
-      }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afs[mt][j], bf[nt][s][j], acc[mt][nt], 0, 0, 0);
     }
     if constexpr (KT) {  // 8-channel tail: group g owns channels 16*K16 + 2g, +1
 #pragma unroll
