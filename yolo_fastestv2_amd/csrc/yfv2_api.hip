@@ -406,7 +406,7 @@ struct PlanBuilder {
     const int c2 = c / 2;
     const char* env = std::getenv("YFV2_FUSED");
     const bool fused = !(env && env[0] == '0');
-    if (fused && (c2 == 24 || c2 == 48 || c2 == 96)) {
+    if (fused && (c2 == 24 || c2 == 48 || c2 == 96) && yfv2_block_s1_rows(c2, H, W) > 0) {
       Folded f1, fd, f2;
       ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", c2, c2, &f1);
       ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", c2, 3, &fd);

@@ -37,14 +37,18 @@ struct S1Cfg {
   static constexpr int W_FL = KC * KC * 256;  // one filter matrix in LDS
   static constexpr int DW_FL = 9 * KC * 16;  // depthwise taps [9][KC*16]
   static constexpr int CST_FL = 6 * KC * 16; // sc1, sh1, scd, shd, sc2, sh2
-  static constexpr bool DWREG = C2 <= 24;    // depthwise taps + BN in registers (KC = 2: 72 VGPRs)
+  static constexpr bool DWREG = false;       // depthwise taps + BN are read from LDS per chunk (register budget goes to staging)
   static constexpr int NTB = 1;              // pixel tiles per phase-B pass (all waves busy on small maps)
+  // per-thread / per-wave bounds of the staged phase A (enforced by yfv2_block_s1_rows):
+  // (sized for the 352x352 plan: 44x44 R=11 / 22x22 / 11x11 whole; other sizes fall back to unfused launches)
+  static constexpr int MAXP = C2 <= 24 ? 14 : (C2 <= 48 ? 13 : 7);  // staged 32-byte pairs per thread
+  static constexpr int MAXU = C2 <= 24 ? 9 : (C2 <= 48 ? 9 : 4);    // (tile x channel-pair) units per wave
 };
 
 #define YFV2_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 template <int C2, int THREADS>
-__global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
+__global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
   using Cfg = S1Cfg<C2>;
   constexpr int KC = Cfg::KC, CP = Cfg::CP, NTB = Cfg::NTB;
   constexpr int NW = THREADS / 64;
@@ -61,33 +65,55 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
   YFV2_STAMP(0);
 
-  // The first work unit's activations do not depend on the LDS prologue: issue their loads
-  // first so that their HBM/L2 latency overlaps the filter copy and the T1 zero fill.
+  // ---- cooperative staging of one item's input tile (rows y0-1 .. y0+rows, all W columns):
+  // every thread requests up to MAXP 32-byte pairs at once, so the whole tile costs ONE
+  // global-latency round (and for the first item that round overlaps the LDS prologue).
   const int tiles_per_img = (H + R - 1) / R;
   const int n_items = a.B * tiles_per_img;
-  f32x4 rcur[KC][2];
-  bool first_item = true;
-  if ((int)blockIdx.x < n_items) {
-    const int b0 = blockIdx.x / tiles_per_img, ti0 = blockIdx.x - b0 * tiles_per_img;
-    const int fy0 = ti0 * R, frows = min(R, H - fy0);
-    const int fn = (frows + 2) * W;
-    const int ft = wave / ((KC + 1) / 2);
-    const int q = 16 * ft + p;
-    const int r = q / W, x = q - r * W, gy = fy0 - 1 + r;
-    const bool inimg = q < fn && gy >= 0 && gy < H;
-    const size_t gp = (size_t)b0 * H * W + (inimg ? (size_t)gy * W + x : 0);
-    const float* src = a.in + gp * C;
+  constexpr int QPP = C2 / 4;  // 32-byte input pairs (= 16-byte odd-channel quads) per pixel
+  constexpr int MAXP = Cfg::MAXP;
+  f32x4 st0[MAXP], st1[MAXP];
+  auto stage_issue = [&](int item_, bool active) {  // always (re)defines every staged register
+    const int item = active ? item_ : 0;
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R, rows = min(R, H - y0);
+    const int npairs = active ? (rows + 2) * W * QPP : 0;
+    const size_t img_px = (size_t)b * H * W;
 #pragma unroll
-    for (int s = 0; s < KC; ++s) {
-      const int cb = 16 * s + 4 * g;
-      rcur[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      rcur[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (cb < C2) {
-        rcur[s][0] = *reinterpret_cast<const f32x4*>(src + 2 * cb);
-        rcur[s][1] = *reinterpret_cast<const f32x4*>(src + 2 * cb + 4);
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      const int pix = i / QPP, q = i - pix * QPP;
+      const int r = pix / W, x = pix - r * W;
+      const int gy = y0 - 1 + r;
+      st0[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      st1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < npairs && gy >= 0 && gy < H) {
+        const float* src = a.in + (img_px + (size_t)gy * W + x) * C + 8 * q;
+        st0[j] = *reinterpret_cast<const f32x4*>(src);
+        st1[j] = *reinterpret_cast<const f32x4*>(src + 4);
       }
     }
-  }
+  };
+  // odd channels -> T1 (zero for rows outside the image = the depthwise zero padding),
+  // even channels -> out[..., 0:C2] for the rows this item owns (shuffle + pass-through + cat)
+  auto stage_commit = [&](int item, float* T1) {
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R, rows = min(R, H - y0);
+    const int npairs = (rows + 2) * W * QPP;
+    const size_t img_px = (size_t)b * H * W;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      if (i >= npairs) continue;
+      const int pix = i / QPP, q = i - pix * QPP;
+      const int r = pix / W, x = pix - r * W;
+      const int gy = y0 - 1 + r;
+      *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = (f32x4){st0[j][1], st0[j][3], st1[j][1], st1[j][3]};
+      if (r >= 1 && r <= rows && gy >= 0 && gy < H)
+        *reinterpret_cast<f32x4*>(a.out + (img_px + (size_t)gy * W + x) * C + 4 * q) = (f32x4){st0[j][0], st0[j][2], st1[j][0], st1[j][2]};
+    }
+  };
+  stage_issue(blockIdx.x, (int)blockIdx.x < n_items);
 
   // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
   // yfv2_load_weights) is one straight coalesced 16-byte copy
@@ -114,107 +140,90 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
     const int rows = min(R, H - y0);
     const size_t img_px = (size_t)b * H * W;
 
-    // ================= phase A: pw1 (+BN+ReLU) over rows y0-1 .. y0+rows, into T1
-    // Work unit = (16-pixel tile, pair of output-channel tiles): on the small maps one image
-    // has only 9..36 pixel tiles for 8 waves, so whole tiles leave most waves idle in the last
-    // round; (tile x channel-pair) units balance to within one short unit.  Two independent
-    // accumulators alternate on the MFMA pipe (a dependent v_mfma_f32_16x16x4_f32 needs 40
-    // cycles, the pipe issues every 32).  The unit that owns channel pair 0 also forwards the
-    // pass-through (even) channels.  Raw loads run one unit ahead.
-    constexpr int NPAIR = (KC + 1) / 2;
-    const int npxA = (rows + 2) * W;
-    const int ntA = (npxA + 15) / 16;
-    auto tile_geom = [&](int t, bool& valid, bool& inimg, bool& interior, int& r, int& x, size_t& gp) {
-      const int q = 16 * t + p;
-      valid = q < npxA;
-      r = q / W;
-      x = q - r * W;
-      const int gy = y0 - 1 + r;
-      inimg = valid && gy >= 0 && gy < H;
-      interior = inimg && r >= 1 && r <= rows;
-      gp = inimg ? img_px + (size_t)gy * W + x : img_px;  // clamped: always readable
-    };
-    auto load_raw = [&](size_t gp, f32x4 (&raw)[KC][2]) {
-      const float* src = a.in + gp * C;
-#pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        if (cb < C2) {
-          raw[s][0] = *reinterpret_cast<const f32x4*>(src + 2 * cb);
-          raw[s][1] = *reinterpret_cast<const f32x4*>(src + 2 * cb + 4);
-        } else {
-          raw[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          raw[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    };
-    f32x4 rnxt[KC][2];
-    if (!first_item) {  // the first item's first unit was loaded before the prologue
-      if (wave < ntA * NPAIR) {
-        bool v_, i_, n_; int r_, x_; size_t gp_;
-        tile_geom(wave / NPAIR, v_, i_, n_, r_, x_, gp_);
-        load_raw(gp_, rcur);
-      }
-    }
-    first_item = false;
-    for (int u = wave; u < ntA * NPAIR; u += NW) {
-      const int t = u / NPAIR, mt = 2 * (u - t * NPAIR);
-      bool valid, inimg, interior; int r, x; size_t gp;
-      tile_geom(t, valid, inimg, interior, r, x, gp);
-      if (u + NW < ntA * NPAIR) {
-        bool v_, i_, n_; int r_, x_; size_t gp_;
-        tile_geom((u + NW) / NPAIR, v_, i_, n_, r_, x_, gp_);
-        load_raw(gp_, rnxt);
-      }
-      float* cp = a.out + gp * C;
-      f32x4 bf[KC];
-#pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        const f32x4 q0 = rcur[s][0], q1 = rcur[s][1];
-        bf[s] = (f32x4){q0[1], q0[3], q1[1], q1[3]};  // odd channels -> main branch (zero for cb >= C2)
-        if (mt == 0 && interior && cb < C2) *reinterpret_cast<f32x4*>(cp + cb) = (f32x4){q0[0], q0[2], q1[0], q1[2]};  // even -> pass-through
-      }
-      float* dst = T1 + (r * WP + x + 1) * CP;
-      const bool two = mt + 1 < KC;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      // all A fragments of the unit are fetched into distinct registers first (left to itself
-      // hipcc reuses one register quad: ds_read -> lgkmcnt(0) -> 4 dependent MFMAs per step)
-      f32x4 afa[KC], afb[KC];
-#pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        afa[s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-        afb[s] = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < KC; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[s][j], bf[s][j], acc0, 0, 0, 0);
-          if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afb[s][j], bf[s][j], acc1, 0, 0, 0);  // wave-uniform
-        }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int cb = 16 * (mt + h) + 4 * g;
-        if (valid && cb < C2 && (h == 0 || two)) {
-          const f32x4 acc = h ? acc1 : acc0;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
-          f32x4 y;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float uu = __builtin_fmaf(acc[k], sc[k], sh[k]);
-            y[k] = (inimg && uu > 0.f) ? uu : 0.f;  // rows outside the image are conv zero padding
-          }
-          *reinterpret_cast<f32x4*>(dst + cb) = y;
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < KC; ++s) { rcur[s][0] = rnxt[s][0]; rcur[s][1] = rnxt[s][1]; }
-    }
-    YFV2_STAMP(3);  // this wave's phase A done
+    // ================= phase A: pw1 (+BN+ReLU) over rows y0-1 .. y0+rows, IN PLACE in T1
+    // stage: the raw tile (requested above / at the end of the previous item) lands in T1.
+    stage_commit(item, T1);
     __syncthreads();
+    YFV2_STAMP(8);
+    // Work unit = (16-pixel tile, pair of output-channel tiles): one image has only 9..36 pixel
+    // tiles for 8 waves, so whole tiles would leave most waves idle in the last round.
+    // A1: every wave pulls the B fragments of ALL its units out of T1 into registers;
+    // (barrier) A2: MFMAs with two independent accumulators, BN + ReLU, results overwrite the
+    // same T1 pixels (rows outside the image stay zero = depthwise zero padding).
+    constexpr int NPAIR = (KC + 1) / 2;
+    constexpr int MAXU = Cfg::MAXU;
+    const int npxA = (rows + 2) * W;
+    const int nunits = ((npxA + 15) / 16) * NPAIR;
+    // Two passes over the units (each pass covers whole tiles: UPASS*NW is a multiple of NPAIR)
+    // halve the registers that hold B fragments across the barrier.
+    constexpr int UPASS = NPAIR == 3 ? 3 : (MAXU + 1) / 2;  // 2 * UPASS >= MAXU in every configuration
+    static_assert(2 * UPASS >= MAXU, "two passes must cover all units");
+    static_assert((UPASS * NW) % NPAIR == 0, "a pass must not split a tile's channel pairs");
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const int ubase = pass * UPASS * NW;
+      f32x4 bfu[UPASS][KC];
+#pragma unroll
+      for (int k = 0; k < UPASS; ++k) {
+        const int u = ubase + wave + k * NW;
+        const int t = (u < nunits ? u : 0) / NPAIR;
+        const int q = 16 * t + p;
+        const int qc = q < npxA ? q : npxA - 1;
+        const int r = qc / W, x = qc - r * W;
+        const float* src = T1 + (r * WP + x + 1) * CP;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          const int cb = 16 * s + 4 * g;
+          bfu[k][s] = (cb < C2) ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < UPASS; ++k) {
+        const int u = ubase + wave + k * NW;
+        if (u >= nunits) continue;  // wave-uniform
+        const int t = u / NPAIR, mt = 2 * (u - t * NPAIR);
+        const int q = 16 * t + p;
+        const bool valid = q < npxA;
+        const int r = q / W, x = q - r * W;
+        const int gy = y0 - 1 + r;
+        const bool inimg = valid && gy >= 0 && gy < H;
+        float* dst = T1 + (r * WP + x + 1) * CP;
+        const bool two = mt + 1 < KC;
+        f32x4 afa[KC], afb[KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          afa[s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+          afb[s] = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[s][j], bfu[k][s][j], acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afb[s][j], bfu[k][s][j], acc1, 0, 0, 0);  // wave-uniform
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int cb = 16 * (mt + h) + 4 * g;
+          if (valid && cb < C2 && (h == 0 || two)) {
+            const f32x4 acc = h ? acc1 : acc0;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float uu = __builtin_fmaf(acc[c], sc[c], sh[c]);
+              y[c] = (inimg && uu > 0.f) ? uu : 0.f;  // rows outside the image are conv zero padding
+            }
+            *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
+        }
+      }
+      __syncthreads();  // pass 0's writes land before pass 1 reads other tiles; phase B after pass 1
+    }
     YFV2_STAMP(4);  // phase A done (all waves)
 
     // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
@@ -371,7 +380,8 @@ __global__ __launch_bounds__(THREADS) void block_s1_kernel(BlockS1Args a) {
       }
     }
     YFV2_STAMP(5);  // this wave's phase B done
-    __syncthreads();  // T1 is rewritten by the next item's phase A
+    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);  // next item's tile: in flight across the barrier
+    __syncthreads();  // T1 is rewritten by the next item's stage_commit
     YFV2_STAMP(6);
   }
 }
@@ -398,12 +408,19 @@ int yfv2_block_s1_rows(int c2, int H, int W) {
   const int kc = (c2 + 15) / 16;
   const long fixed = 2L * kc * kc * 256 + 9L * kc * 16 + 6L * kc * 16 + 16;
   const long budget = (c2 == 24 ? 78 : 158) * 1024 / 4;  // C2=24 (44x44): two workgroups per CU
-  int best = 1;
+  const int threads = c2 == 24 ? 256 : 512, nw = threads / 64, npair = (kc + 1) / 2;
+  const int maxp = c2 <= 24 ? S1Cfg<24>::MAXP : (c2 <= 48 ? S1Cfg<48>::MAXP : S1Cfg<96>::MAXP);
+  const int maxu = c2 <= 24 ? S1Cfg<24>::MAXU : (c2 <= 48 ? S1Cfg<48>::MAXU : S1Cfg<96>::MAXU);
+  int best = 0;
   for (int r = 1; r <= H; ++r) {
     if (H % r) continue;
-    if (fixed + (long)(r + 2) * (W + 2) * (c2 + 4) <= budget) best = r;
+    const long px = (long)(r + 2) * W;
+    if (fixed + (long)(r + 2) * (W + 2) * (c2 + 4) > budget) continue;   // LDS
+    if (px * (c2 / 4) > (long)maxp * threads) continue;                    // staged pairs per thread
+    if (((px + 15) / 16) * npair > (long)maxu * nw) continue;              // phase-A units per wave
+    best = r;
   }
-  return best;
+  return best;  // 0: no legal tiling -> the plan falls back to the unfused launches
 }
 
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
@@ -656,6 +673,7 @@ struct S2Cfg {
   static constexpr int W_FL = KC * KC * 256;  // fragment-major filter (see S1Cfg)
   static constexpr int DW_FL = 9 * KC * 16;
   static constexpr int NCS = 10;  // sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
+  static constexpr int MAXT = CIN <= 24 ? 10 : 6;  // phase-A tiles per wave (8 waves): ceil((2R+1)*W/16/8) for the planned R
 };
 
 template <int CIN, int THREADS>
@@ -723,20 +741,25 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         raw[s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     };
-    f32x4 bf[KC], bn[KC];
-    if (wave * 16 < npxA) {
+    // A wave's compute per tile (<= 1.5k cycles) is far shorter than a global-load round trip, so
+    // a one-ahead prefetch would leave every iteration latency-bound: the raw data of ALL tiles
+    // this wave owns in the item (<= MAXT) is requested up front, all loads in flight together.
+    constexpr int MAXT = Cfg::MAXT;
+    f32x4 rawA[MAXT][KC];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + i * NW;
       bool v_, i_; int r_, x_; size_t gp_;
-      geomA(wave, v_, i_, r_, x_, gp_);
-      loadA(gp_, bf);
+      geomA(t * 16 < npxA ? t : wave, v_, i_, r_, x_, gp_);  // clamped: a valid, readable tile
+      loadA(gp_, rawA[i]);
     }
-    for (int t = wave; t * 16 < npxA; t += NW) {
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + i * NW;
+      if (t * 16 >= npxA) continue;  // wave-uniform (no break: the loop must unroll so rawA stays in registers)
       bool valid, inimg; int r, x; size_t gp;
       geomA(t, valid, inimg, r, x, gp);
-      if ((t + NW) * 16 < npxA) {
-        bool v_, i_; int r_, x_; size_t gp_;
-        geomA(t + NW, v_, i_, r_, x_, gp_);
-        loadA(gp_, bn);
-      }
+      f32x4 (&bf)[KC] = rawA[i];
       float* dst = T1 + (r * WP + x + 1) * CP;
       // all filter fragments first (distinct registers), then KC independent MFMA chains interleaved
       f32x4 afA[KC][KC], accA[KC];
@@ -770,8 +793,6 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
           *reinterpret_cast<f32x4*>(dst + cb) = y;
         }
       }
-#pragma unroll
-      for (int s = 0; s < KC; ++s) bf[s] = bn[s];
     }
     __syncthreads();
 
@@ -894,7 +915,11 @@ int yfv2_block_s2_rows(int cin, int H, int W) {
   }
   if (best == 0) return 0;
   const int tiles = (OH + best - 1) / best;
-  return (OH + tiles - 1) / tiles;  // even split
+  int R = (OH + tiles - 1) / tiles;  // even split
+  // phase A preloads every tile a wave owns: keep (2R+1)*W/16 within 8 waves x MAXT
+  const int maxt = cin == 24 ? S2Cfg<24>::MAXT : S2Cfg<48>::MAXT;
+  while (R > 1 && ((2 * R + 1) * W + 15) / 16 > 8 * maxt) --R;
+  return R;
 }
 
 template <int CIN>
