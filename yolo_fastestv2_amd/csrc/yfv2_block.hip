@@ -673,7 +673,6 @@ struct S2Cfg {
   static constexpr int W_FL = KC * KC * 256;  // fragment-major filter (see S1Cfg)
   static constexpr int DW_FL = 9 * KC * 16;
   static constexpr int NCS = 10;  // sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
-  static constexpr int MAXT = CIN <= 24 ? 10 : 6;  // phase-A tiles per wave (8 waves): ceil((2R+1)*W/16/8) for the planned R
 };
 
 template <int CIN, int THREADS>
@@ -741,25 +740,20 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         raw[s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     };
-    // A wave's compute per tile (<= 1.5k cycles) is far shorter than a global-load round trip, so
-    // a one-ahead prefetch would leave every iteration latency-bound: the raw data of ALL tiles
-    // this wave owns in the item (<= MAXT) is requested up front, all loads in flight together.
-    constexpr int MAXT = Cfg::MAXT;
-    f32x4 rawA[MAXT][KC];
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t = wave + i * NW;
+    f32x4 bf[KC], bn[KC];
+    if (wave * 16 < npxA) {
       bool v_, i_; int r_, x_; size_t gp_;
-      geomA(t * 16 < npxA ? t : wave, v_, i_, r_, x_, gp_);  // clamped: a valid, readable tile
-      loadA(gp_, rawA[i]);
+      geomA(wave, v_, i_, r_, x_, gp_);
+      loadA(gp_, bf);
     }
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t = wave + i * NW;
-      if (t * 16 >= npxA) continue;  // wave-uniform (no break: the loop must unroll so rawA stays in registers)
+    for (int t = wave; t * 16 < npxA; t += NW) {
       bool valid, inimg; int r, x; size_t gp;
       geomA(t, valid, inimg, r, x, gp);
-      f32x4 (&bf)[KC] = rawA[i];
+      if ((t + NW) * 16 < npxA) {
+        bool v_, i_; int r_, x_; size_t gp_;
+        geomA(t + NW, v_, i_, r_, x_, gp_);
+        loadA(gp_, bn);
+      }
       float* dst = T1 + (r * WP + x + 1) * CP;
       // all filter fragments first (distinct registers), then KC independent MFMA chains interleaved
       f32x4 afA[KC][KC], accA[KC];
@@ -793,6 +787,8 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
           *reinterpret_cast<f32x4*>(dst + cb) = y;
         }
       }
+#pragma unroll
+      for (int s = 0; s < KC; ++s) bf[s] = bn[s];
     }
     __syncthreads();
 
@@ -915,11 +911,7 @@ int yfv2_block_s2_rows(int cin, int H, int W) {
   }
   if (best == 0) return 0;
   const int tiles = (OH + best - 1) / best;
-  int R = (OH + tiles - 1) / tiles;  // even split
-  // phase A preloads every tile a wave owns: keep (2R+1)*W/16 within 8 waves x MAXT
-  const int maxt = cin == 24 ? S2Cfg<24>::MAXT : S2Cfg<48>::MAXT;
-  while (R > 1 && ((2 * R + 1) * W + 15) / 16 > 8 * maxt) --R;
-  return R;
+  return (OH + tiles - 1) / tiles;  // even split
 }
 
 template <int CIN>
