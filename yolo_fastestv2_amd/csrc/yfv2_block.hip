@@ -121,12 +121,12 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     constexpr int N4 = (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4;
-    int i = tid;
-    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
-      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
-      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
-    }
-    for (; i < N4; i += THREADS) dst[i] = src[i];
+    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // <= 11: every load is issued before the first store
+    f32x4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
   }
   YFV2_STAMP(1);  // image copy issued
   // T1's border stays zero for every item
@@ -468,12 +468,12 @@ __global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     constexpr int N4 = (TW_WP_FL + MH * TW_WH_FL + 25 * KC * 16 + 5 * 96) / 4;
-    int i = tid;
-    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
-      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
-      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
-    }
-    for (; i < N4; i += THREADS) dst[i] = src[i];
+    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // <= 11: every load is issued before the first store
+    f32x4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
   }
   __syncthreads();
 
@@ -700,12 +700,12 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     constexpr int N4 = (3 * Cfg::W_FL + 2 * Cfg::DW_FL + Cfg::NCS * KS) / 4;
-    int i = tid;
-    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
-      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
-      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
-    }
-    for (; i < N4; i += THREADS) dst[i] = src[i];
+    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // <= 11: every load is issued before the first store
+    f32x4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
   }
   for (int i = tid; i < t1_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // column 0 (input col -1) stays zero
   __syncthreads();
@@ -966,12 +966,12 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     constexpr int N4 = (TW_WP_FL + MH * TW_WH_FL + 25 * KC * 16 + 5 * 96) / 4;
-    int i = tid;
-    for (; i + 3 * THREADS < N4; i += 4 * THREADS) {  // four independent 16-byte loads in flight
-      const f32x4 v0 = src[i], v1 = src[i + THREADS], v2 = src[i + 2 * THREADS], v3 = src[i + 3 * THREADS];
-      dst[i] = v0; dst[i + THREADS] = v1; dst[i + 2 * THREADS] = v2; dst[i + 3 * THREADS] = v3;
-    }
-    for (; i < N4; i += THREADS) dst[i] = src[i];
+    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // <= 11: every load is issued before the first store
+    f32x4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
   }
   for (int i = tid; i < tin_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(TIN)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the 2-pixel halo stays zero
   __syncthreads();

@@ -150,7 +150,8 @@ void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
 //   4. greedy   walk the sorted list; a kept box suppresses later boxes whose
 //               (double)iou > iou_thres; stop after max_det (300) kept boxes
 //               (the reference truncates the full result to 300, same set)
-constexpr int NMS_THREADS = 256;
+constexpr int NMS_THREADS = 1024;  // 16 waves: one workgroup per image is latency-bound, occupancy is what hides it
+constexpr int NMS_NQ = NMS_THREADS / 64;  // thread groups per 64-candidate chunk
 constexpr int NMS_CAP = 2048;      // >= rows (1815); power of two for the bitonic network
 constexpr int NMS_MAX_DET = 300;   // utils/utils.py:243 (== YFV2_MAX_DET)
 
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   __shared__ unsigned char supp[NMS_CAP];
   __shared__ unsigned char cls_of_row[NMS_CAP];
   __shared__ int keep[NMS_MAX_DET];
-  __shared__ unsigned long long pmask[4][64];
+  __shared__ unsigned long long pmask[NMS_NQ][64];
   __shared__ int n_cand, n_keep, n_obj;
 
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
 
   // ---- 4. greedy suppression, one wave width (64 sorted candidates) at a time.
   // A candidate is kept iff no EARLIER KEPT candidate overlaps it by more than the
-  // threshold (torchvision's loop).  Per chunk:  (a) all 256 threads test the chunk
-  // members against the boxes kept so far (4 threads per member, early exit);  (b) the
+  // threshold (torchvision's loop).  Per chunk:  (a) all threads test the chunk
+  // members against the boxes kept so far (16 threads per member, early exit);  (b) the
   // same threads build, per member j, the 64-bit mask of earlier chunk members i < j with
   // iou(i, j) > thr;  (c) wave 0 walks the chunk in order with scalar bit operations -
   // 3 barriers per 64 candidates instead of one per kept box.  Stops at max_det kept
@@ -292,14 +293,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
       const int cj = c0 + j;
       for (int k = q; k < nk; k += NMS_THREADS / 64)
         if (overlaps(keep[k], cj)) { supp[cj] = 1; break; }
-      const int i_hi = min(16 * q + 16, j);
-      for (int i = 16 * q; i < i_hi; ++i)
+      constexpr int PER = 64 / NMS_NQ;  // earlier chunk members examined by this thread
+      const int i_hi = min(PER * q + PER, j);
+      for (int i = PER * q; i < i_hi; ++i)
         if (overlaps(c0 + i, cj)) bits |= 1ull << i;
     }
     pmask[q][j] = bits;
     __syncthreads();
     if (tid < 64) {
-      const unsigned long long S = pmask[0][tid] | pmask[1][tid] | pmask[2][tid] | pmask[3][tid];
+      unsigned long long S = 0ull;
+#pragma unroll
+      for (int qq = 0; qq < NMS_NQ; ++qq) S |= pmask[qq][tid];
       const bool alive = tid < m && !supp[c0 + tid];
       const unsigned long long alive_mask = __ballot(alive);
       unsigned long long kmask = 0ull;
