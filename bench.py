@@ -52,6 +52,31 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(stage_name):
+    """HBM bytes per launch of the kernel behind a forward stage, from the newest committed PMC
+    summary (profiles/*_traffic.json, produced by tools/gpu_traffic.sh + tools/traffic_summary.py:
+    FETCH_SIZE and WRITE_SIZE in separate --pmc passes, gfx950 half-read correction, calibrated on a
+    known-size copy).  PMC counters cannot be collected from inside this process -> None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    kern = json.load(open(files[-1])).get("kernels", {})
+    n = stage_name
+    if n.startswith("stem"):
+        key = "stem_kernel"
+    elif "fused s2 block" in n:
+        key = "block_s2_kernel<24" if "stage2" in n else "block_s2_kernel<48"
+    elif "fused s1 block" in n:
+        key = "block_s1_kernel<24" if "stage2" in n else ("block_s1_kernel<48" if "stage3" in n else "block_s1_kernel<96")
+    else:
+        return None, os.path.basename(files[-1])
+    for k, v in kern.items():
+        if key in k:
+            return v["total_bytes"], os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
+
+
 def timed(fn, steps, sync, barrier):
     barrier(); sync()
     t0 = time.perf_counter()
@@ -139,8 +164,9 @@ def main():
         dom = max(kern, key=lambda k: k["ms"])
         # every launch of this net is left of the fp32 ridge (19.7 flop/B) unfused, so price
         # the dominant launch against HBM; pointwise launches also carry their MFMA fraction
+        traffic, traffic_src = measured_traffic(dom["name"])
         roof = {"kernel": dom["name"], "bound": "hbm", "achieved": round(dom["gbs"], 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(dom["ms"], 4), "algorithmic_bytes_per_launch": dom["bytes"],
                 "mfma_tflops": round(dom["tflops"], 2) if dom["mfma"] else None,
                 "mfma_frac": round(dom["tflops"] / MFMA_F32_PEAK_TF, 4) if dom["mfma"] else None}
