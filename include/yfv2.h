@@ -110,7 +110,8 @@ YFV2_API int yfv2_nms(yfv2_handle h, const float* boxes, int32_t B, float conf_t
              void* stream);
 
 /* forward -> decode -> NMS in one call (test.py:42,48,49 / utils/utils.py:379-383).
- * Intermediate logits and the decoded tensor live in the handle's workspace. */
+ * Intermediate logits and compact candidate rows live in the handle's workspace; the
+ * (B,rows,5+classes) tensor is not materialised on this path (same arithmetic, same result). */
 YFV2_API int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, double iou_thres,
                 float* dets, int32_t* idx, int32_t* count, void* stream);
 

@@ -37,11 +37,8 @@ struct Step {
   BlockS1Args s1{};
   TowerArgs tw{};
   BlockS2Args s2{};
-  size_t pj_d[3] = {0, 0, 0}, pj_p[3] = {0, 0, 0};  // s2 block: proj dw / proj pw (w, scale, shift)
-  size_t wh_off = 0, bh_off = 0;  // tower: chained output conv
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
-  size_t w2_off = 0, sc2_off = 0, sh2_off = 0, wd_off = 0, scd_off = 0, shd_off = 0;
   // offsets into the param blob, resolved to pointers after the upload
   size_t w_off = 0, scale_off = 0, shift_off = 0;
   size_t img_off = 0;         // host-packed LDS image of this launch
@@ -70,7 +67,6 @@ struct yfv2_ctx {
   // workspace (NHWC fp32), sized for cfg.max_batch
   Buf a1, s2[2], s3[2], s4[2], t1, t2, t3, f2, f3, ta, tb;
   Buf logits[6];
-  Buf decoded;
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries)
   long long* d_trace = nullptr;  // YFV2_TRACE=1: cycle stamps of the last fused s1 launch (debug)
@@ -442,7 +438,6 @@ struct PlanBuilder {
     s.tw.in = in; s.tw.out = out;
     s.tw.H = H; s.tw.W = W;
     s.tw.mh = mh; s.tw.split = split;
-    s.tw.R = yfv2_tower_rows(fh ? (mh + 15) / 16 : 0, H, W);
     s.img_off = wp.image_tower(fd, fp, fh, mh);
     s.has_head = fh != nullptr;
     s.head0 = head0; s.head1 = head1;
@@ -457,7 +452,7 @@ struct PlanBuilder {
     const int px = H * W;
     {
       const char* env = std::getenv("YFV2_FUSED");
-      if (!(env && env[0] == '0')) {
+      if (!(env && env[0] == '0') && yfv2_tower2_supported(H, W)) {
         Folded fd1, fp1, fd2, fp2, fh;
         ok &= wp.dw(p + ".0", p + ".1", 72, 5, &fd1);
         ok &= wp.pw(p + ".3", p + ".4", 72, 72, &fp1);
@@ -605,8 +600,7 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
       }
-      static const bool tower_v1 = [] { const char* e = std::getenv("YFV2_TOWER"); return e && e[0] == '1'; }();
-      if (!(!tower_v1 && yfv2_launch_tower2(a, s)) && !yfv2_launch_tower(a, s))
+      if (!yfv2_launch_tower2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S1) {
       BlockS1Args a = st.s1;
@@ -693,7 +687,6 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   A(&h->ta, (H / 16) * (W / 16) * 72);
   A(&h->tb, (H / 16) * (W / 16) * 72);
   for (int i = 0; i < 6; ++i) A(&h->logits[i], logit_elems(h, i));
-  A(&h->decoded, (size_t)rows * (5 + cfg->classes));
   A(&h->cand, (size_t)rows * 8);
   if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 256 * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, YFV2_ERR_DEVICE, "hipMalloc(class filter) failed");
@@ -716,7 +709,6 @@ void yfv2_destroy(yfv2_handle h) {
   free_buf(&h->t1); free_buf(&h->t2); free_buf(&h->t3);
   free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->ta); free_buf(&h->tb);
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
-  free_buf(&h->decoded);
   free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);
   if (h->d_params) (void)hipFree(h->d_params);

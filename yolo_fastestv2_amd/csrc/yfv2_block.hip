@@ -37,7 +37,6 @@ struct S1Cfg {
   static constexpr int W_FL = KC * KC * 256;  // one filter matrix in LDS
   static constexpr int DW_FL = 9 * KC * 16;  // depthwise taps [9][KC*16]
   static constexpr int CST_FL = 6 * KC * 16; // sc1, sh1, scd, shd, sc2, sh2
-  static constexpr bool DWREG = false;       // depthwise taps + BN are read from LDS per chunk (register budget goes to staging)
   static constexpr int NTB = 1;              // pixel tiles per phase-B pass (all waves busy on small maps)
   // per-thread / per-wave bounds of the staged phase A (enforced by yfv2_block_s1_rows):
   // (sized for the 352x352 plan: 44x44 R=11 / 22x22 / 11x11 whole; other sizes fall back to unfused launches)
@@ -227,81 +226,8 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
     YFV2_STAMP(4);  // phase A done (all waves)
 
     // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
-    // (re)loaded per item so that they are not live across phase A
-    // depthwise taps / BN of this lane's channel quads, in registers when they fit
-    f32x4 wk[Cfg::DWREG ? KC : 1][9], dsc[Cfg::DWREG ? KC : 1], dsh[Cfg::DWREG ? KC : 1];
-    if constexpr (Cfg::DWREG) {
-  #pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-  #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[s][k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-        dsc[s] = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-        dsh[s] = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-      }
-    }
     const int npxB = rows * W;
-    if constexpr (Cfg::DWREG) {
-      // small C2: all depthwise fragments of the tile first (taps in registers), then one
-      // output-channel tile at a time with a single live accumulator
-      for (int t = wave; t * 16 < npxB; t += NW) {
-        const int q = 16 * t + p;
-        const bool pvv = q < npxB;
-        const int qc = pvv ? q : npxB - 1;
-        const int r = qc / W, x = qc - r * W;
-        const float* tp = T1 + (r * WP + x) * CP;  // top-left of the 3x3 window (halo row + zero column included)
-        // window taps and all A fragments are fetched up front, then the FMAs / MFMAs run
-        // back to back with KC independent accumulators
-        f32x4 win[KC][9], af[KC][KC];
-#pragma unroll
-        for (int s = 0; s < KC; ++s)
-#pragma unroll
-          for (int k = 0; k < 9; ++k) win[s][k] = *reinterpret_cast<const f32x4*>(tp + ((k / 3) * WP + (k % 3)) * CP + 16 * s + 4 * g);
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-          for (int s = 0; s < KC; ++s) af[mt][s] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 bfr[KC];
-#pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          const int cb = 16 * s + 4 * g;
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[s][k][c], wk[s][k][c], d[c]);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) bfr[s][c] = cb < C2 ? __builtin_fmaf(d[c], dsc[s][c], dsh[s][c]) : 0.f;
-        }
-        f32x4 acc[KC];
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KC; ++s)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt)
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][s][j], bfr[s][j], acc[mt], 0, 0, 0);
-        float* dst = a.out + (img_px + (size_t)(y0 + r) * W + x) * C + C2;
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
-          const int cb = 16 * mt + 4 * g;
-          if (pvv && cb < C2) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + cb);
-            f32x4 y;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float u = __builtin_fmaf(acc[mt][k], sc[k], sh[k]);
-              y[k] = u > 0.f ? u : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(dst + cb) = y;
-          }
-        }
-      }
-    } else {
+    {
       for (int t0 = wave * NTB; t0 * 16 < npxB; t0 += NW * NTB) {
         int base[NTB];
         size_t opx[NTB];
@@ -320,7 +246,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
         for (int mt = 0; mt < KC; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NTB; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll(Cfg::DWREG ? Cfg::KC : 1)
+#pragma unroll 1
         for (int s = 0; s < KC; ++s) {
           const int cb = 16 * s + 4 * g;
           // everything this chunk needs from LDS - 9 taps, BN, the 3x3 window of each pixel tile
@@ -431,227 +357,11 @@ bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
 }
 
 // ============================================================================
-// fused DWConvblock half ("tower half"), 72 channels
+// fused DWConvblock half ("tower half"), 72 channels: shared constants (kernel: tower2_kernel below)
 // ============================================================================
-// Reference (model/fpn.py:12-25): DWConvblock = [dw5x5+BN+ReLU -> pw72+BN] x 2, and
-// model/detector.py:25-31 applies a biased 1x1 output conv to the block's result.
-// One launch = one half:   dw5x5 (pad 2) + BN + ReLU  ->  pw 72->72 + BN  [-> output conv + bias]
-//   phase 0  the input tile (R rows + 2 halo rows/cols each side, zero outside the image)
-//            is copied NHWC -> LDS (the 25-fold tap reuse lives in LDS, not L1)
-//   phase 1  per 16-pixel tile pair, each lane computes the depthwise 5x5 of ITS pixel and
-//            ITS 4 channels in registers (= the MFMA B fragment) and runs the pointwise
-//            GEMM; with HEAD the BN'd accumulator tile t IS the B fragment of chunk t of
-//            the output conv (D and B fragments share the lane map), so the chained 1x1
-//            conv starts from registers and writes the NCHW logits directly.
-// Filters, taps and BN constants stay in LDS for the life of the persistent workgroup.
-constexpr int TW_C = 72, TW_KC = 5, TW_CP = 76, TW_NT = 2;
+constexpr int TW_C = 72, TW_KC = 5;
 constexpr int TW_WP_FL = TW_KC * TW_KC * 256;   // pointwise filter, fragment-major
 constexpr int TW_WH_FL = TW_KC * 256;           // per output-conv M tile
-
-template <int MH /* output-conv M tiles, 0 = no head */>
-__global__ __launch_bounds__(512) void tower_kernel(TowerArgs a) {
-  constexpr int KC = TW_KC, CP = TW_CP, NT = TW_NT, C = TW_C;
-  constexpr int THREADS = 512, NW = THREADS / 64;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* WP_ = lds;                                 // [80][KP]  pointwise filter
-  float* WH = WP_ + TW_WP_FL;                       // output conv, MH tiles (HEAD only)
-  float* WD = WH + MH * TW_WH_FL;                   // [25][80] depthwise taps
-  float* CS = WD + 25 * KC * 16;                    // scd, shd, scp, shp, bias(head): 5 x 96
-  float* TIN = CS + 5 * 96;
-  const int H = a.H, W = a.W, R = a.R;
-  const int WP4 = W + 4;
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
-
-  // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
-  // yfv2_load_weights) is one straight coalesced 16-byte copy
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    constexpr int N4 = (TW_WP_FL + MH * TW_WH_FL + 25 * KC * 16 + 5 * 96) / 4;
-    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // <= 11: every load is issued before the first store
-    f32x4 tmp[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
-  }
-  __syncthreads();
-
-  const int tiles_per_img = (H + R - 1) / R;
-  const int n_items = a.B * tiles_per_img;
-  const int HW = H * W;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
-    const int y0 = ti * R;
-    const int rows = min(R, H - y0);
-    const float* img = a.in + (size_t)b * HW * C;
-
-    // ---- phase 0: stage rows y0-2 .. y0+rows+1, cols -2 .. W+1 (zero outside the image)
-    const int nq = (rows + 4) * WP4 * (C / 4);
-    for (int i = tid; i < nq; i += THREADS) {
-      const int c4 = i % (C / 4);
-      const int px = i / (C / 4);
-      const int r = px / WP4, xx = px - r * WP4;
-      const int gy = y0 - 2 + r, gx = xx - 2;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(img + ((size_t)gy * W + gx) * C + 4 * c4);
-      *reinterpret_cast<f32x4*>(TIN + px * CP + 4 * c4) = v;
-    }
-    __syncthreads();
-
-    // ---- phase 1
-    const int npx = rows * W;
-    for (int t0 = wave * NT; t0 * 16 < npx; t0 += NW * NT) {
-      int base[NT], opix[NT];
-      bool pv[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int q = 16 * (t0 + nt) + p;
-        pv[nt] = q < npx;
-        const int qc = pv[nt] ? q : npx - 1;
-        const int r = qc / W, x = qc - r * W;
-        base[nt] = (r * WP4 + x) * CP;  // top-left of the 5x5 window
-        opix[nt] = (y0 + r) * W + x;
-      }
-      f32x4 acc[KC][NT];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        f32x4 d[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) d[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int ky = 0; ky < 5; ++ky) {  // one tap row at a time keeps the live LDS loads at 15
-          const float* wrow = WD + ky * 5 * KC * 16 + cb;
-          const float* trow = TIN + ky * WP4 * CP + cb;
-#pragma unroll
-          for (int kx = 0; kx < 5; ++kx) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * KC * 16);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(trow + base[nt] + kx * CP);
-#pragma unroll
-              for (int k = 0; k < 4; ++k) d[nt][k] = __builtin_fmaf(v[k], w[k], d[nt][k]);
-            }
-          }
-        }
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + cb);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + cb);
-        f32x4 bfr[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float u = __builtin_fmaf(d[nt][k], sc[k], sh[k]);  // channels >= 72: sc = sh = 0 -> 0
-            bfr[nt][k] = (cb < C && u > 0.f) ? u : 0.f;
-          }
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
-        }
-      }
-      // pointwise BN (no ReLU: fpn.py:16-17,23-24)
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 2 * 96 + 16 * mt + 4 * g);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 3 * 96 + 16 * mt + 4 * g);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc[mt][nt][k] = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
-      }
-      if constexpr (MH == 0) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (!pv[nt]) continue;
-          float* dst = a.out + ((size_t)b * HW + opix[nt]) * C;
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt)
-            if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
-        }
-      } else {
-        // chained output conv: acc[s] (channels 16s+4g..) is the B fragment of chunk s.  One
-        // output-channel tile at a time (single live accumulator pair, stored immediately).
-#pragma unroll 1
-        for (int m = 0; m < MH; ++m) {
-          f32x4 hacc[NT];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < KC; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                hacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], acc[s][nt][j], hacc[nt], 0, 0, 0);
-          }
-          const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 4 * 96 + 16 * m + 4 * g);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            if (!pv[nt]) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = 16 * m + 4 * g + r;
-              if (co < a.mh) {
-                const float y = hacc[nt][r] + bias[r];
-                if (co < a.split)
-                  a.nchw0[((size_t)b * a.split + co) * HW + opix[nt]] = y;
-                else
-                  a.nchw1[((size_t)b * (a.mh - a.split) + (co - a.split)) * HW + opix[nt]] = y;
-              }
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();  // TIN is restaged by the next item
-  }
-}
-
-static size_t tower_lds_floats(int mh_tiles, int R, int W) {
-  return (size_t)TW_WP_FL + (size_t)mh_tiles * TW_WH_FL + 25 * TW_KC * 16 + 5 * 96 + (size_t)(R + 4) * (W + 4) * TW_CP + 16;
-}
-
-int yfv2_tower_rows(int mh_tiles, int H, int W) {
-  int best = 1;
-  for (int r = 1; r <= H; ++r)
-    if (tower_lds_floats(mh_tiles, r, W) * 4 <= 158 * 1024) best = r;
-  // prefer an even split of the image rows
-  const int tiles = (H + best - 1) / best;
-  return (H + tiles - 1) / tiles;
-}
-
-template <int MH>
-static void launch_tower(const TowerArgs& a, hipStream_t s) {
-  const size_t lds = tower_lds_floats(MH, a.R, a.W) * sizeof(float);
-  const int tiles = (a.H + a.R - 1) / a.R;
-  int blocks = a.B * tiles;
-  if (blocks > 256) blocks = 256;  // persistent, one workgroup per CU (LDS-limited)
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel<MH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((tower_kernel<MH>), dim3(blocks), dim3(512), lds, s, a);
-}
-
-bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s) {
-  const int mh_tiles = a.has_head ? (a.mh + 15) / 16 : 0;
-  if (mh_tiles == 0) { launch_tower<0>(a, s); return true; }
-  if (mh_tiles == 1) { launch_tower<1>(a, s); return true; }
-  if (mh_tiles <= 6) { launch_tower<6>(a, s); return true; }
-  return false;
-}
 
 // ============================================================================
 // fused ShuffleV2 stride-2 block (first block of a stage)
@@ -937,7 +647,11 @@ bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
 // ============================================================================
 // tower half, version 2: one image per workgroup, channel-chunk loop outermost
 // ============================================================================
-// Same math as tower_kernel above.  A wave owns NT fixed 16-pixel tiles of the image and
+// Reference (model/fpn.py:12-25): DWConvblock = [dw5x5+BN+ReLU -> pw72+BN] x 2, and
+// model/detector.py:25-31 applies a biased 1x1 output conv to the block's result.  One launch =
+// one half: dw5x5 (pad 2) + BN + ReLU -> pw 72->72 + BN [-> output conv + bias, chained in
+// registers: the BN'd accumulator tile t IS the B fragment of chunk t of the output conv].
+// A wave owns NT fixed 16-pixel tiles of the image and
 // keeps their pointwise accumulators in registers while the workgroup walks the five
 // 16-channel chunks: per chunk only that channel slice of the (zero-haloed) input image
 // is in LDS (26x26x16 floats at 22x22 instead of a 10-row x 72-channel tile), staged with a
@@ -1136,6 +850,8 @@ static void launch_tower2(const TowerArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
+
+bool yfv2_tower2_supported(int H, int W) { return H * W <= 16 * 4 * 8; }
 
 // whole-image variant: needs H*W <= 16 * NT * waves and the staged slice to fit the thread grid
 bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s) {

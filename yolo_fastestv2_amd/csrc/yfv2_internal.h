@@ -81,7 +81,7 @@ struct TowerArgs {
   int has_head;      // chained output conv present
   int mh, split;     // co < split -> nchw0[b][co][hw], else nchw1[b][co-split][hw]
   float* nchw0; float* nchw1;
-  int B, H, W, R;
+  int B, H, W;
 };
 
 // ---- decode (handel_preds) and NMS
@@ -120,8 +120,7 @@ int yfv2_block_s1_rows(int c2, int H, int W);
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
 int yfv2_block_s2_rows(int cin, int H, int W);
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s);
-int yfv2_tower_rows(int mh_tiles, int H, int W);
-bool yfv2_launch_tower(const TowerArgs& a, hipStream_t s);
-bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s);  // whole-image variant (<= 22x22)
+bool yfv2_tower2_supported(int H, int W);                    // whole-image tower kernel: maps up to 22x22
+bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);

@@ -58,63 +58,93 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
   m = fmaxf(m, __shfl_xor(m, 1));
   m = fmaxf(m, __shfl_xor(m, 2));
   float sum = 0.f;
-  float* srow = stage + (size_t)lc * 3 * rowlen;
+  float ev[MAXPER];
 #pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
-    const int c = c_lo + i;
-    if (c < c_hi) {
-      const float e = expf(__fsub_rn(lv[i], m));
-      sum = __fadd_rn(sum, e);
-      if (ok) srow[5 + c] = e;  // normalised below
+    ev[i] = 0.f;
+    if (c_lo + i < c_hi) {
+      ev[i] = expf(__fsub_rn(lv[i], m));
+      sum = __fadd_rn(sum, ev[i]);
     }
   }
   sum = __fadd_rn(sum, __shfl_xor(sum, 1));
   sum = __fadd_rn(sum, __shfl_xor(sum, 2));
-  if (ok) {
-    for (int c = c_lo; c < c_hi; ++c) {
-      const float pr = __fdiv_rn(srow[5 + c], sum);
-      srow[5 + c] = pr;
-      srow[rowlen + 5 + c] = pr;  // the 3 anchors share the class scores (utils.py:324-326)
-      srow[2 * rowlen + 5 + c] = pr;
-    }
-    // ---- box + objectness for anchor `part` (App. B steps 2-4)
-    if (part < 3) {
-      const int an = part;
-      const int y = cell / fw, x = cell - y * fw;
-      const float* reg = a.reg[sc] + ((size_t)b * 12 + an * 4) * hw + cell;
-      const float t0 = reg[0], t1 = reg[(size_t)hw], t2 = reg[(size_t)2 * hw], t3 = reg[(size_t)3 * hw];
-      const float ob = a.obj[sc][((size_t)b * 3 + an) * hw + cell];
-      const float st = a.stride[sc];
-      float* o = srow + an * rowlen;
-      o[0] = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t0), 2.0f), 0.5f), (float)x), st);
-      o[1] = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t1), 2.0f), 0.5f), (float)y), st);
-      const float qw = __fmul_rn(sigmoid_f32(t2), 2.0f), qh = __fmul_rn(sigmoid_f32(t3), 2.0f);
-      // fp32 square, then a float64 multiply by the float64 anchor, one rounding to fp32
-      o[2] = (float)((double)__fmul_rn(qw, qw) * a.anchors[(sc * 3 + an) * 2 + 0]);
-      o[3] = (float)((double)__fmul_rn(qh, qh) * a.anchors[(sc * 3 + an) * 2 + 1]);
-      o[4] = sigmoid_f32(ob);
-    }
-  }
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXPER; ++i) ev[i] = __fdiv_rn(ev[i], sum);  // class probabilities of this lane's slice
+
+  // ---- box + objectness of anchor `an` at this cell (App. B steps 2-4)
+  auto box_of = [&](int an, float (&o)[5]) {
+    const int y = cell / fw, x = cell - y * fw;
+    const float* reg = a.reg[sc] + ((size_t)b * 12 + an * 4) * hw + cell;
+    const float t0 = reg[0], t1 = reg[(size_t)hw], t2 = reg[(size_t)2 * hw], t3 = reg[(size_t)3 * hw];
+    const float ob = a.obj[sc][((size_t)b * 3 + an) * hw + cell];
+    const float st = a.stride[sc];
+    o[0] = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t0), 2.0f), 0.5f), (float)x), st);
+    o[1] = __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t1), 2.0f), 0.5f), (float)y), st);
+    const float qw = __fmul_rn(sigmoid_f32(t2), 2.0f), qh = __fmul_rn(sigmoid_f32(t3), 2.0f);
+    // fp32 square, then a float64 multiply by the float64 anchor, one rounding to fp32
+    o[2] = (float)((double)__fmul_rn(qw, qw) * a.anchors[(sc * 3 + an) * 2 + 0]);
+    o[3] = (float)((double)__fmul_rn(qh, qh) * a.anchors[(sc * 3 + an) * 2 + 1]);
+    o[4] = sigmoid_f32(ob);
+  };
   const size_t row0 = (size_t)b * a.rows + (sc ? 3 * a.fh[0] * a.fw[0] : 0) + (size_t)cell0 * 3;
+
   if constexpr (COMPACT) {
-    // yfv2_detect path: emit only what NMS consumes - box, obj, conf = max_j fl32(cls_j*obj)
-    // (first maximal j, utils.py:261,267) and the class - as one 32-byte row; the 85-wide
-    // tensor (617 KB/image) is never written.  Same arithmetic as nms_kernel's filter.
-    if (ok && part < 3) {
-      const float* o = srow + part * rowlen;
-      const float obj = o[4];
-      float best = __fmul_rn(o[5], obj);
-      int bj = 0;
-      for (int j = 1; j < nc; ++j) {
-        const float pj = __fmul_rn(o[5 + j], obj);
-        if (pj > best) { best = pj; bj = j; }
+    // yfv2_detect path, all in registers (no LDS -> full occupancy): emit only what NMS consumes -
+    // box, obj, conf = max_j fl32(cls_j*obj) with the FIRST maximal j (utils.py:261,267) and the
+    // class - as one 32-byte row; the 85-wide tensor (617 KB/image) is never written.  Every lane
+    // scans its class slice for each of the 3 anchors, a 4-lane xor-shuffle picks the maximum
+    // with the lowest class index among equals (slices ascend with the lane).
+    float best[3];
+    int bj[3];
+#pragma unroll
+    for (int an = 0; an < 3; ++an) {
+      const float obj = sigmoid_f32(a.obj[sc][((size_t)b * 3 + an) * hw + cc]);
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < MAXPER; ++i)
+        if (c_lo + i < c_hi) {
+          const float pj = __fmul_rn(ev[i], obj);
+          if (pj > bv) { bv = pj; bi = c_lo + i; }  // strict: first maximal index of this slice
+        }
+#pragma unroll
+      for (int msk = 1; msk < 4; msk <<= 1) {
+        const float ob_ = __shfl_xor(bv, msk);
+        const int oi = __shfl_xor(bi, msk);
+        if (ob_ > bv || (ob_ == bv && oi < bi)) { bv = ob_; bi = oi; }
       }
+      best[an] = bv;
+      bj[an] = bi;
+    }
+    if (ok && part < 3) {
+      float o[5];
+      box_of(part, o);
       float* d = a.cand + (row0 + (size_t)lc * 3 + part) * 8;
       *reinterpret_cast<f32x4*>(d) = (f32x4){o[0], o[1], o[2], o[3]};
-      *reinterpret_cast<f32x4*>(d + 4) = (f32x4){obj, best, (float)bj, 0.f};
+      *reinterpret_cast<f32x4*>(d + 4) = (f32x4){o[4], best[part], (float)bj[part], 0.f};
     }
   } else {
+    float* srow = stage + (size_t)lc * 3 * rowlen;
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < MAXPER; ++i) {
+        const int c = c_lo + i;
+        if (c < c_hi) {
+          srow[5 + c] = ev[i];
+          srow[rowlen + 5 + c] = ev[i];  // the 3 anchors share the class scores (utils.py:324-326)
+          srow[2 * rowlen + 5 + c] = ev[i];
+        }
+      }
+      if (part < 3) {
+        float o[5];
+        box_of(part, o);
+        float* d = srow + part * rowlen;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] = o[k];
+      }
+    }
+    __syncthreads();
     float* dst = a.boxes + row0 * rowlen;
     const int n = ncell * 3 * rowlen;
     for (int i = tid; i < n; i += DEC_THREADS) dst[i] = stage[i];
@@ -132,7 +162,7 @@ void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
     attr_done = true;
   }
   if (a.cand)
-    hipLaunchKernelGGL(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
+    hipLaunchKernelGGL(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), 0, s, a, b0, b1);
   else
     hipLaunchKernelGGL(decode_kernel<false>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
 }
