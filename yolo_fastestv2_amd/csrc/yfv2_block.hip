@@ -25,6 +25,8 @@
 //
 // HBM traffic per block: read c*H*W, write c*H*W floats (plus halo re-reads served by
 // L2) instead of 3 reads + 3 writes of activations in the unfused plan.
+#include <cstdlib>
+
 #include "yfv2_internal.h"
 
 template <int C2>
@@ -859,6 +861,13 @@ bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s) {
   const int hw = a.H * a.W;
   if (hw <= 16 * 4 * 8 && hw * 4 <= 4 * 512) {           // up to 22x22: 512 threads, 4 tiles per wave
     if (hw > 16 * 1 * 8) {
+      // 16 waves x 2 tiles (<= 128 VGPRs) vs 8 waves x 4 tiles (<= 256 VGPRs): A/B switch
+      static const bool w16 = [] { const char* e = std::getenv("YFV2_TOWER_W16"); return e && e[0] == '1'; }();
+      if (w16) {
+        if (mh_tiles == 0) { launch_tower2<0, 1024, 2, 2>(a, s); return true; }
+        if (mh_tiles == 1) { launch_tower2<1, 1024, 2, 2>(a, s); return true; }
+        if (mh_tiles <= 6) { launch_tower2<6, 1024, 2, 2>(a, s); return true; }
+      }
       if (mh_tiles == 0) { launch_tower2<0, 512, 4, 4>(a, s); return true; }
       if (mh_tiles == 1) { launch_tower2<1, 512, 4, 4>(a, s); return true; }
       if (mh_tiles <= 6) { launch_tower2<6, 512, 4, 4>(a, s); return true; }
