@@ -36,15 +36,16 @@ constexpr int STEM_CS = 24;    // conv-ring floats per conv pixel
 constexpr int STEM_IOFF = 4;   // input-ring column of staged column 0
 constexpr int STEM_NPRE = 3;   // staged float4 per thread per iteration: ceil(4*3*SW4/256)
 
-// Column split: every band is cut into two overlapping column halves of th = ceil(ntiles/2)
-// 16-column conv tiles (352 wide: tiles 0..5 and 5..10, one tile recomputed).  A half needs
+// Column split: every band is cut into two overlapping column halves of th = ntiles/2 + 1
+// 16-column conv tiles (352 wide: tiles 0..5 and 5..10, one tile recomputed; the overlap gives the
+// right half the conv column just left of its first pooled pixel).  A half needs
 // only 40 KB of LDS, so four workgroups share a CU and hide each other's barriers and
 // pooling, and its 2*th tiles per iteration deal out evenly to the 4 waves.
 __global__ __launch_bounds__(STEM_THREADS, 4) void stem_kernel(StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int H = a.H, W = a.W, CW = W >> 1, PH = H >> 2, PW = W >> 2;
   const int ntiles = CW >> 4;            // W % 32 == 0, ntiles <= 12
-  const int th = (ntiles + 1) >> 1;      // tiles per half
+  const int th = (ntiles >> 1) + 1;      // tiles per half: the halves overlap by >= 1 tile, so the right half owns conv column 2*px-1 of its first pooled pixel
   const int SW = 32 * th + 4;            // staged input columns per row (multiple of 4)
   const int SW4 = SW >> 2;
   const int WI = SW + 8;                 // input-ring row: 4 pad | SW data | 4 pad
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(STEM_THREADS, 4) void stem_kernel(StemArgs a) {
   const int band = bb % bands, b = bb / bands;
   const int py0 = band * a.R;
   const int c0 = half ? 16 * (ntiles - th) : 0;    // first conv column of this half
-  const int sx0 = half ? 2 * c0 - 4 : 0;           // first staged input column (multiple of 4)
+  const int sx0 = (half && c0 > 0) ? 2 * c0 - 4 : 0;  // first staged input column (multiple of 4)
   const int px_lo = half ? 8 * th : 0;             // pooled columns written by this half
   const int px_hi = half ? PW : min(PW, 8 * th);
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(STEM_THREADS, 4) void stem_kernel(StemArgs a) {
       const int ci = rem / SW4, c4 = rem - ci * SW4;
       const int iy = iy_first + k, ix = sx0 + 4 * c4;
       pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (k < nrows && iy >= 0 && iy < H && ix < W) pre[j] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ci * H + iy) * W + ix);
+      if (k < nrows && iy >= 0 && iy < H && ix >= 0 && ix < W) pre[j] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ci * H + iy) * W + ix);
     }
   };
   auto stage_store = [&](int iy_first, int nrows, const f32x4 (&pre)[STEM_NPRE]) {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(STEM_THREADS, 4) void stem_kernel(StemArgs a) {
 
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
   const int bands = (a.H / 4) / a.R;
-  const int ntiles = (a.W / 2) / 16, th = (ntiles + 1) / 2;
+  const int ntiles = (a.W / 2) / 16, th = ntiles / 2 + 1;
   const size_t lds = sizeof(float) * ((size_t)5 * 3 * (32 * th + 4 + 8) + (size_t)3 * (16 * th + 2) * STEM_CS);
   hipLaunchKernelGGL(stem_kernel, dim3(a.B * bands * 2), dim3(STEM_THREADS), lds, s, a);
 }
