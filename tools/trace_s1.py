@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""YFV2_TRACE=1 python tools/trace_s1.py : cycle stamps (workgroup 0, thread 0) of the LAST fused
-stride-1 block launch of a forward (stage4.3, C2=96) and, with --stage3, of stage3.7."""
+"""YFV2_TRACE=1 python tools/trace_s1.py : cycle stamps (workgroup 0, thread 0) of the LAST launch of the
+block_s1 instantiation selected by YFV2_TRACE_C2 (default C2=48: stage3.7)."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,5 +19,5 @@ for B in (16, 256):
     _lib.lib().yfv2_debug_activation(eng._h, 100, B, C.c_void_p(buf.data_ptr()), 64)
     st = buf.view(torch.int64).tolist()
     d = [st[i] - st[0] for i in range(7)]
-    print("   tile stamps (entry, frags+stores, mfma+epilogue done, next raw arrived):", [st[i] - st[0] for i in range(8, 16)])
+    print("   staged+committed=%d  A-reads-done(last pass)=%d" % (st[8] - st[0], st[9] - st[0]))
     print("B=%d stamps (cycles since entry): copy_issued=%d prologue_done=%d waveA=%d phaseA=%d waveB=%d end=%d" % (B, d[1], d[2], d[3], d[4], d[5], d[6]))

@@ -46,7 +46,10 @@ struct S1Cfg {
   static constexpr int MAXU = C2 <= 24 ? 9 : (C2 <= 48 ? 9 : 4);    // (tile x channel-pair) units per wave
 };
 
-#define YFV2_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define YFV2_STAMP(i) do { if (C2 == YFV2_TRACE_C2 && a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifndef YFV2_TRACE_C2
+#define YFV2_TRACE_C2 48  // which block_s1 instantiation writes debug cycle stamps (YFV2_TRACE=1)
+#endif
 
 template <int C2, int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
