@@ -46,24 +46,18 @@ struct S1Cfg {
   static constexpr int MAXU = C2 <= 24 ? 9 : (C2 <= 48 ? 9 : 4);    // (tile x channel-pair) units per wave
 };
 
-#define YFV2_STAMP(i) do { if (C2 == YFV2_TRACE_C2 && a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
-#ifndef YFV2_TRACE_C2
-#define YFV2_TRACE_C2 48  // which block_s1 instantiation writes debug cycle stamps (YFV2_TRACE=1)
-#endif
+#define YFV2_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
-template <int C2, int THREADS, bool W2G = false>
+template <int C2, int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
   using Cfg = S1Cfg<C2>;
   constexpr int KC = Cfg::KC, CP = Cfg::CP, NTB = Cfg::NTB;
   constexpr int NW = THREADS / 64;
   constexpr int C = 2 * C2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // W2G: the second filter stays in global memory (fragment-major: one coalesced 1 KB load per
-  // fragment, L1/L2-resident) so that two workgroups fit on a CU and overlap each other's
-  // load / compute / store phases
   float* W1 = lds;
-  const float* W2 = W2G ? a.img + Cfg::W_FL : W1 + Cfg::W_FL;
-  float* WD = W1 + (W2G ? 1 : 2) * Cfg::W_FL;
+  float* W2 = W1 + Cfg::W_FL;
+  float* WD = W2 + Cfg::W_FL;
   float* CS = WD + Cfg::DW_FL;  // [6][KC*16]
   float* T1 = CS + Cfg::CST_FL;
   const int H = a.H, W = a.W, R = a.R;
@@ -78,7 +72,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
   const int tiles_per_img = (H + R - 1) / R;
   const int n_items = a.B * tiles_per_img;
   constexpr int QPP = C2 / 4;  // 32-byte input pairs (= 16-byte odd-channel quads) per pixel
-  constexpr int MAXP = (C2 == 48 && THREADS == 256) ? 14 : Cfg::MAXP;  // half-image / 256-thread variant
+  constexpr int MAXP = Cfg::MAXP;
   f32x4 st0[MAXP], st1[MAXP];
   auto stage_issue = [&](int item_, bool active) {  // always (re)defines every staged register
     const int item = active ? item_ : 0;
@@ -123,20 +117,15 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
   stage_issue(blockIdx.x, (int)blockIdx.x < n_items);
 
   // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
-  // yfv2_load_weights) is a straight coalesced 16-byte copy (W2G: the W2 segment is skipped)
+  // yfv2_load_weights) is one straight coalesced 16-byte copy
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    constexpr int SEG0 = Cfg::W_FL / 4;                                   // W1
-    constexpr int SKIP = W2G ? Cfg::W_FL / 4 : 0;                         // W2 (left in global)
-    constexpr int N4 = ((W2G ? 1 : 2) * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4;
-    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // every load is issued before the first store
+    constexpr int N4 = (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4;
+    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // <= 11: every load is issued before the first store
     f32x4 tmp[NIT];
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int i = tid + k * THREADS;
-      tmp[k] = i < N4 ? src[i < SEG0 ? i : i + SKIP] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
   }
@@ -325,38 +314,30 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
   }
 }
 
-template <int C2, int THREADS, bool W2G = false>
+template <int C2, int THREADS>
 static void launch_s1(const BlockS1Args& a, int blocks_per_cu, hipStream_t s) {
   using Cfg = S1Cfg<C2>;
-  const size_t lds = sizeof(float) * (size_t)((W2G ? 1 : 2) * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + (a.R + 2) * (a.W + 2) * Cfg::CP + 16);
+  const size_t lds = sizeof(float) * (size_t)(2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + (a.R + 2) * (a.W + 2) * Cfg::CP + 16);
   const int tiles = (a.H + a.R - 1) / a.R;
   int blocks = a.B * tiles;
   const int cap = 256 * blocks_per_cu;  // persistent: filters are staged once per workgroup
   if (blocks > cap) blocks = cap;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1_kernel<C2, THREADS, W2G>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1_kernel<C2, THREADS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((block_s1_kernel<C2, THREADS, W2G>), dim3(blocks), dim3(THREADS), lds, s, a);
-}
-
-// LDS budget decides the row tile: the whole image when it fits (no halo recompute).
-// C2 = 48 variant switch (A/B): half-image items, 256 threads, W2 in global -> two workgroups per CU
-static bool s1_48_half() {
-  static const bool v = [] { const char* e = std::getenv("YFV2_S1_48_HALF"); return e && e[0] == '1'; }();
-  return v;
+  hipLaunchKernelGGL((block_s1_kernel<C2, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 
 // LDS budget decides the row tile: the whole image when it fits (no halo recompute).
 int yfv2_block_s1_rows(int c2, int H, int W) {
   const int kc = (c2 + 15) / 16;
-  const bool half48 = c2 == 48 && s1_48_half();
-  const long fixed = (half48 ? 1L : 2L) * kc * kc * 256 + 9L * kc * 16 + 6L * kc * 16 + 16;
-  const long budget = ((c2 == 24 || half48) ? 78 : 158) * 1024 / 4;  // 78 KB: two workgroups per CU
-  const int threads = (c2 == 24 || half48) ? 256 : 512, nw = threads / 64, npair = (kc + 1) / 2;
-  const int maxp = half48 ? 14 : (c2 <= 24 ? S1Cfg<24>::MAXP : (c2 <= 48 ? S1Cfg<48>::MAXP : S1Cfg<96>::MAXP));
+  const long fixed = 2L * kc * kc * 256 + 9L * kc * 16 + 6L * kc * 16 + 16;
+  const long budget = (c2 == 24 ? 78 : 158) * 1024 / 4;  // C2=24 (44x44): two workgroups per CU
+  const int threads = c2 == 24 ? 256 : 512, nw = threads / 64, npair = (kc + 1) / 2;
+  const int maxp = c2 <= 24 ? S1Cfg<24>::MAXP : (c2 <= 48 ? S1Cfg<48>::MAXP : S1Cfg<96>::MAXP);
   const int maxu = c2 <= 24 ? S1Cfg<24>::MAXU : (c2 <= 48 ? S1Cfg<48>::MAXU : S1Cfg<96>::MAXU);
   int best = 0;
   for (int r = 1; r <= H; ++r) {
@@ -372,11 +353,7 @@ int yfv2_block_s1_rows(int c2, int H, int W) {
 
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
   if (c2 == 24) { launch_s1<24, 256>(a, 2, s); return true; }
-  if (c2 == 48) {
-    if (s1_48_half()) launch_s1<48, 256, true>(a, 2, s);
-    else launch_s1<48, 512>(a, 1, s);
-    return true;
-  }
+  if (c2 == 48) { launch_s1<48, 512>(a, 1, s); return true; }
   if (c2 == 96) { launch_s1<96, 512>(a, 1, s); return true; }
   return false;
 }
