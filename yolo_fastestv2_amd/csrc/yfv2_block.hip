@@ -861,13 +861,7 @@ bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s) {
   const int hw = a.H * a.W;
   if (hw <= 16 * 4 * 8 && hw * 4 <= 4 * 512) {           // up to 22x22: 512 threads, 4 tiles per wave
     if (hw > 16 * 1 * 8) {
-      // 16 waves x 2 tiles (<= 128 VGPRs) vs 8 waves x 4 tiles (<= 256 VGPRs): A/B switch
-      static const bool w16 = [] { const char* e = std::getenv("YFV2_TOWER_W16"); return e && e[0] == '1'; }();
-      if (w16) {
-        if (mh_tiles == 0) { launch_tower2<0, 1024, 2, 2>(a, s); return true; }
-        if (mh_tiles == 1) { launch_tower2<1, 1024, 2, 2>(a, s); return true; }
-        if (mh_tiles <= 6) { launch_tower2<6, 1024, 2, 2>(a, s); return true; }
-      }
+      // (a 16-wave x 2-tile variant at <= 128 VGPRs measured 5-8 % slower than 8 waves x 4 tiles)
       if (mh_tiles == 0) { launch_tower2<0, 512, 4, 4>(a, s); return true; }
       if (mh_tiles == 1) { launch_tower2<1, 512, 4, 4>(a, s); return true; }
       if (mh_tiles <= 6) { launch_tower2<6, 512, 4, 4>(a, s); return true; }
