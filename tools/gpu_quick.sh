@@ -5,5 +5,5 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
 SW=${1:-}
 echo "== parity ($SW)"
 env $SW timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider -k "stage_activations or real_images or random_weights or batch_invariance or end_to_end_survivors" 2>&1 | tail -6
-echo "== probe baseline"; timeout 200 python tools/scale_probe.py 256 2>&1 | grep -E "stage3.1|stage3.4|TOTAL"
-echo "== probe $SW"; env $SW timeout 200 python tools/scale_probe.py 256 2>&1 | grep -E "stage3.1|stage3.4|TOTAL"
+echo "== probe baseline"; timeout 200 python tools/scale_probe.py 256 2>&1 | grep -E "stem|stage2.0|stage3.0|stage3.1|TOTAL"
+echo "== probe $SW"; env $SW timeout 200 python tools/scale_probe.py 256 2>&1 | grep -E "stem|stage2.0|stage3.0|stage3.1|TOTAL"

@@ -372,12 +372,14 @@ constexpr int TW_WH_FL = TW_KC * 256;           // per output-conv M tile
 //   proj = ReLU(BN(pw(BN(dw3x3 s2(x)))))                       CIN -> CIN at H/2 x W/2
 //   main = ReLU(BN(pw2(BN(dw3x3 s2(ReLU(BN(pw1(x))))))))       CIN -> CIN
 //   out  = cat(proj, main)                                     2*CIN channels
-// Work item = (image, R output rows).  phase A: pw1 (+BN+ReLU) of the 2R+1 input rows the
-// tile's depthwise windows touch -> LDS tile T1 (left zero column, zero top row at the
-// image edge).  phase B: per 16 output pixels each lane forms the stride-2 depthwise
-// (+BN) of its pixel / its 4 channels in registers from T1 = B fragment of pw2.
-// phase C: the proj branch the same way, its depthwise taps read straight from the
-// (L1/L2-hot) input.  One launch replaces five and removes four intermediate tensors.
+// Work item = (image, R output rows).  stage: the 2R+1 raw input rows the tile's depthwise
+// windows touch are copied into the LDS tile T1 by all threads at once (left zero column, zero
+// top row at the image edge).  proj: per 16 output pixels each lane forms the stride-2
+// depthwise (+BN) of its pixel / its 4 channels in registers from T1 = B fragment of the proj
+// pointwise.  pw1 (+BN+ReLU) then overwrites T1 in place, and the main branch repeats the
+// depthwise -> pointwise step on it.  The input leaves HBM once (the first version gathered the
+// proj taps from global: 1.8x the algorithmic traffic by PMC); one launch replaces five and
+// removes four intermediate tensors.
 template <int CIN>
 struct S2Cfg {
   static constexpr int KC = (CIN + 15) / 16;
@@ -385,6 +387,9 @@ struct S2Cfg {
   static constexpr int W_FL = KC * KC * 256;  // fragment-major filter (see S1Cfg)
   static constexpr int DW_FL = 9 * KC * 16;
   static constexpr int NCS = 10;  // sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
+  // static bounds of the staged tile (512 threads, 8 waves), enforced by yfv2_block_s2_rows:
+  static constexpr int MAXP = 14;                     // staged 16-byte quads per thread
+  static constexpr int MAXT = CIN <= 24 ? 10 : 6;     // pw1 pixel tiles per wave
 };
 
 template <int CIN, int THREADS>
@@ -406,6 +411,45 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   const int t1_fl = (2 * R + 1) * WP * CP + 16;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
 
+  // ---- cooperative staging of one item's raw input tile (input rows 2*y0-1 .. 2*y0+2*rows-1):
+  // every thread requests up to MAXP 16-byte quads at once -> one global-latency round per item,
+  // overlapped with the LDS prologue (first item) or the previous item's tail
+  const int tiles_per_img = (OH + R - 1) / R;
+  const int n_items = a.B * tiles_per_img;
+  constexpr int QPP = CIN / 4;
+  constexpr int MAXP = Cfg::MAXP;
+  f32x4 st[MAXP];
+  auto stage_issue = [&](int item_, bool active) {  // always (re)defines every staged register
+    const int item = active ? item_ : 0;
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R, rows = min(R, OH - y0);
+    const int nq = active ? (2 * rows + 1) * W * QPP : 0;
+    const size_t in_px = (size_t)b * H * W;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      const int pix = i / QPP, q = i - pix * QPP;
+      const int r = pix / W, x = pix - r * W;
+      const int gy = 2 * y0 - 1 + r;
+      st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < nq && gy >= 0 && gy < H) st[j] = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)gy * W + x) * CIN + 4 * q);
+    }
+  };
+  auto stage_commit = [&](int item) {
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R, rows = min(R, OH - y0);
+    const int nq = (2 * rows + 1) * W * QPP;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      if (i >= nq) continue;
+      const int pix = i / QPP, q = i - pix * QPP;
+      const int r = pix / W, x = pix - r * W;
+      *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = st[j];
+    }
+  };
+  stage_issue(blockIdx.x, (int)blockIdx.x < n_items);
+
   // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
   // yfv2_load_weights) is one straight coalesced 16-byte copy
   {
@@ -422,8 +466,6 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   for (int i = tid; i < t1_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // column 0 (input col -1) stays zero
   __syncthreads();
 
-  const int tiles_per_img = (OH + R - 1) / R;
-  const int n_items = a.B * tiles_per_img;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R;                 // first output row
@@ -431,144 +473,55 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     const int iy0 = 2 * y0 - 1;            // first input row of T1
     const size_t in_px = (size_t)b * H * W;
     const size_t out_px = (size_t)b * OH * OW;
-
-    // ================= phase A: pw1 (+BN+ReLU) over input rows iy0 .. iy0 + 2*rows
-    // (one-tile-ahead software pipeline on the global loads, as in the stride-1 block)
     const int npxA = (2 * rows + 1) * W;
-    auto geomA = [&](int t, bool& valid, bool& inimg, int& r, int& x, size_t& gp) {
-      const int q = 16 * t + p;
-      valid = q < npxA;
-      r = q / W;
-      x = q - r * W;
-      const int gy = iy0 + r;
-      inimg = valid && gy >= 0 && gy < H;
-      gp = inimg ? in_px + (size_t)gy * W + x : in_px;
-    };
-    auto loadA = [&](size_t gp, f32x4 (&raw)[KC]) {
-      const float* src = a.in + gp * CIN;
-#pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        raw[s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    };
-    f32x4 bf[KC], bn[KC];
-    if (wave * 16 < npxA) {
-      bool v_, i_; int r_, x_; size_t gp_;
-      geomA(wave, v_, i_, r_, x_, gp_);
-      loadA(gp_, bf);
-    }
-    for (int t = wave; t * 16 < npxA; t += NW) {
-      bool valid, inimg; int r, x; size_t gp;
-      geomA(t, valid, inimg, r, x, gp);
-      if ((t + NW) * 16 < npxA) {
-        bool v_, i_; int r_, x_; size_t gp_;
-        geomA(t + NW, v_, i_, r_, x_, gp_);
-        loadA(gp_, bn);
-      }
-      float* dst = T1 + (r * WP + x + 1) * CP;
-      // all filter fragments first (distinct registers), then KC independent MFMA chains interleaved
-      f32x4 afA[KC][KC], accA[KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KC; ++s) afA[mt][s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < KC; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt)
-            accA[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afA[mt][s][j], bf[s][j], accA[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        const f32x4 acc = accA[mt];
-        const int cb = 16 * mt + 4 * g;
-        if (valid && cb < CIN) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KS + cb);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KS + cb);
-          f32x4 y;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
-            y[k] = (inimg && u > 0.f) ? u : 0.f;  // input row -1 is the depthwise zero padding
-          }
-          *reinterpret_cast<f32x4*>(dst + cb) = y;
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < KC; ++s) bf[s] = bn[s];
-    }
+    const int npxB = rows * OW;
+
+    // ---- stage: the raw input rows iy0 .. iy0+2*rows (requested before the prologue / at the
+    // end of the previous item) land in T1; rows above the image and column -1 are zero
+    stage_commit(item);
     __syncthreads();
 
-    // ================= phases B (main) and C (proj): depthwise s2 in registers -> pointwise
-    const int npxB = rows * OW;
-#pragma unroll 1
-    for (int branch = 0; branch < 2; ++branch) {
+    // ---- one depthwise(s2, 3x3, +BN) -> pointwise(+BN+ReLU) branch over the tile's output pixels,
+    // depthwise taps read from T1: branch 1 = proj on the RAW input (T1 as staged),
+    // branch 0 = main on pw1's output (T1 after the in-place pass below)
+    auto dw_pw_branch = [&](const int branch) {
       const float* taps = branch == 0 ? WD : WE;
       const float* wmat = branch == 0 ? W2 : WJ;
       const float* dsc_p = CS + (branch == 0 ? 2 : 6) * KS;
       const float* dsh_p = CS + (branch == 0 ? 3 : 7) * KS;
       const float* psc_p = CS + (branch == 0 ? 4 : 8) * KS;
       const float* psh_p = CS + (branch == 0 ? 5 : 9) * KS;
-      f32x4 wk[KC][9], dsc[KC], dsh[KC];
-#pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wk[s][k] = *reinterpret_cast<const f32x4*>(taps + k * KS + cb);
-        dsc[s] = *reinterpret_cast<const f32x4*>(dsc_p + cb);
-        dsh[s] = *reinterpret_cast<const f32x4*>(dsh_p + cb);
-      }
       for (int t = wave; t * 16 < npxB; t += NW) {
         const int q = 16 * t + p;
         const bool pv = q < npxB;
         const int qc = pv ? q : npxB - 1;
         const int r = qc / OW, x = qc - r * OW;
         const int oy = y0 + r;
+        const float* tp = T1 + ((2 * r) * WP + 2 * x) * CP;  // window rows 2r..2r+2, T1 cols 2x..2x+2
         f32x4 bfr[KC];
-        if (branch == 0) {
-          const float* tp = T1 + ((2 * r) * WP + 2 * x) * CP;  // window rows 2r..2r+2, T1 cols 2x..2x+2
+#pragma unroll 1
+        for (int s = 0; s < KC; ++s) {
+          const int cb = 16 * s + 4 * g;
+          f32x4 win[9], wk[9];  // the chunk's window and taps in flight together, then the FMAs
 #pragma unroll
-          for (int s = 0; s < KC; ++s) {
-            const int cb = 16 * s + 4 * g;
-            f32x4 win[9];  // the chunk's 9 window taps in flight together, then the FMAs
-#pragma unroll
-            for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(tp + ((k / 3) * WP + (k % 3)) * CP + cb);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-#pragma unroll
-              for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wk[s][k][c], d[c]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bfr[s][k] = cb < CIN ? __builtin_fmaf(d[k], dsc[s][k], dsh[s][k]) : 0.f;
+          for (int k = 0; k < 9; ++k) {
+            win[k] = *reinterpret_cast<const f32x4*>(tp + ((k / 3) * WP + (k % 3)) * CP + cb);
+            wk[k] = *reinterpret_cast<const f32x4*>(taps + k * KS + cb);
           }
-        } else {
-          // proj: taps from the raw input; only input row -1 / col -1 can be outside (pad 1, stride 2)
-          const int iy = 2 * oy - 1, ix = 2 * x - 1;
+          const f32x4 dsc = *reinterpret_cast<const f32x4*>(dsc_p + cb);
+          const f32x4 dsh = *reinterpret_cast<const f32x4*>(dsh_p + cb);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < KC; ++s) {
-            const int cb = 16 * s + 4 * g;
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            if (cb < CIN) {
+          for (int k = 0; k < 9; ++k)
 #pragma unroll
-              for (int ky = 0; ky < 3; ++ky)
+            for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wk[k][c], d[c]);
+          f32x4 y;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                  const int yy = iy + ky, xx = ix + kx;
-                  const bool ok = yy >= 0 && xx >= 0;
-                  const f32x4 v = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)(ok ? yy : 0) * W + (ok ? xx : 0)) * CIN + cb);
-#pragma unroll
-                  for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(ok ? v[k] : 0.f, wk[s][ky * 3 + kx][k], d[k]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bfr[s][k] = cb < CIN ? __builtin_fmaf(d[k], dsc[s][k], dsh[s][k]) : 0.f;
-          }
+          for (int c = 0; c < 4; ++c) y[c] = cb < CIN ? __builtin_fmaf(d[c], dsc[c], dsh[c]) : 0.f;
+          if (s == 0) bfr[0] = y;
+          if (KC > 1 && s == 1) bfr[KC > 1 ? 1 : 0] = y;
+          if (KC > 2 && s == 2) bfr[KC > 2 ? 2 : 0] = y;
         }
         float* dst = a.out + (out_px + (size_t)oy * OW + x) * CO + (branch == 0 ? CIN : 0);
         f32x4 afB[KC][KC], accB[KC];
@@ -588,7 +541,6 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
               accB[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afB[mt][s][j], bfr[s][j], accB[mt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) {
-          const f32x4 acc = accB[mt];
           const int cb = 16 * mt + 4 * g;
           if (pv && cb < CIN) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(psc_p + cb);
@@ -596,15 +548,87 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
             f32x4 y;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float u = __builtin_fmaf(acc[k], sc[k], sh[k]);
+              const float u = __builtin_fmaf(accB[mt][k], sc[k], sh[k]);
               y[k] = u > 0.f ? u : 0.f;
             }
             *reinterpret_cast<f32x4*>(dst + cb) = y;
           }
         }
       }
+    };
+
+    // ================= proj branch first: its depthwise reads the raw tile
+    dw_pw_branch(1);
+    __syncthreads();
+
+    // ================= pw1 (+BN+ReLU) IN PLACE over the staged tile, two passes over the wave's
+    // tiles: B fragments out of T1 into registers, barrier, MFMAs, results overwrite the pixels
+    constexpr int MAXT = Cfg::MAXT, TP = (MAXT + 1) / 2;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      f32x4 bfu[TP][KC];
+#pragma unroll
+      for (int k = 0; k < TP; ++k) {
+        const int t = wave + (pass * TP + k) * NW;
+        const int q = 16 * (t * 16 < npxA ? t : 0) + p;
+        const int qc = q < npxA ? q : npxA - 1;
+        const int r = qc / W, x = qc - r * W;
+        const float* src = T1 + (r * WP + x + 1) * CP;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          const int cb = 16 * s + 4 * g;
+          bfu[k][s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < TP; ++k) {
+        const int t = wave + (pass * TP + k) * NW;
+        if (t * 16 >= npxA) continue;  // wave-uniform
+        const int q = 16 * t + p;
+        const bool valid = q < npxA;
+        const int r = q / W, x = q - r * W;
+        const int gy = iy0 + r;
+        const bool inimg = valid && gy >= 0 && gy < H;
+        float* dst = T1 + (r * WP + x + 1) * CP;
+        f32x4 afA[KC][KC], accA[KC];
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KC; ++s) afA[mt][s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < KC; ++mt)
+              accA[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afA[mt][s][j], bfu[k][s][j], accA[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const int cb = 16 * mt + 4 * g;
+          if (valid && cb < CIN) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KS + cb);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KS + cb);
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float u = __builtin_fmaf(accA[mt][c], sc[c], sh[c]);
+              y[c] = (inimg && u > 0.f) ? u : 0.f;  // input row -1 is the depthwise zero padding
+            }
+            *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();  // T1 is rewritten by the next item's phase A
+
+    // ================= main branch: depthwise on pw1's output
+    dw_pw_branch(0);
+    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);  // next item's tile flies across the barrier
+    __syncthreads();  // T1 is restaged by the next item
   }
 }
 
@@ -623,7 +647,11 @@ int yfv2_block_s2_rows(int cin, int H, int W) {
   }
   if (best == 0) return 0;
   const int tiles = (OH + best - 1) / best;
-  return (OH + tiles - 1) / tiles;  // even split
+  int R = (OH + tiles - 1) / tiles;  // even split
+  // static bounds of the staged kernel (512 threads, 8 waves)
+  const int maxt = cin == 24 ? S2Cfg<24>::MAXT : S2Cfg<48>::MAXT;
+  while (R > 0 && ((long)(2 * R + 1) * W * (cin / 4) > 14L * 512 || ((2 * R + 1) * W + 15) / 16 > 8 * maxt)) --R;
+  return R;
 }
 
 template <int CIN>
