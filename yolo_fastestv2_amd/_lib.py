@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyfv2.so")
+# YFV2_LIB: opt-in override used only for same-box A/B of two builds (tools/gpu_quick.sh)
+LIB_PATH = os.environ.get("YFV2_LIB") or os.path.join(_HERE, "libyfv2.so")
 ABI_VERSION = 1
 MAX_DET = 300
 
