@@ -479,7 +479,6 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     // ---- stage: the raw input rows iy0 .. iy0+2*rows (requested before the prologue / at the
     // end of the previous item) land in T1; rows above the image and column -1 are zero
     stage_commit(item);
-    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);  // next item's tile: its load round overlaps this item's compute
     __syncthreads();
 
     // ---- one depthwise(s2, 3x3, +BN) -> pointwise(+BN+ReLU) branch over the tile's output pixels,
@@ -628,6 +627,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
 
     // ================= main branch: depthwise on pw1's output
     dw_pw_branch(0);
+    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);  // next item's tile flies across the barrier
     __syncthreads();  // T1 is restaged by the next item
   }
 }
