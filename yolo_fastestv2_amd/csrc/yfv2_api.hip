@@ -266,25 +266,17 @@ struct WeightPacker {
     push_vec(im, fh ? &blob[fh->shift] : nullptr, mh, 96);
     return put(im);
   }
-  // stem_kernel: lane-major fragments [64][32]: af[2][7] (+2 pad), sc[2][4], sh[2][4]
+  // stem_px_kernel: filter registers in the 4x4x1 broadcast form [11][64]: register q, lane 4j+i holds
+  // scale[co] * W[co = 4m+i][k] for (m*27 + k) = 16q + j, k = ky*9 + ci*3 + kx; then shift[24]
   size_t image_stem(const Folded& f) {
-    std::vector<float> im(64 * 32, 0.f);
-    const float* w = &blob[f.w];  // [27 taps][24 co]
-    for (int lane = 0; lane < 64; ++lane) {
-      const int p = lane & 15, g = lane >> 4;
-      float* d = &im[(size_t)lane * 32];
-      for (int mt = 0; mt < 2; ++mt)
-        for (int ks = 0; ks < 7; ++ks) {
-          const int co = 16 * mt + p, k = 4 * ks + g;
-          d[mt * 8 + ks] = (co < 24 && k < 27) ? w[k * 24 + co] : 0.f;
-        }
-      for (int mt = 0; mt < 2; ++mt)
-        for (int r = 0; r < 4; ++r) {
-          const int co = 16 * mt + 4 * g + r;
-          d[16 + mt * 4 + r] = co < 24 ? blob[f.scale + co] : 0.f;
-          d[24 + mt * 4 + r] = co < 24 ? blob[f.shift + co] : 0.f;
-        }
-    }
+    std::vector<float> im(11 * 64 + 24, 0.f);
+    const float* w = &blob[f.w];  // [27 taps t = ci*9 + ky*3 + kx][24 co]
+    for (int idx = 0; idx < 162; ++idx)
+      for (int i = 0; i < 4; ++i) {
+        const int co = 4 * (idx / 27) + i, k = idx % 27, ky = k / 9, ci = (k % 9) / 3, kx = k % 3;
+        im[(idx >> 4) * 64 + 4 * (idx & 15) + i] = w[(ci * 9 + ky * 3 + kx) * 24 + co] * blob[f.scale + co];
+      }
+    for (int co = 0; co < 24; ++co) im[11 * 64 + co] = blob[f.shift + co];
     return put(im);
   }
 };
@@ -305,10 +297,7 @@ struct PlanBuilder {
     s.stem.out = out.p;
     s.stem.H = h->cfg.height;
     s.stem.W = h->cfg.width;
-    const int ph = h->cfg.height / 4;
-    int R = 11;  // pooled rows per band: halo recompute (2R+1)/(2R)
-    while (ph % R) --R;
-    s.stem.R = R;
+    s.stem.R = 0;  // bands are chosen by the launcher
     s.img_off = wp.image_stem(f);
     s.name = "stem conv3x3s2+bn+relu+maxpool3x3s2";
     const double ch = h->cfg.height / 2.0, cw = h->cfg.width / 2.0;
@@ -877,9 +866,9 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
 }
 
 int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap) {
-  if (h && which == 100 && h->d_trace && host_dst && cap >= 64) {  // debug: 32 cycle stamps as int64 in 64 floats
+  if (h && which == 100 && h->d_trace && host_dst && cap >= 128) {  // debug: 64 cycle stamps as int64 in 128 floats
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host_dst, h->d_trace, 32 * sizeof(long long), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host_dst, h->d_trace, 64 * sizeof(long long), hipMemcpyDeviceToHost);
     return 64;
   }
   if (!h || which < 0 || which > 5 || !h->dbg[which] || B < 1 || B > h->cfg.max_batch) {

@@ -1,5 +1,5 @@
 // yfv2_conv.hip - gfx950 (CDNA4, wave64) kernels of the Yolo-FastestV2 forward:
-//   stem_kernel : conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2   (implicit GEMM on the fp32 MFMA)
+//   (the stem lives in yfv2_stem.hip)
 //   pw_kernel   : every pointwise 1x1 conv (+BN, +ReLU) on v_mfma_f32_16x16x4_f32,
 //                 with channel-shuffle / concat / nearest-upsample / NCHW-head
 //                 folded into its operand loads and stores
@@ -13,226 +13,6 @@
 // and stores are 16 B per lane; the API surface stays NCHW (input image and the
 // six logit maps).
 #include "yfv2_internal.h"
-
-// ============================================================================
-// stem: conv3x3 s2 + BN + ReLU + maxpool3x3 s2
-// ============================================================================
-// One workgroup (4 waves) = one band of R pooled rows of one image, streamed top to
-// bottom one pooled row (= two conv rows = four new input rows) per iteration:
-//   stage   the 4 new input rows x 3 channels are copied NCHW -> LDS input ring with
-//           coalesced 16-byte loads that were issued one iteration earlier (register
-//           prefetch); the image border is plain zero padding in LDS (row -1, column -1)
-//   conv    each 16-pixel tile of the two conv rows is an implicit GEMM on the fp32 MFMA:
-//             D[co][pixel] = sum_k W[co][k] * patch[k][pixel],  K = 27 taps (padded to 28 =
-//             7 steps of v_mfma_f32_16x16x4_f32), M = 24 channels (2 tiles, 8 rows idle)
-//           A (the filter) lives in 14 VGPRs per lane for the whole kernel; B is gathered
-//           from the LDS input ring (lane = pixel, one tap per k-step).  A direct global
-//           gather of these stride-2 dwords is bound by the texture-address rate (measured
-//           320 us/launch), LDS serves them at 2-way bank conflicts.
-//   pool    BN+ReLU rows sit in a 3-row LDS conv ring; the block max-pools the ring into one
-//           NHWC output row, so the 24x176x176 conv map (2.97 MB/image) never touches HBM.
-constexpr int STEM_THREADS = 256;
-constexpr int STEM_CS = 24;    // conv-ring floats per conv pixel
-constexpr int STEM_IOFF = 4;   // input-ring column of staged column 0
-constexpr int STEM_NPRE = 3;   // staged float4 per thread per iteration: ceil(4*3*SW4/256)
-
-// Column split: every band is cut into two overlapping column halves of th = ntiles/2 + 1
-// 16-column conv tiles (352 wide: tiles 0..5 and 5..10, one tile recomputed; the overlap gives the
-// right half the conv column just left of its first pooled pixel).  A half needs
-// only 40 KB of LDS, so four workgroups share a CU and hide each other's barriers and
-// pooling, and its 2*th tiles per iteration deal out evenly to the 4 waves.
-__global__ __launch_bounds__(STEM_THREADS, 4) void stem_kernel(StemArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int H = a.H, W = a.W, CW = W >> 1, PH = H >> 2, PW = W >> 2;
-  const int ntiles = CW >> 4;            // W % 32 == 0, ntiles <= 12
-  const int th = (ntiles >> 1) + 1;      // tiles per half: the halves overlap by >= 1 tile, so the right half owns conv column 2*px-1 of its first pooled pixel
-  const int SW = 32 * th + 4;            // staged input columns per row (multiple of 4)
-  const int SW4 = SW >> 2;
-  const int WI = SW + 8;                 // input-ring row: 4 pad | SW data | 4 pad
-  const int SR = 3 * WI;                 // one input row, 3 channels
-  const int RC = 16 * th + 2;            // conv-ring columns: 1 pad | 16*th | 1 pad
-  float* iring = lds;                    // [5 rows][3][WI]
-  float* ring = lds + 5 * SR;            // conv ring [3][RC][STEM_CS]
-  const int RS = RC * STEM_CS;
-  const int bands = PH / a.R;
-  const int half = blockIdx.x & 1;
-  const int bb = blockIdx.x >> 1;
-  const int band = bb % bands, b = bb / bands;
-  const int py0 = band * a.R;
-  const int c0 = half ? 16 * (ntiles - th) : 0;    // first conv column of this half
-  const int sx0 = (half && c0 > 0) ? 2 * c0 - 4 : 0;  // first staged input column (multiple of 4)
-  const int px_lo = half ? 8 * th : 0;             // pooled columns written by this half
-  const int px_hi = half ? PW : min(PW, 8 * th);
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const float* __restrict__ xb = a.x + (size_t)b * 3 * H * W;
-
-  // A fragments af[mt][ks] = W[co = 16mt + p][k = 4ks + g] and the BN constants of the D rows
-  // this lane owns (co = 16mt + 4g + r), pre-packed lane-major on the host: 8 independent
-  // 16-byte loads instead of 30 guarded scalar ones
-  float af[2][7];
-  f32x4 sc[2], sh[2];
-  {
-    const f32x4* im = reinterpret_cast<const f32x4*>(a.img + lane * 32);
-    const f32x4 q0 = im[0], q1 = im[1], q2 = im[2], q3 = im[3];
-    af[0][0] = q0[0]; af[0][1] = q0[1]; af[0][2] = q0[2]; af[0][3] = q0[3];
-    af[0][4] = q1[0]; af[0][5] = q1[1]; af[0][6] = q1[2];
-    af[1][0] = q2[0]; af[1][1] = q2[1]; af[1][2] = q2[2]; af[1][3] = q2[3];
-    af[1][4] = q3[0]; af[1][5] = q3[1]; af[1][6] = q3[2];
-    sc[0] = im[4]; sc[1] = im[5]; sh[0] = im[6]; sh[1] = im[7];
-  }
-  // tap of k-step ks for this lane group: k = 4ks + g -> (ci, ky, kx); k = 27 is the zero-weight pad
-  int tky[7], tofs[7];
-#pragma unroll
-  for (int ks = 0; ks < 7; ++ks) {
-    const int k = 4 * ks + g, kk = k < 27 ? k : 26;
-    const int ci = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
-    tky[ks] = ky;
-    tofs[ks] = ci * WI + kx + STEM_IOFF - 1 - sx0;  // + 2*cx + slot(row) * SR   (input col 2cx-1+kx)
-  }
-
-  // zero both rings once: pad columns (image border / conv-ring border) stay zero forever
-  for (int i = tid; i < (5 * SR + 3 * RS) / 4; i += STEM_THREADS) reinterpret_cast<f32x4*>(lds)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- staging of input rows [iy_first, iy_first + nrows) x columns [sx0, sx0 + SW) into the input ring
-  const int per_row = 3 * SW4;
-  auto stage_load = [&](int iy_first, int nrows, f32x4 (&pre)[STEM_NPRE]) {
-#pragma unroll
-    for (int j = 0; j < STEM_NPRE; ++j) {
-      const int i = tid + j * STEM_THREADS;
-      const int k = i / per_row, rem = i - k * per_row;
-      const int ci = rem / SW4, c4 = rem - ci * SW4;
-      const int iy = iy_first + k, ix = sx0 + 4 * c4;
-      pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (k < nrows && iy >= 0 && iy < H && ix >= 0 && ix < W) pre[j] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ci * H + iy) * W + ix);
-    }
-  };
-  auto stage_store = [&](int iy_first, int nrows, const f32x4 (&pre)[STEM_NPRE]) {
-#pragma unroll
-    for (int j = 0; j < STEM_NPRE; ++j) {
-      const int i = tid + j * STEM_THREADS;
-      const int k = i / per_row, rem = i - k * per_row;
-      const int ci = rem / SW4, c4 = rem - ci * SW4;
-      const int iy = iy_first + k;
-      if (k < nrows) *reinterpret_cast<f32x4*>(iring + ((iy + 5) % 5) * SR + ci * WI + STEM_IOFF + 4 * c4) = pre[j];
-    }
-  };
-  // ---- one 16-pixel conv tile: gather from the input ring, 14 MFMAs, BN + ReLU, store to conv ring
-  auto conv_tile = [&](int cy, int cx, float* row) {
-    const int r0 = 2 * cy - 1 + 5;  // input row of ky = 0, biased so that % is on a non-negative value
-    const int s0 = (r0 % 5) * SR, s1 = ((r0 + 1) % 5) * SR, s2 = ((r0 + 2) % 5) * SR;
-    float bv[7];
-#pragma unroll
-    for (int ks = 0; ks < 7; ++ks) bv[ks] = iring[(tky[ks] == 0 ? s0 : (tky[ks] == 1 ? s1 : s2)) + tofs[ks] + 2 * cx];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 7; ++ks) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], bv[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], bv[ks], acc1, 0, 0, 0);
-    }
-    f32x4 y0, y1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
-      const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
-      y0[r] = u0 > 0.f ? u0 : 0.f;
-      y1[r] = u1 > 0.f ? u1 : 0.f;
-    }
-    float* dst = row + (cx - c0 + 1) * STEM_CS + 4 * g;
-    *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
-    if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
-  };
-
-  f32x4 pre[STEM_NPRE];
-  // prologue: conv row 2*py0-1 needs input rows 4*py0-3 .. 4*py0-1 (zeros above the image)
-  stage_load(4 * py0 - 3, 3, pre);
-  __syncthreads();  // ring zero-fill complete
-  stage_store(4 * py0 - 3, 3, pre);
-  stage_load(4 * py0, 4, pre);  // first iteration's rows: in flight during the prologue conv
-  __syncthreads();
-  if (py0 > 0)  // for py0 == 0 conv row -1 is the max-pool padding: ring slot 0 stays zero
-    for (int t = wave; t < th; t += 4) conv_tile(2 * py0 - 1, c0 + 16 * t + p, ring);
-
-  int old = 0;  // conv-ring slot of conv row 2py-1
-  for (int py = py0; py < py0 + a.R; ++py) {
-    float* r0 = ring + old * RS;
-    float* r1 = ring + ((old + 1) % 3) * RS;
-    float* r2 = ring + ((old + 2) % 3) * RS;
-    __syncthreads();  // previous conv phase has finished reading the input ring / pooling the conv ring
-    stage_store(4 * py, 4, pre);
-    if (py + 1 < py0 + a.R) stage_load(4 * (py + 1), 4, pre);  // flies during conv + pool
-    __syncthreads();
-    // the 2*th (<= 12) tiles of conv rows 2py, 2py+1 are dealt round-robin to the 4 waves: all
-    // gathers of the wave's (<= 3) tiles are issued first, then the MFMAs run back to back
-    {
-      constexpr int TPW = 3;
-      float bvs[TPW][7];
-      int tcx[TPW];
-      float* trow[TPW];
-      bool tok[TPW];
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int u = wave + 4 * i;
-        tok[i] = u < 2 * th;
-        const int uc = tok[i] ? u : 0;
-        const int rr = uc >= th ? 1 : 0;
-        const int cy = 2 * py + rr;
-        tcx[i] = c0 + 16 * (uc - rr * th) + p;
-        trow[i] = rr ? r2 : r1;
-        const int rb = 2 * cy - 1 + 5;
-        const int s0 = (rb % 5) * SR, s1 = ((rb + 1) % 5) * SR, s2 = ((rb + 2) % 5) * SR;
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) bvs[i][ks] = iring[(tky[ks] == 0 ? s0 : (tky[ks] == 1 ? s1 : s2)) + tofs[ks] + 2 * tcx[i]];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        if (!tok[i]) continue;  // wave-uniform
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], bvs[i][ks], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], bvs[i][ks], acc1, 0, 0, 0);
-        }
-        f32x4 y0, y1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float u0 = __builtin_fmaf(acc0[r], sc[0][r], sh[0][r]);
-          const float u1 = __builtin_fmaf(acc1[r], sc[1][r], sh[1][r]);
-          y0[r] = u0 > 0.f ? u0 : 0.f;
-          y1[r] = u1 > 0.f ? u1 : 0.f;
-        }
-        float* dst = trow[i] + (tcx[i] - c0 + 1) * STEM_CS + 4 * g;
-        *reinterpret_cast<f32x4*>(dst) = y0;                 // channels 4g .. 4g+3
-        if (g < 2) *reinterpret_cast<f32x4*>(dst + 16) = y1;  // channels 16+4g .. (< 24)
-      }
-    }
-    __syncthreads();
-    float* orow = a.out + ((size_t)(b * PH + py) * PW) * 24;
-    for (int i = tid; i < (px_hi - px_lo) * 6; i += STEM_THREADS) {
-      const int px = px_lo + i / 6, q = i % 6;
-      const int base = (2 * px - c0) * STEM_CS + 4 * q;  // conv col 2px-1 sits at ring col 2px-c0
-      f32x4 m = *reinterpret_cast<const f32x4*>(r0 + base);
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int o = base + dx * STEM_CS;
-        const f32x4 u0 = *reinterpret_cast<const f32x4*>(r0 + o);
-        const f32x4 u1 = *reinterpret_cast<const f32x4*>(r1 + o);
-        const f32x4 u2 = *reinterpret_cast<const f32x4*>(r2 + o);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], u0[k]), fmaxf(u1[k], u2[k]));
-      }
-      *reinterpret_cast<f32x4*>(orow + (size_t)px * 24 + 4 * q) = m;
-    }
-    old = (old + 2) % 3;
-  }
-}
-
-void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
-  const int bands = (a.H / 4) / a.R;
-  const int ntiles = (a.W / 2) / 16, th = ntiles / 2 + 1;
-  const size_t lds = sizeof(float) * ((size_t)5 * 3 * (32 * th + 4 + 8) + (size_t)3 * (16 * th + 2) * STEM_CS);
-  hipLaunchKernelGGL(stem_kernel, dim3(a.B * bands * 2), dim3(STEM_THREADS), lds, s, a);
-}
 
 // ============================================================================
 // pointwise 1x1 conv on the fp32 matrix cores

@@ -11,9 +11,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct StemArgs {
   const float* x;      // (B,3,H,W)
   float* out;          // (B,H/4,W/4,24)
-  const float* img;    // lane-major fragment image [64 lanes][32]: af[2][7] (+2 pad), sc[2][4], sh[2][4]
+  const float* img;    // broadcast-form filter [11 regs][64 lanes] (BN scale folded) + shift[24], see WeightPacker::image_stem
   int B, H, W;
-  int R;               // pooled rows per band (H/4 % R == 0)
+  int R;               // pooled rows per band (set by the launcher, divides H/4)
 };
 
 // ---- pointwise 1x1 conv on the fp32 MFMA, NHWC
