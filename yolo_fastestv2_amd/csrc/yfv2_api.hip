@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_REPACK = 6, STEP_S1PX = 7 };
 
 struct Step {
   int kind = 0;
@@ -37,6 +37,8 @@ struct Step {
   BlockS1Args s1{};
   TowerArgs tw{};
   BlockS2Args s2{};
+  S1PxArgs s1px{};
+  const float* rp_in = nullptr; float* rp_out = nullptr; int rp_hw = 0;   // STEP_REPACK
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
   // offsets into the param blob, resolved to pointers after the upload
@@ -66,6 +68,11 @@ struct yfv2_ctx {
 
   // workspace (NHWC fp32), sized for cfg.max_batch
   Buf a1, s2[2], s3[2], s4[2], t1, t2, t3, f2, f3, ta, tb;
+  Buf s2pp;  // stage 2 in pair planes: two buffers back to back, [2][max_batch][24 pairs][H/8][W/8][2]
+  // pair-plane bookkeeping at the END of stage 2 (for the stride-2 consumer and for yfv2_debug_activation)
+  bool s2_px = false;
+  int s2_label[48] = {0};   // logical channel stored in slot 2*pair + element
+  int s2_buf[24] = {0};     // which of the two buffers holds pair p
   Buf logits[6];
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries)
@@ -266,6 +273,63 @@ struct WeightPacker {
     push_vec(im, fh ? &blob[fh->shift] : nullptr, mh, 96);
     return put(im);
   }
+  // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
+  // pointwise 24->24 in the 4x4x1 broadcast form [10][64]: register q, lane 4j+i holds entry (m, k) of
+  // output position 4m+i, (m*25 + k) = 16q + j; k = 24 is the bias column.  row(n) / col(k) give the
+  // filter row / column of output position n / input position k.
+  template <class RowFn, class ColFn, class BiasFn>
+  static void push_pw24_bcast(std::vector<float>& im, RowFn row, ColFn col, BiasFn bias, const float* w, const float* scale) {
+    const size_t base = im.size();
+    im.resize(base + 640, 0.f);
+    for (int m = 0; m < 6; ++m)
+      for (int i = 0; i < 4; ++i) {
+        const int r = row(4 * m + i);
+        for (int k = 0; k < 25; ++k) {
+          const int idx = m * 25 + k;
+          im[base + (idx >> 4) * 64 + 4 * (idx & 15) + i] = k < 24 ? w[(size_t)r * 24 + col(k)] * scale[r] : bias(r);
+        }
+      }
+  }
+  // s1px_kernel image: w1q | w2q | depthwise taps [54][64] (lane&3 = k holds scaled tap 4q+k, flat index c*9 + dy*3 + dx).
+  // order[n] = which branch-input channel sits at input position n = which branch-output channel goes to output position n
+  size_t image_s1px(const Folded& f1, const Folded& fd, const Folded& f2, const int (&order)[24]) {
+    std::vector<float> im;
+    const float* w1 = &blob[f1.w]; const float* w2 = &blob[f2.w]; const float* wd = &blob[fd.w];
+    const float* sc1 = &blob[f1.scale]; const float* sh1 = &blob[f1.shift];
+    const float* scd = &blob[fd.scale]; const float* shd = &blob[fd.shift];
+    const float* sc2 = &blob[f2.scale]; const float* sh2 = &blob[f2.shift];
+    push_pw24_bcast(im, [](int n) { return n; }, [&](int k) { return order[k]; }, [&](int r) { return sh1[r]; }, w1, sc1);
+    // the depthwise BN shift goes through pw2 (linear): bias2 = shift2 + scale2 * (W2 . shiftd)
+    push_pw24_bcast(im, [&](int n) { return order[n]; }, [](int k) { return k; },
+                    [&](int r) { double acc = 0; for (int k = 0; k < 24; ++k) acc += (double)w2[(size_t)r * 24 + k] * shd[k]; return sh2[r] + sc2[r] * (float)acc; },
+                    w2, sc2);
+    const size_t base = im.size();
+    im.resize(base + 54 * 64, 0.f);
+    for (int c = 0; c < 24; ++c)
+      for (int t = 0; t < 9; ++t) {
+        const int f = c * 9 + t;
+        for (int quad = 0; quad < 16; ++quad) im[base + (f >> 2) * 64 + 4 * quad + (f & 3)] = wd[(size_t)t * 24 + c] * scd[c];
+      }
+    return put(im);
+  }
+  // copies with the INPUT channels re-ordered: position k takes logical channel label[k]
+  Folded permuted_pw_inputs(const Folded& f, int co, int ci, const int* label) {
+    Folded g = f;
+    g.w = reserve((size_t)co * ci);
+    for (int r = 0; r < co; ++r)
+      for (int k = 0; k < ci; ++k) blob[g.w + (size_t)r * ci + k] = blob[f.w + (size_t)r * ci + label[k]];
+    return g;
+  }
+  Folded permuted_dw_channels(const Folded& f, int c, int kk, const int* label) {
+    Folded g;
+    g.w = reserve((size_t)c * kk); g.scale = reserve(c); g.shift = reserve(c);
+    for (int k = 0; k < c; ++k) {
+      for (int t = 0; t < kk; ++t) blob[g.w + (size_t)t * c + k] = blob[f.w + (size_t)t * c + label[k]];
+      blob[g.scale + k] = blob[f.scale + label[k]];
+      blob[g.shift + k] = blob[f.shift + label[k]];
+    }
+    return g;
+  }
   // stem_px_kernel: filter registers in the 4x4x1 broadcast form [11][64]: register q, lane 4j+i holds
   // scale[co] * W[co = 4m+i][k] for (m*27 + k) = 16q + j, k = ky*9 + ci*3 + kx; then shift[24]
   size_t image_stem(const Folded& f) {
@@ -348,7 +412,10 @@ struct PlanBuilder {
   }
 
   // ShuffleV2Block stride 2 (shufflenetv2.py:19-44,52-55): out = cat(proj(x), main(x))
-  void block_s2(const std::string& p, int cin, int H, int W, const Buf& x, const Buf& y) {
+  // pp_label != nullptr: the input is stage 2's pair-plane layout (slot k holds logical channel pp_label[k],
+  // pair p lives in buffer pp_buf[p]); only the fused kernel reads it
+  void block_s2(const std::string& p, int cin, int H, int W, const Buf& x, const Buf& y, const int* pp_label = nullptr,
+                const int* pp_buf = nullptr, long long pp_bufstride = 0) {
     Folded f;
     const int oh = H / 2, ow = W / 2, co = 2 * cin;
     const char* env = std::getenv("YFV2_FUSED");
@@ -365,6 +432,14 @@ struct PlanBuilder {
       s.c2 = cin;
       s.s2.in = x.p; s.s2.out = y.p;
       s.s2.H = H; s.s2.W = W; s.s2.R = rfused;
+      if (pp_label && ok) {  // channel position k of the staged tile = slot k: re-order every per-input-channel parameter
+        f1 = wp.permuted_pw_inputs(f1, cin, cin, pp_label);
+        fpd = wp.permuted_dw_channels(fpd, cin, 9, pp_label);
+        fpp = wp.permuted_pw_inputs(fpp, cin, cin, pp_label);
+        s.s2.pp_in = 1;
+        s.s2.pp_bufstride = pp_bufstride;
+        for (int q = 0; q < cin / 2; ++q) if (pp_buf[q]) s.s2.pp_mask |= 1u << q;
+      }
       s.img_off = wp.image_s2(f1, fd, f2, fpd, fpp, cin);
       s.name = p + " fused s2 block: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) | cat";
       s.flops = 2.0 * ((double)H * W * cin * cin + 2.0 * oh * ow * cin * cin + 2.0 * oh * ow * 9 * cin);
@@ -382,6 +457,59 @@ struct PlanBuilder {
     add_dw(p + ".main.dw3x3s2+bn", 3, 2, cin, H, W, h->t1.p, cin, h->t2.p, cin, false, f);
     ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", cin, cin, &f);
     add_pw(p + ".main.pw2+bn+relu", cin, PW_PLAIN, cin, oh * ow, h->t2.p, cin, 0, y.p, co, cin, true, f);
+  }
+
+  // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip).  Bookkeeping of the pair-plane layout:
+  // label[slot] = logical channel (numbered as the input of the NEXT block) stored in slot 2*pair + element,
+  // buf[pair] = which of the two stage buffers holds the pair.  A stride-1 block (shufflenetv2.py:57-63,
+  // 48-51) sends its even input channels 2j to output channel j untouched and its odd input channels 2i+1
+  // through the branch to output channel c2+i: in slot terms the even-labelled pairs are simply re-labelled
+  // (label /= 2) and the odd-labelled pairs are read, transformed and written to the OTHER buffer's copy of
+  // the same pair (no in-place halo races), re-labelled c2 + (label-1)/2.  yfv2_stage2_channel() places the
+  // stride-2 block's 48 outputs so that every pair stays wholly even or wholly odd for all three blocks.
+  struct Stage2Layout {
+    int label[48];
+    int buf[24];
+  };
+  void s1px_block(const std::string& p, int H, int W, Stage2Layout& L, long long bufstride) {
+    Folded f1, fd, f2;
+    ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", 24, 24, &f1);
+    ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", 24, 3, &fd);
+    ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", 24, 24, &f2);
+    Step s;
+    s.kind = STEP_S1PX;
+    int order[24], kk = 0;
+    for (int q = 0; q < 24; ++q) {
+      const bool odd0 = L.label[2 * q] & 1, odd1 = L.label[2 * q + 1] & 1;
+      if (odd0 != odd1) { ok = false; return; }   // cannot happen with yfv2_stage2_channel's placement
+      if (!odd0) continue;
+      if (kk >= 12) { ok = false; return; }
+      order[2 * kk] = (L.label[2 * q] - 1) / 2;
+      order[2 * kk + 1] = (L.label[2 * q + 1] - 1) / 2;
+      s.s1px.src_off[kk] = (int)(((long long)L.buf[q] * bufstride + (long long)q * H * W * 2) * 4);
+      s.s1px.dst_off[kk] = (int)(((long long)(1 - L.buf[q]) * bufstride + (long long)q * H * W * 2) * 4);
+      ++kk;
+    }
+    if (kk != 12) { ok = false; return; }
+    for (int q = 0; q < 24; ++q) {
+      if (L.label[2 * q] & 1) {
+        L.label[2 * q] = 24 + (L.label[2 * q] - 1) / 2;
+        L.label[2 * q + 1] = 24 + (L.label[2 * q + 1] - 1) / 2;
+        L.buf[q] ^= 1;
+      } else {
+        L.label[2 * q] /= 2;
+        L.label[2 * q + 1] /= 2;
+      }
+    }
+    s.s1px.act = h->s2pp.p;
+    s.s1px.H = H; s.s1px.W = W;
+    s.s1px.img_stride = 48 * H * W;
+    s.s1px.num_records = (int)((bufstride + 48LL * H * W) * 4);
+    if (ok) s.img_off = wp.image_s1px(f1, fd, f2, order);
+    s.name = p + " s1 block, lane-per-pixel: pw1+bn+relu -> dw3x3+bn -> pw2+bn+relu on the 12 branch pairs (shuffle/pass/cat = bookkeeping)";
+    s.flops = 2.0 * H * W * (2.0 * 24 * 24 + 9.0 * 24);
+    s.bytes = 4.0 * H * W * (2.0 * 48);  // the layer's logical input + output; the launch itself moves half of it
+    h->plan.push_back(s);
   }
 
   // ShuffleV2Block stride 1 (shufflenetv2.py:48-51,57-63): even channels pass through,
@@ -494,22 +622,52 @@ struct PlanBuilder {
     const int repeats[3] = {4, 8, 4};
     const Buf* x = &h->a1;
     h->dbg[0] = h->a1.p; h->dbg_per_img[0] = h->a1.per_img; h->dbg_c[0] = 24;
+    Stage2Layout L2{};
+    bool px_pending = false;   // the next stride-2 block reads stage 2's pair planes
+    const long long pp_bufstride = (long long)h->cfg.max_batch * 48 * (H / 8) * (W / 8);
     for (int si = 0; si < 3; ++si) {
       const int cout = cin * 2;
       int cur = 0;
+      const char* envf = std::getenv("YFV2_FUSED");
+      const char* envp = std::getenv("YFV2_S2PX");
+      const bool use_px = si == 0 && !(envf && envf[0] == '0') && !(envp && envp[0] == '0') && h->s2pp.p &&
+                          yfv2_s1px_supported(hh / 2, ww / 2) && yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0 &&
+                          (pp_bufstride + 48LL * (hh / 2) * (ww / 2)) * 4 < (1LL << 31);
       for (int i = 0; i < repeats[si]; ++i) {
         const std::string p = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i);
         const Buf* y = &stage_bufs[si][cur];
         if (i == 0) {
-          block_s2(p, cin, hh, ww, *x, *y);
+          if (px_pending) block_s2(p, cin, hh, ww, h->s2pp, *y, L2.label, L2.buf, pp_bufstride);
+          else block_s2(p, cin, hh, ww, *x, *y);
+          px_pending = false;
           hh /= 2; ww /= 2;
+          if (use_px) {   // NHWC -> pair planes (buffer 0), logical channel c at slot(c)
+            Step s;
+            s.kind = STEP_REPACK;
+            s.rp_in = y->p; s.rp_out = h->s2pp.p; s.rp_hw = hh * ww;
+            s.name = p + " -> pair planes (repack)";
+            s.bytes = 4.0 * hh * ww * 96;
+            h->plan.push_back(s);
+            for (int k = 0; k < 48; ++k) L2.label[k] = yfv2_stage2_channel(k);
+            for (int q = 0; q < 24; ++q) L2.buf[q] = 0;
+          }
+        } else if (use_px) {
+          s1px_block(p, hh, ww, L2, pp_bufstride);
         } else {
           block_s1(p, cout, hh, ww, *x, *y);
         }
         x = y;
         cur ^= 1;
       }
-      h->dbg[1 + si] = x->p; h->dbg_per_img[1 + si] = x->per_img; h->dbg_c[1 + si] = cout;
+      if (use_px) {
+        px_pending = true;
+        h->s2_px = true;
+        for (int k = 0; k < 48; ++k) h->s2_label[k] = L2.label[k];
+        for (int q = 0; q < 24; ++q) h->s2_buf[q] = L2.buf[q];
+        h->dbg[1] = h->s2pp.p; h->dbg_per_img[1] = (size_t)48 * hh * ww; h->dbg_c[1] = cout;
+      } else {
+        h->dbg[1 + si] = x->p; h->dbg_per_img[1 + si] = x->per_img; h->dbg_c[1 + si] = cout;
+      }
       cin = cout;
     }
     const Buf* c2 = nullptr; const Buf* c3 = x;
@@ -591,6 +749,13 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
       }
       if (!yfv2_launch_tower2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_REPACK) {
+      yfv2_launch_repack_pp(st.rp_in, st.rp_out, B, st.rp_hw, (size_t)48 * st.rp_hw, s);
+    } else if (st.kind == STEP_S1PX) {
+      S1PxArgs a = st.s1px;
+      a.B = B;
+      a.img = params + st.img_off;
+      yfv2_launch_s1px(a, s);
     } else if (st.kind == STEP_S1) {
       BlockS1Args a = st.s1;
       a.B = B;
@@ -668,6 +833,7 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     A(&h->s3[i], (H / 16) * (W / 16) * 96);
     A(&h->s4[i], (H / 32) * (W / 32) * 192);
   }
+  A(&h->s2pp, 2 * (H / 8) * (W / 8) * 48);
   A(&h->t1, (H / 4) * (W / 4) * 24);
   A(&h->t2, (H / 4) * (W / 4) * 24);
   A(&h->t3, (H / 4) * (W / 4) * 24);
@@ -695,6 +861,7 @@ void yfv2_destroy(yfv2_handle h) {
   DeviceGuard guard(h->device);
   free_buf(&h->a1);
   for (int i = 0; i < 2; ++i) { free_buf(&h->s2[i]); free_buf(&h->s3[i]); free_buf(&h->s4[i]); }
+  free_buf(&h->s2pp);
   free_buf(&h->t1); free_buf(&h->t2); free_buf(&h->t3);
   free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->ta); free_buf(&h->tb);
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
@@ -879,6 +1046,23 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
   const int64_t n = (int64_t)h->dbg_per_img[which] * B;
   if (!host_dst) return n;
   if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
+  if (which == 1 && h->s2_px) {  // stage 2 lives in pair planes: gather the logical NHWC tensor on the host
+    const size_t per = h->dbg_per_img[1], hw = per / 48, bufstride = (size_t)h->cfg.max_batch * per;
+    std::vector<float> tmp(2 * (size_t)n);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(tmp.data(), h->s2pp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(tmp.data() + n, h->s2pp.p + bufstride, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+      fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");
+      return YFV2_ERR_DEVICE;
+    }
+    for (int b = 0; b < B; ++b)
+      for (int q = 0; q < 24; ++q) {
+        const float* src = tmp.data() + (size_t)h->s2_buf[q] * n + (size_t)b * per + (size_t)q * hw * 2;
+        for (size_t px = 0; px < hw; ++px)
+          for (int e = 0; e < 2; ++e) host_dst[((size_t)b * hw + px) * 48 + h->s2_label[2 * q + e]] = src[px * 2 + e];
+      }
+    return n;
+  }
   if (hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(host_dst, h->dbg[which], (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
     fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");

@@ -392,7 +392,7 @@ struct S2Cfg {
   static constexpr int MAXT = CIN <= 24 ? 10 : 6;     // pw1 pixel tiles per wave
 };
 
-template <int CIN, int THREADS>
+template <int CIN, int THREADS, bool PPIN>
 __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   using Cfg = S2Cfg<CIN>;
   constexpr int KC = Cfg::KC, CP = Cfg::CP, KS = KC * 16;
@@ -418,34 +418,79 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   const int n_items = a.B * tiles_per_img;
   constexpr int QPP = CIN / 4;
   constexpr int MAXP = Cfg::MAXP;
-  f32x4 st[MAXP];
+  // PPIN: the input is stage 2's pair-plane layout (yfv2_stage2.hip): per pair plane the tile's rows are ONE
+  // contiguous run of 8-byte pairs, staged into channel positions 2p, 2p+1 of the tile (the filters were
+  // re-ordered to slot order on the host).  Twice the requests of half the size, same registers.
+  constexpr int NST = PPIN ? 2 * MAXP : MAXP;
+  f32x2 st[PPIN ? NST : 2 * NST];   // NHWC mode uses them as MAXP float4 (two consecutive entries)
   auto stage_issue = [&](int item_, bool active) {  // always (re)defines every staged register
     const int item = active ? item_ : 0;
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R, rows = min(R, OH - y0);
-    const int nq = active ? (2 * rows + 1) * W * QPP : 0;
-    const size_t in_px = (size_t)b * H * W;
+    if constexpr (PPIN) {
+      const int npx = (2 * rows + 1) * W;                 // pixels of the tile (rows 2*y0-1 .. 2*y0+2*rows-1)
+      const int nq = active ? npx * (CIN / 2) : 0;
+      const float inv = 1.0f / (float)npx;
+      const float* img_base = a.in + (size_t)b * CIN * H * W;
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
-      const int pix = i / QPP, q = i - pix * QPP;
-      const int r = pix / W, x = pix - r * W;
-      const int gy = 2 * y0 - 1 + r;
-      st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (i < nq && gy >= 0 && gy < H) st[j] = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)gy * W + x) * CIN + 4 * q);
+      for (int j = 0; j < NST; ++j) {
+        const int i = tid + j * THREADS;
+        int pr = (int)(((float)i + 0.5f) * inv);
+        int pix = i - pr * npx;
+        if (pix < 0) { --pr; pix += npx; }
+        if (pix >= npx) { ++pr; pix -= npx; }
+        const int gpix = (2 * y0 - 1) * W + pix;          // pixel index inside the plane; < 0 only in image row -1
+        st[j] = (f32x2){0.f, 0.f};
+        if (i < nq && gpix >= 0)
+          st[j] = *reinterpret_cast<const f32x2*>(img_base + (size_t)pr * H * W * 2 + (((a.pp_mask >> pr) & 1u) ? a.pp_bufstride : 0) + (size_t)gpix * 2);
+      }
+    } else {
+      const int nq = active ? (2 * rows + 1) * W * QPP : 0;
+      const size_t in_px = (size_t)b * H * W;
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j) {
+        const int i = tid + j * THREADS;
+        const int pix = i / QPP, q = i - pix * QPP;
+        const int r = pix / W, x = pix - r * W;
+        const int gy = 2 * y0 - 1 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < nq && gy >= 0 && gy < H) v = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)gy * W + x) * CIN + 4 * q);
+        st[2 * j] = (f32x2){v[0], v[1]};
+        st[2 * j + 1] = (f32x2){v[2], v[3]};
+      }
     }
   };
   auto stage_commit = [&](int item) {
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R, rows = min(R, OH - y0);
-    const int nq = (2 * rows + 1) * W * QPP;
+    if constexpr (PPIN) {
+      const int npx = (2 * rows + 1) * W;
+      const int nq = npx * (CIN / 2);
+      const float inv = 1.0f / (float)npx, invw = 1.0f / (float)W;
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
-      if (i >= nq) continue;
-      const int pix = i / QPP, q = i - pix * QPP;
-      const int r = pix / W, x = pix - r * W;
-      *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = st[j];
+      for (int j = 0; j < NST; ++j) {
+        const int i = tid + j * THREADS;
+        if (i >= nq) continue;
+        int pr = (int)(((float)i + 0.5f) * inv);
+        int pix = i - pr * npx;
+        if (pix < 0) { --pr; pix += npx; }
+        if (pix >= npx) { ++pr; pix -= npx; }
+        int r = (int)(((float)pix + 0.5f) * invw);
+        int x = pix - r * W;
+        if (x < 0) { --r; x += W; }
+        if (x >= W) { ++r; x -= W; }
+        *reinterpret_cast<f32x2*>(T1 + (r * WP + x + 1) * CP + 2 * pr) = st[j];
+      }
+    } else {
+      const int nq = (2 * rows + 1) * W * QPP;
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j) {
+        const int i = tid + j * THREADS;
+        if (i >= nq) continue;
+        const int pix = i / QPP, q = i - pix * QPP;
+        const int r = pix / W, x = pix - r * W;
+        *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = (f32x4){st[2 * j][0], st[2 * j][1], st[2 * j + 1][0], st[2 * j + 1][1]};
+      }
     }
   };
   stage_issue(blockIdx.x, (int)blockIdx.x < n_items);
@@ -662,10 +707,12 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
   if (blocks > 256) blocks = 256;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((block_s2_kernel<CIN, 512>), dim3(blocks), dim3(512), lds, s, a);
+  if (a.pp_in) hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true>), dim3(blocks), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {

@@ -6,6 +6,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
@@ -71,7 +72,35 @@ struct BlockS2Args {
   const float* img;  // LDS image: W1 | W2 | Wproj | main dw taps | proj dw taps | 10 BN vectors [10][KS]
   int B, H, W;       // input size
   int R;             // output rows per work item
+  // pair-plane input (stage 2 in lane-per-pixel form, yfv2_stage2.hip): in = buffer 0 of the stage, pair p of
+  // image b lives at in + b*CIN*H*W + p*H*W*2 (+ pp_bufstride floats if bit p of pp_mask is set)
+  int pp_in;
+  unsigned pp_mask;
+  long long pp_bufstride;
 };
+
+// ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
+// slot s = 2*pair + element of the pair-plane layout -> logical channel of the stage's FIRST block output
+// (the stride-2 block) stored there.  Slots are grouped by the low three bits of the channel: stride-1
+// block j of the stage reads exactly the pairs whose slot label has bit j set (see Stage2Layout).
+__host__ __device__ inline int yfv2_stage2_channel(int slot) {
+  const int p = slot >> 1, e = slot & 1;
+  const int b0 = p / 12, b1 = (p % 12) / 6, b2 = (p % 6) / 3, h = 2 * (p % 3) + e;
+  return b0 + 2 * b1 + 4 * b2 + 8 * h;
+}
+struct S1PxArgs {
+  float* act;          // buffer 0 of the stage: [max_batch][24 pairs][H][W][2]; buffer 1 follows at + bufstride
+  const float* img;    // w1q[10][64] | w2q[10][64] | (unused 24) | dw taps [9][24]  (yfv2_api.hip image_s1px)
+  int B, H, W;
+  int nstrips, nb, R;  // set by the launcher
+  int img_stride;      // floats per image (48*H*W)
+  int num_records;     // bytes addressable from an image base (covers its copy in buffer 1)
+  int src_off[12];     // byte offsets (from the image base in buffer 0) of the 12 branch pairs: where they are read ...
+  int dst_off[12];     // ... and where the block's output for the same pairs is written (the other buffer)
+};
+bool yfv2_s1px_supported(int H, int W);
+void yfv2_launch_s1px(const S1PxArgs& a, hipStream_t s);
+void yfv2_launch_repack_pp(const float* in, float* out, int B, int HW, size_t out_img_stride, hipStream_t s);
 
 // ---- fused DWConvblock half (yfv2_block.hip): dw5x5+BN+ReLU -> pw72+BN [-> output conv]
 struct TowerArgs {

@@ -1,0 +1,220 @@
+// yfv2_stage2.hip - gfx950 (CDNA4, wave64): ShuffleNetV2 stage 2 (44x44 maps, 24-channel branches) in
+// "one pixel per lane" form on v_mfma_f32_4x4x1_16b_f32.
+//
+// Reference layers (read for behaviour only): model/backbone/shufflenetv2.py:19-63 (ShuffleV2Block,
+// channel_shuffle), :102-109 (stage loop).
+//
+// Why a second formulation for this stage: with 24-channel branches the 16x16x4 tile pads M and K
+// from 24 to 32 and the depthwise 3x3 between the two pointwise convs has to go through LDS; the fused
+// LDS kernel (yfv2_block.hip) measured 70 us per block at 256 images.  In the 16-block 4x4x1 MFMA a
+// block is 4 adjacent lanes and D_blk[i][j] += A_blk[i] * B_blk[j]: with B = "channel k of this lane's
+// own pixel" and A = W[4m + i][k] (broadcast from one block, cbsz/abid) one instruction is 64 pixels x 4
+// output channels x 1 input channel - no padding at any channel count that is a multiple of 4 - and
+// a lane ends up holding all channels of ITS pixel in registers.  The depthwise conv is then plain
+// per-lane FMAs over three register rows (vertical taps) plus two DPP row shifts (horizontal taps):
+// no LDS anywhere, no barriers.
+//
+// Activation layout of stage 2 ("pair planes"): [image][24 pairs][H][W][2] fp32.  A lane = a pixel reads /
+// writes one 8-byte pair per instruction, 16 lanes = 128 contiguous bytes.  Which logical channel sits in
+// which (pair, element) slot, and in which of the two stage buffers a pair currently lives, is tracked on
+// the host (yfv2_api.hip, Stage2Layout): a stride-1 block only ever reads the 12 pairs that hold its odd
+// (branch) channels and writes the branch result into the other buffer's copy of the same 12 pairs; the
+// even (pass-through) channels are never touched, channel_shuffle / concat are pure bookkeeping that is
+// folded into the order of the filter columns / rows when the weights are packed.
+#include "yfv2_internal.h"
+#include <utility>
+
+namespace {
+
+__device__ __forceinline__ float row_shr1(float v) {   // lane l <- lane l-1 inside its 16-lane row, 0 at l = 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+// tap k (0..3) of the lane's quad: the depthwise taps live four to a register in the lanes of every quad
+// (all quads identical), DPP quad_perm:[k,k,k,k] hands tap k to all lanes without touching SGPRs or LDS
+template <int K>
+__device__ __forceinline__ float quad_mul(float tap4, float v) {   // tap4[quad lane K] * v
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tap4), K * 0x55, 0xf, 0xf, false)) * v;
+}
+// acc += tap4[quad lane K] * v as ONE v_fmac_f32_dpp (hipcc folds the DPP into v_mul but not into v_fmac: it
+// emits v_mov 0 + v_mov_dpp + v_fmac).  tap4 is never written inside the loop and all lanes are active, so
+// the asm has no DPP hazard to guard.
+template <int K>
+__device__ __forceinline__ void quad_fmac(float& acc, float tap4, float v) {
+  if constexpr (K == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
+  if constexpr (K == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
+  if constexpr (K == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
+  if constexpr (K == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
+}
+__device__ __forceinline__ float row_shl1(float v) {   // lane l <- lane l+1 inside its 16-lane row, 0 at l = 15
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+
+// 24 -> 24 pointwise conv of the lane's pixel: acc[m] (4 consecutive output positions) = sum_k W[4m+i][k] * in[k]
+// + shift, as 6 x 25 MFMAs: input "channel" 24 is the constant 1 and carries the BN shift, so the
+// accumulator starts from the inline constant 0 and no shift registers exist.  wq[q], lane 4j+i holds the
+// (BN-scale-folded) filter entry (m, k) with m*25 + k = 16q + j.
+template <int K>
+__device__ __forceinline__ void pw24_step(const float (&wq)[10], float bv, f32x4 (&acc)[6]) {
+#define YFV2_PW24_MM(M)                                                                                        \
+  acc[M] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[((M) * 25 + K) >> 4], bv, K == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[M], 4, \
+                                               ((M) * 25 + K) & 15, 0)
+  YFV2_PW24_MM(0); YFV2_PW24_MM(1); YFV2_PW24_MM(2); YFV2_PW24_MM(3); YFV2_PW24_MM(4); YFV2_PW24_MM(5);
+#undef YFV2_PW24_MM
+}
+template <int... Ks>
+__device__ __forceinline__ void pw24_impl(const float (&wq)[10], const float (&in)[24], float one, f32x4 (&acc)[6],
+                                          std::integer_sequence<int, Ks...>) {
+  (pw24_step<Ks>(wq, in[Ks], acc), ...);
+  pw24_step<24>(wq, one, acc);
+}
+__device__ __forceinline__ void pw24(const float (&wq)[10], const float (&in)[24], float one, f32x4 (&acc)[6]) {
+  pw24_impl(wq, in, one, acc, std::make_integer_sequence<int, 24>{});
+}
+
+// image offsets (floats)
+constexpr int S1PX_W1 = 0, S1PX_W2 = 640, S1PX_TAPS = 1280, S1PX_FL = 1280 + 54 * 64;   // taps: [54 regs][64 lanes], lane&3 = k holds tap 4q+k, flat tap index = c*9 + dy*3 + dx
+
+}  // namespace
+
+// ----------------------------------------------------------------------------
+// stride-1 ShuffleV2 block, 24-channel branch: pw1+BN+ReLU -> dw3x3+BN -> pw2+BN+ReLU on the 12 branch pairs
+// ----------------------------------------------------------------------------
+// Work unit = 16 lanes = (column strip, row band) of one image; a wave = four units of the same image
+// (the buffer resource is wave-uniform).  Strip s covers columns 14s .. 14s+15: the outer lanes of an inner
+// strip edge are halo lanes (their pw1 output is needed by the neighbour's 3x3 window, their own output
+// is not stored); at the image edge the DPP zero fill IS the conv's zero padding, so 44 columns are
+// exactly three strips.  A lane slides down its column: per step it runs pw1 on row r (24 inputs -> t),
+// the depthwise 3x3 of row r-1 from the t rows r-2, r-1, r held in registers, pw2, and hands the 24
+// outputs to the next step, which stores them before it issues its own prefetch (one in-order vmcnt).
+// Rows above/below the image and columns >= W get t = 0 (v_med3 against a per-lane 0 / +inf limit).
+__global__ __launch_bounds__(64, 1) void s1px_kernel(S1PxArgs a) {
+  const int H = a.H, W = a.W;
+  const int nstrips = a.nstrips, nb = a.nb, R = a.R;
+  const int units = nstrips * nb, wpi = (units + 3) >> 2;
+  const int nwg = gridDim.x;
+  const int wid = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+  const int b = __builtin_amdgcn_readfirstlane(wid / wpi), wi = __builtin_amdgcn_readfirstlane(wid - b * wpi);
+  const int lane = threadIdx.x, l = lane & 15;
+  const int uid = wi * 4 + (lane >> 4);
+  const int band = uid % nb, strip = uid / nb;
+  const int x = 14 * strip + l;
+  const bool xok = uid < units && x < W;
+  const bool st_lane = xok && (l > 0 || strip == 0) && (l < 15 || strip == nstrips - 1);
+  const int y0 = band * R, y1 = min(H, y0 + R);
+
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.act + (size_t)b * a.img_stride), 0, a.num_records, 0x00020000);
+  const int rowb = W * 8;                         // bytes per row of one pair plane
+  const int OOB = (int)0x80000000;
+
+  float w1q[10], w2q[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { w1q[q] = a.img[S1PX_W1 + q * 64 + lane]; w2q[q] = a.img[S1PX_W2 + q * 64 + lane]; }
+  float tq[54];
+#pragma unroll
+  for (int q = 0; q < 54; ++q) tq[q] = a.img[S1PX_TAPS + q * 64 + lane];
+  const float one = 1.0f;
+
+  auto load_row = [&](int r, float (&in)[24]) {
+    const int vo = (xok && r >= 0 && r < H) ? (r * W + x) * 8 : OOB;
+#pragma unroll
+    for (int kk = 0; kk < 12; ++kk) {
+      const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, a.src_off[kk], 0));
+      in[2 * kk] = v[0]; in[2 * kk + 1] = v[1];
+    }
+  };
+
+  float cur[24], nxt[24];
+  float tA[24], tB[24], tC[24];
+  f32x4 pend[6];
+  int pend_vo = OOB;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) pend[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 24; ++c) { tA[c] = 0.f; tB[c] = 0.f; tC[c] = 0.f; }
+  load_row(y0 - 1, cur);
+
+  // step j: pw1 of row r = y0-1+j into tn; for j >= 2 the block output of row r-1 from (tp2, tp1, tn)
+  auto step = [&](int j, const float (&tp2)[24], const float (&tp1)[24], float (&tn)[24]) {
+    const int r = y0 - 1 + j;
+    // last step's outputs go out first, then this step's prefetch
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){pend[m][0], pend[m][1]}), rsrc, pend_vo, a.dst_off[2 * m], 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){pend[m][2], pend[m][3]}), rsrc, pend_vo, a.dst_off[2 * m + 1], 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(r + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[6];
+    pw24(w1q, cur, one, acc);
+    const float lim = (xok && r >= 0 && r < H) ? __builtin_inff() : 0.f;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) tn[c] = __builtin_amdgcn_fmed3f(acc[c >> 2][c & 3], 0.f, lim);   // ReLU, and 0 outside the image
+
+    float d[24];
+    // depthwise 3x3 (BN scale folded into the taps, BN shift folded into pw2's bias): vertical taps are
+    // per-lane FMAs over the three t rows, the dx = 0 / dx = 2 column sums move one lane right / left
+    auto dw_ch = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+#define YFV2_TQ(t) tq[(c * 9 + (t)) >> 2]
+#define YFV2_TK(t) ((c * 9 + (t)) & 3)
+      float a0 = quad_mul<YFV2_TK(0)>(YFV2_TQ(0), tp2[c]), a1 = quad_mul<YFV2_TK(1)>(YFV2_TQ(1), tp2[c]), a2 = quad_mul<YFV2_TK(2)>(YFV2_TQ(2), tp2[c]);
+      quad_fmac<YFV2_TK(3)>(a0, YFV2_TQ(3), tp1[c]); quad_fmac<YFV2_TK(4)>(a1, YFV2_TQ(4), tp1[c]); quad_fmac<YFV2_TK(5)>(a2, YFV2_TQ(5), tp1[c]);
+      quad_fmac<YFV2_TK(6)>(a0, YFV2_TQ(6), tn[c]); quad_fmac<YFV2_TK(7)>(a1, YFV2_TQ(7), tn[c]); quad_fmac<YFV2_TK(8)>(a2, YFV2_TQ(8), tn[c]);
+#undef YFV2_TQ
+#undef YFV2_TK
+      d[c] = a1 + row_shr1(a0) + row_shl1(a2);
+    };
+    [&]<int... Cs>(std::integer_sequence<int, Cs...>) { (dw_ch(std::integral_constant<int, Cs>{}), ...); }(std::make_integer_sequence<int, 24>{});
+    pw24(w2q, d, one, acc);
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pend[m][e] = __builtin_fmaxf(acc[m][e], 0.f);
+    pend_vo = (st_lane && j >= 2 && r - 1 < y1) ? ((r - 1) * W + x) * 8 : OOB;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) cur[c] = nxt[c];
+  };
+
+  const int nsteps = R + 2;
+  for (int j = 0; j < nsteps; j += 3) {
+    step(j, tB, tC, tA);
+    if (j + 1 < nsteps) step(j + 1, tC, tA, tB);
+    if (j + 2 < nsteps) step(j + 2, tA, tB, tC);
+  }
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){pend[m][0], pend[m][1]}), rsrc, pend_vo, a.dst_off[2 * m], 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){pend[m][2], pend[m][3]}), rsrc, pend_vo, a.dst_off[2 * m + 1], 0);
+  }
+}
+
+bool yfv2_s1px_supported(int H, int W) { return H >= 8 && W >= 16 && (long)48 * H * W * 4 < (1L << 28); }
+
+void yfv2_launch_s1px(const S1PxArgs& a0, hipStream_t s) {
+  S1PxArgs a = a0;
+  a.nstrips = a.W <= 16 ? 1 : (a.W - 2 + 13) / 14;
+  a.nb = 4;
+  a.R = (a.H + a.nb - 1) / a.nb;
+  const int units = a.nstrips * a.nb;
+  hipLaunchKernelGGL(s1px_kernel, dim3(a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
+}
+
+// ----------------------------------------------------------------------------
+// NHWC (48 channels) -> pair planes, logical channel c at slot(c)  (yfv2_stage2_slot, shared with the host)
+// ----------------------------------------------------------------------------
+__global__ void repack_pp_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW, size_t out_img_stride) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (b, pair, pixel)
+  const size_t total = (size_t)B * 24 * HW;
+  if (i >= total) return;
+  const int px = (int)(i % HW), p = (int)((i / HW) % 24), b = (int)(i / ((size_t)24 * HW));
+  const float* src = in + ((size_t)b * HW + px) * 48;
+  const f32x2 v = {src[yfv2_stage2_channel(2 * p)], src[yfv2_stage2_channel(2 * p + 1)]};
+  *reinterpret_cast<f32x2*>(out + (size_t)b * out_img_stride + ((size_t)p * HW + px) * 2) = v;
+}
+
+void yfv2_launch_repack_pp(const float* in, float* out, int B, int HW, size_t out_img_stride, hipStream_t s) {
+  const size_t total = (size_t)B * 24 * HW;
+  hipLaunchKernelGGL(repack_pp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, HW, out_img_stride);
+}
