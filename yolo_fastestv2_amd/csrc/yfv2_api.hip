@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_REPACK = 6, STEP_S1PX = 7 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_REPACK = 6, STEP_S1PX = 7, STEP_S2PX = 8 };
 
 struct Step {
   int kind = 0;
@@ -38,6 +38,8 @@ struct Step {
   TowerArgs tw{};
   BlockS2Args s2{};
   S1PxArgs s1px{};
+  S2PxArgs s2px{};
+  size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role)
   const float* rp_in = nullptr; float* rp_out = nullptr; int rp_hw = 0;   // STEP_REPACK
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
@@ -71,6 +73,7 @@ struct yfv2_ctx {
   Buf s2pp;  // stage 2 in pair planes: two buffers back to back, [2][max_batch][24 pairs][H/8][W/8][2]
   // pair-plane bookkeeping at the END of stage 2 (for the stride-2 consumer and for yfv2_debug_activation)
   bool s2_px = false;
+  bool stem_pp = false;     // the stem writes pair planes [12][H/4][W/4][2] (consumed by s2px_kernel)
   int s2_label[48] = {0};   // logical channel stored in slot 2*pair + element
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
   Buf logits[6];
@@ -303,6 +306,11 @@ struct WeightPacker {
     push_pw24_bcast(im, [&](int n) { return order[n]; }, [](int k) { return k; },
                     [&](int r) { double acc = 0; for (int k = 0; k < 24; ++k) acc += (double)w2[(size_t)r * 24 + k] * shd[k]; return sh2[r] + sc2[r] * (float)acc; },
                     w2, sc2);
+    push_taps_quad(im, wd, scd);
+    return put(im);
+  }
+  // depthwise 3x3 taps of 24 channels, BN scale folded: [54][64], lane&3 = k of register q holds tap 4q+k, flat index c*9 + dy*3 + dx
+  static void push_taps_quad(std::vector<float>& im, const float* wd, const float* scd) {
     const size_t base = im.size();
     im.resize(base + 54 * 64, 0.f);
     for (int c = 0; c < 24; ++c)
@@ -310,6 +318,24 @@ struct WeightPacker {
         const int f = c * 9 + t;
         for (int quad = 0; quad < 16; ++quad) im[base + (f >> 2) * 64 + 4 * quad + (f & 3)] = wd[(size_t)t * 24 + c] * scd[c];
       }
+  }
+  // s2px_kernel role images.  pos[n] = branch-local output channel at output position n of the role's last pointwise conv
+  size_t image_s2px_proj(const Folded& fpd, const Folded& fpp, const int (&pos)[24]) {
+    std::vector<float> im;
+    const float* w = &blob[fpp.w]; const float* sc = &blob[fpp.scale]; const float* sh = &blob[fpp.shift]; const float* shd = &blob[fpd.shift];
+    push_pw24_bcast(im, [&](int n) { return pos[n]; }, [](int k) { return k; },
+                    [&](int r) { double acc = 0; for (int k = 0; k < 24; ++k) acc += (double)w[(size_t)r * 24 + k] * shd[k]; return sh[r] + sc[r] * (float)acc; }, w, sc);
+    push_taps_quad(im, &blob[fpd.w], &blob[fpd.scale]);
+    return put(im);
+  }
+  size_t image_s2px_main(const Folded& f1, const Folded& fd, const Folded& f2, const int (&pos)[24]) {
+    std::vector<float> im;
+    const float* w2 = &blob[f2.w]; const float* sc2 = &blob[f2.scale]; const float* sh2 = &blob[f2.shift]; const float* shd = &blob[fd.shift];
+    const float* sh1 = &blob[f1.shift];
+    push_pw24_bcast(im, [](int n) { return n; }, [](int k) { return k; }, [&](int r) { return sh1[r]; }, &blob[f1.w], &blob[f1.scale]);
+    push_pw24_bcast(im, [&](int n) { return pos[n]; }, [](int k) { return k; },
+                    [&](int r) { double acc = 0; for (int k = 0; k < 24; ++k) acc += (double)w2[(size_t)r * 24 + k] * shd[k]; return sh2[r] + sc2[r] * (float)acc; }, w2, sc2);
+    push_taps_quad(im, &blob[fd.w], &blob[fd.scale]);
     return put(im);
   }
   // copies with the INPUT channels re-ordered: position k takes logical channel label[k]
@@ -353,7 +379,7 @@ struct PlanBuilder {
   WeightPacker& wp;
   bool ok = true;
 
-  void add_stem(const Buf& out) {
+  void add_stem(const Buf& out, bool pp_out) {
     Folded f;
     ok &= wp.stem("backbone.first_conv.0", "backbone.first_conv.1", &f);
     Step s;
@@ -362,6 +388,7 @@ struct PlanBuilder {
     s.stem.H = h->cfg.height;
     s.stem.W = h->cfg.width;
     s.stem.R = 0;  // bands are chosen by the launcher
+    s.stem.pp_out = pp_out ? 1 : 0;
     s.img_off = wp.image_stem(f);
     s.name = "stem conv3x3s2+bn+relu+maxpool3x3s2";
     const double ch = h->cfg.height / 2.0, cw = h->cfg.width / 2.0;
@@ -471,6 +498,44 @@ struct PlanBuilder {
     int label[48];
     int buf[24];
   };
+  // stage2.0 in lane-per-pixel form: reads the stem's pair planes, writes logical channel c to slot(c) of buffer 0
+  void s2px_block(const std::string& p, int IH, int IW) {
+    Folded f1, fd, f2, fpd, fpp;
+    ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", 24, 3, &fpd);
+    ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", 24, 24, &fpp);
+    ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", 24, 24, &f1);
+    ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", 24, 3, &fd);
+    ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", 24, 24, &f2);
+    const int OH = IH / 2, OW = IW / 2;
+    int slot_of[48];
+    for (int k = 0; k < 48; ++k) slot_of[yfv2_stage2_channel(k)] = k;
+    Step s;
+    s.kind = STEP_S2PX;
+    // output positions: 0..15 = the role's eight whole pairs, 16..23 = its halves of the eight mixed pairs
+    int pos[2][24];
+    for (int j = 0; j < 8; ++j) {
+      pos[0][2 * j] = j;      pos[0][2 * j + 1] = 8 + j;   pos[0][16 + j] = 16 + j;   // proj: logical channels 0..23
+      pos[1][2 * j] = 8 + j;  pos[1][2 * j + 1] = 16 + j;  pos[1][16 + j] = j;        // main: logical 24 + (..)
+    }
+    for (int role = 0; role < 2; ++role) {
+      for (int i = 0; i < 8; ++i) {
+        const int s0 = slot_of[24 * role + pos[role][2 * i]], s1 = slot_of[24 * role + pos[role][2 * i + 1]];
+        if ((s0 & 1) || s1 != s0 + 1) { ok = false; return; }
+        s.s2px.st2_off[role][i] = (s0 >> 1) * OH * OW * 8;
+        const int ss = slot_of[24 * role + pos[role][16 + i]];
+        s.s2px.st1_off[role][i] = (ss >> 1) * OH * OW * 8 + (ss & 1) * 4;
+      }
+    }
+    s.s2px.in = h->a1.p; s.s2px.act = h->s2pp.p;
+    s.s2px.IH = IH; s.s2px.IW = IW;
+    s.s2px.in_stride = 24 * IH * IW; s.s2px.out_stride = 48 * OH * OW;
+    s.s2px.in_records = 24 * IH * IW * 4; s.s2px.out_records = 48 * OH * OW * 4;
+    if (ok) { s.img_off = wp.image_s2px_proj(fpd, fpp, pos[0]); s.img_off2 = wp.image_s2px_main(f1, fd, f2, pos[1]); }
+    s.name = p + " s2 block, lane-per-pixel: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) -> pair planes";
+    s.flops = 2.0 * ((double)IH * IW * 24 * 24 + 2.0 * OH * OW * 24 * 24 + 2.0 * OH * OW * 9 * 24);
+    s.bytes = 4.0 * ((double)IH * IW * 24 + (double)OH * OW * 48);
+    h->plan.push_back(s);
+  }
   void s1px_block(const std::string& p, int H, int W, Stage2Layout& L, long long bufstride) {
     Folded f1, fd, f2;
     ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", 24, 24, &f1);
@@ -616,38 +681,34 @@ struct PlanBuilder {
 
   void build() {
     const int H = h->cfg.height, W = h->cfg.width;
-    add_stem(h->a1);
     int hh = H / 4, ww = W / 4, cin = 24;
+    const long long pp_bufstride = (long long)h->cfg.max_batch * 48 * (H / 8) * (W / 8);
+    const char* envf = std::getenv("YFV2_FUSED");
+    const char* envp = std::getenv("YFV2_S2PX");
+    const bool stage2_px = !(envf && envf[0] == '0') && !(envp && envp[0] == '0') && h->s2pp.p && yfv2_s1px_supported(hh / 2, ww / 2) &&
+                           yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0 && (pp_bufstride + 48LL * (hh / 2) * (ww / 2)) * 4 < (1LL << 31);
+    add_stem(h->a1, stage2_px);
+    h->stem_pp = stage2_px;
     Buf* stage_bufs[3] = {h->s2, h->s3, h->s4};
     const int repeats[3] = {4, 8, 4};
     const Buf* x = &h->a1;
     h->dbg[0] = h->a1.p; h->dbg_per_img[0] = h->a1.per_img; h->dbg_c[0] = 24;
     Stage2Layout L2{};
     bool px_pending = false;   // the next stride-2 block reads stage 2's pair planes
-    const long long pp_bufstride = (long long)h->cfg.max_batch * 48 * (H / 8) * (W / 8);
     for (int si = 0; si < 3; ++si) {
       const int cout = cin * 2;
       int cur = 0;
-      const char* envf = std::getenv("YFV2_FUSED");
-      const char* envp = std::getenv("YFV2_S2PX");
-      const bool use_px = si == 0 && !(envf && envf[0] == '0') && !(envp && envp[0] == '0') && h->s2pp.p &&
-                          yfv2_s1px_supported(hh / 2, ww / 2) && yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0 &&
-                          (pp_bufstride + 48LL * (hh / 2) * (ww / 2)) * 4 < (1LL << 31);
+      const bool use_px = si == 0 && stage2_px;
       for (int i = 0; i < repeats[si]; ++i) {
         const std::string p = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i);
         const Buf* y = &stage_bufs[si][cur];
         if (i == 0) {
-          if (px_pending) block_s2(p, cin, hh, ww, h->s2pp, *y, L2.label, L2.buf, pp_bufstride);
+          if (use_px) s2px_block(p, hh, ww);
+          else if (px_pending) block_s2(p, cin, hh, ww, h->s2pp, *y, L2.label, L2.buf, pp_bufstride);
           else block_s2(p, cin, hh, ww, *x, *y);
           px_pending = false;
           hh /= 2; ww /= 2;
-          if (use_px) {   // NHWC -> pair planes (buffer 0), logical channel c at slot(c)
-            Step s;
-            s.kind = STEP_REPACK;
-            s.rp_in = y->p; s.rp_out = h->s2pp.p; s.rp_hw = hh * ww;
-            s.name = p + " -> pair planes (repack)";
-            s.bytes = 4.0 * hh * ww * 96;
-            h->plan.push_back(s);
+          if (use_px) {   // logical channel c sits at slot(c) of buffer 0
             for (int k = 0; k < 48; ++k) L2.label[k] = yfv2_stage2_channel(k);
             for (int q = 0; q < 24; ++q) L2.buf[q] = 0;
           }
@@ -751,6 +812,12 @@ int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_REPACK) {
       yfv2_launch_repack_pp(st.rp_in, st.rp_out, B, st.rp_hw, (size_t)48 * st.rp_hw, s);
+    } else if (st.kind == STEP_S2PX) {
+      S2PxArgs a = st.s2px;
+      a.B = B;
+      a.img[0] = params + st.img_off;
+      a.img[1] = params + st.img_off2;
+      yfv2_launch_s2px(a, s);
     } else if (st.kind == STEP_S1PX) {
       S1PxArgs a = st.s1px;
       a.B = B;
@@ -1038,6 +1105,14 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
     (void)hipMemcpy(host_dst, h->d_trace, 64 * sizeof(long long), hipMemcpyDeviceToHost);
     return 64;
   }
+  if (h && which == 101 && h->s2_px && host_dst) {  // debug: both raw stage-2 pair-plane buffers, B images each
+    const size_t per = h->dbg_per_img[1], bufstride = (size_t)h->cfg.max_batch * per, nn = (size_t)B * per;
+    if (cap < (int64_t)(2 * nn)) return YFV2_ERR_ARG;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host_dst, h->s2pp.p, nn * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host_dst + nn, h->s2pp.p + bufstride, nn * sizeof(float), hipMemcpyDeviceToHost);
+    return (int64_t)(2 * nn);
+  }
   if (!h || which < 0 || which > 5 || !h->dbg[which] || B < 1 || B > h->cfg.max_batch) {
     fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: bad argument");
     return YFV2_ERR_ARG;
@@ -1046,6 +1121,19 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
   const int64_t n = (int64_t)h->dbg_per_img[which] * B;
   if (!host_dst) return n;
   if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
+  if (which == 0 && h->stem_pp) {  // stem output in pair planes [12][PH*PW][2] -> NHWC
+    const size_t per = h->dbg_per_img[0], hw = per / 24;
+    std::vector<float> tmp((size_t)n);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(tmp.data(), h->dbg[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+      fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");
+      return YFV2_ERR_DEVICE;
+    }
+    for (int b = 0; b < B; ++b)
+      for (int q = 0; q < 12; ++q)
+        for (size_t px = 0; px < hw; ++px)
+          for (int e = 0; e < 2; ++e) host_dst[((size_t)b * hw + px) * 24 + 2 * q + e] = tmp[(size_t)b * per + ((size_t)q * hw + px) * 2 + e];
+    return n;
+  }
   if (which == 1 && h->s2_px) {  // stage 2 lives in pair planes: gather the logical NHWC tensor on the host
     const size_t per = h->dbg_per_img[1], hw = per / 48, bufstride = (size_t)h->cfg.max_batch * per;
     std::vector<float> tmp(2 * (size_t)n);

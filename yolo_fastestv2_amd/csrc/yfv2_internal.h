@@ -11,10 +11,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
   const float* x;      // (B,3,H,W)
-  float* out;          // (B,H/4,W/4,24)
+  float* out;          // (B,H/4,W/4,24) NHWC, or pair planes (pp_out)
   const float* img;    // broadcast-form filter [11 regs][64 lanes] (BN scale folded) + shift[24], see WeightPacker::image_stem
   int B, H, W;
   int R;               // pooled rows per band (set by the launcher, divides H/4)
+  int pp_out;          // 1: write pair planes [B][12][H/4][W/4][2] (stage 2 in lane-per-pixel form), 0: NHWC
 };
 
 // ---- pointwise 1x1 conv on the fp32 MFMA, NHWC
@@ -98,6 +99,19 @@ struct S1PxArgs {
   int src_off[12];     // byte offsets (from the image base in buffer 0) of the 12 branch pairs: where they are read ...
   int dst_off[12];     // ... and where the block's output for the same pairs is written (the other buffer)
 };
+// stride-2 block of stage 2 (24 -> 48 channels) in lane-per-pixel form; two wave roles (proj / main branch)
+struct S2PxArgs {
+  const float* in;     // stem output in pair planes: [B][12 pairs][IH][IW][2]
+  float* act;          // stage-2 buffer 0: [max_batch][24 pairs][OH][OW][2]
+  const float* img[2]; // role images: [0] proj: pwq[10][64] | taps[54][64]; [1] main: w1q | w2q | taps
+  int B, IH, IW;
+  int nstrips, nb, R;  // set by the launcher
+  int in_stride, out_stride;       // floats per image
+  int in_records, out_records;     // bytes addressable from an image base
+  int st2_off[2][8];   // per role: byte offsets of the 8 pair planes its output positions 0..15 fill (8-byte stores)
+  int st1_off[2][8];   // per role: byte offsets (plane + element) of output positions 16..23 (4-byte stores)
+};
+void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);
 bool yfv2_s1px_supported(int H, int W);
 void yfv2_launch_s1px(const S1PxArgs& a, hipStream_t s);
 void yfv2_launch_repack_pp(const float* in, float* out, int B, int HW, size_t out_img_stride, hipStream_t s);

@@ -38,8 +38,12 @@ __device__ __forceinline__ float quad_mul(float tap4, float v) {   // tap4[quad 
 // acc += tap4[quad lane K] * v as ONE v_fmac_f32_dpp (hipcc folds the DPP into v_mul but not into v_fmac: it
 // emits v_mov 0 + v_mov_dpp + v_fmac).  tap4 is never written inside the loop and all lanes are active, so
 // the asm has no DPP hazard to guard.
-template <int K>
+template <int K, bool ASM = true>
 __device__ __forceinline__ void quad_fmac(float& acc, float tap4, float v) {
+  if constexpr (!ASM) {   // plain builtins (v_mov 0 + v_mov_dpp + v_fmac): for values that come straight from loads
+    acc = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tap4), K * 0x55, 0xf, 0xf, false)), v, acc);
+    return;
+  }
   if constexpr (K == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
   if constexpr (K == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
   if constexpr (K == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
@@ -188,6 +192,168 @@ __global__ __launch_bounds__(64, 1) void s1px_kernel(S1PxArgs a) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){pend[m][0], pend[m][1]}), rsrc, pend_vo, a.dst_off[2 * m], 0);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){pend[m][2], pend[m][3]}), rsrc, pend_vo, a.dst_off[2 * m + 1], 0);
   }
+}
+
+// ----------------------------------------------------------------------------
+// stride-2 ShuffleV2 block 24 -> 48 (stage2.0): proj = dw3x3s2+BN -> pw+BN+ReLU, main = pw1+BN+ReLU -> dw3x3s2+BN -> pw2+BN+ReLU
+// ----------------------------------------------------------------------------
+// A lane owns output column ox, i.e. input columns 2ox and 2ox+1 (one aligned 16-byte load per pair plane and
+// input row gives both columns of two channels); input column 2ox-1 is the left neighbour's second column,
+// so the dx = 0 column sums travel one lane to the right (DPP row_shr, zero fill = left padding) and only a
+// LEFT halo lane is needed: 44 output columns = strips of 16 + 15 + 13.  A lane slides down its column one
+// output row (two input rows) per step; input rows are consumed as they arrive - pw1 (main role) and the
+// vertical taps are accumulated into the column sums S (dx = 1, 2) and Q (dx = 0) of the current output
+// row, the odd input row is kept as the dy = 0 row of the next one - so no t or raw rows pile up.
+// The two branches need ~250 registers of state each, so they are two wave ROLES over the same units
+// (role = workgroup parity; both read the same input rows through L2) writing disjoint output slots.
+constexpr int S2PX_PW_A = 0, S2PX_PW_B = 640, S2PX_TAPS_MAIN = 1280, S2PX_TAPS_PROJ = 640;
+
+template <bool MAIN>
+__device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
+  constexpr int ROLE = MAIN ? 1 : 0;
+  const int IH = a.IH, IW = a.IW, OH = IH >> 1, OW = IW >> 1;
+  const int nstrips = a.nstrips, nb = a.nb, R = a.R;
+  const int units = nstrips * nb, wpi = (units + 3) >> 2;
+  const int b = __builtin_amdgcn_readfirstlane(wid / wpi), wi = __builtin_amdgcn_readfirstlane(wid - b * wpi);
+  const int lane = threadIdx.x, l = lane & 15;
+  const int uid = wi * 4 + (lane >> 4);
+  const int band = uid % nb, strip = uid / nb;
+  const int ox = 15 * strip + l;
+  const bool xok = uid < units && ox < OW;
+  const bool st_lane = xok && (l > 0 || strip == 0);
+  const int y0 = band * R, y1 = min(OH, y0 + R);
+  const int OOB = (int)0x80000000;
+
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * a.in_stride), 0, a.in_records, 0x00020000);
+  __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.act + (size_t)b * a.out_stride), 0, a.out_records, 0x00020000);
+  const int plane = IH * IW * 8;                  // bytes per input pair plane
+
+  const float* img = a.img[ROLE];
+  float wA[10], wB[10], tq[54];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { wA[q] = img[S2PX_PW_A + q * 64 + lane]; wB[q] = MAIN ? img[S2PX_PW_B + q * 64 + lane] : 0.f; }
+#pragma unroll
+  for (int q = 0; q < 54; ++q) tq[q] = img[(MAIN ? S2PX_TAPS_MAIN : S2PX_TAPS_PROJ) + q * 64 + lane];
+  const float one = 1.0f;
+
+  // one input row: X[q] = {col 2ox: ch 2q, 2q+1 ; col 2ox+1: ch 2q, 2q+1}
+  auto load_row = [&](int iy, f32x4 (&X)[12]) {
+    const int vo = (xok && iy >= 0 && iy < IH) ? (iy * IW + 2 * ox) * 8 : OOB;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) X[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vo, q * plane, 0));
+  };
+  // the branch's depthwise input of one input row: col = 0/1 -> 24 channels (main: pw1+BN+ReLU of the raw column, 0 outside the image)
+  auto column = [&](const f32x4 (&X)[12], int col, float lim, float (&v)[24]) {
+    float raw[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) raw[k] = X[k >> 1][2 * col + (k & 1)];
+    if constexpr (MAIN) {
+      f32x4 acc[6];
+      pw24(wA, raw, one, acc);
+#pragma unroll
+      for (int c = 0; c < 24; ++c) v[c] = __builtin_amdgcn_fmed3f(acc[c >> 2][c & 3], 0.f, lim);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 24; ++c) v[c] = raw[c];
+    }
+  };
+#define YFV2_TQ(c, t) tq[((c) * 9 + (t)) >> 2]
+#define YFV2_TK(c, t) (((c) * 9 + (t)) & 3)
+  // vertical tap row DY of the 3x3 (taps index dy*3 + dx): S += w[dy][1]*v0 + w[dy][2]*v1, Q += w[dy][0]*v1
+  auto acc_row = [&](auto dyc, const float (&v0)[24], const float (&v1)[24], float (&S)[24], float (&Q)[24]) {
+    constexpr int DY = decltype(dyc)::value;
+    [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
+      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(Cs, 0), v1[Cs]))
+                : (void)(quad_fmac<YFV2_TK(Cs, DY * 3 + 1), MAIN>(S[Cs], YFV2_TQ(Cs, DY * 3 + 1), v0[Cs]), quad_fmac<YFV2_TK(Cs, DY * 3), MAIN>(Q[Cs], YFV2_TQ(Cs, DY * 3), v1[Cs])),
+        quad_fmac<YFV2_TK(Cs, DY * 3 + 2), MAIN>(S[Cs], YFV2_TQ(Cs, DY * 3 + 2), v1[Cs])), ...);
+    }(std::make_integer_sequence<int, 24>{});
+  };
+
+  f32x4 X[12], Y[12];
+  float T0[24], T1[24];                            // the odd input row above the current output row (dy = 0)
+  {
+    const int iy = 2 * y0 - 1;
+    load_row(iy, X);
+    load_row(iy + 1, Y);
+    const float lim = (xok && iy >= 0) ? __builtin_inff() : 0.f;
+    column(X, 0, lim, T0);
+    column(X, 1, lim, T1);
+    load_row(iy + 2, X);
+  }
+  const float limx = xok ? __builtin_inff() : 0.f;
+  // proj role: the loaded rows feed the v_fmac_f32_dpp asm statements directly, and hipcc does not insert
+  // s_waitcnt for registers that only inline asm reads (seen as stale-row results), so this role counts its
+  // own vmcnt: every step issues, in this order, 16 stores (the previous row, or out-of-range dummies),
+  // the use of Y, 12 loads, the use of X, 12 loads -> 28 younger operations behind each row that is due.
+  f32x4 pend[6];
+  int pend_vo = OOB;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) pend[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto flush = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){pend[i >> 1][2 * (i & 1)], pend[i >> 1][2 * (i & 1) + 1]}), rout, pend_vo, a.st2_off[ROLE][i], 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = pend[4 + (i >> 2)][i & 3];   // by value: bit_cast on a vector ELEMENT lvalue reads element 0 (hipcc 7.2)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rout, pend_vo, a.st1_off[ROLE][i], 0);
+    }
+  };
+  if constexpr (!MAIN) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // prologue row has landed (MAIN: the MFMAs' own waits)
+  for (int j = 0; j < R; ++j) {
+    const int oy = y0 + j;
+    float S[24], Q[24], v0[24], v1[24];
+    if constexpr (!MAIN) { flush(); __builtin_amdgcn_sched_barrier(0); }
+    acc_row(std::integral_constant<int, 0>{}, T0, T1, S, Q);
+    // even input row 2oy (in Y), dy = 1
+    if constexpr (!MAIN) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    column(Y, 0, limx, v0);
+    column(Y, 1, limx, v1);
+    acc_row(std::integral_constant<int, 1>{}, v0, v1, S, Q);
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 2, Y);                       // next step's even row
+    __builtin_amdgcn_sched_barrier(0);
+    // odd input row 2oy+1 (in X), dy = 2; it is the next output row's dy = 0 row
+    if constexpr (!MAIN) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    column(X, 0, limx, T0);
+    column(X, 1, limx, T1);
+    acc_row(std::integral_constant<int, 2>{}, T0, T1, S, Q);
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 3, X);
+    __builtin_amdgcn_sched_barrier(0);
+    float d[24];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) d[c] = S[c] + row_shr1(Q[c]);
+    f32x4 acc[6];
+    pw24(MAIN ? wB : wA, d, one, acc);
+    const int vo = (st_lane && oy < y1) ? (oy * OW + ox) * 8 : OOB;
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pend[m][e] = __builtin_fmaxf(acc[m][e], 0.f);
+    pend_vo = vo;
+    if constexpr (MAIN) flush();
+  }
+  if constexpr (!MAIN) flush();
+#undef YFV2_TQ
+#undef YFV2_TK
+}
+
+__global__ __launch_bounds__(64, 1) void s2px_kernel(S2PxArgs a) {
+  // main-branch waves (5x the work of a proj wave) get the low workgroup ids so they start first
+  const int nwg = gridDim.x >> 1;
+  if ((int)blockIdx.x < nwg) s2px_body<true>(a, blockIdx.x);
+  else s2px_body<false>(a, blockIdx.x - nwg);
+}
+
+void yfv2_launch_s2px(const S2PxArgs& a0, hipStream_t s) {
+  S2PxArgs a = a0;
+  const int OW = a.IW / 2, OH = a.IH / 2;
+  a.nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+  a.nb = 4;
+  a.R = (OH + a.nb - 1) / a.nb;
+  const int units = a.nstrips * a.nb;
+  hipLaunchKernelGGL(s2px_kernel, dim3(2 * a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
 }
 
 bool yfv2_s1px_supported(int H, int W) { return H >= 8 && W >= 16 && (long)48 * H * W * 4 < (1L << 28); }

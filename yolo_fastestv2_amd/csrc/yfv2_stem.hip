@@ -65,6 +65,7 @@ __device__ __forceinline__ void stem_px_conv(const float (&wq)[11], const f32x4 
   stem_px_conv_impl<COL>(wq, sh, r0, r1, r2, acc, std::make_integer_sequence<int, 27>{});
 }
 
+template <bool PPOUT>   // output layout: pair planes [12][PH][PW][2] (for s2px_kernel) or NHWC
 __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
   const int H = a.H, W = a.W, PH = H >> 2, PW = W >> 2;
   const int strips = (PW - 1 + 14) / 15;
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
       for (int m = 0; m < 6; ++m) { cv0[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; cv1[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
   }
-  float* __restrict__ ob = a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
+  float* __restrict__ ob = PPOUT ? a.out + (size_t)b * 24 * PH * PW + ((size_t)py0 * PW + (st_ok ? px : 0)) * 2
+                                 : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
 
   f32x4 pend[6];
   auto compute = [&](const f32x4 (&cur)[4][3]) {
@@ -169,9 +171,16 @@ __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
     if (have) {
       if (st_ok) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) *reinterpret_cast<f32x4*>(ob + 4 * m) = pend[m];
+        for (int m = 0; m < 6; ++m) {
+          if constexpr (PPOUT) {
+            *reinterpret_cast<f32x2*>(ob + (size_t)(2 * m) * PH * PW * 2) = (f32x2){pend[m][0], pend[m][1]};
+            *reinterpret_cast<f32x2*>(ob + (size_t)(2 * m + 1) * PH * PW * 2) = (f32x2){pend[m][2], pend[m][3]};
+          } else {
+            *reinterpret_cast<f32x4*>(ob + 4 * m) = pend[m];
+          }
+        }
       }
-      ob += (size_t)PW * 24;
+      ob += PPOUT ? (size_t)PW * 2 : (size_t)PW * 24;
     }
     have = true;
     __builtin_amdgcn_sched_barrier(0);
@@ -203,5 +212,6 @@ void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
   while (nb > 1 && (PH % nb || PH / nb < 4)) nb >>= 1;
   b.R = PH / nb;
   const int strips = (PW - 1 + 14) / 15;
-  hipLaunchKernelGGL(stem_px_kernel, dim3(a.B * ((strips * nb + 3) / 4)), dim3(64), 0, s, b);
+  if (a.pp_out) hipLaunchKernelGGL(stem_px_kernel<true>, dim3(a.B * ((strips * nb + 3) / 4)), dim3(64), 0, s, b);
+  else hipLaunchKernelGGL(stem_px_kernel<false>, dim3(a.B * ((strips * nb + 3) / 4)), dim3(64), 0, s, b);
 }
