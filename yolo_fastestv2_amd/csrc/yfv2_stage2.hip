@@ -36,19 +36,35 @@ __device__ __forceinline__ float quad_mul(float tap4, float v) {   // tap4[quad 
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tap4), K * 0x55, 0xf, 0xf, false)) * v;
 }
 // acc += tap4[quad lane K] * v as ONE v_fmac_f32_dpp (hipcc folds the DPP into v_mul but not into v_fmac: it
-// emits v_mov 0 + v_mov_dpp + v_fmac).  tap4 is never written inside the loop and all lanes are active, so
-// the asm has no DPP hazard to guard.
-template <int K, bool ASM = true>
-__device__ __forceinline__ void quad_fmac(float& acc, float tap4, float v) {
-  if constexpr (!ASM) {   // plain builtins (v_mov 0 + v_mov_dpp + v_fmac): for values that come straight from loads
-    acc = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tap4), K * 0x55, 0xf, 0xf, false)), v, acc);
-    return;
-  }
-  if constexpr (K == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
-  if constexpr (K == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
-  if constexpr (K == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
-  if constexpr (K == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tap4), "v"(v));
+// emits v_mov 0 + v_mov_dpp + v_fmac).  Inline asm hides two gfx9 hazards from the compiler's hazard recognizer,
+// both met in practice (wrong depthwise sums in one wave role only):
+//   * the tap register may just have been written by a VALU op the compiler inserted (a v_accvgpr_read of a
+//     spilled tap): "VALU writes VGPR -> DPP reads it" needs 2 wait states -> every asm block starts with s_nop 1;
+//   * the asm WRITES acc with a VALU op, and a compiler-generated DPP (row_shr1/row_shl1 of a column sum) may
+//     read it next -> dpp_src_ready() below.
+// Groups of FMAs share one block (one s_nop).  KA.. are the quad lanes of the taps (immediates).
+#define YFV2_QP(n) "quad_perm:[%" #n ",%" #n ",%" #n ",%" #n "] row_mask:0xf bank_mask:0xf\n\t"
+template <int KA>
+__device__ __forceinline__ void quad_fmac1(float& s, float ta, float v) {
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 " YFV2_QP(3) : "+v"(s) : "v"(ta), "v"(v), "n"(KA));
 }
+// s += ta*v0; q += tb*v1; s += tc*v1   (one vertical tap row of a stride-2 window: dx = 1, 0, 2)
+template <int KA, int KB, int KC>
+__device__ __forceinline__ void quad_fmac3(float& s, float& q, float ta, float tb, float tc, float v0, float v1) {
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %2, %5 " YFV2_QP(7) "v_fmac_f32_dpp %1, %3, %6 " YFV2_QP(8) "v_fmac_f32_dpp %0, %4, %6 " YFV2_QP(9)
+      : "+v"(s), "+v"(q) : "v"(ta), "v"(tb), "v"(tc), "v"(v0), "v"(v1), "n"(KA), "n"(KB), "n"(KC));
+}
+// a0 += t3*u + t6*w; a1 += t4*u + t7*w; a2 += t5*u + t8*w   (rows dy = 1, 2 of a stride-1 window, all three dx)
+template <int K3, int K4, int K5, int K6, int K7, int K8>
+__device__ __forceinline__ void quad_fmac6(float& a0, float& a1, float& a2, float t3, float t4, float t5, float t6, float t7, float t8,
+                                           float u, float w) {
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %3, %9 " YFV2_QP(11) "v_fmac_f32_dpp %1, %4, %9 " YFV2_QP(12) "v_fmac_f32_dpp %2, %5, %9 " YFV2_QP(13)
+      "v_fmac_f32_dpp %0, %6, %10 " YFV2_QP(14) "v_fmac_f32_dpp %1, %7, %10 " YFV2_QP(15) "v_fmac_f32_dpp %2, %8, %10 " YFV2_QP(16)
+      : "+v"(a0), "+v"(a1), "+v"(a2)
+      : "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7), "v"(t8), "v"(u), "v"(w), "n"(K3), "n"(K4), "n"(K5), "n"(K6), "n"(K7), "n"(K8));
+}
+// 2 wait states between an inline-asm VALU write of v and a DPP read of v (gfx9 "VALU writes VGPR -> DPP reads it")
+__device__ __forceinline__ void dpp_src_ready(float& v) { asm volatile("s_nop 1" : "+v"(v)); }
 __device__ __forceinline__ float row_shl1(float v) {   // lane l <- lane l+1 inside its 16-lane row, 0 at l = 15
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
 }
@@ -164,8 +180,8 @@ __global__ __launch_bounds__(64, 1) void s1px_kernel(S1PxArgs a) {
 #define YFV2_TQ(t) tq[(c * 9 + (t)) >> 2]
 #define YFV2_TK(t) ((c * 9 + (t)) & 3)
       float a0 = quad_mul<YFV2_TK(0)>(YFV2_TQ(0), tp2[c]), a1 = quad_mul<YFV2_TK(1)>(YFV2_TQ(1), tp2[c]), a2 = quad_mul<YFV2_TK(2)>(YFV2_TQ(2), tp2[c]);
-      quad_fmac<YFV2_TK(3)>(a0, YFV2_TQ(3), tp1[c]); quad_fmac<YFV2_TK(4)>(a1, YFV2_TQ(4), tp1[c]); quad_fmac<YFV2_TK(5)>(a2, YFV2_TQ(5), tp1[c]);
-      quad_fmac<YFV2_TK(6)>(a0, YFV2_TQ(6), tn[c]); quad_fmac<YFV2_TK(7)>(a1, YFV2_TQ(7), tn[c]); quad_fmac<YFV2_TK(8)>(a2, YFV2_TQ(8), tn[c]);
+      quad_fmac6<YFV2_TK(3), YFV2_TK(4), YFV2_TK(5), YFV2_TK(6), YFV2_TK(7), YFV2_TK(8)>(a0, a1, a2, YFV2_TQ(3), YFV2_TQ(4), YFV2_TQ(5), YFV2_TQ(6),
+                                                                                       YFV2_TQ(7), YFV2_TQ(8), tp1[c], tn[c]);
 #undef YFV2_TQ
 #undef YFV2_TK
       d[c] = a1 + row_shr1(a0) + row_shl1(a2);
@@ -263,9 +279,10 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
   auto acc_row = [&](auto dyc, const float (&v0)[24], const float (&v1)[24], float (&S)[24], float (&Q)[24]) {
     constexpr int DY = decltype(dyc)::value;
     [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
-      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(Cs, 0), v1[Cs]))
-                : (void)(quad_fmac<YFV2_TK(Cs, DY * 3 + 1), MAIN>(S[Cs], YFV2_TQ(Cs, DY * 3 + 1), v0[Cs]), quad_fmac<YFV2_TK(Cs, DY * 3), MAIN>(Q[Cs], YFV2_TQ(Cs, DY * 3), v1[Cs])),
-        quad_fmac<YFV2_TK(Cs, DY * 3 + 2), MAIN>(S[Cs], YFV2_TQ(Cs, DY * 3 + 2), v1[Cs])), ...);
+      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(Cs, 0), v1[Cs]),
+                         quad_fmac1<YFV2_TK(Cs, 2)>(S[Cs], YFV2_TQ(Cs, 2), v1[Cs]))
+                : (void)quad_fmac3<YFV2_TK(Cs, DY * 3 + 1), YFV2_TK(Cs, DY * 3), YFV2_TK(Cs, DY * 3 + 2)>(
+                      S[Cs], Q[Cs], YFV2_TQ(Cs, DY * 3 + 1), YFV2_TQ(Cs, DY * 3), YFV2_TQ(Cs, DY * 3 + 2), v0[Cs], v1[Cs])), ...);
     }(std::make_integer_sequence<int, 24>{});
   };
 
@@ -281,10 +298,7 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
     load_row(iy + 2, X);
   }
   const float limx = xok ? __builtin_inff() : 0.f;
-  // proj role: the loaded rows feed the v_fmac_f32_dpp asm statements directly, and hipcc does not insert
-  // s_waitcnt for registers that only inline asm reads (seen as stale-row results), so this role counts its
-  // own vmcnt: every step issues, in this order, 16 stores (the previous row, or out-of-range dummies),
-  // the use of Y, 12 loads, the use of X, 12 loads -> 28 younger operations behind each row that is due.
+  // (proj role: stores are deferred to the next step like the stem's)
   f32x4 pend[6];
   int pend_vo = OOB;
 #pragma unroll
@@ -299,14 +313,12 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rout, pend_vo, a.st1_off[ROLE][i], 0);
     }
   };
-  if constexpr (!MAIN) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // prologue row has landed (MAIN: the MFMAs' own waits)
   for (int j = 0; j < R; ++j) {
     const int oy = y0 + j;
     float S[24], Q[24], v0[24], v1[24];
     if constexpr (!MAIN) { flush(); __builtin_amdgcn_sched_barrier(0); }
     acc_row(std::integral_constant<int, 0>{}, T0, T1, S, Q);
     // even input row 2oy (in Y), dy = 1
-    if constexpr (!MAIN) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
     column(Y, 0, limx, v0);
     column(Y, 1, limx, v1);
     acc_row(std::integral_constant<int, 1>{}, v0, v1, S, Q);
@@ -314,7 +326,6 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
     load_row(2 * oy + 2, Y);                       // next step's even row
     __builtin_amdgcn_sched_barrier(0);
     // odd input row 2oy+1 (in X), dy = 2; it is the next output row's dy = 0 row
-    if constexpr (!MAIN) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
     column(X, 0, limx, T0);
     column(X, 1, limx, T1);
     acc_row(std::integral_constant<int, 2>{}, T0, T1, S, Q);
@@ -323,7 +334,7 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
     __builtin_amdgcn_sched_barrier(0);
     float d[24];
 #pragma unroll
-    for (int c = 0; c < 24; ++c) d[c] = S[c] + row_shr1(Q[c]);
+    for (int c = 0; c < 24; ++c) { dpp_src_ready(Q[c]); d[c] = S[c] + row_shr1(Q[c]); }
     f32x4 acc[6];
     pw24(MAIN ? wB : wA, d, one, acc);
     const int vo = (st_lane && oy < y1) ? (oy * OW + ox) * 8 : OOB;
@@ -338,6 +349,7 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
 #undef YFV2_TQ
 #undef YFV2_TK
 }
+#undef YFV2_QP
 
 __global__ __launch_bounds__(64, 1) void s2px_kernel(S2PxArgs a) {
   // main-branch waves (5x the work of a proj wave) get the low workgroup ids so they start first
