@@ -918,7 +918,7 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     return rc;
   }
   if (const char* tr = std::getenv("YFV2_TRACE"))
-    if (tr[0] == '1') (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 64 * sizeof(long long));
+    if (tr[0] == '1') { (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
   *out = h;
   return YFV2_OK;
 }
@@ -1100,10 +1100,11 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
 }
 
 int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap) {
-  if (h && which == 100 && h->d_trace && host_dst && cap >= 128) {  // debug: 64 cycle stamps as int64 in 128 floats
+  if (h && which == 100 && h->d_trace && host_dst && cap >= 128) {  // debug: cycle stamps as int64 (2 floats each), as many as fit (<= 8192)
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host_dst, h->d_trace, 64 * sizeof(long long), hipMemcpyDeviceToHost);
-    return 64;
+    const int64_t n64 = cap / 2 < 8192 ? cap / 2 : 8192;
+    (void)hipMemcpy(host_dst, h->d_trace, (size_t)n64 * sizeof(long long), hipMemcpyDeviceToHost);
+    return n64;
   }
   if (h && which == 101 && h->s2_px && host_dst) {  // debug: both raw stage-2 pair-plane buffers, B images each
     const size_t per = h->dbg_per_img[1], bufstride = (size_t)h->cfg.max_batch * per, nn = (size_t)B * per;
