@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64, 1) void s1px_kernel(S1PxArgs a) {
                                                                                        YFV2_TQ(7), YFV2_TQ(8), tp1[c], tn[c]);
 #undef YFV2_TQ
 #undef YFV2_TK
+      dpp_src_ready(a2);   // a2 is the asm block's last write and the next DPP source (a0 has two instructions behind it)
       d[c] = a1 + row_shr1(a0) + row_shl1(a2);
     };
     [&]<int... Cs>(std::integer_sequence<int, Cs...>) { (dw_ch(std::integral_constant<int, Cs>{}), ...); }(std::make_integer_sequence<int, 24>{});
