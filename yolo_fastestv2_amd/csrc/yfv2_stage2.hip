@@ -370,7 +370,7 @@ void yfv2_launch_s2px(const S2PxArgs& a0, hipStream_t s) {
   S2PxArgs a = a0;
   const int OW = a.IW / 2, OH = a.IH / 2;
   a.nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
-  a.nb = 4;
+  a.nb = 5;   // measured 110 us vs 123 (4 bands), 119 (6), 113 (8)
   a.R = (OH + a.nb - 1) / a.nb;
   const int units = a.nstrips * a.nb;
   hipLaunchKernelGGL(s2px_kernel, dim3(2 * a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
@@ -381,7 +381,7 @@ bool yfv2_s1px_supported(int H, int W) { return H >= 8 && W >= 16 && (long)48 * 
 void yfv2_launch_s1px(const S1PxArgs& a0, hipStream_t s) {
   S1PxArgs a = a0;
   a.nstrips = a.W <= 16 ? 1 : (a.W - 2 + 13) / 14;
-  a.nb = 4;
+  a.nb = 5;   // 3 strips x 5 bands = 15 units = 4 waves per image: 1024 waves at 256 images, 11 steps each (4 bands: 768 waves x 13 steps measured 7 % slower, 6 or 8 bands 15-30 % slower)
   a.R = (a.H + a.nb - 1) / a.nb;
   const int units = a.nstrips * a.nb;
   hipLaunchKernelGGL(s1px_kernel, dim3(a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
