@@ -64,7 +64,11 @@ def measured_traffic(stage_name):
     kern = json.load(open(files[-1])).get("kernels", {})
     n = stage_name
     if n.startswith("stem"):
-        key = "stem_kernel"
+        key = "stem_"                      # stem_px_kernel<...> (stem_kernel in rounds before r01p)
+    elif "s2 block, lane-per-pixel" in n:
+        key = "s2px_kernel"
+    elif "s1 block, lane-per-pixel" in n:
+        key = "s1px_kernel"
     elif "fused s2 block" in n:
         key = "block_s2_kernel<24" if "stage2" in n else "block_s2_kernel<48"
     elif "fused s1 block" in n:
@@ -157,7 +161,7 @@ def main():
         ms = eng.profile_forward(x, iters=a.profile_iters)
         kern = []
         for s, m in zip(stages, ms):
-            is_mfma = " pw" in s["name"] or ".pw" in s["name"] or "output_" in s["name"] or "conv1x1" in s["name"]
+            is_mfma = any(t in s["name"] for t in (" pw", ".pw", "output_", "conv1x1", "stem", "lane-per-pixel"))   # launches whose conv runs on the MFMA
             by, fl = s["bytes_per_image"] * a.batch, s["flops_per_image"] * a.batch
             kern.append({"name": s["name"], "ms": m, "gbs": by / (m * 1e-3) / 1e9 if m > 0 else 0.0,
                          "tflops": fl / (m * 1e-3) / 1e12 if m > 0 else 0.0, "mfma": is_mfma, "bytes": by, "flops": fl})
