@@ -364,3 +364,30 @@ def test_other_input_size_320(yfv2, dev):
     o_rows, o_idx = oracle.non_max_suppression(dec.numpy(), 0.3, 0.4)
     for b in range(3):
         assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)) and np.array_equal(idx[b].numpy(), o_idx[b])
+
+
+@pytest.mark.parametrize("env", [{"YFV2_S2PX": "0"}, {"YFV2_FUSED": "0"}], ids=["stage2-on-LDS-kernels", "layer-by-layer"])
+def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
+    """The two fallback launch plans (stage 2 on the LDS kernels / everything layer by layer, both NHWC) are what
+    runs for shapes the lane-per-pixel or fused kernels do not cover: same logits as the oracle, and the same
+    survivors as the default plan."""
+    x = (torch.from_numpy(images_u8[:3]).float() / 255.0)
+    ref = oracle.forward(coco_weights, x)
+    sd = {k: torch.as_tensor(np.asarray(v)) for k, v in coco_weights.items()}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        eng = yfv2.Engine(dev, 352, 352, 80, 3, max_batch=4)   # the plan is built from the environment at load time
+        eng.load_state_dict(sd)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    names = [s["name"] for s in eng.stages()]
+    assert not any("lane-per-pixel" in n for n in names), names
+    got = eng.forward(x.to(dev))
+    for g, r, k in zip(got, ref, LOGIT_KEYS):
+        err = float((g.cpu() - r).abs().max())
+        assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)

@@ -111,7 +111,7 @@ struct S2PxArgs {
   int st2_off[2][8];   // per role: byte offsets of the 8 pair planes its output positions 0..15 fill (8-byte stores)
   int st1_off[2][8];   // per role: byte offsets (plane + element) of output positions 16..23 (4-byte stores)
 };
-void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);
+void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // two kernels (proj role, main role)
 bool yfv2_s1px_supported(int H, int W);
 void yfv2_launch_s1px(const S1PxArgs& a, hipStream_t s);
 void yfv2_launch_repack_pp(const float* in, float* out, int B, int HW, size_t out_img_stride, hipStream_t s);

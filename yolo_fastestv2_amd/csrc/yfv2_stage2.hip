@@ -352,28 +352,40 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
 }
 #undef YFV2_QP
 
-__global__ __launch_bounds__(64, 1) void s2px_kernel(S2PxArgs a) {
-  // Workgroup ids are dealt round-robin to the 8 XCDs: give every XCD a contiguous range of waves, and order
-  // the waves image by image (main-role strips, then proj-role strips).  Neighbouring strips overlap by one
-  // column and are not 128-byte aligned (a strip is 240 input bytes wide), both roles read the same rows:
-  // waves that run side by side behind ONE L2 turn those re-reads into hits (measured fabric reads before
-  // this ordering: 598 MB per launch for 190 MB of input).
+// The two roles are two kernels launched back to back, each with its own decomposition (main: 5 row bands per image
+// = 960 one-wave workgroups at 256 images; proj: 4 bands).  A proj-role wave has almost no arithmetic between its
+// row loads and spends its life in memory latency: timed alone it takes 50 us, the main role 58-63 us.  As two roles
+// of ONE kernel (each wave holding a whole SIMD: 256 + 31 registers) they added up to 108 us AND left the next
+// launch 16 us slower than its twins; as two kernels the pair costs 116 us and that penalty is gone (-8 us net).
+// Tried and measured worse: proj compiled for two waves per SIMD (needs 84 bytes of scratch: 143-165 us for the
+// pair), more/shorter proj bands (122-130 us).  A proj wave cannot share a SIMD with a main wave either
+// (287 + >=232 registers > 512), so overlapping the two kernels on two streams has no room to work with.
+template <bool MAIN>
+__device__ __forceinline__ void s2px_dispatch(const S2PxArgs& a) {
+  // Workgroup ids are dealt round-robin to the 8 XCDs: give every XCD a contiguous range of waves, image by image.
+  // Neighbouring strips overlap by one column and are not 128-byte aligned (a strip is 240 input bytes wide), and
+  // both roles read the same rows: waves that run side by side behind ONE L2 turn those re-reads into hits
+  // (measured fabric reads: 598 MB per launch without this ordering, 299 MB with it, for 190 MB of input).
   const int nwg = gridDim.x;
   const int wid = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
-  const int wpi = (a.nstrips * a.nb + 3) >> 2;
-  const int b = wid / (2 * wpi), r = wid - b * 2 * wpi;
-  if (r < wpi) s2px_body<true>(a, b * wpi + r);
-  else s2px_body<false>(a, b * wpi + r - wpi);
+  s2px_body<MAIN>(a, wid);
 }
+__global__ __launch_bounds__(64, 1) void s2px_main_kernel(S2PxArgs a) { s2px_dispatch<true>(a); }
+__global__ __launch_bounds__(64, 1) void s2px_proj_kernel(S2PxArgs a) { s2px_dispatch<false>(a); }
 
 void yfv2_launch_s2px(const S2PxArgs& a0, hipStream_t s) {
-  S2PxArgs a = a0;
-  const int OW = a.IW / 2, OH = a.IH / 2;
-  a.nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
-  a.nb = 5;   // measured 110 us vs 123 (4 bands), 119 (6), 113 (8)
-  a.R = (OH + a.nb - 1) / a.nb;
-  const int units = a.nstrips * a.nb;
-  hipLaunchKernelGGL(s2px_kernel, dim3(2 * a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
+  const int OW = a0.IW / 2, OH = a0.IH / 2;
+  for (int role = 0; role < 2; ++role) {
+    S2PxArgs a = a0;
+    a.nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+    a.nb = role ? 5 : 4;
+    a.R = (OH + a.nb - 1) / a.nb;
+    a.nb = (OH + a.R - 1) / a.R;
+    const int units = a.nstrips * a.nb;
+    const dim3 grid(a.B * ((units + 3) / 4));
+    if (role) hipLaunchKernelGGL(s2px_main_kernel, grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(s2px_proj_kernel, grid, dim3(64), 0, s, a);
+  }
 }
 
 bool yfv2_s1px_supported(int H, int W) { return H >= 8 && W >= 16 && (long)48 * H * W * 4 < (1L << 28); }
