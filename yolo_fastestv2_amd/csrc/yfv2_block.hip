@@ -420,29 +420,27 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   constexpr int MAXP = Cfg::MAXP;
   // PPIN: the input is stage 2's pair-plane layout (yfv2_stage2.hip): per pair plane the tile's rows are ONE
   // contiguous run of 8-byte pairs, staged into channel positions 2p, 2p+1 of the tile (the filters were
-  // re-ordered to slot order on the host).  Twice the requests of half the size, same registers.
-  constexpr int NST = PPIN ? 2 * MAXP : MAXP;
-  f32x2 st[PPIN ? NST : 2 * NST];   // NHWC mode uses them as MAXP float4 (two consecutive entries)
+  // re-ordered to slot order on the host).
+  // Thread t owns tile pixels t and t + THREADS (a tile has at most 14*THREADS/QPP <= 2*THREADS pixels) in EVERY
+  // pair plane: the pixel -> (row, column) split is done once per thread, the plane loop only adds uniform offsets.
+  constexpr int NPL = CIN / 2;
+  constexpr int NST = PPIN ? 2 * NPL : 2 * MAXP;   // f32x2 registers (NHWC mode: MAXP float4 as two consecutive entries)
+  f32x2 st[NST];
   auto stage_issue = [&](int item_, bool active) {  // always (re)defines every staged register
     const int item = active ? item_ : 0;
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R, rows = min(R, OH - y0);
     if constexpr (PPIN) {
-      const int npx = (2 * rows + 1) * W;                 // pixels of the tile (rows 2*y0-1 .. 2*y0+2*rows-1)
-      const int nq = active ? npx * (CIN / 2) : 0;
-      const float inv = 1.0f / (float)npx;
-      const float* img_base = a.in + (size_t)b * CIN * H * W;
+      const int npx = active ? (2 * rows + 1) * W : 0;    // pixels of the tile (rows 2*y0-1 .. 2*y0+2*rows-1): one contiguous run per plane
+      const int g0 = (2 * y0 - 1) * W;                    // plane pixel index of the tile's first pixel; < 0 only in image row -1
+      const bool okA = tid < npx && g0 + tid >= 0, okB = tid + THREADS < npx && g0 + tid + THREADS >= 0;
+      const float* pA = a.in + (size_t)b * CIN * H * W + (okA ? (size_t)(g0 + tid) * 2 : 0);
+      const float* pB = a.in + (size_t)b * CIN * H * W + (okB ? (size_t)(g0 + tid + THREADS) * 2 : 0);
 #pragma unroll
-      for (int j = 0; j < NST; ++j) {
-        const int i = tid + j * THREADS;
-        int pr = (int)(((float)i + 0.5f) * inv);
-        int pix = i - pr * npx;
-        if (pix < 0) { --pr; pix += npx; }
-        if (pix >= npx) { ++pr; pix -= npx; }
-        const int gpix = (2 * y0 - 1) * W + pix;          // pixel index inside the plane; < 0 only in image row -1
-        st[j] = (f32x2){0.f, 0.f};
-        if (i < nq && gpix >= 0)
-          st[j] = *reinterpret_cast<const f32x2*>(img_base + (size_t)pr * H * W * 2 + (((a.pp_mask >> pr) & 1u) ? a.pp_bufstride : 0) + (size_t)gpix * 2);
+      for (int pl = 0; pl < NPL; ++pl) {
+        const size_t po = (size_t)pl * H * W * 2 + (((a.pp_mask >> pl) & 1u) ? (size_t)a.pp_bufstride : 0);   // uniform
+        st[2 * pl] = okA ? *reinterpret_cast<const f32x2*>(pA + po) : (f32x2){0.f, 0.f};
+        st[2 * pl + 1] = okB ? *reinterpret_cast<const f32x2*>(pB + po) : (f32x2){0.f, 0.f};
       }
     } else {
       const int nq = active ? (2 * rows + 1) * W * QPP : 0;
@@ -465,21 +463,14 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     const int y0 = ti * R, rows = min(R, OH - y0);
     if constexpr (PPIN) {
       const int npx = (2 * rows + 1) * W;
-      const int nq = npx * (CIN / 2);
-      const float inv = 1.0f / (float)npx, invw = 1.0f / (float)W;
+      const int rA = tid / W, xA = tid - rA * W, rB = (tid + THREADS) / W, xB = tid + THREADS - rB * W;
+      float* tA = T1 + (rA * WP + xA + 1) * CP;
+      float* tB = T1 + (rB * WP + xB + 1) * CP;
+      const bool okA = tid < npx, okB = tid + THREADS < npx;
 #pragma unroll
-      for (int j = 0; j < NST; ++j) {
-        const int i = tid + j * THREADS;
-        if (i >= nq) continue;
-        int pr = (int)(((float)i + 0.5f) * inv);
-        int pix = i - pr * npx;
-        if (pix < 0) { --pr; pix += npx; }
-        if (pix >= npx) { ++pr; pix -= npx; }
-        int r = (int)(((float)pix + 0.5f) * invw);
-        int x = pix - r * W;
-        if (x < 0) { --r; x += W; }
-        if (x >= W) { ++r; x -= W; }
-        *reinterpret_cast<f32x2*>(T1 + (r * WP + x + 1) * CP + 2 * pr) = st[j];
+      for (int pl = 0; pl < NPL; ++pl) {
+        if (okA) *reinterpret_cast<f32x2*>(tA + 2 * pl) = st[2 * pl];
+        if (okB) *reinterpret_cast<f32x2*>(tB + 2 * pl) = st[2 * pl + 1];
       }
     } else {
       const int nq = (2 * rows + 1) * W * QPP;
