@@ -61,6 +61,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
   float* CS = WD + Cfg::DW_FL;  // [6][KC*16]
   float* T1 = CS + Cfg::CST_FL;
   const int H = a.H, W = a.W, R = a.R;
+  const float invW = 1.0f / (float)W;
   const int WP = W + 2;
   const int t1_fl = (R + 2) * WP * CP + 16;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
     for (int j = 0; j < MAXP; ++j) {
       const int i = tid + j * THREADS;
       const int pix = i / QPP, q = i - pix * QPP;
-      const int r = pix / W, x = pix - r * W;
+      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
       const int gy = y0 - 1 + r;
       st0[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       st1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
       const int i = tid + j * THREADS;
       if (i >= npairs) continue;
       const int pix = i / QPP, q = i - pix * QPP;
-      const int r = pix / W, x = pix - r * W;
+      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
       const int gy = y0 - 1 + r;
       *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = (f32x4){st0[j][1], st0[j][3], st1[j][1], st1[j][3]};
       if (r >= 1 && r <= rows && gy >= 0 && gy < H)
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
         const int t = (u < nunits ? u : 0) / NPAIR;
         const int q = 16 * t + p;
         const int qc = q < npxA ? q : npxA - 1;
-        const int r = qc / W, x = qc - r * W;
+        const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
         const float* src = T1 + (r * WP + x + 1) * CP;
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
         const int t = u / NPAIR, mt = 2 * (u - t * NPAIR);
         const int q = 16 * t + p;
         const bool valid = q < npxA;
-        const int r = q / W, x = q - r * W;
+        const int r = yfv2_fdiv(q, invW), x = q - r * W;
         const int gy = y0 - 1 + r;
         const bool inimg = valid && gy >= 0 && gy < H;
         float* dst = T1 + (r * WP + x + 1) * CP;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
           const int q = 16 * (t0 + nt) + p;
           pv[nt] = q < npxB;
           const int qc = pv[nt] ? q : npxB - 1;
-          const int r = qc / W, x = qc - r * W;
+          const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
           base[nt] = (r * WP + x) * CP;  // top-left of the 3x3 window in T1 (halo row + zero column included)
           opx[nt] = img_px + (size_t)(y0 + r) * W + x;
         }
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   float* CS = WE + Cfg::DW_FL;      // [10][KS]
   float* T1 = CS + Cfg::NCS * KS;
   const int H = a.H, W = a.W, R = a.R, OH = H >> 1, OW = W >> 1;
+  const float invW = 1.0f / (float)W, invOW = 1.0f / (float)OW;
   const int WP = W + 1;
   const int t1_fl = (2 * R + 1) * WP * CP + 16;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
       for (int j = 0; j < MAXP; ++j) {
         const int i = tid + j * THREADS;
         const int pix = i / QPP, q = i - pix * QPP;
-        const int r = pix / W, x = pix - r * W;
+        const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
         const int gy = 2 * y0 - 1 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (i < nq && gy >= 0 && gy < H) v = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)gy * W + x) * CIN + 4 * q);
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     const int y0 = ti * R, rows = min(R, OH - y0);
     if constexpr (PPIN) {
       const int npx = (2 * rows + 1) * W;
-      const int rA = tid / W, xA = tid - rA * W, rB = (tid + THREADS) / W, xB = tid + THREADS - rB * W;
+      const int rA = yfv2_fdiv(tid, invW), xA = tid - rA * W, rB = yfv2_fdiv(tid + THREADS, invW), xB = tid + THREADS - rB * W;
       float* tA = T1 + (rA * WP + xA + 1) * CP;
       float* tB = T1 + (rB * WP + xB + 1) * CP;
       const bool okA = tid < npx, okB = tid + THREADS < npx;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         const int i = tid + j * THREADS;
         if (i >= nq) continue;
         const int pix = i / QPP, q = i - pix * QPP;
-        const int r = pix / W, x = pix - r * W;
+        const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
         *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = (f32x4){st[2 * j][0], st[2 * j][1], st[2 * j + 1][0], st[2 * j + 1][1]};
       }
     }
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         const int q = 16 * t + p;
         const bool pv = q < npxB;
         const int qc = pv ? q : npxB - 1;
-        const int r = qc / OW, x = qc - r * OW;
+        const int r = yfv2_fdiv(qc, invOW), x = qc - r * OW;
         const int oy = y0 + r;
         const float* tp = T1 + ((2 * r) * WP + 2 * x) * CP;  // window rows 2r..2r+2, T1 cols 2x..2x+2
         f32x4 bfr[KC];
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         const int t = wave + (pass * TP + k) * NW;
         const int q = 16 * (t * 16 < npxA ? t : 0) + p;
         const int qc = q < npxA ? q : npxA - 1;
-        const int r = qc / W, x = qc - r * W;
+        const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
         const float* src = T1 + (r * WP + x + 1) * CP;
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         if (t * 16 >= npxA) continue;  // wave-uniform
         const int q = 16 * t + p;
         const bool valid = q < npxA;
-        const int r = q / W, x = q - r * W;
+        const int r = yfv2_fdiv(q, invW), x = q - r * W;
         const int gy = iy0 + r;
         const bool inimg = valid && gy >= 0 && gy < H;
         float* dst = T1 + (r * WP + x + 1) * CP;
@@ -738,6 +740,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
   float* CS = WD + 25 * KC * 16;
   float* TIN = CS + 5 * 96;
   const int H = a.H, W = a.W, HW = H * W;
+  const float invW = 1.0f / (float)W;
   const int WP4 = W + 4;
   const int tin_fl = (H + 4) * WP4 * PS + 16;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
     const int q = 16 * (wave * NT + nt) + p;
     pv[nt] = q < HW;
     const int qc = pv[nt] ? q : HW - 1;
-    const int r = qc / W, x = qc - r * W;
+    const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
     base[nt] = (r * WP4 + x) * PS;  // top-left of the 5x5 window
     opix[nt] = qc;
   }
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
     const int i = tid + j * THREADS;
     const int px = i >> 2, c4 = i & 3;
     const bool ok = px < HW;
-    const int y = ok ? px / W : 0, x = ok ? px - y * W : 0;
+    const int y = ok ? yfv2_fdiv(px, invW) : 0, x = ok ? px - y * W : 0;
     s_src[j] = ok ? px * C + 4 * c4 : -1;
     s_dst[j] = ((y + 2) * WP4 + x + 2) * PS + 4 * c4;
   }

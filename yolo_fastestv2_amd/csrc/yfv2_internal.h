@@ -8,6 +8,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// n / d for 0 <= n < 2^16 and 8 <= d <= 1024 through the float pipe (cvt, fma, cvt instead of the ~25-instruction
+// integer division): (n + 0.5) / d is at least 0.5/d away from an integer, far more than the fp32 error of the product.
+#ifdef __HIPCC__
+__device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+#endif
+
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
   const float* x;      // (B,3,H,W)
