@@ -15,8 +15,8 @@ for B in (16, 256):
     for _ in range(3):
         eng.forward(x)
     torch.cuda.synchronize()
-    buf = torch.zeros(64, dtype=torch.float32)
-    _lib.lib().yfv2_debug_activation(eng._h, 100, B, C.c_void_p(buf.data_ptr()), 64)
+    buf = torch.zeros(128, dtype=torch.float32)
+    _lib.lib().yfv2_debug_activation(eng._h, 100, B, C.c_void_p(buf.data_ptr()), 128)
     st = buf.view(torch.int64).tolist()
     d = [st[i] - st[0] for i in range(7)]
     print("   staged+committed=%d  A-reads-done(last pass)=%d" % (st[8] - st[0], st[9] - st[0]))

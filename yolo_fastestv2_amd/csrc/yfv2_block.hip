@@ -147,6 +147,75 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
     stage_commit(item, T1);
     __syncthreads();
     YFV2_STAMP(8);
+    const int npxA = (rows + 2) * W;
+    if constexpr (KC == 3) {
+      // Whole 16-pixel tiles per wave, the filter's A fragments in registers (KC*KC float4, read from LDS once per
+      // item): a tile's pw1 output overwrites exactly the pixels its own B fragments came from, so a wave reads
+      // its tile, runs KC*KC*4 MFMAs and writes it back without any barrier or second pass; the next tile's B
+      // fragments are fetched before the current tile's MFMAs.  (Cycle stamps of the channel-pair scheme below at
+      // 22x22: phase A 19 k cycles for 8.9 k cycles of MFMA - LDS fragment re-reads per unit and four barriers.)
+      f32x4 aw[KC][KC];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt)
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
+      f32x4 sc1[KC], sh1[KC];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
+        sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+      }
+      auto tile_src = [&](int t) {
+        const int q = 16 * t + p;
+        const int qc = q < npxA ? q : npxA - 1;
+        const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
+        return (r * WP + x + 1) * CP;
+      };
+      f32x4 bf[KC], bn[KC];
+      int t = wave;
+      if (t * 16 < npxA) {
+        const int o = tile_src(t);
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = (16 * s2 + 4 * g < C2) ? *reinterpret_cast<const f32x4*>(T1 + o + 16 * s2 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      for (; t * 16 < npxA; t += NW) {
+        const int tn = t + NW;
+        const int on = tile_src(tn * 16 < npxA ? tn : t);
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) bn[s2] = (16 * s2 + 4 * g < C2) ? *reinterpret_cast<const f32x4*>(T1 + on + 16 * s2 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int q = 16 * t + p;
+        const bool valid = q < npxA;
+        const int r = yfv2_fdiv(valid ? q : 0, invW);
+        const int gy = y0 - 1 + r;
+        const bool inimg = valid && gy >= 0 && gy < H;
+        float* dst = T1 + tile_src(t);
+        f32x4 acc[KC];
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const int cb = 16 * mt + 4 * g;
+          if (valid && cb < C2) {
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
+              y[c] = (inimg && uu > 0.f) ? uu : 0.f;  // rows outside the image are conv zero padding
+            }
+            *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = bn[s2];
+      }
+      __syncthreads();  // phase B reads the neighbours' tiles
+    } else {
     // Work unit = (16-pixel tile, pair of output-channel tiles): one image has only 9..36 pixel
     // tiles for 8 waves, so whole tiles would leave most waves idle in the last round.
     // A1: every wave pulls the B fragments of ALL its units out of T1 into registers;
@@ -154,7 +223,6 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
     // same T1 pixels (rows outside the image stay zero = depthwise zero padding).
     constexpr int NPAIR = (KC + 1) / 2;
     constexpr int MAXU = Cfg::MAXU;
-    const int npxA = (rows + 2) * W;
     const int nunits = ((npxA + 15) / 16) * NPAIR;
     // Two passes over the units (each pass covers whole tiles: UPASS*NW is a multiple of NPAIR)
     // halve the registers that hold B fragments across the barrier.
@@ -225,6 +293,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
         }
       }
       __syncthreads();  // pass 0's writes land before pass 1 reads other tiles; phase B after pass 1
+    }
     }
     YFV2_STAMP(4);  // phase A done (all waves)
 
