@@ -148,17 +148,22 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
     __syncthreads();
     YFV2_STAMP(8);
     const int npxA = (rows + 2) * W;
-    if constexpr (KC == 3) {
+    if constexpr (KC == 3 || KC == 6) {
       // Whole 16-pixel tiles per wave, the filter's A fragments in registers (KC*KC float4, read from LDS once per
       // item): a tile's pw1 output overwrites exactly the pixels its own B fragments came from, so a wave reads
       // its tile, runs KC*KC*4 MFMAs and writes it back without any barrier or second pass; the next tile's B
       // fragments are fetched before the current tile's MFMAs.  (Cycle stamps of the channel-pair scheme below at
       // 22x22: phase A 19 k cycles for 8.9 k cycles of MFMA - LDS fragment re-reads per unit and four barriers.)
-      f32x4 aw[KC][KC];
+      // (KC = 6, 96 channels: 36 fragments do not fit in registers and an 11x11 map is one tile per wave anyway,
+      // so there the fragments are read per output-channel tile right before use)
+      constexpr bool AREG = KC <= 3;
+      f32x4 aw[AREG ? KC : 1][KC];
+      if constexpr (AREG) {
 #pragma unroll
-      for (int mt = 0; mt < KC; ++mt)
+        for (int mt = 0; mt < KC; ++mt)
 #pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
+          for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
+      }
       f32x4 sc1[KC], sh1[KC];
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
@@ -192,12 +197,32 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
         f32x4 acc[KC];
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (AREG) {
 #pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2)
+          for (int s2 = 0; s2 < KC; ++s2)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
+              for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int mp = 0; mp < KC; mp += 2) {   // two output-channel tiles at a time: 2*KC fragment reads, then 8*KC MFMAs on two accumulators
+            f32x4 af0[KC], af1[KC];
+#pragma unroll
+            for (int s2 = 0; s2 < KC; ++s2) {
+              af0[s2] = *reinterpret_cast<const f32x4*>(W1 + ((mp * KC + s2) * 64 + lane) * 4);
+              af1[s2] = *reinterpret_cast<const f32x4*>(W1 + (((mp + 1) * KC + s2) * 64 + lane) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < KC; ++s2)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                acc[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[s2][j], bf[s2][j], acc[mp], 0, 0, 0);
+                acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[s2][j], bf[s2][j], acc[mp + 1], 0, 0, 0);
+              }
+          }
+        }
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) {
           const int cb = 16 * mt + 4 * g;
