@@ -225,6 +225,16 @@ __global__ __launch_bounds__(64, 1) void s1px_kernel(S1PxArgs a) {
 // (role = workgroup parity; both read the same input rows through L2) writing disjoint output slots.
 constexpr int S2PX_PW_A = 0, S2PX_PW_B = 640, S2PX_TAPS_MAIN = 1280, S2PX_TAPS_PROJ = 640;
 
+// proj role: its depthwise inputs are registers written by buffer loads and read ONLY by inline asm - hipcc inserts
+// s_waitcnt for its own instructions' operands, not for asm operands, so without this the FMAs could run on a row
+// that has not landed yet (it "worked" only because the loads are issued half a step ahead).  The wait is an asm
+// statement that takes the row's 12 registers as read-write operands, so no reader can be scheduled above it.
+// When a row is due the only younger loads are the 12 of the other row buffer: vmcnt(12) is exact if stores are not
+// counted in vmcnt and merely conservative if they are.
+#define YFV2_WAIT_ROW(Z)                                                                                                             \
+  asm volatile("s_waitcnt vmcnt(12)"                                                                                                  \
+               : "+v"(Z[0]), "+v"(Z[1]), "+v"(Z[2]), "+v"(Z[3]), "+v"(Z[4]), "+v"(Z[5]), "+v"(Z[6]), "+v"(Z[7]), "+v"(Z[8]), "+v"(Z[9]), \
+                 "+v"(Z[10]), "+v"(Z[11]))
 template <bool MAIN>
 __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
   constexpr int ROLE = MAIN ? 1 : 0;
@@ -294,6 +304,7 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
     load_row(iy, X);
     load_row(iy + 1, Y);
     const float lim = (xok && iy >= 0) ? __builtin_inff() : 0.f;
+    if constexpr (!MAIN) YFV2_WAIT_ROW(X);         // (MAIN: the rows go through MFMA builtins, which get the compiler's own waits)
     column(X, 0, lim, T0);
     column(X, 1, lim, T1);
     load_row(iy + 2, X);
@@ -320,6 +331,7 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
     if constexpr (!MAIN) { flush(); __builtin_amdgcn_sched_barrier(0); }
     acc_row(std::integral_constant<int, 0>{}, T0, T1, S, Q);
     // even input row 2oy (in Y), dy = 1
+    if constexpr (!MAIN) YFV2_WAIT_ROW(Y);
     column(Y, 0, limx, v0);
     column(Y, 1, limx, v1);
     acc_row(std::integral_constant<int, 1>{}, v0, v1, S, Q);
@@ -327,6 +339,7 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
     load_row(2 * oy + 2, Y);                       // next step's even row
     __builtin_amdgcn_sched_barrier(0);
     // odd input row 2oy+1 (in X), dy = 2; it is the next output row's dy = 0 row
+    if constexpr (!MAIN) YFV2_WAIT_ROW(X);
     column(X, 0, limx, T0);
     column(X, 1, limx, T1);
     acc_row(std::integral_constant<int, 2>{}, T0, T1, S, Q);
@@ -351,6 +364,7 @@ __device__ __forceinline__ void s2px_body(const S2PxArgs& a, int wid) {
 #undef YFV2_TK
 }
 #undef YFV2_QP
+#undef YFV2_WAIT_ROW
 
 // The two roles are two kernels launched back to back, each with its own decomposition (main: 5 row bands per image
 // = 960 one-wave workgroups at 256 images; proj: 4 bands).  A proj-role wave has almost no arithmetic between its
