@@ -693,68 +693,69 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     dw_pw_branch(1);
     __syncthreads();
 
-    // ================= pw1 (+BN+ReLU) IN PLACE over the staged tile, two passes over the wave's
-    // tiles: B fragments out of T1 into registers, barrier, MFMAs, results overwrite the pixels
-    constexpr int MAXT = Cfg::MAXT, TP = (MAXT + 1) / 2;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      f32x4 bfu[TP][KC];
+    // ================= pw1 (+BN+ReLU) IN PLACE over the staged tile.  A wave takes whole 16-pixel tiles with the
+    // filter's KC*KC A fragments held in registers: a tile's output overwrites exactly the pixels its own B fragments
+    // came from, so no barrier separates reads from writes; the next tile's B fragments are fetched before the
+    // current tile's MFMAs (same scheme as block_s1_kernel's phase A).
+    {
+      f32x4 aw[KC][KC], sc1[KC], sh1[KC];
 #pragma unroll
-      for (int k = 0; k < TP; ++k) {
-        const int t = wave + (pass * TP + k) * NW;
-        const int q = 16 * (t * 16 < npxA ? t : 0) + p;
+      for (int mt = 0; mt < KC; ++mt) {
+#pragma unroll
+        for (int s = 0; s < KC; ++s) aw[mt][s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+        sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KS + 16 * mt + 4 * g);
+        sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KS + 16 * mt + 4 * g);
+      }
+      auto tile_off = [&](int t) {
+        const int q = 16 * t + p;
         const int qc = q < npxA ? q : npxA - 1;
         const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
-        const float* src = T1 + (r * WP + x + 1) * CP;
+        return (r * WP + x + 1) * CP;
+      };
+      f32x4 bf[KC], bn[KC];
+      int t = wave;
+      if (t * 16 < npxA) {
+        const int o = tile_off(t);
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          const int cb = 16 * s + 4 * g;
-          bfu[k][s] = cb < CIN ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int s = 0; s < KC; ++s) bf[s] = (16 * s + 4 * g < CIN) ? *reinterpret_cast<const f32x4*>(T1 + o + 16 * s + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      __syncthreads();
+      for (; t * 16 < npxA; t += NW) {
+        const int tn = t + NW;
+        const int on = tile_off(tn * 16 < npxA ? tn : t);
 #pragma unroll
-      for (int k = 0; k < TP; ++k) {
-        const int t = wave + (pass * TP + k) * NW;
-        if (t * 16 >= npxA) continue;  // wave-uniform
+        for (int s = 0; s < KC; ++s) bn[s] = (16 * s + 4 * g < CIN) ? *reinterpret_cast<const f32x4*>(T1 + on + 16 * s + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const int q = 16 * t + p;
         const bool valid = q < npxA;
-        const int r = yfv2_fdiv(q, invW), x = q - r * W;
+        const int r = yfv2_fdiv(valid ? q : 0, invW);
         const int gy = iy0 + r;
         const bool inimg = valid && gy >= 0 && gy < H;
-        float* dst = T1 + (r * WP + x + 1) * CP;
-        f32x4 afA[KC][KC], accA[KC];
+        float* dst = T1 + tile_off(t);
+        f32x4 accA[KC];
 #pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
-          accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < KC; ++s) afA[mt][s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int mt = 0; mt < KC; ++mt) accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KC; ++s)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < KC; ++mt)
-              accA[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afA[mt][s][j], bfu[k][s][j], accA[mt], 0, 0, 0);
+            for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s][j], bf[s][j], accA[mt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) {
           const int cb = 16 * mt + 4 * g;
           if (valid && cb < CIN) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KS + cb);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KS + cb);
             f32x4 y;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const float u = __builtin_fmaf(accA[mt][c], sc[c], sh[c]);
+              const float u = __builtin_fmaf(accA[mt][c], sc1[mt][c], sh1[mt][c]);
               y[c] = (inimg && u > 0.f) ? u : 0.f;  // input row -1 is the depthwise zero padding
             }
             *reinterpret_cast<f32x4*>(dst + cb) = y;
           }
         }
+#pragma unroll
+        for (int s = 0; s < KC; ++s) bf[s] = bn[s];
       }
-      __syncthreads();
+      __syncthreads();  // the main branch's windows reach into the neighbours' tiles
     }
 
     // ================= main branch: depthwise on pw1's output
