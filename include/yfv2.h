@@ -93,6 +93,14 @@ YFV2_API int yfv2_set_anchors(yfv2_handle h, const double anchors[12]);
  * shapes (B,4A,H/16,W/16) (B,A,..) (B,classes,..) and the same at H/32. */
 YFV2_API int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream);
 
+/* Same forward from the image layout the reference's callers hold BEFORE their pre-process step
+ * (test.py:34-38, utils/datasets.py:106-111): uint8 (B, height, width, 3) - HWC, channel order as decoded
+ * (BGR for cv2), values 0..255 - already resized to the configured size.  Replaces
+ * `img.reshape(1,H,W,3); torch.from_numpy(img.transpose(0,3,1,2)); img.to(device).float()/255.0` + Detector.forward:
+ * the transpose/cast is done by the stem kernel's loads, the 1/255 is folded into its filter (logits agree with
+ * the fp32 path to rounding, same 1e-4 bound).  SURVEY.md section 8(f) row 1. */
+YFV2_API int yfv2_forward_u8(yfv2_handle h, const uint8_t* x, int32_t B, float* const out6[6], void* stream);
+
 /* replaces: utils/utils.py:303-358 handel_preds (+ make_grid :298-300).
  * boxes: (B, rows, 5+classes) fp32, rows = A*(H/16*W/16 + H/32*W/32) = 1815,
  * row order (y, x, anchor) per scale, scale 0 then 1; columns cx,cy,w,h,obj,cls. */
@@ -114,6 +122,10 @@ YFV2_API int yfv2_nms(yfv2_handle h, const float* boxes, int32_t B, float conf_t
  * (B,rows,5+classes) tensor is not materialised on this path (same arithmetic, same result). */
 YFV2_API int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, double iou_thres,
                 float* dets, int32_t* idx, int32_t* count, void* stream);
+
+/* yfv2_detect from uint8 (B, height, width, 3) images (see yfv2_forward_u8). */
+YFV2_API int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres, double iou_thres,
+                            float* dets, int32_t* idx, int32_t* count, void* stream);
 
 /* ---- introspection / measurement (bench.py, tests) ------------------------- */
 

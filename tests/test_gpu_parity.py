@@ -391,3 +391,29 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     for g, r, k in zip(got, ref, LOGIT_KEYS):
         err = float((g.cpu() - r).abs().max())
         assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)
+
+
+def test_uint8_hwc_input_matches_float_path(yfv2, model, dev, images_u8, coco_weights):
+    """the pre-process of test.py:34-38 (HWC uint8 -> NCHW fp32 / 255) inside the stem kernel.
+    images_u8 is stored NCHW; the entry point takes the decoder's HWC layout.  Same logits as the oracle on the
+    float()/255 tensor (the 1/255 is folded into the filter: rounding-level differences only), same survivors as
+    the fp32 entry point end to end."""
+    x_chw = torch.from_numpy(images_u8[:5])
+    x_hwc = x_chw.permute(0, 2, 3, 1).contiguous()
+    assert x_hwc.dtype == torch.uint8 and tuple(x_hwc.shape[1:]) == (352, 352, 3)
+    ref = oracle.forward(coco_weights, x_chw.float() / 255.0)
+    got = model(x_hwc.to(dev))
+    for g, r, k in zip(got, ref, LOGIT_KEYS):
+        assert tuple(g.shape) == tuple(r.shape)
+        err = float((g.cpu() - r).abs().max())
+        assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)
+    eng = model.engine_for(x_hwc.to(dev))
+    d8, i8, c8 = eng.detect(x_hwc.to(dev), 0.3, 0.4)
+    df, if_, cf = eng.detect((x_chw.float() / 255.0).to(dev), 0.3, 0.4)
+    assert torch.equal(c8, cf)
+    for b in range(x_hwc.shape[0]):
+        n = int(cf[b])
+        assert torch.equal(i8[b, :n], if_[b, :n])
+        assert float((d8[b, :n] - df[b, :n]).abs().max()) <= 1e-3 if n else True
+    with pytest.raises(ValueError):
+        eng.forward(x_chw.to(dev))   # uint8 in NCHW is not a supported layout

@@ -41,11 +41,14 @@ _PROTOTYPES = {
     "yfv2_load_weights": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_int32]),
     "yfv2_set_anchors": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "yfv2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),
+    "yfv2_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),
     "yfv2_decode": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p]),
     "yfv2_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_double, C.POINTER(C.c_int32), C.c_int32,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "yfv2_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p]),
+    "yfv2_detect_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
     "yfv2_num_rows": (C.c_int32, [C.c_void_p]),
     "yfv2_num_stages": (C.c_int32, [C.c_void_p]),
     "yfv2_stage_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),

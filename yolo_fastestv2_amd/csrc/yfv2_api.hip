@@ -39,7 +39,7 @@ struct Step {
   BlockS2Args s2{};
   S1PxArgs s1px{};
   S2PxArgs s2px{};
-  size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role)
+  size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
   const float* rp_in = nullptr; float* rp_out = nullptr; int rp_hw = 0;   // STEP_REPACK
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
@@ -358,13 +358,14 @@ struct WeightPacker {
   }
   // stem_px_kernel: filter registers in the 4x4x1 broadcast form [11][64]: register q, lane 4j+i holds
   // scale[co] * W[co = 4m+i][k] for (m*27 + k) = 16q + j, k = ky*9 + ci*3 + kx; then shift[24]
-  size_t image_stem(const Folded& f) {
+  // in_scale: 1 for fp32 input in [0,1]; 1/255 for the uint8 entry points (test.py:38's float()/255 folded into the filter)
+  size_t image_stem(const Folded& f, float in_scale = 1.0f) {
     std::vector<float> im(11 * 64 + 24, 0.f);
     const float* w = &blob[f.w];  // [27 taps t = ci*9 + ky*3 + kx][24 co]
     for (int idx = 0; idx < 162; ++idx)
       for (int i = 0; i < 4; ++i) {
         const int co = 4 * (idx / 27) + i, k = idx % 27, ky = k / 9, ci = (k % 9) / 3, kx = k % 3;
-        im[(idx >> 4) * 64 + 4 * (idx & 15) + i] = w[(ci * 9 + ky * 3 + kx) * 24 + co] * blob[f.scale + co];
+        im[(idx >> 4) * 64 + 4 * (idx & 15) + i] = w[(ci * 9 + ky * 3 + kx) * 24 + co] * blob[f.scale + co] * in_scale;
       }
     for (int co = 0; co < 24; ++co) im[11 * 64 + co] = blob[f.shift + co];
     return put(im);
@@ -390,6 +391,7 @@ struct PlanBuilder {
     s.stem.R = 0;  // bands are chosen by the launcher
     s.stem.pp_out = pp_out ? 1 : 0;
     s.img_off = wp.image_stem(f);
+    s.img_off2 = wp.image_stem(f, 1.0f / 255.0f);
     s.name = "stem conv3x3s2+bn+relu+maxpool3x3s2";
     const double ch = h->cfg.height / 2.0, cw = h->cfg.width / 2.0;
     s.flops = 2.0 * ch * cw * 27 * 24;
@@ -772,15 +774,16 @@ size_t logit_elems(const yfv2_ctx* h, int i) {
   return (size_t)c * h->fh[sc] * h->fw[sc];
 }
 
-int run_plan(yfv2_ctx* h, const float* x, int B, float* const out6[6], hipStream_t s, hipEvent_t* ev /*nullable: 2 per step*/) {
+int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6], hipStream_t s, hipEvent_t* ev /*nullable: 2 per step*/) {
   const float* params = h->d_params;
   for (size_t i = 0; i < h->plan.size(); ++i) {
     Step& st = h->plan[i];
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i], s));
     if (st.kind == STEP_STEM) {
       StemArgs a = st.stem;
-      a.x = x; a.B = B;
+      a.x = x; a.B = B; a.u8_in = x_u8 ? 1 : 0;
       a.img = params + st.img_off;
+      a.img_u8 = params + st.img_off2;
       yfv2_launch_stem(a, s);
     } else if (st.kind == STEP_PW) {
       PwArgs a = st.pw;
@@ -978,7 +981,17 @@ int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6],
   for (int i = 0; i < 6; ++i)
     if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_forward: null output tensor");
   DeviceGuard guard(h->device);
-  return run_plan(h, x, B, out6, static_cast<hipStream_t>(stream), nullptr);
+  return run_plan(h, x, false, B, out6, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int yfv2_forward_u8(yfv2_handle h, const uint8_t* x, int32_t B, float* const out6[6], void* stream) {
+  int rc = check_call(h, B, true);
+  if (rc) return rc;
+  if (!x || !out6) return fail(h, YFV2_ERR_ARG, "yfv2_forward_u8: null pointer");
+  for (int i = 0; i < 6; ++i)
+    if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_forward_u8: null output tensor");
+  DeviceGuard guard(h->device);
+  return run_plan(h, x, true, B, out6, static_cast<hipStream_t>(stream), nullptr);
 }
 
 static int decode_impl(yfv2_handle h, const float* const out6[6], int32_t B, float* boxes, float* cand, void* stream);
@@ -1059,6 +1072,19 @@ int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, doub
   return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
 }
 
+int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres, double iou_thres, float* dets, int32_t* idx,
+                   int32_t* count, void* stream) {
+  int rc = check_call(h, B, true);
+  if (rc) return rc;
+  float* out6[6];
+  for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
+  rc = yfv2_forward_u8(h, x, B, out6, stream);
+  if (rc) return rc;
+  rc = decode_impl(h, out6, B, nullptr, h->cand.p, stream);
+  if (rc) return rc;
+  return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
+}
+
 int32_t yfv2_num_rows(yfv2_handle h) { return h ? h->rows : 0; }
 
 int32_t yfv2_num_stages(yfv2_handle h) { return h ? (int32_t)h->plan.size() : 0; }
@@ -1084,7 +1110,7 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
   for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
   std::vector<double> acc(n, 0.0);
   for (int it = 0; it < iters && rc == YFV2_OK; ++it) {
-    rc = run_plan(h, x, B, out6, s, ev.data());
+    rc = run_plan(h, x, false, B, out6, s, ev.data());
     if (rc) break;
     HIP_TRY(h, hipStreamSynchronize(s));
     for (size_t i = 0; i < n; ++i) {

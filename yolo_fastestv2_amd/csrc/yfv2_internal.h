@@ -7,6 +7,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
 // n / d for 0 <= n < 2^16 and 8 <= d <= 1024 through the float pipe (cvt, fma, cvt instead of the ~25-instruction
 // integer division): (n + 0.5) / d is at least 0.5/d away from an integer, far more than the fp32 error of the product.
@@ -16,11 +17,13 @@ __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((fl
 
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
-  const float* x;      // (B,3,H,W)
+  const void* x;       // fp32 (B,3,H,W) in [0,1], or (u8_in) uint8 (B,H,W,3) in 0..255
   float* out;          // (B,H/4,W/4,24) NHWC, or pair planes (pp_out)
   const float* img;    // broadcast-form filter [11 regs][64 lanes] (BN scale folded) + shift[24], see WeightPacker::image_stem
   int B, H, W;
   int R;               // pooled rows per band (set by the launcher, divides H/4)
+  int u8_in;           // input is uint8 NHWC; img_u8 = the filter image with 1/255 folded in
+  const float* img_u8;
   int pp_out;          // 1: write pair planes [B][12][H/4][W/4][2] (stage 2 in lane-per-pixel form), 0: NHWC
 };
 

@@ -65,7 +65,11 @@ __device__ __forceinline__ void stem_px_conv(const float (&wq)[11], const f32x4 
   stem_px_conv_impl<COL>(wq, sh, r0, r1, r2, acc, std::make_integer_sequence<int, 27>{});
 }
 
-template <bool PPOUT>   // output layout: pair planes [12][PH][PW][2] (for s2px_kernel) or NHWC
+// PPOUT: output layout pair planes [12][PH][PW][2] (for s2px_kernel) or NHWC.
+// U8IN: the input is the camera/decoder layout uint8 (B,H,W,3) (test.py:34-38 before its permute/float()/255): a lane's four
+// columns x three channels are 12 contiguous bytes = ONE load per input row instead of three 16-byte ones and a
+// quarter of the traffic; bytes become floats with v_cvt_f32_ubyteN and the 1/255 is folded into the filter.
+template <bool PPOUT, bool U8IN>
 __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
   const int H = a.H, W = a.W, PH = H >> 2, PW = W >> 2;
   const int strips = (PW - 1 + 14) / 15;
@@ -84,33 +88,54 @@ __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
   const int py0 = band * a.R;
   const bool st_ok = lvalid && (r > 0 || strip == 0);
 
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * 3 * H * W), 0, 3 * H * W * 4, 0x00020000);
-  const int rowb = W * 4;                          // bytes per input row
+  constexpr int ESZ = U8IN ? 3 : 4;               // bytes per input column in a row (u8: 3 interleaved channels; fp32: one plane)
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + (size_t)b * 3 * H * W * (U8IN ? 1 : 4)), 0,
+                                                                    3 * H * W * (U8IN ? 1 : 4), 0x00020000);
+  const int rowb = W * ESZ;                        // bytes per input row
   // voffset of (row 4py0, column 4px); invalid lanes sit beyond num_records and read zeros
-  int voff = lvalid ? (4 * py0 * W + 4 * px) * 4 : (int)0x80000000;
+  int voff = lvalid ? (4 * py0 * W + 4 * px) * ESZ : (int)0x80000000;
 
   float wq[11];
   f32x4 shiftv[6];
+  const float* wimg = U8IN ? a.img_u8 : a.img;
 #pragma unroll
-  for (int q = 0; q < 11; ++q) wq[q] = a.img[q * 64 + lane];
+  for (int q = 0; q < 11; ++q) wq[q] = wimg[q * 64 + lane];
   {
-    const f32x4* sh = reinterpret_cast<const f32x4*>(a.img + 11 * 64);
+    const f32x4* sh = reinterpret_cast<const f32x4*>(wimg + 11 * 64);
 #pragma unroll
     for (int m = 0; m < 6; ++m) shiftv[m] = sh[m];
   }
 
-  auto load4 = [&](int vo, f32x4 (&raw)[4][3]) {   // input rows vo .. vo+3 (all three channels)
+  // one input row of the lane's four columns: fp32 = three 16-byte plane pieces, u8 = 12 interleaved bytes
+  struct RawRow { f32x4 f[U8IN ? 1 : 3]; u32x3 u; };
+  auto load4 = [&](int vo, RawRow (&raw)[4]) {     // input rows vo .. vo+3 (all three channels)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int rr = 0; rr < 4; ++rr) {
+      if constexpr (U8IN) {
+        raw[rr].u = __builtin_amdgcn_raw_buffer_load_b96(rsrc, vo, rr * rowb, 0);
+      } else {
 #pragma unroll
-      for (int ci = 0; ci < 3; ++ci)
-        raw[rr][ci] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, (ci * H + rr) * rowb, 0));
+        for (int ci = 0; ci < 3; ++ci)
+          raw[rr].f[ci] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, (ci * H + rr) * rowb, 0));
+      }
+    }
   };
-  auto unpack = [&](const f32x4 (&raw)[3], StemRow& o) {
+  auto unpack = [&](const RawRow& raw, StemRow& o) {
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci) {
-      o.v[ci][0] = yfv2_row_shr1(raw[ci][3]);
-      o.v[ci][1] = raw[ci][0]; o.v[ci][2] = raw[ci][1]; o.v[ci][3] = raw[ci][2]; o.v[ci][4] = raw[ci][3];
+      float v[4];
+      if constexpr (U8IN) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {              // byte 3c + ci of the 12
+          const unsigned w = (3 * c + ci) >> 2 == 0 ? raw.u[0] : ((3 * c + ci) >> 2 == 1 ? raw.u[1] : raw.u[2]);
+          const int k = (3 * c + ci) & 3;
+          v[c] = (float)((w >> (8 * k)) & 0xffu);   // -> v_cvt_f32_ubyte{k}
+        }
+      } else {
+        v[0] = raw.f[ci][0]; v[1] = raw.f[ci][1]; v[2] = raw.f[ci][2]; v[3] = raw.f[ci][3];
+      }
+      o.v[ci][0] = yfv2_row_shr1(v[3]);
+      o.v[ci][1] = v[0]; o.v[ci][2] = v[1]; o.v[ci][3] = v[2]; o.v[ci][4] = v[3];
     }
   };
 
@@ -118,9 +143,9 @@ __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
   // with ReLU, which is applied once to the pooled value, and 0 stands in for the -inf padding
   StemRow carry;
   f32x4 cv0[6], cv1[6];
-  f32x4 bufA[4][3], bufB[4][3];
+  RawRow bufA[4], bufB[4];
   {
-    f32x4 raw[4][3];
+    RawRow raw[4];
     load4(py0 > 0 ? voff - 4 * rowb : (int)0x80000000, raw);   // rows 4py0-4 .. 4py0-1 (row -4 unused)
     load4(voff, bufA);                                          // first pooled row's inputs fly during the halo conv
     StemRow r1, r2;
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
                                  : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
 
   f32x4 pend[6];
-  auto compute = [&](const f32x4 (&cur)[4][3]) {
+  auto compute = [&](const RawRow (&cur)[4]) {
     StemRow r0, r1, r2, r3;
     unpack(cur[0], r0); unpack(cur[1], r1); unpack(cur[2], r2); unpack(cur[3], r3);
     f32x4 A[6], B[6], m0[6];
@@ -212,6 +237,12 @@ void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
   while (nb > 1 && (PH % nb || PH / nb < 4)) nb >>= 1;
   b.R = PH / nb;
   const int strips = (PW - 1 + 14) / 15;
-  if (a.pp_out) hipLaunchKernelGGL(stem_px_kernel<true>, dim3(a.B * ((strips * nb + 3) / 4)), dim3(64), 0, s, b);
-  else hipLaunchKernelGGL(stem_px_kernel<false>, dim3(a.B * ((strips * nb + 3) / 4)), dim3(64), 0, s, b);
+  const dim3 grid(a.B * ((strips * nb + 3) / 4));
+  if (a.u8_in) {
+    if (a.pp_out) hipLaunchKernelGGL((stem_px_kernel<true, true>), grid, dim3(64), 0, s, b);
+    else hipLaunchKernelGGL((stem_px_kernel<false, true>), grid, dim3(64), 0, s, b);
+  } else {
+    if (a.pp_out) hipLaunchKernelGGL((stem_px_kernel<true, false>), grid, dim3(64), 0, s, b);
+    else hipLaunchKernelGGL((stem_px_kernel<false, false>), grid, dim3(64), 0, s, b);
+  }
 }

@@ -111,10 +111,15 @@ class Engine:
         return [(B, 4 * A, h2, w2), (B, A, h2, w2), (B, nc, h2, w2), (B, 4 * A, h3, w3), (B, A, h3, w3), (B, nc, h3, w3)]
 
     def _check_x(self, x):
+        """fp32 (B,3,H,W) in [0,1] (the reference's Detector input), or uint8 (B,H,W,3) in 0..255: the decoded,
+        resized image BEFORE test.py:34-38's reshape/permute/float()/255, which the stem kernel then does itself."""
         if x.device != self.device:
             raise ValueError("input on %s, engine on %s" % (x.device, self.device))
-        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (3, self.height, self.width):
-            raise ValueError("expected fp32 (B,3,%d,%d), got %s %s" % (self.height, self.width, x.dtype, tuple(x.shape)))
+        if x.dtype == torch.uint8:
+            if x.dim() != 4 or tuple(x.shape[1:]) != (self.height, self.width, 3):
+                raise ValueError("expected uint8 (B,%d,%d,3), got %s" % (self.height, self.width, tuple(x.shape)))
+        elif x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (3, self.height, self.width):
+            raise ValueError("expected fp32 (B,3,%d,%d) or uint8 (B,%d,%d,3), got %s %s" % (self.height, self.width, self.height, self.width, x.dtype, tuple(x.shape)))
         return x.contiguous()
 
     # ---- the hot path ---------------------------------------------------------------------
@@ -125,7 +130,8 @@ class Engine:
         if out is None:
             out = [torch.empty(s, device=self.device, dtype=torch.float32) for s in self.logit_shapes(B)]
         ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in out])
-        check(_lib.lib().yfv2_forward(self._h, _ptr(x), B, ptrs, _stream(self.device)), self._h)
+        fn = _lib.lib().yfv2_forward_u8 if x.dtype == torch.uint8 else _lib.lib().yfv2_forward
+        check(fn(self._h, _ptr(x), B, ptrs, _stream(self.device)), self._h)
         return tuple(out)
 
     def decode(self, preds, out=None):
@@ -168,8 +174,8 @@ class Engine:
         B = x.shape[0]
         self.ensure_batch(B)
         dets, idx, cnt = out if out is not None else self.new_det_buffers(B)
-        check(_lib.lib().yfv2_detect(self._h, _ptr(x), B, float(conf_thres), float(iou_thres), _ptr(dets), _ptr(idx),
-                                     _ptr(cnt), _stream(self.device)), self._h)
+        fn = _lib.lib().yfv2_detect_u8 if x.dtype == torch.uint8 else _lib.lib().yfv2_detect
+        check(fn(self._h, _ptr(x), B, float(conf_thres), float(iou_thres), _ptr(dets), _ptr(idx), _ptr(cnt), _stream(self.device)), self._h)
         return dets, idx, cnt
 
     # ---- introspection --------------------------------------------------------------------

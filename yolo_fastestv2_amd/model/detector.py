@@ -133,10 +133,11 @@ class Detector(nn.Module):
         return tuple((t._version, t.data_ptr()) for t in self.state_dict(keep_vars=True).values())
 
     def engine_for(self, x):
-        key = (str(x.device), int(x.shape[2]), int(x.shape[3]))
+        hh, ww = (int(x.shape[1]), int(x.shape[2])) if (x.dtype == torch.uint8 and x.shape[-1] == 3) else (int(x.shape[2]), int(x.shape[3]))
+        key = (str(x.device), hh, ww)
         eng = self._engines.get(key)
         if eng is None:
-            eng = Engine(x.device, x.shape[2], x.shape[3], self.classes, self.anchor_num, max_batch=int(x.shape[0]))
+            eng = Engine(x.device, hh, ww, self.classes, self.anchor_num, max_batch=int(x.shape[0]))
             self._engines[key] = eng
         tok = self._version_token()
         if self._synced.get(key) != tok:
@@ -152,7 +153,10 @@ class Detector(nn.Module):
         if x.device.type != "cuda":
             raise RuntimeError("yolo_fastestv2_amd.Detector has no CPU path: move the input to the MI355X (.to('cuda'))")
         eng = self.engine_for(x)
-        out = eng.forward(x.float() if x.dtype != torch.float32 else x)
+        # extension over the reference surface: a uint8 (B,H,W,3) tensor is the image before test.py:34-38's
+        # reshape/permute/float()/255 - the stem kernel does that pre-process in its loads
+        u8_hwc = x.dtype == torch.uint8 and x.dim() == 4 and x.shape[-1] == 3
+        out = eng.forward(x if (u8_hwc or x.dtype == torch.float32) else x.float())
         out[0]._yfv2_engine = eng  # lets handel_preds reuse this handle (utils/utils.py)
         if self.export_onnx:
             # detector.py:33-44 export layout: post-sigmoid/softmax, NHWC, 12 reg + 3 obj + classes
