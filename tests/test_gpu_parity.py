@@ -417,3 +417,21 @@ def test_uint8_hwc_input_matches_float_path(yfv2, model, dev, images_u8, coco_we
         assert float((d8[b, :n] - df[b, :n]).abs().max()) <= 1e-3 if n else True
     with pytest.raises(ValueError):
         eng.forward(x_chw.to(dev))   # uint8 in NCHW is not a supported layout
+
+
+def test_non_square_input_288x384(yfv2, dev):
+    """Height != width (36/18/9 x 48/24/12 maps): strips, bands and halo masks of the lane-per-pixel kernels and the
+    tile bounds of the LDS kernels are all per-axis."""
+    w = yfv2.random_state_dict(5)
+    m = yfv2.Detector(80, 3, True).to(dev)
+    m.load_state_dict(w)
+    m.eval()
+    torch.manual_seed(4)
+    x = torch.rand(2, 3, 288, 384)
+    ref = oracle.forward(w, x)
+    got = m(x.to(dev))
+    for g, r, k in zip(got, ref, LOGIT_KEYS):
+        assert tuple(g.shape) == tuple(r.shape)
+        scale = max(1.0, float(r.abs().max()))
+        err = float((g.cpu() - r).abs().max())
+        assert err <= LOGIT_ATOL * scale, "%s: max abs err %g (scale %g)" % (k, err, scale)
