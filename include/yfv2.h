@@ -127,6 +127,18 @@ YFV2_API int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_th
 YFV2_API int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres, double iou_thres,
                             float* dets, int32_t* idx, int32_t* count, void* stream);
 
+/* replaces: utils/utils.py:194-230 get_batch_statistics (with bbox_iou :76-108), the per-detection loop of
+ * evaluation() (:361-395).  dets/count: the padded output of yfv2_nms / yfv2_detect; targets: (T,6) fp32 device rows
+ * [image index, label, x1, y1, x2, y2] in pixels, i.e. what evaluation() holds after utils.py:372-376; tp: (B,300)
+ * int32, 1 where the reference's true_positives is 1.  Same walk as the reference: detections in their (score-
+ * descending) order, best-IoU target over all of the image's targets (first on ties), IoU with the "+1 pixel"
+ * convention in fp32, threshold compared in fp32, a target is matched once, stop when all targets are matched.
+ * At most 1024 targets per image (YFV2_ERR_ARG otherwise; COCO's maximum is below 100).  Unlike the other entry points
+ * this one waits for the stream before it returns (it reads that overflow flag back; its result is consumed on the host
+ * by evaluation() anyway).  SURVEY.md section 8(f) row 2. */
+YFV2_API int yfv2_batch_statistics(yfv2_handle h, const float* dets, const int32_t* count, int32_t B, const float* targets,
+                                   int32_t T, float iou_threshold, int32_t* tp, void* stream);
+
 /* ---- introspection / measurement (bench.py, tests) ------------------------- */
 
 YFV2_API int32_t yfv2_num_rows(yfv2_handle h);   /* 1815 for 352x352, A=3 */

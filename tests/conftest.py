@@ -62,6 +62,12 @@ def coco_weights():
     return yfv2_oracle.load_weights(os.path.join(GOLDEN, "weights_coco.npz"))
 
 
+@pytest.fixture(scope="session")
+def golden_stats():
+    """NMS rows of the stress set + synthetic targets + the REFERENCE's get_batch_statistics flags (make_golden.py)."""
+    return dict(np.load(os.path.join(GOLDEN, "golden_stats.npz")))
+
+
 def unpack_ragged(z, prefix):
     """inverse of make_golden.pack_ragged -> (list of rows, list of idx)"""
     cnt = z[prefix + "_count"]

@@ -18,6 +18,7 @@ Outputs (all small, committed):
   golden_kat.npz       hand-made one-hot logit tuples -> decoded rows (known answers)
   golden_nms_stress.npz synthetic decoded tensors (clusters, ties, many classes)
                        -> reference non_max_suppression rows
+  golden_stats.npz     NMS rows of the stress set + synthetic targets -> reference get_batch_statistics
 
 usage: PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -179,6 +180,42 @@ def main():
         pack_ragged(nm, r, i, stress)
         print(nm, [x.shape[0] for x in r])
     np.savez_compressed(os.path.join(HERE, "golden_nms_stress.npz"), **stress)
+
+    # --- evaluation statistics: the reference's get_batch_statistics on those NMS rows -----------------
+    # targets = jittered copies of some survivors (true positives at several IoU levels), duplicates of one
+    # target (a target is matched once), boxes with a label no detection has, an image without targets,
+    # exact IoU ties (identical targets), more targets than detections
+    r_det, _ = ref_nms_per_image(uu, dec, 0.3, 0.4)
+    trng = np.random.default_rng(11)
+    tg = []
+    for si, d in enumerate(r_det):
+        if si == 5:
+            continue                                   # an image with detections and no targets
+        n = d.shape[0]
+        pick = trng.choice(n, min(n, (6, 40, 12, 300, 10, 0)[si]), replace=False) if n else []
+        for k in pick:
+            b = d[k, :4] + trng.normal(0, (1.0, 4.0, 12.0, 2.0, 0.0, 0)[si], 4).astype(np.float32)
+            tg.append([si, d[k, 5], b[0], b[1], b[2], b[3]])
+            if trng.random() < 0.2:
+                tg.append([si, d[k, 5], b[0], b[1], b[2], b[3]])          # identical twin: IoU tie, matched once each
+            if trng.random() < 0.15:
+                tg.append([si, (d[k, 5] + 1) % 80, b[0], b[1], b[2], b[3]])  # same box, other label
+        for _ in range(3):
+            tg.append([si, 79 - si, 5.0 + si, 7.0, 30.0 + si, 44.0])       # far away, label usually unseen
+    tg = np.asarray(tg, np.float32)
+    tg = tg[trng.permutation(tg.shape[0])]             # targets of different images interleaved, like a collated batch
+    stats = {"targets": tg}
+    pack_ragged("dets", r_det, [np.zeros(x.shape[0], np.int64) for x in r_det], stats)
+    for thr, nm in ((0.5, "tp_050"), (0.75, "tp_075")):
+        ref = uu.get_batch_statistics([torch.from_numpy(x) for x in r_det], torch.from_numpy(tg), thr, torch.device("cpu"))
+        mine = oracle.get_batch_statistics(r_det, tg, thr)
+        for (a, sc, lb), (b2, sc2, lb2) in zip(ref, mine):
+            assert np.array_equal(a, b2), "oracle get_batch_statistics != reference"
+            assert np.array_equal(sc.numpy(), sc2) and np.array_equal(lb.numpy(), lb2)
+        stats[nm] = np.concatenate([a for a, _, _ in ref]).astype(np.uint8)
+        stats[nm + "_count"] = np.asarray([a.shape[0] for a, _, _ in ref], np.int64)
+        print(nm, [int(a.sum()) for a, _, _ in ref], "of", [a.shape[0] for a, _, _ in ref])
+    np.savez_compressed(os.path.join(HERE, "golden_stats.npz"), **stats)
     for f in sorted(os.listdir(HERE)):
         print("%10d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 

@@ -435,3 +435,25 @@ def test_non_square_input_288x384(yfv2, dev):
         scale = max(1.0, float(r.abs().max()))
         err = float((g.cpu() - r).abs().max())
         assert err <= LOGIT_ATOL * scale, "%s: max abs err %g (scale %g)" % (k, err, scale)
+
+
+def test_batch_statistics_bit_exact_vs_reference_golden(yfv2, dev, golden_stats):
+    """evaluation()'s matching loop (utils.py:194-230) as one kernel launch; flags identical to
+    the ones the reference function produced on the same detections / targets (jittered copies, twins with tied
+    IoU, foreign labels, an image without targets, interleaved image order), through both surfaces."""
+    dets, _ = unpack_ragged(golden_stats, "dets")
+    targets = torch.from_numpy(golden_stats["targets"])
+    outs = [torch.from_numpy(d) for d in dets]
+    for thr, key in ((0.5, "tp_050"), (0.75, "tp_075")):
+        got = yfv2.get_batch_statistics(outs, targets, thr, dev)
+        assert len(got) == len(outs)
+        flat = np.concatenate([t for t, _, _ in got])
+        assert flat.dtype == np.float64
+        assert np.array_equal(flat.astype(np.uint8), golden_stats[key])
+        for (t, sc, lb), o in zip(got, outs):
+            assert torch.equal(sc, o[:, 4]) and torch.equal(lb, o[:, -1])
+    # None entries are skipped like in the reference; no targets at all -> all zeros
+    got = yfv2.get_batch_statistics([None, outs[1]], targets, 0.5, dev)
+    assert len(got) == 1
+    got = yfv2.get_batch_statistics(outs[:2], torch.zeros((0, 6)), 0.5, dev)
+    assert all(t.sum() == 0 for t, _, _ in got)

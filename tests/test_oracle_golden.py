@@ -120,3 +120,17 @@ def test_random_weights_are_complete(coco_weights):
     assert all(torch.isfinite(p).all() for p in preds)
     assert float(preds[2].abs().max()) > 1e-3  # activations neither vanish nor explode
     assert float(preds[2].abs().max()) < 1e3
+
+
+def test_oracle_batch_statistics_match_reference_golden(golden_stats):
+    """utils.py:194-230 restated (oracle.get_batch_statistics) vs the flags the reference function produced."""
+    dets, _ = unpack_ragged(golden_stats, "dets")
+    for thr, key in ((0.5, "tp_050"), (0.75, "tp_075")):
+        got = oracle.get_batch_statistics(dets, golden_stats["targets"], thr)
+        flat = np.concatenate([t for t, _, _ in got])
+        assert np.array_equal(flat.astype(np.uint8), golden_stats[key])
+        assert [t.shape[0] for t, _, _ in got] == golden_stats[key + "_count"].tolist()
+    # the semantics the fixture was built to exercise
+    got = oracle.get_batch_statistics(dets, golden_stats["targets"], 0.5)
+    assert got[5][0].sum() == 0 and got[5][0].shape[0] == dets[5].shape[0]       # image without targets: all false positives
+    assert oracle.get_batch_statistics([None, dets[1]], golden_stats["targets"], 0.5).__len__() == 1   # None outputs are skipped

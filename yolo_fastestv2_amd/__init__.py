@@ -6,6 +6,7 @@ anchor decode and class-aware NMS as hand-written HIP kernels behind a C ABI
     Detector(classes, anchor_num, load_param, export_onnx=False)   model/detector.py:8
     handel_preds(preds, cfg, device)                               utils/utils.py:303
     non_max_suppression(prediction, conf_thres, iou_thres, classes) utils/utils.py:232
+    get_batch_statistics(outputs, targets, iou_threshold, device)   utils/utils.py:194  (evaluation's matching loop)
 
 There is no CPU / PyTorch fallback: importing works anywhere, running needs the
 built libyfv2.so and an MI355X.
@@ -13,7 +14,7 @@ built libyfv2.so and an MI355X.
 from ._lib import LIB_PATH, Yfv2Error  # noqa: F401
 from .engine import Engine, get_engine, unpack_detections  # noqa: F401
 from .model.detector import Detector  # noqa: F401
-from .utils.utils import handel_preds, load_datafile, nms_with_indices, non_max_suppression  # noqa: F401
+from .utils.utils import get_batch_statistics, handel_preds, load_datafile, nms_with_indices, non_max_suppression  # noqa: F401
 from .weights import random_state_dict  # noqa: F401
 from .sharded import detect_sharded, gather_detections, shard_range  # noqa: F401
 
@@ -27,3 +28,4 @@ def install(reference_detector_module=None, reference_utils_module=None):
     if reference_utils_module is not None:
         reference_utils_module.handel_preds = handel_preds
         reference_utils_module.non_max_suppression = non_max_suppression
+        reference_utils_module.get_batch_statistics = get_batch_statistics   # evaluation()'s matching loop

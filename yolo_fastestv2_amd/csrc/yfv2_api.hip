@@ -1085,6 +1085,26 @@ int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres,
   return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
 }
 
+int yfv2_batch_statistics(yfv2_handle h, const float* dets, const int32_t* count, int32_t B, const float* targets, int32_t T,
+                          float iou_threshold, int32_t* tp, void* stream) {
+  int rc = check_call(h, B, false);
+  if (rc) return rc;
+  if (!dets || !count || !tp || T < 0 || (T > 0 && !targets)) return fail(h, YFV2_ERR_ARG, "yfv2_batch_statistics: bad argument");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(h, hipMemsetAsync(h->d_classes, 0, sizeof(int32_t), s));   // reused as the overflow flag
+  StatsArgs a{};
+  a.dets = dets; a.count = count; a.targets = targets; a.tp = tp; a.overflow = h->d_classes;
+  a.B = B; a.T = T; a.iou_thres = iou_threshold;
+  yfv2_launch_stats(a, s);
+  HIP_TRY(h, hipGetLastError());
+  int32_t over = 0;
+  HIP_TRY(h, hipMemcpyAsync(&over, h->d_classes, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  if (over) return fail(h, YFV2_ERR_ARG, "yfv2_batch_statistics: an image has more than 1024 targets");
+  return YFV2_OK;
+}
+
 int32_t yfv2_num_rows(yfv2_handle h) { return h ? h->rows : 0; }
 
 int32_t yfv2_num_stages(yfv2_handle h) { return h ? (int32_t)h->plan.size() : 0; }

@@ -174,5 +174,17 @@ int yfv2_block_s2_rows(int cin, int H, int W);
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s);
 bool yfv2_tower2_supported(int H, int W);                    // whole-image tower kernel: maps up to 22x22
 bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s);
+// ---- evaluation statistics (get_batch_statistics): which detections are true positives
+struct StatsArgs {
+  const float* dets;     // (B, 300, 6) x1,y1,x2,y2,conf,cls rows of yfv2_nms / yfv2_detect
+  const int32_t* count;  // (B)
+  const float* targets;  // (T, 6) image index, label, x1, y1, x2, y2 (pixels), the layout evaluation() builds (utils.py:372-376)
+  int32_t* tp;           // (B, 300) 1 = true positive
+  int32_t* overflow;     // set to 1 if an image has more than STATS_MAX_TARGETS targets (result then invalid)
+  int B, T;
+  float iou_thres;
+};
+constexpr int STATS_MAX_TARGETS = 1024;
+void yfv2_launch_stats(const StatsArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);

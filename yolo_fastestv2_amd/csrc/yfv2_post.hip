@@ -377,3 +377,75 @@ void yfv2_launch_nms(const NmsArgs& a, hipStream_t s) {
   else
     hipLaunchKernelGGL(nms_kernel<false>, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
 }
+
+// ============================================================================
+// get_batch_statistics (utils/utils.py:194-230) with bbox_iou (:76-108, the "+1 pixel" convention)
+// ============================================================================
+// One wave per image.  The reference walks the image's detections in order (score-descending, as NMS returned them):
+//   stop once every target has been matched; skip a detection whose label is not among the image's target labels;
+//   otherwise take the target with the largest IoU over ALL of the image's targets (first one on ties), and count
+//   the detection as a true positive if IoU >= iou_threshold and that target has not been matched yet.
+// The walk is sequential through the matched set; lanes run over the targets (kept in LDS with their matched flag).
+// fp32 arithmetic in the reference's operation order (this file is compiled with -ffp-contract=off); the
+// threshold is compared in fp32, as torch does for a float32 tensor against a Python float.
+__global__ __launch_bounds__(64) void stats_kernel(StatsArgs a) {
+  __shared__ float tx1[STATS_MAX_TARGETS], ty1[STATS_MAX_TARGETS], tx2[STATS_MAX_TARGETS], ty2[STATS_MAX_TARGETS], tlab[STATS_MAX_TARGETS];
+  __shared__ int tdone[STATS_MAX_TARGETS];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  // this image's targets, in their order of appearance (box_index of the reference = position in this list)
+  int nt = 0;
+  for (int t0 = 0; t0 < a.T; t0 += 64) {
+    const int t = t0 + lane;
+    const bool mine = t < a.T && a.targets[(size_t)t * 6] == (float)b;
+    const unsigned long long m = __ballot(mine);
+    if (mine) {
+      const int pos = nt + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < STATS_MAX_TARGETS) {
+        tlab[pos] = a.targets[(size_t)t * 6 + 1];
+        tx1[pos] = a.targets[(size_t)t * 6 + 2]; ty1[pos] = a.targets[(size_t)t * 6 + 3];
+        tx2[pos] = a.targets[(size_t)t * 6 + 4]; ty2[pos] = a.targets[(size_t)t * 6 + 5];
+        tdone[pos] = 0;
+      }
+    }
+    nt += __popcll(m);
+  }
+  if (nt > STATS_MAX_TARGETS) { if (lane == 0) *a.overflow = 1; nt = STATS_MAX_TARGETS; }
+  __syncthreads();
+  const int n = a.count[b];
+  int* tp = a.tp + (size_t)b * NMS_MAX_DET;
+  for (int i = lane; i < NMS_MAX_DET; i += 64) tp[i] = 0;
+  if (nt == 0) return;
+  const float thr = a.iou_thres;
+  int matched = 0;
+  for (int i = 0; i < n && matched < nt; ++i) {
+    const float* d = a.dets + ((size_t)b * NMS_MAX_DET + i) * 6;
+    const float bx1 = d[0], by1 = d[1], bx2 = d[2], by2 = d[3], lab = d[5];
+    const float barea = __fmul_rn(__fadd_rn(__fsub_rn(bx2, bx1), 1.f), __fadd_rn(__fsub_rn(by2, by1), 1.f));
+    bool has = false;
+    float best = -1.f;
+    int bidx = 0x7fffffff;
+    for (int t = lane; t < nt; t += 64) {
+      has |= tlab[t] == lab;
+      const float ix1 = fmaxf(bx1, tx1[t]), iy1 = fmaxf(by1, ty1[t]), ix2 = fminf(bx2, tx2[t]), iy2 = fminf(by2, ty2[t]);
+      const float iw = fmaxf(__fadd_rn(__fsub_rn(ix2, ix1), 1.f), 0.f), ih = fmaxf(__fadd_rn(__fsub_rn(iy2, iy1), 1.f), 0.f);
+      const float inter = __fmul_rn(iw, ih);
+      const float tarea = __fmul_rn(__fadd_rn(__fsub_rn(tx2[t], tx1[t]), 1.f), __fadd_rn(__fsub_rn(ty2[t], ty1[t]), 1.f));
+      const float iou = __fdiv_rn(inter, __fadd_rn(__fsub_rn(__fadd_rn(barea, tarea), inter), 1e-16f));
+      if (iou > best) { best = iou; bidx = t; }   // ascending t per lane: the first maximum stays
+    }
+    if (__ballot(has) == 0ull) continue;          // label not among the target labels (wave-uniform)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {      // (max IoU, lowest index) over the wave
+      const float ob = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bidx, off);
+      if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (best >= thr && tdone[bidx] == 0) {        // wave-uniform
+      if (lane == 0) { tp[i] = 1; tdone[bidx] = 1; }
+      ++matched;
+    }
+    __syncthreads();
+  }
+}
+
+void yfv2_launch_stats(const StatsArgs& a, hipStream_t s) { hipLaunchKernelGGL(stats_kernel, dim3(a.B), dim3(64), 0, s, a); }

@@ -178,6 +178,19 @@ class Engine:
         check(fn(self._h, _ptr(x), B, float(conf_thres), float(iou_thres), _ptr(dets), _ptr(idx), _ptr(cnt), _stream(self.device)), self._h)
         return dets, idx, cnt
 
+    def batch_statistics(self, dets, cnt, targets, iou_threshold):
+        """True-positive flags (B, 300) int32 for the padded detections of nms()/detect() against targets (T,6)
+        [image index, label, x1, y1, x2, y2] - utils/utils.py:194-230 get_batch_statistics on the device."""
+        B = dets.shape[0]
+        if tuple(dets.shape) != (B, MAX_DET, 6) or dets.dtype != torch.float32 or dets.device != self.device:
+            raise ValueError("dets must be fp32 (B,%d,6) on %s" % (MAX_DET, self.device))
+        targets = targets.to(self.device, torch.float32).reshape(-1, 6).contiguous()
+        self.ensure_batch(B)
+        tp = torch.empty((B, MAX_DET), device=self.device, dtype=torch.int32)
+        check(_lib.lib().yfv2_batch_statistics(self._h, _ptr(dets.contiguous()), _ptr(cnt.contiguous()), B, _ptr(targets) if targets.numel() else None,
+                                               int(targets.shape[0]), float(iou_threshold), _ptr(tp), _stream(self.device)), self._h)
+        return tp
+
     # ---- introspection --------------------------------------------------------------------
     def stages(self):
         L = _lib.lib()

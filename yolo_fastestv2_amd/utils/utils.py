@@ -83,6 +83,40 @@ def nms_with_indices(prediction, conf_thres=0.3, iou_thres=0.45, classes=None):
     return unpack_detections(dets, idx, cnt)
 
 
+def get_batch_statistics(outputs, targets, iou_threshold, device=None):
+    """utils/utils.py:194-230 with the same signature and return structure: a list with one
+    [true_positives (np.float64 array), pred_scores (tensor), pred_labels (tensor)] entry per non-None output.
+    The per-detection matching loop (the part that dominates evaluation() once the model is fast) runs as one
+    kernel launch for the whole batch; outputs are the (n_i, 6) tensors non_max_suppression returned."""
+    import numpy as np
+    if not torch.cuda.is_available():
+        raise RuntimeError("get_batch_statistics: no MI355X visible (there is no CPU path)")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None or torch.device(device).type != "cuda" else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    B = len(outputs)
+    eng = get_engine(dev, 352, 352, 80, 3)   # the statistics kernel does not depend on the model configuration
+    MAXD = 300
+    dets = torch.zeros((B, MAXD, 6), dtype=torch.float32)
+    cnt = torch.zeros((B,), dtype=torch.int32)
+    for i, o in enumerate(outputs):
+        if o is None:
+            continue
+        n = min(int(o.shape[0]), MAXD)
+        dets[i, :n] = o[:n].detach().to("cpu", torch.float32)
+        cnt[i] = n
+    tp = eng.batch_statistics(dets.to(dev), cnt.to(dev), torch.as_tensor(targets), iou_threshold).cpu().numpy()
+    metrics = []
+    for i, o in enumerate(outputs):
+        if o is None:
+            continue
+        n = int(o.shape[0])
+        t = np.zeros(n)
+        t[:min(n, MAXD)] = tp[i, :min(n, MAXD)]
+        metrics.append([t, o[:, 4], o[:, -1]])
+    return metrics
+
+
 def _engine_for_rows(device, rows, classes):
     for h in range(32, 2049, 32):  # square inputs first (the reference only ever uses H == W)
         if 3 * ((h // 16) ** 2 + (h // 32) ** 2) == rows and h <= 384:
