@@ -152,6 +152,14 @@ def main():
         eng.forward(x, out=logit_bufs)
     dt_f = timed(lambda: eng.forward(x, out=logit_bufs), a.steps, sync, barrier)
     fwd_img_s = world * a.batch * a.steps / dt_f
+    # the same forward fed with uint8 (B,H,W,3) images (yfv2_forward_u8: test.py:34-38's pre-process inside the stem) -
+    # an extra, never `value`: the contract's input is the fp32 tensor
+    xu = (x.permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
+    for _ in range(2):
+        eng.forward(xu, out=logit_bufs)
+    dt_u = timed(lambda: eng.forward(xu, out=logit_bufs), a.steps, sync, barrier)
+    fwd_u8_img_s = world * a.batch * a.steps / dt_u
+    del xu
 
     cnt_h = det_bufs[2].float().cpu()
     out = None
@@ -237,6 +245,7 @@ def main():
                                    % (a.batch, a.conf, a.iou, " + RCCL all-gather of padded detections" if use_dist else ""),
                        "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
+            "forward_from_uint8_hwc_img_s": round(fwd_u8_img_s, 1), "forward_from_uint8_hwc_ms": round(1e3 * dt_u / a.steps, 4),
             "roofline": roof, "cpu_baseline": cpu,
             "detections_per_image": {"mean": round(float(cnt_h.mean()), 1), "max": int(cnt_h.max())},
             "forward_launches": len(kern), "forward_sum_of_launch_ms": round(tot_ms, 4), "kernel_groups": groups,
