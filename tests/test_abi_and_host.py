@@ -155,3 +155,43 @@ def test_gather_is_identity_without_process_group():
     d, i, c = torch.rand(2, 300, 6), torch.zeros(2, 300, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
     out = gather_detections(d, i, c)
     assert out[0] is d and out[1] is i and out[2] is c
+
+
+def test_export_weights_container_round_trip(tmp_path):
+    """The flat container include/yfv2.hpp's Detector::loadModel reads: every floating tensor, in order, bit-exact;
+    integer buffers (num_batches_tracked) skipped."""
+    import struct
+
+    import numpy as np
+
+    import yolo_fastestv2_amd as yfv2
+
+    w = yfv2.random_state_dict(seed=3)
+    path = str(tmp_path / "w.yfv2w")
+    n = yfv2.export_weights(w, path)
+    floats = [(k, v) for k, v in w.items() if v.is_floating_point()]
+    assert n == len(floats) and n < len(w)
+    buf = open(path, "rb").read()
+    assert buf[:8] == b"YFV2W1\0\0" and struct.unpack_from("<i", buf, 8)[0] == n
+    off = 12
+    for k, v in floats:
+        (ln,) = struct.unpack_from("<i", buf, off); off += 4
+        assert buf[off:off + ln].decode() == k; off += ln
+        (numel,) = struct.unpack_from("<q", buf, off); off += 8
+        assert numel == v.numel()
+        assert np.array_equal(np.frombuffer(buf, "<f4", numel, off), v.numpy().ravel()); off += 4 * numel
+    assert off == len(buf)
+
+
+def test_cpp_host_header_compiles_against_the_c_abi():
+    """include/yfv2.hpp is header-only over include/yfv2.h: the test driver built by build() must exist and link libyfv2.so."""
+    import os
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "tests", "cpp", "yfv2_cpp_test")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libyfv2.so" in out and "not found" not in out.split("libyfv2.so")[1].splitlines()[0]

@@ -457,3 +457,48 @@ def test_batch_statistics_bit_exact_vs_reference_golden(yfv2, dev, golden_stats)
     assert len(got) == 1
     got = yfv2.get_batch_statistics(outs[:2], torch.zeros((0, 6)), 0.5, dev)
     assert all(t.sum() == 0 for t, _, _ in got)
+
+
+def test_cpp_host_class_matches_python_surface(yfv2, model, dev, cfg, images_u8, coco_weights, tmp_path):
+    """include/yfv2.hpp (the counterpart of the reference's ncnn sample class, no Python in the
+    process) must report exactly the detections of the Python surface for the same uint8 image: same survivors, same
+    scores, boxes = the float boxes scaled to the source image and truncated like yolo-fastestv2.cpp's int casts.
+    Case 1: source already 352x352 (no resize, scale 1).  Case 2: a 2x nearest-upsampled source (704x704): the host
+    bilinear resize maps it back onto 352x352 within one grey level, boxes come back scaled by 2."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "yfv2_cpp_test")
+    assert os.path.exists(exe), "tests/cpp/yfv2_cpp_test missing: run __graft_entry__.build()"
+    wpath = str(tmp_path / "coco.yfv2w")
+    assert yfv2.export_weights(coco_weights, wpath) > 0
+    anchors = ",".join(repr(float(a)) for a in cfg["anchors"])
+    hwc = np.ascontiguousarray(images_u8[0].transpose(1, 2, 0))
+
+    def run(img, cols, rows):
+        ipath = str(tmp_path / ("img_%dx%d.raw" % (cols, rows)))
+        img.tofile(ipath)
+        r = subprocess.run([exe, wpath, anchors, ipath, str(cols), str(rows), "0.3", "0.4"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return [ln.split() for ln in r.stdout.strip().splitlines() if ln.strip()]
+
+    x = torch.from_numpy(hwc)[None].to(dev)
+    eng = model.engine_for(x)
+    d, i, c = eng.detect(x, 0.3, 0.4)
+    n = int(c[0])
+    assert n > 0
+    want = d[0, :n].cpu().numpy()
+
+    got = run(hwc, 352, 352)
+    assert len(got) == n
+    for g, w in zip(got, want):
+        assert [int(v) for v in g[:4]] == [int(np.float32(v)) for v in w[:4]]
+        assert int(g[4]) == int(w[5])
+        assert np.float32(float(g[5])) == np.float32(w[4])
+
+    up = np.ascontiguousarray(hwc.repeat(2, axis=0).repeat(2, axis=1))
+    got2 = run(up, 704, 704)   # (x + 0.5) * 2 - 0.5 = 2x + 0.5: the mean of two equal pixels, so the resized image is identical
+    assert len(got2) == n
+    for g, w in zip(got2, want):
+        assert [int(v) for v in g[:4]] == [int(np.float32(v) * np.float32(2.0)) for v in w[:4]]
+        assert int(g[4]) == int(w[5])
+        assert np.float32(float(g[5])) == np.float32(w[4])

@@ -15,7 +15,7 @@ from ._lib import LIB_PATH, Yfv2Error  # noqa: F401
 from .engine import Engine, get_engine, unpack_detections  # noqa: F401
 from .model.detector import Detector  # noqa: F401
 from .utils.utils import get_batch_statistics, handel_preds, load_datafile, nms_with_indices, non_max_suppression  # noqa: F401
-from .weights import random_state_dict  # noqa: F401
+from .weights import export_weights, random_state_dict  # noqa: F401
 from .sharded import detect_sharded, gather_detections, shard_range  # noqa: F401
 
 

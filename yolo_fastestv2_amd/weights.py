@@ -63,3 +63,26 @@ def random_state_dict(seed=0, classes=80, anchor_num=3):
         conv(name, co, 72, 1)
         w[name + ".bias"] = 0.1 * torch.randn(co, generator=g)
     return w
+
+
+def export_weights(state, path):
+    """Write a reference state_dict as the flat container include/yfv2.hpp's Detector::loadModel reads
+    (the C++ host path has no pickle reader):  b"YFV2W1\\0\\0" | int32 n | n x { int32 name_len | name |
+    int64 numel | numel x float32 }, little endian.  Integer buffers (num_batches_tracked) are skipped, exactly
+    like Engine.load_state_dict."""
+    import struct
+
+    items = []
+    for k, v in state.items():
+        v = torch.as_tensor(v)
+        if v.is_floating_point():
+            items.append((k.encode(), v.detach().to("cpu", torch.float32).contiguous().numpy()))
+    with open(path, "wb") as f:
+        f.write(b"YFV2W1\0\0")
+        f.write(struct.pack("<i", len(items)))
+        for name, arr in items:
+            f.write(struct.pack("<i", len(name)))
+            f.write(name)
+            f.write(struct.pack("<q", arr.size))
+            f.write(arr.astype("<f4", copy=False).tobytes())
+    return len(items)
