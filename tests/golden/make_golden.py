@@ -19,6 +19,7 @@ Outputs (all small, committed):
   golden_nms_stress.npz synthetic decoded tensors (clusters, ties, many classes)
                        -> reference non_max_suppression rows
   golden_stats.npz     NMS rows of the stress set + synthetic targets -> reference get_batch_statistics
+  golden_ap.npz        synthetic detection statistics -> reference ap_per_class (python make_golden.py ap)
 
 usage: PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -220,5 +221,42 @@ def main():
         print("%10d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 
 
+def make_ap_golden():
+    """golden_ap.npz: synthetic (tp, conf, pred_cls, target labels) sets -> the reference's ap_per_class 4-tuple
+    (utils/utils.py:136-192), float64.  Cases: a typical set, confidence ties, classes with ground truth but no
+    prediction, predictions of classes without ground truth, a single detection, all-wrong and all-right sets."""
+    _, uu = import_reference()
+    rng = np.random.default_rng(23)
+    cases = []
+
+    def case(n, ncls_pred, ncls_gt, n_gt, p_tp, ties=False):
+        conf = rng.random(n).astype(np.float32)
+        if ties:
+            conf = (np.round(conf * 20) / 20).astype(np.float32)
+        cls = rng.integers(0, ncls_pred, n).astype(np.float32)
+        tp = (rng.random(n) < p_tp).astype(np.float64)
+        labels = rng.integers(0, ncls_gt, n_gt).astype(np.float32).tolist()
+        cases.append((tp, conf, cls, labels))
+
+    case(4000, 80, 80, 1500, 0.4)
+    case(3000, 20, 80, 900, 0.6, ties=True)      # ground-truth classes nobody predicted
+    case(2500, 80, 10, 300, 0.2)                 # predictions of classes without ground truth
+    case(1, 1, 1, 1, 1.0)
+    case(500, 5, 5, 200, 0.0)
+    case(500, 5, 5, 200, 1.0, ties=True)
+    out = {"n": np.asarray(len(cases))}
+    for i, (tp, conf, cls, labels) in enumerate(cases):
+        ref = uu.ap_per_class(tp, conf, cls, labels)
+        out["tp%d" % i], out["conf%d" % i], out["cls%d" % i] = tp.astype(np.uint8), conf, cls
+        out["labels%d" % i] = np.asarray(labels, np.float64)
+        out["ref%d" % i] = np.asarray(ref, np.float64)
+        print("ap case", i, [float(v) for v in ref])
+    np.savez_compressed(os.path.join(HERE, "golden_ap.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ap":
+        make_ap_golden()      # only golden_ap.npz (the other files are left as committed)
+    else:
+        main()
+        make_ap_golden()

@@ -195,3 +195,20 @@ def test_cpp_host_header_compiles_against_the_c_abi():
         __graft_entry__.build()
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
     assert "libyfv2.so" in out and "not found" not in out.split("libyfv2.so")[1].splitlines()[0]
+
+
+def test_ap_per_class_bit_exact_vs_reference_golden():
+    """Host arithmetic of evaluation() (utils/utils.py:110-192): float64 results must equal the reference's own
+    function bit for bit on the golden sets (tests/golden/make_golden.py ap: ties, unseen classes, degenerate sets)."""
+    import os
+
+    import numpy as np
+
+    import yolo_fastestv2_amd as yfv2
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ap.npz"))
+    for i in range(int(z["n"])):
+        got = yfv2.ap_per_class(z["tp%d" % i].astype(np.float64), z["conf%d" % i], z["cls%d" % i], z["labels%d" % i].tolist())
+        assert np.array_equal(np.asarray(got, np.float64).view(np.uint64), z["ref%d" % i].view(np.uint64)), (i, got, z["ref%d" % i])
+    # compute_ap on a hand-checkable curve: recall 0.5 -> 1.0, precision 1.0 -> 0.5: 0.5*1.0 + 0.5*0.5
+    assert yfv2.compute_ap(np.array([0.5, 1.0]), np.array([1.0, 0.5])) == 0.75

@@ -502,3 +502,45 @@ def test_cpp_host_class_matches_python_surface(yfv2, model, dev, cfg, images_u8,
         assert [int(v) for v in g[:4]] == [int(np.float32(v) * np.float32(2.0)) for v in w[:4]]
         assert int(g[4]) == int(w[5])
         assert np.float32(float(g[5])) == np.float32(w[4])
+
+
+def test_evaluation_loop_matches_oracle_pipeline(yfv2, model, dev, cfg, images_u8, coco_weights):
+    """SURVEY.md 8(f) row 2, the whole loop: evaluation() (utils/utils.py:360-397 signature) over a two-batch loader of
+    the reference images with targets derived from the oracle's own detections, against the same loop composed from
+    the oracle (forward/decode/NMS at conf 0.01, get_batch_statistics restatement) and ap_per_class (pinned bit-exact
+    against the reference on CPU).  A detection whose confidence sits within fp32 noise of 0.01 may fall on either side,
+    so the four means are compared to 5e-3, not bitwise."""
+    imgs = torch.from_numpy(images_u8[:6])
+    x = imgs.float() / 255.0
+    _, _, (rows03, _) = oracle.detect(coco_weights, x, cfg["anchors"], cfg["height"], 0.3, 0.4)
+    rng = np.random.default_rng(5)
+    W, H = float(cfg["width"]), float(cfg["height"])
+
+    def targets_for(lo, hi):
+        t = []
+        for b in range(lo, hi):
+            for r in rows03[b]:
+                bx = r[:4] + rng.normal(0, 3.0, 4).astype(np.float32)
+                t.append([b - lo, r[5], (bx[0] + bx[2]) / 2 / W, (bx[1] + bx[3]) / 2 / H, (bx[2] - bx[0]) / W, (bx[3] - bx[1]) / H])
+            t.append([b - lo, 79.0, 0.1, 0.1, 0.05, 0.05])      # a ground-truth object nobody finds
+        return torch.tensor(np.asarray(t, np.float32))
+
+    loader = [(imgs[0:4], targets_for(0, 4)), (imgs[4:6], targets_for(4, 6))]
+    got = yfv2.evaluation(loader, cfg, model, dev)
+    assert got is not None and len(got) == 4
+
+    tps, confs, clss, labels = [], [], [], []
+    for bi, tg in loader:
+        _, _, (rows, _) = oracle.detect(coco_weights, bi.float() / 255.0, cfg["anchors"], cfg["height"], 0.01, 0.4)
+        t = tg.numpy().copy()
+        labels += t[:, 1].tolist()
+        c = t[:, 2:].copy()
+        t[:, 2], t[:, 3] = c[:, 0] - c[:, 2] / np.float32(2), c[:, 1] - c[:, 3] / np.float32(2)
+        t[:, 4], t[:, 5] = c[:, 0] + c[:, 2] / np.float32(2), c[:, 1] + c[:, 3] / np.float32(2)
+        t[:, 2:] *= np.asarray([W, H, W, H], np.float32)
+        for tp, sc, lb in oracle.get_batch_statistics(rows, t, 0.5):
+            tps.append(tp); confs.append(sc); clss.append(lb)
+    want = yfv2.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(clss), labels)
+    assert want[2] > 0.2, "the synthetic targets should be found: mean AP %g" % want[2]
+    assert np.allclose(np.asarray(got), np.asarray(want), atol=5e-3), (got, want)
+    assert yfv2.evaluation([], cfg, model, dev) is None

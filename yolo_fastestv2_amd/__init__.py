@@ -14,7 +14,8 @@ built libyfv2.so and an MI355X.
 from ._lib import LIB_PATH, Yfv2Error  # noqa: F401
 from .engine import Engine, get_engine, unpack_detections  # noqa: F401
 from .model.detector import Detector  # noqa: F401
-from .utils.utils import get_batch_statistics, handel_preds, load_datafile, nms_with_indices, non_max_suppression  # noqa: F401
+from .utils.utils import (ap_per_class, compute_ap, evaluation, get_batch_statistics, handel_preds, load_datafile,  # noqa: F401
+                          nms_with_indices, non_max_suppression)
 from .weights import export_weights, random_state_dict  # noqa: F401
 from .sharded import detect_sharded, gather_detections, shard_range  # noqa: F401
 
@@ -29,3 +30,4 @@ def install(reference_detector_module=None, reference_utils_module=None):
         reference_utils_module.handel_preds = handel_preds
         reference_utils_module.non_max_suppression = non_max_suppression
         reference_utils_module.get_batch_statistics = get_batch_statistics   # evaluation()'s matching loop
+        reference_utils_module.evaluation = evaluation                       # the loop itself, device-resident between batches

@@ -1,7 +1,11 @@
 """Drop-ins for the hot-path functions of the reference's ``utils/utils.py``:
 ``handel_preds`` (:303-358) and ``non_max_suppression`` (:232-296), same
 signatures and return types, executed by libyfv2's HIP kernels.  Also
-``load_datafile`` (:13-65), the ``.data`` config reader those callers need.
+``load_datafile`` (:13-65), the ``.data`` config reader those callers need, and the
+evaluation loop around the path: ``get_batch_statistics`` (:194-230,
+one kernel launch per batch), ``evaluation`` (:360-397, device-resident until the last line)
+and the dataset-level host arithmetic ``ap_per_class`` / ``compute_ap`` (:110-192, numpy like
+the reference: a few thousand float64 operations once per evaluation).
 """
 import os
 
@@ -115,6 +119,81 @@ def get_batch_statistics(outputs, targets, iou_threshold, device=None):
         t[:min(n, MAXD)] = tp[i, :min(n, MAXD)]
         metrics.append([t, o[:, 4], o[:, -1]])
     return metrics
+
+
+def compute_ap(recall, precision):
+    """utils/utils.py:110-134: area under the precision envelope, summed where recall changes."""
+    import numpy as np
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([0.0], precision, [0.0]))
+    mpre = np.maximum.accumulate(mpre[::-1])[::-1]      # running max from the right = the reference's backward loop
+    k = np.flatnonzero(mrec[1:] != mrec[:-1])
+    return np.sum((mrec[k + 1] - mrec[k]) * mpre[k + 1])
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls):
+    """utils/utils.py:136-192, same arguments and the same 4-tuple (mean precision, mean recall, mean AP, mean F1
+    over the classes that occur in ``target_cls``).  Detections are ranked with the same ``np.argsort(-conf)`` call,
+    so equal-confidence ties fall exactly as they do in the reference."""
+    import numpy as np
+    tp, conf, pred_cls, target_cls = np.asarray(tp), np.asarray(conf), np.asarray(pred_cls), np.asarray(target_cls)
+    rank = np.argsort(-conf)
+    tp, pred_cls = tp[rank], pred_cls[rank]
+    p, r, ap = [], [], []
+    for c in np.unique(target_cls):
+        mine = pred_cls == c
+        n_gt = (target_cls == c).sum()
+        if not mine.any():          # a ground-truth class nobody predicted scores zero on all three
+            p.append(0); r.append(0); ap.append(0)
+            continue
+        hits = tp[mine]
+        tpc, fpc = hits.cumsum(), (1 - hits).cumsum()
+        recall, precision = tpc / (n_gt + 1e-16), tpc / (tpc + fpc)
+        r.append(recall[-1]); p.append(precision[-1]); ap.append(compute_ap(recall, precision))
+    p, r, ap = np.array(p), np.array(r), np.array(ap)
+    f1 = 2 * p * r / (p + r + 1e-16)
+    return np.mean(p), np.mean(r), np.mean(ap), np.mean(f1)
+
+
+def evaluation(val_dataloader, cfg, model, device, conf_thres=0.01, nms_thresh=0.4, iou_thres=0.5):
+    """utils/utils.py:360-397 with the same signature and return value (``ap_per_class``'s 4-tuple, or None when the
+    loader is empty).  Per batch: the pre-process (`float()/255`, or none for a uint8 (B,H,W,3) batch), ONE fused
+    forward+decode+NMS call and ONE matching launch; detections, true-positive flags and counts stay on the GPU and
+    come back in a single copy after the last batch.  ``model`` is a yolo_fastestv2_amd.Detector."""
+    import numpy as np
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("evaluation: no CPU path, pass the MI355X device")
+    labels, kept = [], []
+    scale = None
+    for imgs, targets in val_dataloader:
+        imgs = imgs.to(device)
+        u8_hwc = imgs.dtype == torch.uint8 and imgs.dim() == 4 and imgs.shape[-1] == 3
+        x = imgs if u8_hwc else imgs.float() / 255.0
+        targets = targets.to(device).clone()
+        labels += targets[:, 1].tolist()
+        # normalised (cx, cy, w, h) -> corner pixels, in fp32 on the device like the reference (:372-376)
+        c = targets[:, 2:].clone()
+        targets[:, 2] = c[:, 0] - c[:, 2] / 2
+        targets[:, 3] = c[:, 1] - c[:, 3] / 2
+        targets[:, 4] = c[:, 0] + c[:, 2] / 2
+        targets[:, 5] = c[:, 1] + c[:, 3] / 2
+        if scale is None:
+            scale = torch.tensor([cfg["width"], cfg["height"], cfg["width"], cfg["height"]]).to(device)
+        targets[:, 2:] *= scale
+        eng = model.engine_for(x)
+        eng.set_anchors(cfg["anchors"])
+        dets, _, cnt = eng.detect(x, conf_thres, nms_thresh)
+        tp = eng.batch_statistics(dets, cnt, targets, iou_thres)
+        live = torch.arange(dets.shape[1], device=device)[None, :] < cnt[:, None]      # image-major, rank order: the order
+        kept.append((tp[live], dets[..., 4][live], dets[..., 5][live]))                 # sample_metrics is concatenated in
+    if not kept:
+        print("---- No detections over whole validation set ----")
+        return None
+    tp = torch.cat([k[0] for k in kept]).cpu().numpy().astype(np.float64)
+    conf = torch.cat([k[1] for k in kept]).cpu().numpy()
+    cls = torch.cat([k[2] for k in kept]).cpu().numpy()
+    return ap_per_class(tp, conf, cls, labels)
 
 
 def _engine_for_rows(device, rows, classes):
