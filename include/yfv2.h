@@ -127,6 +127,13 @@ YFV2_API int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_th
 YFV2_API int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres, double iou_thres,
                             float* dets, int32_t* idx, int32_t* count, void* stream);
 
+/* replaces: cv2.resize(img, (cfg.width, cfg.height), interpolation=cv2.INTER_LINEAR) of test.py:35 and
+ * utils/datasets.py:107 for B equally sized uint8 HWC frames: src (B, src_h, src_w, 3) -> dst (B, cfg.height,
+ * cfg.width, 3), both on the device, dst 4-byte aligned; dst is what yfv2_forward_u8 / yfv2_detect_u8 take.  The
+ * arithmetic is OpenCV's 8-bit fixed-point bilinear path (11-bit coefficients, see yfv2_pre.hip); src size == dst
+ * size is an exact copy.  Source rows up to ~27 000 pixels wide.  SURVEY.md section 8(f) row 1. */
+YFV2_API int yfv2_resize_u8(yfv2_handle h, const uint8_t* src, int32_t B, int32_t src_h, int32_t src_w, uint8_t* dst, void* stream);
+
 /* replaces: utils/utils.py:194-230 get_batch_statistics (with bbox_iou :76-108), the per-detection loop of
  * evaluation() (:361-395).  dets/count: the padded output of yfv2_nms / yfv2_detect; targets: (T,6) fp32 device rows
  * [image index, label, x1, y1, x2, y2] in pixels, i.e. what evaluation() holds after utils.py:372-376; tp: (B,300)

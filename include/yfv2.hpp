@@ -7,9 +7,9 @@
  * conf/IoU thresholds 0.3/0.4, test.py:48-49) because that is what libyfv2 implements and pins - the ncnn
  * sample's own integer NMS (IoU 0.25, explicit class compare) is a different algorithm.
  *
- * detection() = resize on the host (bilinear, half-pixel centres like cv2.INTER_LINEAR but in float: cv2's
- * fixed-point coefficients can differ by one grey level) -> one upload of the uint8 HWC image ->
- * yfv2_detect_u8 -> one download of the padded rows -> boxes scaled back to the source image.
+ * detection() = one upload of the source frame as it is (uint8 HWC) -> yfv2_resize_u8 (cv2.resize INTER_LINEAR's 8-bit
+ * arithmetic on the device, skipped when the frame already has the network size) -> yfv2_detect_u8 -> one download of
+ * the padded rows -> boxes scaled back to the source image.
  *
  * Weights come from a flat container written by `yolo_fastestv2_amd.export_weights(state_dict, path)`:
  *   "YFV2W1\0\0" | int32 n | n x { int32 name_len | name bytes | int64 numel | numel x float32 }.
@@ -19,7 +19,6 @@
 
 #include <hip/hip_runtime.h>
 
-#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -51,10 +50,10 @@ class Detector {
         hipStreamCreate(&stream_) != hipSuccess) {
       rc_ = YFV2_ERR_DEVICE; err_ = "hipMalloc / hipStreamCreate failed";
     }
-    resized_.resize(img);
   }
   ~Detector() {
     if (d_img_) (void)hipFree(d_img_);
+    if (d_src_) (void)hipFree(d_src_);
     if (d_dets_) (void)hipFree(d_dets_);
     if (d_idx_) (void)hipFree(d_idx_);
     if (d_cnt_) (void)hipFree(d_cnt_);
@@ -104,9 +103,20 @@ class Detector {
     if (!ok()) return rc_;
     if (!bgr || cols <= 0 || rows <= 0) return fail(YFV2_ERR_ARG, "detection: bad image");
     const float scaleW = (float)cols / (float)width_, scaleH = (float)rows / (float)height_;   // yolo-fastestv2.cpp:189-190
-    const unsigned char* src = bgr;
-    if (cols != width_ || rows != height_) { resize_bilinear(bgr, cols, rows); src = resized_.data(); }
-    if (hipMemcpyAsync(d_img_, src, (size_t)width_ * height_ * 3, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail(YFV2_ERR_DEVICE, "upload failed");
+    const size_t src_bytes = (size_t)cols * rows * 3;
+    if (cols == width_ && rows == height_) {
+      if (hipMemcpyAsync(d_img_, bgr, src_bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail(YFV2_ERR_DEVICE, "upload failed");
+    } else {
+      if (src_bytes > src_cap_) {
+        if (d_src_) (void)hipFree(d_src_);
+        d_src_ = nullptr; src_cap_ = 0;
+        if (hipMalloc(&d_src_, src_bytes) != hipSuccess) return fail(YFV2_ERR_DEVICE, "hipMalloc for the source frame failed");
+        src_cap_ = src_bytes;
+      }
+      if (hipMemcpyAsync(d_src_, bgr, src_bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail(YFV2_ERR_DEVICE, "upload failed");
+      const int rr = yfv2_resize_u8(h_, static_cast<const uint8_t*>(d_src_), 1, rows, cols, static_cast<uint8_t*>(d_img_), stream_);
+      if (rr != YFV2_OK) return fail(rr, yfv2_last_error(h_));
+    }
     const int rc = yfv2_detect_u8(h_, static_cast<const uint8_t*>(d_img_), 1, thresh, (double)iou_thresh, static_cast<float*>(d_dets_),
                                   static_cast<int32_t*>(d_idx_), static_cast<int32_t*>(d_cnt_), stream_);
     if (rc != YFV2_OK) return fail(rc, yfv2_last_error(h_));
@@ -127,37 +137,14 @@ class Detector {
 
  private:
   int fail(int rc, const std::string& msg) { err_ = msg; return rc; }
-  void resize_bilinear(const unsigned char* s, int cols, int rows) {
-    const float fx = (float)cols / (float)width_, fy = (float)rows / (float)height_;
-    for (int y = 0; y < height_; ++y) {
-      float sy = ((float)y + 0.5f) * fy - 0.5f;
-      int y0 = (int)std::floor(sy); float wy = sy - (float)y0;
-      int y1 = y0 + 1;
-      if (y0 < 0) { y0 = 0; y1 = 0; wy = 0.f; }
-      if (y1 > rows - 1) { y1 = rows - 1; if (y0 > rows - 1) y0 = rows - 1; }
-      for (int x = 0; x < width_; ++x) {
-        float sx = ((float)x + 0.5f) * fx - 0.5f;
-        int x0 = (int)std::floor(sx); float wx = sx - (float)x0;
-        int x1 = x0 + 1;
-        if (x0 < 0) { x0 = 0; x1 = 0; wx = 0.f; }
-        if (x1 > cols - 1) { x1 = cols - 1; if (x0 > cols - 1) x0 = cols - 1; }
-        for (int c = 0; c < 3; ++c) {
-          const float a = s[((size_t)y0 * cols + x0) * 3 + c], b = s[((size_t)y0 * cols + x1) * 3 + c];
-          const float d = s[((size_t)y1 * cols + x0) * 3 + c], e = s[((size_t)y1 * cols + x1) * 3 + c];
-          const float v = (a * (1.f - wx) + b * wx) * (1.f - wy) + (d * (1.f - wx) + e * wx) * wy;
-          resized_[((size_t)y * width_ + x) * 3 + c] = (unsigned char)(v + 0.5f);
-        }
-      }
-    }
-  }
-
   yfv2_handle h_ = nullptr;
   int rc_ = YFV2_OK;
   int width_, height_;
   std::string err_;
   void* d_img_ = nullptr; void* d_dets_ = nullptr; void* d_idx_ = nullptr; void* d_cnt_ = nullptr;
   hipStream_t stream_ = nullptr;
-  std::vector<unsigned char> resized_;
+  void* d_src_ = nullptr;
+  size_t src_cap_ = 0;
 };
 
 }  // namespace yfv2

@@ -463,8 +463,8 @@ def test_cpp_host_class_matches_python_surface(yfv2, model, dev, cfg, images_u8,
     """include/yfv2.hpp (the counterpart of the reference's ncnn sample class, no Python in the
     process) must report exactly the detections of the Python surface for the same uint8 image: same survivors, same
     scores, boxes = the float boxes scaled to the source image and truncated like yolo-fastestv2.cpp's int casts.
-    Case 1: source already 352x352 (no resize, scale 1).  Case 2: a 2x nearest-upsampled source (704x704): the host
-    bilinear resize maps it back onto 352x352 within one grey level, boxes come back scaled by 2."""
+    Case 1: source already 352x352 (no resize, scale 1).  Case 2: a 2x nearest-upsampled source (704x704): the device
+    resize maps it back onto exactly the 352x352 image, boxes come back scaled by 2.  Case 3: a 640x480 frame."""
     import subprocess
 
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "yfv2_cpp_test")
@@ -495,8 +495,23 @@ def test_cpp_host_class_matches_python_surface(yfv2, model, dev, cfg, images_u8,
         assert int(g[4]) == int(w[5])
         assert np.float32(float(g[5])) == np.float32(w[4])
 
+    # Case 3: an arbitrary frame size (480 rows x 640 columns): same detections as Engine.resize + Engine.detect, boxes
+    # scaled by 640/352, 480/352 in fp32 and truncated.
+    rng = np.random.default_rng(3)
+    frame = oracle.resize_linear_u8(hwc, 640, 480)                       # just a plausible 640x480 picture
+    frame = np.clip(frame.astype(int) + rng.integers(-3, 4, frame.shape), 0, 255).astype(np.uint8)
+    f_dev = torch.from_numpy(frame)[None].to(dev)
+    d3, _, c3 = eng.detect(eng.resize(f_dev), 0.3, 0.4)
+    n3 = int(c3[0])
+    got3 = run(frame, 640, 480)
+    assert len(got3) == n3 and n3 > 0
+    sw, sh = np.float32(640) / np.float32(352), np.float32(480) / np.float32(352)
+    for g, w in zip(got3, d3[0, :n3].cpu().numpy()):
+        assert [int(v) for v in g[:4]] == [int(np.float32(w[0]) * sw), int(np.float32(w[1]) * sh), int(np.float32(w[2]) * sw), int(np.float32(w[3]) * sh)]
+        assert int(g[4]) == int(w[5]) and np.float32(float(g[5])) == np.float32(w[4])
+
     up = np.ascontiguousarray(hwc.repeat(2, axis=0).repeat(2, axis=1))
-    got2 = run(up, 704, 704)   # (x + 0.5) * 2 - 0.5 = 2x + 0.5: the mean of two equal pixels, so the resized image is identical
+    got2 = run(up, 704, 704)   # every output pixel is the rounded mean of four equal pixels: the resized image is identical
     assert len(got2) == n
     for g, w in zip(got2, want):
         assert [int(v) for v in g[:4]] == [int(np.float32(v) * np.float32(2.0)) for v in w[:4]]
@@ -544,3 +559,23 @@ def test_evaluation_loop_matches_oracle_pipeline(yfv2, model, dev, cfg, images_u
     assert want[2] > 0.2, "the synthetic targets should be found: mean AP %g" % want[2]
     assert np.allclose(np.asarray(got), np.asarray(want), atol=5e-3), (got, want)
     assert yfv2.evaluation([], cfg, model, dev) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 480, 640), (2, 120, 160), (1, 352, 352), (1, 1080, 1920), (2, 353, 351), (1, 1, 1), (1, 704, 704)])
+def test_resize_u8_bit_exact_vs_oracle(yfv2, model, dev, shape):
+    """SURVEY.md 8(f) row 1, the resize half: yfv2_resize_u8 against the oracle's restatement of cv2.resize(INTER_LINEAR)
+    for uint8 (bit-exact: integer arithmetic after the float32 coefficient tables).  Reductions, enlargements, odd sizes
+    whose rows start at every byte alignment, a one-pixel frame, and a source buffer that itself starts at an odd address."""
+    B, sh, sw = shape
+    rng = np.random.default_rng(sh * 31 + sw)
+    frames = (rng.random((B, sh, sw, 3)) * 255).astype(np.uint8)
+    want = oracle.resize_linear_u8(frames, 352, 352)
+    eng = yfv2.get_engine(dev, 352, 352)
+    got = eng.resize(torch.from_numpy(frames).to(dev))
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (B, 352, 352, 3)
+    assert np.array_equal(got.cpu().numpy(), want)
+    flat = torch.zeros(frames.size + 1, dtype=torch.uint8, device=dev)
+    flat[1:] = torch.from_numpy(frames).to(dev).reshape(-1)
+    got2 = eng.resize(flat[1:].view(B, sh, sw, 3))      # base pointer = allocation + 1
+    assert np.array_equal(got2.cpu().numpy(), want)

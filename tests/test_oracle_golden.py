@@ -134,3 +134,26 @@ def test_oracle_batch_statistics_match_reference_golden(golden_stats):
     got = oracle.get_batch_statistics(dets, golden_stats["targets"], 0.5)
     assert got[5][0].sum() == 0 and got[5][0].shape[0] == dets[5].shape[0]       # image without targets: all false positives
     assert oracle.get_batch_statistics([None, dets[1]], golden_stats["targets"], 0.5).__len__() == 1   # None outputs are skipped
+
+
+def test_oracle_resize_properties():
+    """oracle.resize_linear_u8 restates cv2.resize(INTER_LINEAR) for uint8 from the published algorithm ("parity unpinned":
+    OpenCV is absent from the image).  What CAN be checked here: the equal-size copy, an exact 2x reduction equals the
+    rounded 2x2 mean (11-bit weights 1024/1024; also what OpenCV's INTER_AREA shortcut for that case computes), a
+    constant frame stays constant, and an enlargement agrees with PIL's bilinear (same sampling positions, different
+    fixed-point rounding) to one grey level."""
+    rng = np.random.default_rng(0)
+    img = (rng.random((120, 160, 3)) * 255).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear_u8(img, 160, 120), img)
+    big = (rng.random((704, 704, 3)) * 255).astype(np.uint8)
+    mean4 = ((big[0::2, 0::2].astype(int) + big[0::2, 1::2] + big[1::2, 0::2] + big[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear_u8(big, 352, 352), mean4)
+    assert np.unique(oracle.resize_linear_u8(np.full((480, 640, 3), 137, np.uint8), 352, 352)).tolist() == [137]
+    out = oracle.resize_linear_u8(np.stack([img, img[::-1]]), 352, 288)
+    assert out.shape == (2, 288, 352, 3) and out.dtype == np.uint8
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    pil = np.asarray(Image.fromarray(img).resize((352, 352), Image.BILINEAR))
+    assert np.abs(oracle.resize_linear_u8(img, 352, 352).astype(int) - pil.astype(int)).max() <= 1

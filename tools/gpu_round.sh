@@ -16,6 +16,8 @@ echo "== bench"
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench_$TAG.log 2>&1; echo "bench rc=$?"; tail -2 $OUT/bench_$TAG.log
 echo "== scale probe"
 timeout 300 python tools/scale_probe.py > $OUT/scale_$TAG.log 2>&1; echo "probe rc=$?"
+echo "== resize probe"
+timeout 120 python tools/resize_probe.py > $OUT/resize_$TAG.log 2>&1; echo "resize rc=$?"; tail -4 $OUT/resize_$TAG.log
 echo "== rocprofv3"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"

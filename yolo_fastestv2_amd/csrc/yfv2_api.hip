@@ -1105,6 +1105,23 @@ int yfv2_batch_statistics(yfv2_handle h, const float* dets, const int32_t* count
   return YFV2_OK;
 }
 
+int yfv2_resize_u8(yfv2_handle h, const uint8_t* src, int32_t B, int32_t src_h, int32_t src_w, uint8_t* dst, void* stream) {
+  if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
+  if (!src || !dst || B < 1 || src_h < 1 || src_w < 1) return fail(h, YFV2_ERR_ARG, "yfv2_resize_u8: bad argument");
+  if ((reinterpret_cast<uintptr_t>(dst) & 3) != 0) return fail(h, YFV2_ERR_ARG, "yfv2_resize_u8: dst must be 4-byte aligned");
+  if (yfv2_resize_lds_bytes(src_w, h->cfg.width) > 160 * 1024 || (long long)B * h->cfg.height > 0x7fffffffll)
+    return fail(h, YFV2_ERR_ARG, "yfv2_resize_u8: source rows wider than " + std::to_string((160 * 1024 - 3 * h->cfg.width) / 6 - 2) + " pixels are not supported");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ResizeArgs a{};
+  a.src = src; a.dst = dst; a.B = B; a.SH = src_h; a.SW = src_w; a.H = h->cfg.height; a.W = h->cfg.width;
+  a.scale_x = 1.0 / ((double)a.W / (double)src_w);      // cv::resize: inv_scale = dsize / ssize, scale = 1 / inv_scale
+  a.scale_y = 1.0 / ((double)a.H / (double)src_h);
+  yfv2_launch_resize(a, s);
+  HIP_TRY(h, hipGetLastError());
+  return YFV2_OK;
+}
+
 int32_t yfv2_num_rows(yfv2_handle h) { return h ? h->rows : 0; }
 
 int32_t yfv2_num_stages(yfv2_handle h) { return h ? (int32_t)h->plan.size() : 0; }

@@ -186,5 +186,14 @@ struct StatsArgs {
 };
 constexpr int STATS_MAX_TARGETS = 1024;
 void yfv2_launch_stats(const StatsArgs& a, hipStream_t s);
+// ---- pre-process: bilinear resize of uint8 HWC frames (yfv2_pre.hip)
+struct ResizeArgs {
+  const unsigned char* src;  // (B, SH, SW, 3)
+  unsigned char* dst;        // (B, H, W, 3), 4-byte aligned, W % 4 == 0
+  int B, SH, SW, H, W;
+  double scale_x, scale_y;   // 1 / (W / SW), 1 / (H / SH) in double, like cv::resize derives them
+};
+size_t yfv2_resize_lds_bytes(int SW, int W);
+void yfv2_launch_resize(const ResizeArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);

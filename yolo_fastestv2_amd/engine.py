@@ -178,6 +178,18 @@ class Engine:
         check(fn(self._h, _ptr(x), B, float(conf_thres), float(iou_thres), _ptr(dets), _ptr(idx), _ptr(cnt), _stream(self.device)), self._h)
         return dets, idx, cnt
 
+    def resize(self, frames, out=None):
+        """uint8 (B, h, w, 3) frames on the GPU -> uint8 (B, height, width, 3): cv2.resize(..., INTER_LINEAR) of test.py:35 /
+        utils/datasets.py:107 on the device; the result feeds forward()/detect() directly."""
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3 or frames.device != self.device:
+            raise ValueError("frames must be uint8 (B,h,w,3) on %s" % self.device)
+        frames = frames.contiguous()
+        B, sh, sw = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        if out is None:
+            out = torch.empty((B, self.height, self.width, 3), device=self.device, dtype=torch.uint8)
+        check(_lib.lib().yfv2_resize_u8(self._h, _ptr(frames), B, sh, sw, _ptr(out), _stream(self.device)), self._h)
+        return out
+
     def batch_statistics(self, dets, cnt, targets, iou_threshold):
         """True-positive flags (B, 300) int32 for the padded detections of nms()/detect() against targets (T,6)
         [image index, label, x1, y1, x2, y2] - utils/utils.py:194-230 get_batch_statistics on the device."""
