@@ -822,11 +822,17 @@ bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
 // is in LDS (26x26x16 floats at 22x22 instead of a 10-row x 72-channel tile), staged with a
 // one-chunk-ahead register prefetch.  No halo re-staging, every wave busy, and the
 // accumulators never leave registers until the (chained) output conv is done.
-constexpr int TW2_PS = 20;  // LDS floats per staged pixel (16 channels + 4 pad)
+// The staged slice is kept as four PLANES, one per channel quad: [quad][row][W + 16][4 floats], each plane padded to
+// a multiple of 256 bytes.  ds_read_b128 is serviced in four 16-lane groups that mix two quads ({0-3,12-15,20-27}, ...):
+// with the quad offset a multiple of 256 bytes the 16 lanes of a group read 16 consecutive 16-byte slots (a row pitch
+// of W + 16 slots keeps a 16-pixel run consecutive mod 16 across a row wrap) - no bank conflicts; the pixel-major
+// [pixel][20] tile this replaces had three colliding slots in every group (SQ_LDS_BANK_CONFLICT = 50 % of LDS-active).
+__host__ __device__ constexpr int tw2_row_pitch(int W) { return W + 16; }                                        // 16-byte slots
+__host__ __device__ constexpr int tw2_plane_slots(int H, int W) { return ((H + 4) * tw2_row_pitch(W) + 15) & ~15; }
 
 template <int MH, int THREADS, int NT, int NPF>
 __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
-  constexpr int KC = TW_KC, C = TW_C, PS = TW2_PS;
+  constexpr int KC = TW_KC, C = TW_C;
   constexpr int NW = THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* WP_ = lds;
@@ -836,8 +842,8 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
   float* TIN = CS + 5 * 96;
   const int H = a.H, W = a.W, HW = H * W;
   const float invW = 1.0f / (float)W;
-  const int WP4 = W + 4;
-  const int tin_fl = (H + 4) * WP4 * PS + 16;
+  const int RP = tw2_row_pitch(W), PL = tw2_plane_slots(H, W);   // row pitch / plane size in 16-byte slots
+  const int tin_fl = 4 * PL * 4;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
 
   // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
@@ -865,25 +871,29 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
     pv[nt] = q < HW;
     const int qc = pv[nt] ? q : HW - 1;
     const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
-    base[nt] = (r * WP4 + x) * PS;  // top-left of the 5x5 window
+    base[nt] = (r * RP + x) * 4;  // top-left of the 5x5 window (float offset inside a plane)
     opix[nt] = qc;
   }
-  // staging slots of this thread: float4 i -> (pixel, quad) of the chunk slice
+  // staging slots of this thread: float4 i -> (pixel, quad) of the chunk slice.  Eight consecutive lanes take eight
+  // consecutive pixels of ONE quad (ds_write_b128 is serviced in contiguous 8-lane groups: eight consecutive slots of a
+  // plane), the four quads of those pixels go to the next three 8-lane groups - the wave still reads whole 64-byte
+  // channel runs of 16 pixels from global memory.
   int s_src[NPF], s_dst[NPF];
+  const int my_c4 = (tid >> 3) & 3;          // THREADS is a multiple of 32: the same quad for every j
 #pragma unroll
   for (int j = 0; j < NPF; ++j) {
     const int i = tid + j * THREADS;
-    const int px = i >> 2, c4 = i & 3;
+    const int px = (i & 7) + 8 * (i >> 5);
     const bool ok = px < HW;
     const int y = ok ? yfv2_fdiv(px, invW) : 0, x = ok ? px - y * W : 0;
-    s_src[j] = ok ? px * C + 4 * c4 : -1;
-    s_dst[j] = ((y + 2) * WP4 + x + 2) * PS + 4 * c4;
+    s_src[j] = ok ? px * C + 4 * my_c4 : -1;
+    s_dst[j] = (my_c4 * PL + (y + 2) * RP + x + 2) * 4;
   }
   auto stage_load = [&](const float* img, int s, f32x4 (&pre)[NPF]) {
 #pragma unroll
     for (int j = 0; j < NPF; ++j) {
       pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (s_src[j] >= 0 && 16 * s + 4 * (int)((tid + j * THREADS) & 3) < C)
+      if (s_src[j] >= 0 && 16 * s + 4 * my_c4 < C)
         pre[j] = *reinterpret_cast<const f32x4*>(img + s_src[j] + 16 * s);
     }
   };
@@ -912,13 +922,13 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 #pragma unroll 1
       for (int ky = 0; ky < 5; ++ky) {
         const float* wrow = WD + ky * 5 * KC * 16 + cb;
-        const float* trow = TIN + ky * WP4 * PS + 4 * g;
+        const float* trow = TIN + (g * PL + ky * RP) * 4;
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * KC * 16);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(trow + base[nt] + kx * PS);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(trow + base[nt] + kx * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[nt][k] = __builtin_fmaf(v[k], w[k], d[nt][k]);
           }
@@ -1006,7 +1016,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 template <int MH, int THREADS, int NT, int NPF>
 static void launch_tower2(const TowerArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)TW_WP_FL + (size_t)MH * TW_WH_FL + 25 * TW_KC * 16 + 5 * 96 +
-                                      (size_t)(a.H + 4) * (a.W + 4) * TW2_PS + 16);
+                                      (size_t)16 * tw2_plane_slots(a.H, a.W));
   int blocks = a.B < 256 ? a.B : 256;
   static bool attr_done = false;
   if (!attr_done) {
