@@ -819,7 +819,7 @@ bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
 // A wave owns NT fixed 16-pixel tiles of the image and
 // keeps their pointwise accumulators in registers while the workgroup walks the five
 // 16-channel chunks: per chunk only that channel slice of the (zero-haloed) input image
-// is in LDS (26x26x16 floats at 22x22 instead of a 10-row x 72-channel tile), staged with a
+// is in LDS (four 26-row x 38-slot quad planes at 22x22, see below, instead of a 10-row x 72-channel tile), staged with a
 // one-chunk-ahead register prefetch.  No halo re-staging, every wave busy, and the
 // accumulators never leave registers until the (chained) output conv is done.
 // The staged slice is kept as four PLANES, one per channel quad: [quad][row][W + 16][4 floats], each plane padded to
