@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_REPACK = 6, STEP_S1PX = 7, STEP_S2PX = 8 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8 };
 
 struct Step {
   int kind = 0;
@@ -40,7 +40,6 @@ struct Step {
   S1PxArgs s1px{};
   S2PxArgs s2px{};
   size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
-  const float* rp_in = nullptr; float* rp_out = nullptr; int rp_hw = 0;   // STEP_REPACK
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
   // offsets into the param blob, resolved to pointers after the upload
@@ -813,8 +812,6 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       }
       if (!yfv2_launch_tower2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
-    } else if (st.kind == STEP_REPACK) {
-      yfv2_launch_repack_pp(st.rp_in, st.rp_out, B, st.rp_hw, (size_t)48 * st.rp_hw, s);
     } else if (st.kind == STEP_S2PX) {
       S2PxArgs a = st.s2px;
       a.B = B;

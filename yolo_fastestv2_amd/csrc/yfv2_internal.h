@@ -123,7 +123,6 @@ struct S2PxArgs {
 void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // two kernels (proj role, main role)
 bool yfv2_s1px_supported(int H, int W);
 void yfv2_launch_s1px(const S1PxArgs& a, hipStream_t s);
-void yfv2_launch_repack_pp(const float* in, float* out, int B, int HW, size_t out_img_stride, hipStream_t s);
 
 // ---- fused DWConvblock half (yfv2_block.hip): dw5x5+BN+ReLU -> pw72+BN [-> output conv]
 struct TowerArgs {

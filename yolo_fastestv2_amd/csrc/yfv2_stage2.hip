@@ -412,21 +412,3 @@ void yfv2_launch_s1px(const S1PxArgs& a0, hipStream_t s) {
   const int units = a.nstrips * a.nb;
   hipLaunchKernelGGL(s1px_kernel, dim3(a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
 }
-
-// ----------------------------------------------------------------------------
-// NHWC (48 channels) -> pair planes, logical channel c at slot(c)  (yfv2_stage2_slot, shared with the host)
-// ----------------------------------------------------------------------------
-__global__ void repack_pp_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW, size_t out_img_stride) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (b, pair, pixel)
-  const size_t total = (size_t)B * 24 * HW;
-  if (i >= total) return;
-  const int px = (int)(i % HW), p = (int)((i / HW) % 24), b = (int)(i / ((size_t)24 * HW));
-  const float* src = in + ((size_t)b * HW + px) * 48;
-  const f32x2 v = {src[yfv2_stage2_channel(2 * p)], src[yfv2_stage2_channel(2 * p + 1)]};
-  *reinterpret_cast<f32x2*>(out + (size_t)b * out_img_stride + ((size_t)p * HW + px) * 2) = v;
-}
-
-void yfv2_launch_repack_pp(const float* in, float* out, int B, int HW, size_t out_img_stride, hipStream_t s) {
-  const size_t total = (size_t)B * 24 * HW;
-  hipLaunchKernelGGL(repack_pp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, HW, out_img_stride);
-}
