@@ -233,8 +233,8 @@ struct WeightPacker {
     return off;
   }
   // pw_kernel: filter [MT*16][K+4], scale[MT*16], shift[MT*16]
-  size_t image_pw(const Folded& f, int M, int K) {
-    const int rows = ((M + 15) / 16) * 16, KP = K + 4;
+  size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */) {
+    const int rows = MT * 16, KP = K + 4;
     std::vector<float> im;
     push_matrix(im, &blob[f.w], M, K, rows, KP);
     push_vec(im, &blob[f.scale], M, rows);
@@ -413,7 +413,7 @@ struct PlanBuilder {
     s.pw.H = 0; s.pw.W = 0; s.pw.HW = px;
     s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0;
     s.px_per_img = px;
-    s.img_off = wp.image_pw(f, M, K);
+    s.img_off = wp.image_pw(f, M, K, yfv2_pw_tiles(K, mode, M));
     s.name = name;
     s.flops = 2.0 * px * K * M;
     s.bytes = 4.0 * px * (K + M);

@@ -251,6 +251,14 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 
+// M tiles of the instantiation yfv2_launch_pw picks: the host packs the filter image ([MT*16][K+4] | scale | shift) for
+// exactly that many (the biased output convs run a 6-tile kernel for 2..6 tiles of real channels)
+int yfv2_pw_tiles(int K, int mode, int M) {
+  const int MT = (M + 15) / 16;
+  if (mode == PW_HEAD && K == 72 && MT > 1 && MT <= 6) return 6;
+  return MT;
+}
+
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
   const int MT = (a.M + 15) / 16;
   if (mode == PW_PLAIN) {
