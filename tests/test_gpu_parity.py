@@ -468,6 +468,9 @@ def test_cpp_host_class_matches_python_surface(yfv2, model, dev, cfg, images_u8,
     import subprocess
 
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "yfv2_cpp_test")
+    if not os.path.exists(exe):      # normally prebuilt by __graft_entry__.build() and shipped with the tree
+        import __graft_entry__
+        __graft_entry__.build()
     assert os.path.exists(exe), "tests/cpp/yfv2_cpp_test missing: run __graft_entry__.build()"
     wpath = str(tmp_path / "coco.yfv2w")
     assert yfv2.export_weights(coco_weights, wpath) > 0
