@@ -169,6 +169,12 @@ YFV2_API int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, floa
  * (C3), 4 S2 (fpn 22x22), 5 S3 (fpn 11x11).  Returns the element count. */
 YFV2_API int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap);
 
+/* Host-only test hook: validates cfg, builds the launch plan and packs the weights exactly as yfv2_create +
+ * yfv2_load_weights do, WITHOUT a device (the workspace gets made-up addresses used only for pointer arithmetic);
+ * reports the number of launches and the packed blob size.  Lets the CPU test suite exercise the host logic for every
+ * (classes, height, width) the configuration check admits.  Never launches or computes anything. */
+YFV2_API int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* n_steps, int64_t* blob_floats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -212,3 +212,48 @@ def test_ap_per_class_bit_exact_vs_reference_golden():
         assert np.array_equal(np.asarray(got, np.float64).view(np.uint64), z["ref%d" % i].view(np.uint64)), (i, got, z["ref%d" % i])
     # compute_ap on a hand-checkable curve: recall 0.5 -> 1.0, precision 1.0 -> 0.5: 0.5*1.0 + 0.5*0.5
     assert yfv2.compute_ap(np.array([0.5, 1.0]), np.array([1.0, 0.5])) == 0.75
+
+
+def _dryrun(classes, H, W, drop=None, max_batch=4, weights_classes=None):
+    import ctypes as C
+
+    import yolo_fastestv2_amd as yfv2
+    from yolo_fastestv2_amd import _lib
+    from yolo_fastestv2_amd._lib import Config, TensorDesc
+
+    w = yfv2.random_state_dict(1, classes=weights_classes or min(max(classes, 1), 93))
+    host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point() and k != drop}
+    arr = (TensorDesc * len(host))()
+    for i, (k, t) in enumerate(host.items()):
+        arr[i].name, arr[i].data, arr[i].numel = k.encode(), t.data_ptr(), t.numel()
+    cfg = Config()
+    cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = classes, 3, H, W, max_batch, 0
+    ns, nb = C.c_int32(0), C.c_int64(0)
+    rc = _lib.lib().yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb))
+    return rc, ns.value, nb.value, host
+
+
+def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
+    """yfv2_debug_plan_dryrun runs the host half of yfv2_create + yfv2_load_weights (configuration check, launch plan,
+    BN folding and LDS-image packing) without a device.  Every (classes, size) the configuration check admits must
+    plan and pack; what it does not admit must be refused with the CONFIG code, a missing or mis-sized tensor with the
+    WEIGHTS code - codes, not crashes."""
+    from yolo_fastestv2_amd import _lib
+
+    sizes = [(352, 352), (320, 320), (288, 384), (32, 32), (64, 96), (352, 32)]
+    for classes in (80, 20, 1, 2, 17, 93):
+        blobs = set()
+        for H, W in sizes:
+            rc, steps, blob, _ = _dryrun(classes, H, W)
+            assert rc == 0 and steps >= 25 and blob > 400000, (classes, H, W, rc, steps, blob)
+            blobs.add(blob)
+        assert len(blobs) <= 3      # the packed blob depends on which kernels a size selects, not on the size itself
+    ERR_CONFIG, ERR_WEIGHTS = _lib.ERR_CONFIG, _lib.ERR_WEIGHTS
+    assert _dryrun(80, 384, 384)[0] == ERR_CONFIG      # 2160 decode rows > the NMS kernel's 2048
+    assert _dryrun(94, 352, 352)[0] == ERR_CONFIG
+    assert _dryrun(0, 352, 352)[0] == ERR_CONFIG
+    assert _dryrun(80, 350, 352)[0] == ERR_CONFIG
+    assert _dryrun(80, 352, 416)[0] == ERR_CONFIG
+    assert _dryrun(80, 352, 352, drop="fpn.conv1x1_2.0.weight")[0] == ERR_WEIGHTS
+    assert _dryrun(80, 352, 352, weights_classes=20)[0] == ERR_WEIGHTS     # a 20-class checkpoint into an 80-class handle
+    assert _dryrun(20, 352, 352)[2] < _dryrun(80, 352, 352)[2]

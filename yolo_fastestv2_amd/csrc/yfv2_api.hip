@@ -851,20 +851,8 @@ int check_call(yfv2_ctx* h, int B, bool need_weights) {
   return YFV2_OK;
 }
 
-}  // namespace
-
-// ===========================================================================
-// extern "C" surface
-// ===========================================================================
-extern "C" {
-
-int yfv2_abi_version(void) { return YFV2_ABI_VERSION; }
-
-const char* yfv2_last_error(yfv2_handle h) { return h ? h->err.c_str() : g_tls_error.c_str(); }
-
-int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
-  if (!out || !cfg) return fail(nullptr, YFV2_ERR_ARG, "yfv2_create: null argument");
-  *out = nullptr;
+// configuration checks shared by yfv2_create and the host-only dry run; returns the decode row count through *rows
+int check_config(const yfv2_config* cfg, int* rows_out) {
   if (cfg->anchor_num != 3)
     return fail(nullptr, YFV2_ERR_CONFIG, "anchor_num must be 3 (the reference decode hard-codes 3 anchors per scale)");
   if (cfg->classes < 1 || cfg->classes + cfg->anchor_num > 96)
@@ -874,26 +862,21 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   if (cfg->max_batch < 1) return fail(nullptr, YFV2_ERR_CONFIG, "max_batch must be >= 1");
   const int rows = 3 * ((cfg->height / 16) * (cfg->width / 16) + (cfg->height / 32) * (cfg->width / 32));
   if (rows > 2048) return fail(nullptr, YFV2_ERR_CONFIG, "more than 2048 decode rows per image is not supported by the NMS kernel");
+  *rows_out = rows;
+  return YFV2_OK;
+}
 
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
-    return fail(nullptr, YFV2_ERR_DEVICE, "no usable HIP device (this library has no CPU fallback)");
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
-    return fail(nullptr, YFV2_ERR_DEVICE, "hipGetDeviceProperties failed");
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(nullptr, YFV2_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
-
-  yfv2_ctx* h = new yfv2_ctx();
+// geometry + workspace of a handle; `alloc` is alloc_buf (device memory) or the dry run's address generator
+template <class Alloc>
+int setup_ctx(yfv2_ctx* h, const yfv2_config* cfg, int rows, Alloc alloc) {
   h->cfg = *cfg;
   h->device = cfg->device;
   h->rows = rows;
   h->fh[0] = cfg->height / 16; h->fw[0] = cfg->width / 16;
   h->fh[1] = cfg->height / 32; h->fw[1] = cfg->width / 32;
-  DeviceGuard guard(h->device);
   const size_t H = cfg->height, W = cfg->width;
   int rc = YFV2_OK;
-  auto A = [&](Buf* b, size_t n) { if (rc == YFV2_OK) rc = alloc_buf(h, b, n); };
+  auto A = [&](Buf* b, size_t n) { if (rc == YFV2_OK) rc = alloc(h, b, n); };
   A(&h->a1, (H / 4) * (W / 4) * 24);
   for (int i = 0; i < 2; ++i) {
     A(&h->s2[i], (H / 8) * (W / 8) * 48);
@@ -910,6 +893,38 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   A(&h->tb, (H / 16) * (W / 16) * 72);
   for (int i = 0; i < 6; ++i) A(&h->logits[i], logit_elems(h, i));
   A(&h->cand, (size_t)rows * 8);
+  return rc;
+}
+
+}  // namespace
+
+// ===========================================================================
+// extern "C" surface
+// ===========================================================================
+extern "C" {
+
+int yfv2_abi_version(void) { return YFV2_ABI_VERSION; }
+
+const char* yfv2_last_error(yfv2_handle h) { return h ? h->err.c_str() : g_tls_error.c_str(); }
+
+int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
+  if (!out || !cfg) return fail(nullptr, YFV2_ERR_ARG, "yfv2_create: null argument");
+  *out = nullptr;
+  int rows = 0;
+  if (int rc = check_config(cfg, &rows)) return rc;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, YFV2_ERR_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+    return fail(nullptr, YFV2_ERR_DEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, YFV2_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+
+  yfv2_ctx* h = new yfv2_ctx();
+  DeviceGuard guard(cfg->device);
+  int rc = setup_ctx(h, cfg, rows, alloc_buf);
   if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 256 * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, YFV2_ERR_DEVICE, "hipMalloc(class filter) failed");
   if (rc != YFV2_OK) {
@@ -920,6 +935,35 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   if (const char* tr = std::getenv("YFV2_TRACE"))
     if (tr[0] == '1') { (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
   *out = h;
+  return YFV2_OK;
+}
+
+// Host-only test hook (CPU suite): validate `cfg`, build the launch plan and pack the weights exactly as
+// yfv2_create + yfv2_load_weights do, but without a device - the workspace gets made-up addresses that are only ever
+// used for pointer arithmetic.  Reports the number of launches and the size of the packed parameter blob.
+int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* n_steps, int64_t* blob_floats) {
+  if (!cfg || !tensors || n <= 0) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_dryrun: bad argument");
+  int rows = 0;
+  if (int rc = check_config(cfg, &rows)) return rc;
+  yfv2_ctx ctx;
+  uintptr_t next = 0x100000000ull;
+  auto fake = [&](yfv2_ctx* hh, Buf* b, size_t per_img) {
+    b->per_img = per_img;
+    b->p = reinterpret_cast<float*>(next);
+    next += (per_img * sizeof(float) * (size_t)hh->cfg.max_batch + 4095) & ~(uintptr_t)4095;
+    return (int)YFV2_OK;
+  };
+  setup_ctx(&ctx, cfg, rows, fake);
+  WeightPacker wp;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
+  PlanBuilder pb{&ctx, wp};
+  pb.build();
+  if (!pb.ok || !wp.missing.empty()) return fail(nullptr, YFV2_ERR_WEIGHTS, wp.missing.empty() ? "weight packing failed" : wp.missing);
+  for (const Step& st : ctx.plan)
+    if (st.img_off > wp.blob.size()) return fail(nullptr, YFV2_ERR_WEIGHTS, "step '" + st.name + "': image offset outside the blob");
+  if (n_steps) *n_steps = (int32_t)ctx.plan.size();
+  if (blob_floats) *blob_floats = (int64_t)wp.blob.size();
   return YFV2_OK;
 }
 
