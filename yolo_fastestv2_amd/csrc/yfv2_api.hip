@@ -206,10 +206,6 @@ struct WeightPacker {
 
   // ---- LDS images: the exact, zero-padded block of floats a kernel copies into LDS (or its
   // registers) in its prologue.  Built from the arrays packed above.
-  static void push_matrix(std::vector<float>& im, const float* w, int M, int K, int rows, int KP) {
-    for (int r = 0; r < rows; ++r)
-      for (int c = 0; c < KP; ++c) im.push_back((r < M && c < K) ? w[(size_t)r * K + c] : 0.f);
-  }
   // fragment-major filter: frag (mt, s), lane l -> W[16mt + (l&15)][16s + 4(l>>4) .. +3]  (zero outside M x K)
   static void push_frag(std::vector<float>& im, const float* w, int M, int K, int MT, int KC) {
     for (int mt = 0; mt < MT; ++mt)
@@ -232,11 +228,18 @@ struct WeightPacker {
     std::memcpy(&blob[off], im.data(), sizeof(float) * im.size());
     return off;
   }
-  // pw_kernel: filter [MT*16][K+4], scale[MT*16], shift[MT*16]
-  size_t image_pw(const Folded& f, int M, int K) {
-    const int rows = ((M + 15) / 16) * 16, KP = K + 4;
+  // pw_kernel: filter fragments [MT][K/16][64 lanes][4] (+ an 8-channel tail [MT][64 lanes][2]), scale[MT*16], shift[MT*16]
+  size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */) {
+    const int rows = MT * 16, K16 = K / 16;
     std::vector<float> im;
-    push_matrix(im, &blob[f.w], M, K, rows, KP);
+    push_frag(im, &blob[f.w], M, K, MT, K16);
+    if (K % 16)
+      for (int mt = 0; mt < MT; ++mt)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 2; ++j) {
+            const int r = 16 * mt + (l & 15), c = 16 * K16 + 2 * (l >> 4) + j;
+            im.push_back((r < M && c < K) ? blob[f.w + (size_t)r * K + c] : 0.f);
+          }
     push_vec(im, &blob[f.scale], M, rows);
     push_vec(im, &blob[f.shift], M, rows);
     return put(im);
@@ -413,7 +416,7 @@ struct PlanBuilder {
     s.pw.H = 0; s.pw.W = 0; s.pw.HW = px;
     s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0;
     s.px_per_img = px;
-    s.img_off = wp.image_pw(f, M, K);
+    s.img_off = wp.image_pw(f, M, K, yfv2_pw_tiles(K, mode, M));
     s.name = name;
     s.flops = 2.0 * px * K * M;
     s.bytes = 4.0 * px * (K + M);

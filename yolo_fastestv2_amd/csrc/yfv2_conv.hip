@@ -38,17 +38,22 @@
 //               NCHW logits into two destination tensors split at `split`
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
 __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
-  constexpr int KP = K + 4;  // padded LDS row: (KP/4) odd -> spreads 16-B slots
   constexpr int K16 = K / 16;
   constexpr int KT = K % 16;
   static_assert(KT == 0 || KT == 8, "K must be 16*n or 16*n+8");
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [MT*16][KP]
+  // filter in LDS fragment-major (host-packed, WeightPacker::image_pw): frag (mt, s), lane l holds
+  // W[16mt + (l&15)][16s + 4(l>>4) .. +3] - the 64 lanes of a fragment read touch 64 consecutive 16-byte slots, no bank
+  // conflicts whatever 16-lane groups the hardware forms (a row-padded [M][K+4] image collides 5-7 slots per group);
+  // an 8-channel tail is MT fragments of 8 bytes per lane behind them
+  constexpr int FRAG_FL = MT * K16 * 256;
+  constexpr int FILT_FL = FRAG_FL + (KT ? MT * 128 : 0);
+  extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x;
 
-  {  // prologue: host-packed LDS image of the filter ([MT*16][K+4], zero padded): one coalesced copy
+  {  // prologue: one coalesced copy of the image
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(wl);
-    for (int i = tid; i < MT * 16 * KP / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = tid; i < FILT_FL / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -58,8 +63,8 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   f32x4 sc[MT], sh[MT];  // padded to MT*16 on the host: unconditional 16-byte loads
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    sc[mt] = *reinterpret_cast<const f32x4*>(a.img + MT * 16 * KP + 16 * mt + 4 * g);
-    sh[mt] = *reinterpret_cast<const f32x4*>(a.img + MT * 16 * KP + MT * 16 + 16 * mt + 4 * g);
+    sc[mt] = *reinterpret_cast<const f32x4*>(a.img + FILT_FL + 16 * mt + 4 * g);
+    sh[mt] = *reinterpret_cast<const f32x4*>(a.img + FILT_FL + MT * 16 + 16 * mt + 4 * g);
   }
 
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
         // MFMA chains interleaved - no LDS wait between MFMAs
         f32x4 afs[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+        for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + ((mt * K16 + s) * 64 + lane) * 4);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
     for (int s = 0; s < K16; ++s) {
       f32x4 afs[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + (16 * mt + p) * KP + 16 * s + 4 * g);
+      for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + ((mt * K16 + s) * 64 + lane) * 4);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
     if constexpr (KT) {  // 8-channel tail: group g owns channels 16*K16 + 2g, +1
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const f32x2 af = *reinterpret_cast<const f32x2*>(wl + (16 * mt + p) * KP + 16 * K16 + 2 * g);
+        const f32x2 af = *reinterpret_cast<const f32x2*>(wl + FRAG_FL + (mt * 64 + lane) * 2);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
 static void pw_launch(const PwArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)MT * 16 * (K + 4) * sizeof(float);
+  const size_t lds = (size_t)MT * 16 * K * sizeof(float);   // K/16 fragments of 256 floats + (K%16 == 8) 128 per M tile
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
   int blocks = (n_super + THREADS / 64 - 1) / (THREADS / 64);
   // persistent-ish grid: enough blocks to fill 256 CUs a few times over, few
@@ -249,6 +254,13 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
     attr_done = true;
   }
   hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
+}
+
+// M tiles of the instantiation yfv2_launch_pw picks: the host packs the filter image for exactly that many
+int yfv2_pw_tiles(int K, int mode, int M) {
+  const int MT = (M + 15) / 16;
+  if (mode == PW_HEAD && K == 72 && MT > 1 && MT <= 6) return 6;
+  return MT;
 }
 
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {

@@ -33,7 +33,7 @@ struct PwArgs {
   const float* in;     // NHWC activations (PW_FPN: C3, coarse map)
   const float* in2;    // PW_FPN only: C2, fine map
   float* out;          // NHWC output (unused for PW_HEAD)
-  const float* img;    // LDS image: filter [MT*16][K+4] (zero padded), then scale[MT*16], shift[MT*16]
+  const float* img;    // filter fragments [MT][K/16][64][4] (+ 8-channel tail [MT][64][2]), then scale[MT*16], shift[MT*16]
   int P;               // pixels = B*H*W
   int M;               // real output channels (<= 16*MT)
   int in_stride;       // floats per input pixel
@@ -166,6 +166,7 @@ struct NmsArgs {
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
 // K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
+int yfv2_pw_tiles(int K, int mode, int M);   // M tiles of the kernel instantiation yfv2_launch_pw uses (the host packs for that many)
 bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
 int yfv2_block_s1_rows(int c2, int H, int W);
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
