@@ -248,6 +248,16 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
             assert rc == 0 and steps >= 25 and blob > 400000, (classes, H, W, rc, steps, blob)
             blobs.add(blob)
         assert len(blobs) <= 3      # the packed blob depends on which kernels a size selects, not on the size itself
+    # the fallback plans (layer-by-layer: 77 launches; stage 2 on the LDS kernels) are planned and packed by the same code
+    import os
+    for var, steps_min in (("YFV2_FUSED", 70), ("YFV2_S2PX", 25)):
+        os.environ[var] = "0"
+        try:
+            for classes in (80, 20, 1):
+                rc, steps, blob, _ = _dryrun(classes, 352, 352)
+                assert rc == 0 and steps >= steps_min, (var, classes, rc, steps)
+        finally:
+            del os.environ[var]
     ERR_CONFIG, ERR_WEIGHTS = _lib.ERR_CONFIG, _lib.ERR_WEIGHTS
     assert _dryrun(80, 384, 384)[0] == ERR_CONFIG      # 2160 decode rows > the NMS kernel's 2048
     assert _dryrun(94, 352, 352)[0] == ERR_CONFIG
