@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_DWPW = 9 };
 
 struct Step {
   int kind = 0;
@@ -39,6 +39,7 @@ struct Step {
   BlockS2Args s2{};
   S1PxArgs s1px{};
   S2PxArgs s2px{};
+  DwPwArgs dwpw{};
   size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
@@ -242,6 +243,15 @@ struct WeightPacker {
           }
     push_vec(im, &blob[f.scale], M, rows);
     push_vec(im, &blob[f.shift], M, rows);
+    return put(im);
+  }
+  // dwpw_s2_kernel<C>: pw fragments | dw taps [9][C] | dw scale, shift | pw scale, shift
+  size_t image_dwpw(const Folded& fd, const Folded& fp, int C) {
+    std::vector<float> im;
+    push_frag(im, &blob[fp.w], C, C, C / 16, C / 16);
+    push_rows(im, &blob[fd.w], 9, C, C);
+    push_vec(im, &blob[fd.scale], C, C); push_vec(im, &blob[fd.shift], C, C);
+    push_vec(im, &blob[fp.scale], C, C); push_vec(im, &blob[fp.shift], C, C);
     return put(im);
   }
   // block_s1_kernel<C2>: W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2
@@ -476,6 +486,33 @@ struct PlanBuilder {
       s.flops = 2.0 * ((double)H * W * cin * cin + 2.0 * oh * ow * cin * cin + 2.0 * oh * ow * 9 * cin);
       s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * co);
       h->plan.push_back(s);
+      return;
+    }
+    const char* envd = std::getenv("YFV2_DWPW");
+    if (!(env && env[0] == '0') && !(envd && envd[0] == '0') && cin == 96 && !(H & 1) && !(W & 1)) {
+      // each branch's tail (dw3x3 s2 + BN -> pw + BN + ReLU) as one launch; pw1 stays a plain pointwise launch
+      auto add_dwpw = [&](const std::string& name, const float* in, int out_off, const Folded& fd, const Folded& fp) {
+        Step s;
+        s.kind = STEP_DWPW;
+        s.c2 = cin;
+        s.dwpw.in = in; s.dwpw.out = y.p;
+        s.dwpw.H = H; s.dwpw.W = W;
+        s.dwpw.in_stride = cin; s.dwpw.in_off = 0; s.dwpw.out_stride = co; s.dwpw.out_off = out_off;
+        s.img_off = wp.image_dwpw(fd, fp, cin);
+        s.name = name;
+        s.flops = 2.0 * oh * ow * (9.0 * cin + (double)cin * cin);
+        s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * cin);
+        h->plan.push_back(s);
+      };
+      Folded fd, fp;
+      ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fd);
+      ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &fp);
+      add_dwpw(p + ".proj: dw3x3s2+bn -> pw+bn+relu", x.p, 0, fd, fp);
+      ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", cin, cin, &f);
+      add_pw(p + ".main.pw1+bn+relu", cin, PW_PLAIN, cin, H * W, x.p, cin, 0, h->t1.p, cin, 0, true, f);
+      ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", cin, 3, &fd);
+      ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", cin, cin, &fp);
+      add_dwpw(p + ".main: dw3x3s2+bn -> pw2+bn+relu", h->t1.p, cin, fd, fp);
       return;
     }
     ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &f);
@@ -815,6 +852,12 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       }
       if (!yfv2_launch_tower2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_DWPW) {
+      DwPwArgs a = st.dwpw;
+      a.B = B;
+      a.img = params + st.img_off;
+      if (!yfv2_launch_dwpw(st.c2, a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no fused depthwise+pointwise kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S2PX) {
       S2PxArgs a = st.s2px;
       a.B = B;

@@ -65,6 +65,17 @@ struct DwArgs {
   int relu;
 };
 
+// ---- depthwise 3x3 stride 2 + BN -> pointwise C->C + BN + ReLU in one launch (yfv2_conv.hip; the two tails of a
+// stride-2 block whose three C x C filters do not fit one workgroup's LDS together: 96 -> 192)
+struct DwPwArgs {
+  const float* in;     // NHWC, C channels at in_off of in_stride
+  float* out;          // NHWC, C channels at out_off of out_stride
+  const float* img;    // pw fragments [C/16][C/16][64][4] | dw taps [9][C] | dw scale, shift [C] | pw scale, shift [C]
+  int B, H, W;         // input size (output is H/2 x W/2)
+  int in_stride, in_off, out_stride, out_off;
+};
+bool yfv2_launch_dwpw(int C, const DwPwArgs& a, hipStream_t s);   // C == 96
+
 // ---- fused ShuffleV2 stride-1 block (yfv2_block.hip)
 struct BlockS1Args {
   const float* in;   // (B,H,W,2*C2) NHWC
