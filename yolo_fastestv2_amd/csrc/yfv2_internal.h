@@ -86,6 +86,20 @@ struct BlockS1Args {
   int R;             // rows per work item (H % R == 0)
 };
 
+// two consecutive stride-1 blocks in one launch (block_s1x2_kernel, C2 = 48): logical branch-input channel held at
+// physical position (chunk s, lane group g, element j) of the LDS tile, for the first (a) and the second (b) block -
+// the host permutes the input columns of the two pw1 filters with the same formulas
+__host__ __device__ constexpr int yfv2_s1x2_label_a(int s, int g, int j) { return 16 * s + 8 * (j >> 1) + 2 * g + (j & 1); }
+__host__ __device__ constexpr int yfv2_s1x2_label_b(int s, int g, int j) {
+  // quads written for block B: [0] = held X[4k+2] of chunks 0..3, [1] = chunks 4,5 + A-output tile 0 elements 1,3,
+  // [2] = A-output tiles 1,2 elements 1,3;  held chunk c of lane group g is B-input 4c+g, A-output (mt, g, r odd) is
+  // B-input 24 + 8mt + 2g + (r-1)/2
+  const int v = 4 * s + j;                       // 0..11: the lane's v-th B-input value
+  return v < 6 ? 4 * v + g : 24 + 8 * ((v - 6) >> 1) + 2 * g + ((v - 6) & 1);
+}
+bool yfv2_s1x2_supported(int c2, int H, int W);
+bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s);   // a.img = first block's LDS image | second block's
+
 // ---- fused ShuffleV2 stride-2 block (yfv2_block.hip)
 struct BlockS2Args {
   const float* in;   // (B,H,W,CIN) NHWC
