@@ -4,6 +4,7 @@ image the HOST packed for that launch (yfv2_debug_plan_image), against the oracl
 is the index algebra shared by kernel and host (yfv2_s1x2_label_a/b, the Z store offsets, the fragment-major filter
 packing with permuted input columns); the HIP code itself needs the GPU tests."""
 import ctypes as C
+import ctypes as C_
 
 import numpy as np
 import pytest
@@ -117,3 +118,57 @@ def test_two_block_step_host_packing_and_index_algebra():
     ref = ref[0].permute(1, 2, 0).numpy()
     err = np.abs(got - ref).max()
     assert err <= 1e-4 * max(1.0, np.abs(ref).max()), "two-block dataflow model vs oracle: max abs err %g" % err
+
+
+def test_fused_depthwise_pointwise_step_host_packing():
+    """dwpw_s2_kernel's image (pointwise fragments | depthwise taps [9][C] | dw scale, shift | pw scale, shift) for the two
+    branch tails of the 96 -> 192 block: a numpy model of dw3x3 s2 + BN -> pw + BN + ReLU reading that image, against the
+    oracle's layers."""
+    w = yfv2.random_state_dict(6)
+    C = 96
+    frag_fl = (C // 16) ** 2 * 256
+    torch.manual_seed(1)
+    x = torch.randn(1, C, 22, 22)
+    for substr, pre, convs in (("stage4.0.proj: dw3x3s2", None, ("branch_proj.0", "branch_proj.1", "branch_proj.2", "branch_proj.3")),
+                               ("stage4.0.main: dw3x3s2", None, ("branch_main.3", "branch_main.4", "branch_main.5", "branch_main.6"))):
+        host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point()}
+        arr = (TensorDesc * len(host))()
+        for i, (k, t) in enumerate(host.items()):
+            arr[i].name, arr[i].data, arr[i].numel = k.encode(), t.data_ptr(), t.numel()
+        cfg = Config()
+        cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = 80, 3, 352, 352, 1, 0
+        L = _lib.lib()
+        ns, nb = C_.c_int32(0), C_.c_int64(0)
+        assert L.yfv2_debug_plan_dryrun(C_.byref(cfg), arr, len(host), C_.byref(ns), C_.byref(nb)) == 0
+        name = C_.create_string_buffer(256)
+        buf = np.zeros(frag_fl + 13 * C, np.float32)
+        im = None
+        for st in range(ns.value):
+            n = L.yfv2_debug_plan_image(C_.byref(cfg), arr, len(host), st, name, 256, buf.ctypes.data_as(C_.c_void_p), buf.size)
+            if n > 0 and substr in name.value.decode():
+                im = buf.copy()
+                break
+        if im is None:
+            pytest.skip("this build's plan has no fused depthwise+pointwise launch")
+        KCc = C // 16
+        fr = im[:frag_fl].reshape(KCc, KCc, 64, 4)
+        wp = np.zeros((C, C), np.float32)
+        for mt in range(KCc):
+            for s in range(KCc):
+                for l in range(64):
+                    wp[16 * mt + (l & 15), 16 * s + 4 * (l >> 4):16 * s + 4 * (l >> 4) + 4] = fr[mt, s, l]
+        taps = im[frag_fl:frag_fl + 9 * C].reshape(9, C)
+        cs = im[frag_fl + 9 * C:].reshape(4, C)
+        xin = x[0].permute(1, 2, 0).numpy()
+        pad = np.zeros((24, 24, C), np.float32)
+        pad[1:-1, 1:-1] = xin
+        d = np.zeros((11, 11, C), np.float32)
+        for k in range(9):
+            d += pad[k // 3:k // 3 + 22:2, k % 3:k % 3 + 22:2] * taps[k]
+        d = d * cs[0] + cs[1]
+        got = np.maximum(d @ wp.T * cs[2] + cs[3], 0.0)
+        p = "backbone.stage4.0."
+        ref = oracle._conv_bn(w, p + convs[0], p + convs[1], x, 2, 1, C)
+        ref = oracle._conv_bn(w, p + convs[2], p + convs[3], ref, relu=True)[0].permute(1, 2, 0).numpy()
+        err = np.abs(got - ref).max()
+        assert err <= 1e-4 * max(1.0, np.abs(ref).max()), "%s: max abs err %g" % (substr, err)

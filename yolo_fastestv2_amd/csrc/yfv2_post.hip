@@ -49,7 +49,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
 #pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
     const int c = c_lo + i;
-    lv[i] = cls[(size_t)(c < c_hi ? c : c_lo) * hw];
+    lv[i] = cls[(size_t)(c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw];   // masked slots re-read a valid class (fewer than 4 classes: quarters 1-3 are empty)
   }
   float m = -INFINITY;
 #pragma unroll
