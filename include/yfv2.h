@@ -174,6 +174,10 @@ YFV2_API int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, 
  * reports the number of launches and the packed blob size.  Lets the CPU test suite exercise the host logic for every
  * (classes, height, width) the configuration check admits.  Never launches or computes anything. */
 YFV2_API int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* n_steps, int64_t* blob_floats);
+/* Host-only test hook: the packed LDS image of launch `step` of that plan (up to `cap` floats from the image's start) and
+ * the launch's name; returns the number of floats copied or a negative error code. */
+YFV2_API int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t step, char* name,
+                                       int32_t name_cap, float* dst, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_DWPW = 9, STEP_S1X2 = 10 };
 
 struct Step {
   int kind = 0;
@@ -39,6 +39,7 @@ struct Step {
   BlockS2Args s2{};
   S1PxArgs s1px{};
   S2PxArgs s2px{};
+  DwPwArgs dwpw{};
   size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
@@ -206,10 +207,6 @@ struct WeightPacker {
 
   // ---- LDS images: the exact, zero-padded block of floats a kernel copies into LDS (or its
   // registers) in its prologue.  Built from the arrays packed above.
-  static void push_matrix(std::vector<float>& im, const float* w, int M, int K, int rows, int KP) {
-    for (int r = 0; r < rows; ++r)
-      for (int c = 0; c < KP; ++c) im.push_back((r < M && c < K) ? w[(size_t)r * K + c] : 0.f);
-  }
   // fragment-major filter: frag (mt, s), lane l -> W[16mt + (l&15)][16s + 4(l>>4) .. +3]  (zero outside M x K)
   static void push_frag(std::vector<float>& im, const float* w, int M, int K, int MT, int KC) {
     for (int mt = 0; mt < MT; ++mt)
@@ -232,23 +229,42 @@ struct WeightPacker {
     std::memcpy(&blob[off], im.data(), sizeof(float) * im.size());
     return off;
   }
-  // pw_kernel: filter [MT*16][K+4], scale[MT*16], shift[MT*16]
+  // pw_kernel: filter fragments [MT][K/16][64 lanes][4] (+ an 8-channel tail [MT][64 lanes][2]), scale[MT*16], shift[MT*16]
   size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */) {
-    const int rows = MT * 16, KP = K + 4;
+    const int rows = MT * 16, K16 = K / 16;
     std::vector<float> im;
-    push_matrix(im, &blob[f.w], M, K, rows, KP);
+    push_frag(im, &blob[f.w], M, K, MT, K16);
+    if (K % 16)
+      for (int mt = 0; mt < MT; ++mt)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 2; ++j) {
+            const int r = 16 * mt + (l & 15), c = 16 * K16 + 2 * (l >> 4) + j;
+            im.push_back((r < M && c < K) ? blob[f.w + (size_t)r * K + c] : 0.f);
+          }
     push_vec(im, &blob[f.scale], M, rows);
     push_vec(im, &blob[f.shift], M, rows);
     return put(im);
   }
-  // block_s1_kernel<C2>: W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2
-  size_t image_s1(const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
-    const int KC = (c2 + 15) / 16, KS = 16 * KC;
+  // dwpw_s2_kernel<C>: pw fragments | dw taps [9][C] | dw scale, shift | pw scale, shift
+  size_t image_dwpw(const Folded& fd, const Folded& fp, int C) {
     std::vector<float> im;
+    push_frag(im, &blob[fp.w], C, C, C / 16, C / 16);
+    push_rows(im, &blob[fd.w], 9, C, C);
+    push_vec(im, &blob[fd.scale], C, C); push_vec(im, &blob[fd.shift], C, C);
+    push_vec(im, &blob[fp.scale], C, C); push_vec(im, &blob[fp.shift], C, C);
+    return put(im);
+  }
+  // block_s1_kernel<C2>: W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2
+  void append_s1(std::vector<float>& im, const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
+    const int KC = (c2 + 15) / 16, KS = 16 * KC;
     push_frag(im, &blob[f1.w], c2, c2, KC, KC);
     push_frag(im, &blob[f2.w], c2, c2, KC, KC);
     push_rows(im, &blob[fd.w], 9, c2, KS);
     for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], c2, KS); push_vec(im, &blob[f->shift], c2, KS); }
+  }
+  size_t image_s1(const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
+    std::vector<float> im;
+    append_s1(im, f1, fd, f2, c2);
     return put(im);
   }
   // block_s2_kernel<CIN>: W1 | W2 | Wproj | main dw taps | proj dw taps | sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
@@ -475,6 +491,33 @@ struct PlanBuilder {
       h->plan.push_back(s);
       return;
     }
+    const char* envd = std::getenv("YFV2_DWPW");
+    if (!(env && env[0] == '0') && !(envd && envd[0] == '0') && cin == 96 && !(H & 1) && !(W & 1)) {
+      // each branch's tail (dw3x3 s2 + BN -> pw + BN + ReLU) as one launch; pw1 stays a plain pointwise launch
+      auto add_dwpw = [&](const std::string& name, const float* in, int out_off, const Folded& fd, const Folded& fp) {
+        Step s;
+        s.kind = STEP_DWPW;
+        s.c2 = cin;
+        s.dwpw.in = in; s.dwpw.out = y.p;
+        s.dwpw.H = H; s.dwpw.W = W;
+        s.dwpw.in_stride = cin; s.dwpw.in_off = 0; s.dwpw.out_stride = co; s.dwpw.out_off = out_off;
+        s.img_off = wp.image_dwpw(fd, fp, cin);
+        s.name = name;
+        s.flops = 2.0 * oh * ow * (9.0 * cin + (double)cin * cin);
+        s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * cin);
+        h->plan.push_back(s);
+      };
+      Folded fd, fp;
+      ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fd);
+      ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &fp);
+      add_dwpw(p + ".proj: dw3x3s2+bn -> pw+bn+relu", x.p, 0, fd, fp);
+      ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", cin, cin, &f);
+      add_pw(p + ".main.pw1+bn+relu", cin, PW_PLAIN, cin, H * W, x.p, cin, 0, h->t1.p, cin, 0, true, f);
+      ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", cin, 3, &fd);
+      ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", cin, cin, &fp);
+      add_dwpw(p + ".main: dw3x3s2+bn -> pw2+bn+relu", h->t1.p, cin, fd, fp);
+      return;
+    }
     ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &f);
     add_dw(p + ".proj.dw3x3s2+bn", 3, 2, cin, H, W, x.p, cin, h->t3.p, cin, false, f);
     ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &f);
@@ -580,6 +623,43 @@ struct PlanBuilder {
 
   // ShuffleV2Block stride 1 (shufflenetv2.py:48-51,57-63): even channels pass through,
   // odd channels -> main; out = cat(pass, main)
+  // two consecutive stride-1 blocks as ONE launch (block_s1x2_kernel): both blocks' LDS images back to back, the
+  // input columns of the two pw1 filters permuted to the physical channel order of the kernel's LDS tile
+  void s1x2_block(const std::string& pa, const std::string& pb, int c, int H, int W, const Buf& x, const Buf& y) {
+    const int c2 = c / 2;
+    Folded f1[2], fd[2], f2[2];
+    const std::string* ps[2] = {&pa, &pb};
+    for (int k = 0; k < 2; ++k) {
+      ok &= wp.pw(*ps[k] + ".branch_main.0", *ps[k] + ".branch_main.1", c2, c2, &f1[k]);
+      ok &= wp.dw(*ps[k] + ".branch_main.3", *ps[k] + ".branch_main.4", c2, 3, &fd[k]);
+      ok &= wp.pw(*ps[k] + ".branch_main.5", *ps[k] + ".branch_main.6", c2, c2, &f2[k]);
+    }
+    std::vector<float> im;
+    if (ok) {
+      int la[48], lb[48];
+      for (int s = 0; s < 3; ++s)
+        for (int g = 0; g < 4; ++g)
+          for (int j = 0; j < 4; ++j) {
+            la[16 * s + 4 * g + j] = yfv2_s1x2_label_a(s, g, j);
+            lb[16 * s + 4 * g + j] = yfv2_s1x2_label_b(s, g, j);
+          }
+      const Folded f1a = wp.permuted_pw_inputs(f1[0], c2, c2, la);
+      const Folded f1b = wp.permuted_pw_inputs(f1[1], c2, c2, lb);
+      wp.append_s1(im, f1a, fd[0], f2[0], c2);
+      wp.append_s1(im, f1b, fd[1], f2[1], c2);
+    }
+    Step s;
+    s.kind = STEP_S1X2;
+    s.c2 = c2;
+    s.s1.in = x.p; s.s1.out = y.p;
+    s.s1.H = H; s.s1.W = W; s.s1.R = H;
+    s.img_off = wp.put(im);
+    s.name = pa + " + " + pb.substr(pb.rfind('.') + 1) + " two fused s1 blocks in one launch (the activation between them stays on chip)";
+    s.flops = 2.0 * 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
+    s.bytes = 4.0 * H * W * (2.0 * c);
+    h->plan.push_back(s);
+  }
+
   void block_s1(const std::string& p, int c, int H, int W, const Buf& x, const Buf& y) {
     Folded f;
     const int c2 = c / 2;
@@ -715,6 +795,11 @@ struct PlanBuilder {
           }
         } else if (use_px) {
           s1px_block(p, hh, ww, L2, pp_bufstride);
+        } else if (const char* envf2 = std::getenv("YFV2_FUSED"); !(envf2 && envf2[0] == '0') && i + 1 < repeats[si] &&
+                   yfv2_s1x2_supported(cout / 2, hh, ww) && yfv2_block_s1_rows(cout / 2, hh, ww) == hh) {
+          const std::string pnext = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i + 1);
+          s1x2_block(p, pnext, cout, hh, ww, *x, *y);
+          ++i;                                   // the pair consumed the next block too
         } else {
           block_s1(p, cout, hh, ww, *x, *y);
         }
@@ -812,6 +897,19 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       }
       if (!yfv2_launch_tower2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_S1X2) {
+      BlockS1Args a = st.s1;
+      a.B = B;
+      a.img = params + st.img_off;
+      a.trace = nullptr;
+      if (!yfv2_launch_block_s1x2(a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no two-block kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_DWPW) {
+      DwPwArgs a = st.dwpw;
+      a.B = B;
+      a.img = params + st.img_off;
+      if (!yfv2_launch_dwpw(st.c2, a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no fused depthwise+pointwise kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S2PX) {
       S2PxArgs a = st.s2px;
       a.B = B;
@@ -965,6 +1063,38 @@ int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tenso
   if (n_steps) *n_steps = (int32_t)ctx.plan.size();
   if (blob_floats) *blob_floats = (int64_t)wp.blob.size();
   return YFV2_OK;
+}
+
+// Host-only test hook: the packed LDS image of launch `step` of the plan the dry run builds (at most `cap` floats from the
+// image's start to the end of the blob), and the launch's name.  Lets the CPU suite check host packing against a
+// numpy model of a kernel's dataflow.  Returns the number of floats copied or a negative error code.
+int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t step, char* name, int32_t name_cap,
+                              float* dst, int64_t cap) {
+  if (!cfg || !tensors || n <= 0 || !dst || cap <= 0) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: bad argument");
+  int rows = 0;
+  if (int rc = check_config(cfg, &rows)) return rc;
+  yfv2_ctx ctx;
+  uintptr_t next = 0x100000000ull;
+  auto fake = [&](yfv2_ctx* hh, Buf* b, size_t per_img) {
+    b->per_img = per_img;
+    b->p = reinterpret_cast<float*>(next);
+    next += (per_img * sizeof(float) * (size_t)hh->cfg.max_batch + 4095) & ~(uintptr_t)4095;
+    return (int)YFV2_OK;
+  };
+  setup_ctx(&ctx, cfg, rows, fake);
+  WeightPacker wp;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
+  PlanBuilder pb{&ctx, wp};
+  pb.build();
+  if (!pb.ok || !wp.missing.empty()) return fail(nullptr, YFV2_ERR_WEIGHTS, wp.missing.empty() ? "weight packing failed" : wp.missing);
+  if (step < 0 || step >= (int32_t)ctx.plan.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: step out of range");
+  const Step& st = ctx.plan[step];
+  if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", st.name.c_str());
+  const int64_t avail = (int64_t)wp.blob.size() - (int64_t)st.img_off;
+  const int64_t cnt = avail < cap ? avail : cap;
+  if (cnt > 0) std::memcpy(dst, &wp.blob[st.img_off], sizeof(float) * (size_t)cnt);
+  return cnt;
 }
 
 void yfv2_destroy(yfv2_handle h) {

@@ -426,6 +426,469 @@ static void launch_s1(const BlockS1Args& a, int blocks_per_cu, hipStream_t s) {
   hipLaunchKernelGGL((block_s1_kernel<C2, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 
+// ============================================================================
+// stride-1 block, whole-image variant on a plane-per-quad tile (C2 = 48, maps up to 22x22)
+// ============================================================================
+// Same arithmetic and the same LDS image as block_s1_kernel<48>, different tile: the 48 branch channels of ONE image live
+// in LDS as 12 planes [quad][haloed row][W + 1][4 floats].  A row's left halo column is the previous row's right halo
+// (one shared zero slot), so the image is one linear run of 16-byte slots per plane, and both phases tile that run -
+// 16 consecutive slots per wave tile, halo slots included (they compute zeros / are not stored).  ds_read_b128 is
+// serviced in four 16-lane groups that mix two quads; with planes a multiple of 256 bytes apart and consecutive slots
+// inside a plane no read collides (the pixel-major tile of block_s1_kernel has 5 colliding slots in every group:
+// SQ_LDS_BANK_CONFLICT = 34 % of its LDS-active cycles), and a 22x22 image is 32 tiles in BOTH phases = four full
+// rounds of the 8 waves (the pixel tiling needs 33 in phase A: a fifth round for one tile).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void block_s1w_kernel(BlockS1Args a) {
+  constexpr int C2 = 48;
+  using Cfg = S1Cfg<C2>;
+  constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2;
+  constexpr int NW = THREADS / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* W1 = lds;
+  float* W2 = W1 + Cfg::W_FL;
+  float* WD = W2 + Cfg::W_FL;
+  float* CS = WD + Cfg::DW_FL;  // [6][KC*16]
+  float* T1 = CS + Cfg::CST_FL;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int RP = W + 1;                                   // slots per haloed row (shared halo column)
+  const int PL = ((H + 2) * RP + 1 + 15) & ~15;           // slots per plane
+  const float invW = 1.0f / (float)W, invRP = 1.0f / (float)RP;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int s_first = RP + 1;                             // slot of pixel (0, 0)
+  const int n_slots = (H - 1) * RP + W;                   // ... up to pixel (H-1, W-1)
+
+  // ---- staging: eight consecutive lanes take eight consecutive pixels of one channel quad (ds_write_b128 is serviced in
+  // 8-lane groups), the next 8-lane group the next quad: a wave reads 8 pixels x 8 quads x 32 bytes
+  constexpr int MAXP = 12;                                // ceil(ceil(484 / 8) * 8 * 12 / 512)
+  const int npx8 = (HW + 7) & ~7;
+  f32x4 st0[MAXP], st1[MAXP];
+  auto stage_issue = [&](int b_, bool active) {
+    const float* img = a.in + (size_t)(active ? b_ : 0) * HW * C;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      const int G = i >> 3, q = G % NQ, pix = (G / NQ) * 8 + (i & 7);
+      st0[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      st1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (active && i < npx8 * NQ && pix < HW) {
+        const float* src = img + (size_t)pix * C + 8 * q;
+        st0[j] = *reinterpret_cast<const f32x4*>(src);
+        st1[j] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+    }
+  };
+  auto stage_commit = [&](int b) {
+    float* oimg = a.out + (size_t)b * HW * C;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      const int G = i >> 3, q = G % NQ, pix = (G / NQ) * 8 + (i & 7);
+      if (i >= npx8 * NQ || pix >= HW) continue;
+      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
+      *reinterpret_cast<f32x4*>(T1 + ((size_t)q * PL + (r + 1) * RP + x + 1) * 4) = (f32x4){st0[j][1], st0[j][3], st1[j][1], st1[j][3]};
+      *reinterpret_cast<f32x4*>(oimg + (size_t)pix * C + 4 * q) = (f32x4){st0[j][0], st0[j][2], st1[j][0], st1[j][2]};
+    }
+  };
+  stage_issue(blockIdx.x, (int)blockIdx.x < a.B);
+
+  {  // prologue: the LDS image (same as block_s1_kernel<48>) in one coalesced 16-byte copy, all loads before the first store
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    constexpr int N4 = (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4;
+    constexpr int NIT = (N4 + THREADS - 1) / THREADS;
+    f32x4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
+  }
+  for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
+  __syncthreads();
+
+  // tile t = wave + k * NW covers slots s_first + 16 t .. + 15
+  const float* Tg = T1 + (size_t)g * PL * 4;              // plane of quad g; quad 4 s + g is 4 s planes further
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    stage_commit(b);
+    __syncthreads();
+
+    // ================= phase A: pw1 (+BN+ReLU) in place, a wave reads and rewrites only its own tiles' slots
+    {
+      f32x4 sc1[KC], sh1[KC], aw[KC][KC];   // pw1's BN constants and A fragments: registers for this phase only
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
+        sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
+      }
+      f32x4 bf[KC], bn[KC];
+      int t = wave;
+      auto slot_of = [&](int tt) { const int q = 16 * tt + p; return s_first + (q < n_slots ? q : n_slots - 1); };
+      if (16 * t < n_slots) {
+        const int o = slot_of(t) * 4;
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + (size_t)(4 * s2) * PL * 4 + o);
+      }
+      for (; 16 * t < n_slots; t += NW) {
+        const int tn = t + NW;
+        const int on = slot_of(16 * tn < n_slots ? tn : t) * 4;
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) bn[s2] = *reinterpret_cast<const f32x4*>(Tg + (size_t)(4 * s2) * PL * 4 + on);
+        const int q = 16 * t + p;
+        const bool valid = q < n_slots;
+        const int sl = s_first + (valid ? q : 0);
+        const int r1 = yfv2_fdiv(sl, invRP);
+        const bool real = valid && (sl - r1 * RP) >= 1;      // column 0 of a haloed row is the shared zero column
+        f32x4 acc[KC];
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
+        if (valid) {
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) {
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
+              y[c] = (real && uu > 0.f) ? uu : 0.f;          // the zero column stays zero (depthwise padding)
+            }
+            *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + sl) * 4) = y;
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = bn[s2];
+      }
+    }
+    __syncthreads();  // phase B reads the neighbours' tiles
+
+    // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
+    for (int t = wave; 16 * t < n_slots; t += NW) {
+      const int q = 16 * t + p;
+      const bool valid = q < n_slots;
+      const int sl = s_first + (valid ? q : n_slots - 1);
+      const int r1 = yfv2_fdiv(sl, invRP), xs = sl - r1 * RP;
+      const bool real = valid && xs >= 1;
+      const int pix = (r1 - 1) * W + (xs - 1);
+      const float* win0 = Tg + (size_t)(sl - RP - 1) * 4;    // top-left of the 3x3 window
+      f32x4 acc[KC];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        f32x4 wl[9], lsc, lsh, win[9], af[KC];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
+        lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+        lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], acc[mt], 0, 0, 0);
+      }
+      if (real) {
+        float* dst = a.out + ((size_t)b * HW + pix) * C + C2;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const int cb = 16 * mt + 4 * g;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + cb);
+          f32x4 y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float u = __builtin_fmaf(acc[mt][k], sc[k], sh[k]);
+            y[k] = u > 0.f ? u : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(dst + cb) = y;
+        }
+      }
+    }
+    stage_issue(b + gridDim.x, b + (int)gridDim.x < a.B);  // next image: in flight across the barrier
+    __syncthreads();  // T1 is rewritten by the next image's stage_commit
+  }
+}
+
+// ============================================================================
+// TWO consecutive stride-1 blocks in one launch (C2 = 48, whole image, plane-per-quad tile)
+// ============================================================================
+// Reference: two ShuffleV2Block(stride 1) in a row (shufflenetv2.py:19-32,48-51,57-63).  With X the first block's
+// 96-channel input, Y = cat(X[even], A(X[odd])) its output and Z = cat(Y[even], B(Y[odd])) the pair's output:
+//   X[4k]            passes both blocks                        -> Z[k]                 (stored at load time)
+//   X[4k+2]          passes A, is branch input 4k'.. of B      -> held in registers until A is done
+//   X[2i+1]          is A's branch input i                     -> LDS tile
+//   A's output j     even j: passes B -> Z[24 + j/2];  odd j: B's branch input 24 + (j-1)/2
+//   B's output j                                               -> Z[48 + j]
+// so the 96-channel activation between the two blocks never leaves the chip: per image the pair reads X once and
+// writes Z once (half the HBM traffic of two launches) and the second block starts without a launch boundary.  All
+// splits are lane-local: a lane's 16-byte quad of X is (pass-pass, branch A, hold, branch A), and A's accumulator quad is
+// (pass B, branch B, pass B, branch B) - the physical channel order inside the LDS tile is whatever that produces, the
+// host permutes the input columns of both pw1 filters to match (PlanBuilder::s1x2_block; la[] / lb[] below are the
+// same formulas).  Tile, slot tiling, phases and LDS image are those of block_s1w_kernel; both blocks' images are
+// resident (2 x 21 KB) next to the 12-plane tile.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
+  constexpr int C2 = 48;
+  using Cfg = S1Cfg<C2>;
+  constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2, NT = 4;
+  constexpr int NW = THREADS / 64;
+  constexpr int IMG_FL = 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* T1 = lds + 2 * IMG_FL;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int RP = W + 1;
+  const int PL = ((H + 2) * RP + 1 + 15) & ~15;
+  const float invRP = 1.0f / (float)RP;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int s_first = RP + 1;
+  const int n_slots = (H - 1) * RP + W;                   // <= 16 * NT * NW (launcher)
+
+  {  // prologue: both blocks' LDS images in one coalesced copy
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    constexpr int N4 = 2 * IMG_FL / 4;
+    constexpr int NIT = (N4 + THREADS - 1) / THREADS;
+    f32x4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
+  }
+  for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
+  __syncthreads();
+
+  // this lane's slot in each of its wave's tiles (tile nt of the wave = wave + NW * nt), fixed for every image
+  int sl[NT], pix[NT];
+  bool valid[NT], real[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int q = 16 * (wave + NW * nt) + p;
+    valid[nt] = q < n_slots;
+    sl[nt] = s_first + (valid[nt] ? q : n_slots - 1);
+    const int r1 = yfv2_fdiv(sl[nt], invRP), xs = sl[nt] - r1 * RP;
+    real[nt] = valid[nt] && xs >= 1;                      // column 0 of a haloed row is the shared zero column
+    pix[nt] = (r1 - 1) * W + (xs - 1);
+  }
+  float* Tg = T1 + (size_t)g * PL * 4;                    // plane of quad g; quad 4 s + g is 4 s planes further
+
+  // pw1 (+BN+ReLU) in place over this wave's tiles
+  auto phase_a = [&](const float* IM) {
+    const float* W1 = IM;
+    const float* CS = IM + 2 * Cfg::W_FL + Cfg::DW_FL;
+    f32x4 sc1[KC], sh1[KC], aw[KC][KC];
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt) {
+      sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
+      sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
+      f32x4 bf[KC];
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + sl[nt]) * 4);
+      f32x4 acc[KC];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
+      if (valid[nt]) {
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          f32x4 y;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
+            y[c] = (real[nt] && uu > 0.f) ? uu : 0.f;     // the zero column stays zero (depthwise padding)
+          }
+          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + sl[nt]) * 4) = y;
+        }
+      }
+    }
+  };
+  // dw3x3 (+BN) in registers -> pw2 (+BN+ReLU); the result stays in registers in accumulator layout
+  auto phase_b = [&](const float* IM, f32x4 (&bo)[KC][NT]) {
+    const float* W2 = IM + Cfg::W_FL;
+    const float* WD = IM + 2 * Cfg::W_FL;
+    const float* CS = WD + Cfg::DW_FL;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
+      const float* win0 = Tg + (size_t)(sl[nt] - RP - 1) * 4;
+#pragma unroll 1
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        f32x4 wl[9], lsc, lsh, win[9], af[KC];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
+        lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+        lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], bo[mt][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = __builtin_fmaf(bo[mt][nt][k], sc[k], sh[k]);
+          bo[mt][nt][k] = u > 0.f ? u : 0.f;
+        }
+      }
+    }
+  };
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float* ximg = a.in + (size_t)b * HW * C;
+    float* zimg = a.out + (size_t)b * HW * C;
+    // ---- load X: lane (p, g) takes quad g of each of the six 16-channel chunks of its pixels
+    float hold[6][NT];                                    // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 xq[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        xq[c] = real[nt] ? *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (valid[nt]) {                                    // halo slots store the zeros they loaded: the tile's zero column
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * j + g) * PL + sl[nt]) * 4) = (f32x4){xq[2 * j][1], xq[2 * j][3], xq[2 * j + 1][1], xq[2 * j + 1][3]};
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        hold[c][nt] = xq[c][2];
+        if (real[nt]) zimg[(size_t)pix[nt] * C + 4 * c + g] = xq[c][0];          // X[16 c + 4 g] -> Z[4 c + g]
+      }
+    }
+    __syncthreads();
+    phase_a(lds);
+    __syncthreads();
+    f32x4 bo[KC][NT];
+    phase_b(lds, bo);
+    __syncthreads();                                      // every window read of the first block is done
+    // ---- the second block's branch input into the tile; the first block's even outputs pass straight to Z
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (valid[nt]) {
+        const bool r = real[nt];
+        const f32x4 q0 = {hold[0][nt], hold[1][nt], hold[2][nt], hold[3][nt]};   // loaded as zeros on halo slots
+        f32x4 q1 = {hold[4][nt], hold[5][nt], bo[0][nt][1], bo[0][nt][3]};
+        f32x4 q2 = {bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]};
+        if (!r) { q1[2] = 0.f; q1[3] = 0.f; q2 = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        *reinterpret_cast<f32x4*>(T1 + ((size_t)(0 + g) * PL + sl[nt]) * 4) = q0;
+        *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 + g) * PL + sl[nt]) * 4) = q1;
+        *reinterpret_cast<f32x4*>(T1 + ((size_t)(8 + g) * PL + sl[nt]) * 4) = q2;
+        if (r) {
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt)                 // A-output 16 mt + 4 g + {0, 2} -> Z[24 + 8 mt + 2 g + {0, 1}]
+            *reinterpret_cast<f32x2*>(zimg + (size_t)pix[nt] * C + 24 + 8 * mt + 2 * g) = (f32x2){bo[mt][nt][0], bo[mt][nt][2]};
+        }
+      }
+    }
+    __syncthreads();
+    phase_a(lds + IMG_FL);
+    __syncthreads();
+    phase_b(lds + IMG_FL, bo);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      if (real[nt]) {
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zimg + (size_t)pix[nt] * C + C2 + 16 * mt + 4 * g) = bo[mt][nt];
+      }
+    __syncthreads();                                      // the tile is rewritten by the next image's load
+  }
+}
+
+bool yfv2_s1x2_supported(int c2, int H, int W) {
+  if (c2 != 48) return false;
+  if ((H - 1) * (W + 1) + W > 16 * 4 * 8) return false;   // slots <= 4 tiles x 8 waves
+  const long pl = (((long)(H + 2) * (W + 1) + 1 + 15) & ~15L);
+  const long fl = 2L * (2L * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL) + 12L * pl * 4;
+  if (fl * 4 > 158 * 1024) return false;
+  const char* env = std::getenv("YFV2_S1X2");
+  return !(env && env[0] == '0');
+}
+
+bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s) {
+  if (!yfv2_s1x2_supported(48, a.H, a.W)) return false;
+  using Cfg = S1Cfg<48>;
+  const size_t pl = (((size_t)(a.H + 2) * (a.W + 1) + 1 + 15) & ~(size_t)15);
+  const size_t lds = sizeof(float) * (size_t)(2 * (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) + 12 * pl * 4);
+  const int blocks = a.B < 256 ? a.B : 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1x2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((block_s1x2_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  return true;
+}
+
+// whole-image plane variant: C2 = 48, the tile is the image, staging bound (MAXP = 12 pairs per thread) and LDS fit
+static bool s1w_supported(int c2, const BlockS1Args& a) {
+  if (c2 != 48 || a.R != a.H) return false;
+  const long npx8 = ((long)a.H * a.W + 7) & ~7L;
+  if (npx8 * 12 > 12L * 512) return false;
+  const long pl = (((long)(a.H + 2) * (a.W + 1) + 1 + 15) & ~15L);
+  const long fl = 2L * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + 12L * pl * 4;
+  if (fl * 4 > 158 * 1024) return false;
+  const char* env = std::getenv("YFV2_S1W");
+  return !(env && env[0] == '0');
+}
+
+static void launch_s1w(const BlockS1Args& a, hipStream_t s) {
+  using Cfg = S1Cfg<48>;
+  const size_t pl = (((size_t)(a.H + 2) * (a.W + 1) + 1 + 15) & ~(size_t)15);
+  const size_t lds = sizeof(float) * (size_t)(2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + 12 * pl * 4);
+  const int blocks = a.B < 256 ? a.B : 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1w_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((block_s1w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+}
+
 // LDS budget decides the row tile: the whole image when it fits (no halo recompute).
 int yfv2_block_s1_rows(int c2, int H, int W) {
   const int kc = (c2 + 15) / 16;
@@ -448,6 +911,7 @@ int yfv2_block_s1_rows(int c2, int H, int W) {
 
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
   if (c2 == 24) { launch_s1<24, 256>(a, 2, s); return true; }
+  if (s1w_supported(c2, a)) { launch_s1w(a, s); return true; }
   if (c2 == 48) { launch_s1<48, 512>(a, 1, s); return true; }
   if (c2 == 96) { launch_s1<96, 512>(a, 1, s); return true; }
   return false;

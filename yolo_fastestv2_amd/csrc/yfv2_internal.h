@@ -33,7 +33,7 @@ struct PwArgs {
   const float* in;     // NHWC activations (PW_FPN: C3, coarse map)
   const float* in2;    // PW_FPN only: C2, fine map
   float* out;          // NHWC output (unused for PW_HEAD)
-  const float* img;    // LDS image: filter [MT*16][K+4] (zero padded), then scale[MT*16], shift[MT*16]
+  const float* img;    // filter fragments [MT][K/16][64][4] (+ 8-channel tail [MT][64][2]), then scale[MT*16], shift[MT*16]
   int P;               // pixels = B*H*W
   int M;               // real output channels (<= 16*MT)
   int in_stride;       // floats per input pixel
@@ -65,6 +65,17 @@ struct DwArgs {
   int relu;
 };
 
+// ---- depthwise 3x3 stride 2 + BN -> pointwise C->C + BN + ReLU in one launch (yfv2_conv.hip; the two tails of a
+// stride-2 block whose three C x C filters do not fit one workgroup's LDS together: 96 -> 192)
+struct DwPwArgs {
+  const float* in;     // NHWC, C channels at in_off of in_stride
+  float* out;          // NHWC, C channels at out_off of out_stride
+  const float* img;    // pw fragments [C/16][C/16][64][4] | dw taps [9][C] | dw scale, shift [C] | pw scale, shift [C]
+  int B, H, W;         // input size (output is H/2 x W/2)
+  int in_stride, in_off, out_stride, out_off;
+};
+bool yfv2_launch_dwpw(int C, const DwPwArgs& a, hipStream_t s);   // C == 96
+
 // ---- fused ShuffleV2 stride-1 block (yfv2_block.hip)
 struct BlockS1Args {
   const float* in;   // (B,H,W,2*C2) NHWC
@@ -74,6 +85,20 @@ struct BlockS1Args {
   int B, H, W;
   int R;             // rows per work item (H % R == 0)
 };
+
+// two consecutive stride-1 blocks in one launch (block_s1x2_kernel, C2 = 48): logical branch-input channel held at
+// physical position (chunk s, lane group g, element j) of the LDS tile, for the first (a) and the second (b) block -
+// the host permutes the input columns of the two pw1 filters with the same formulas
+__host__ __device__ constexpr int yfv2_s1x2_label_a(int s, int g, int j) { return 16 * s + 8 * (j >> 1) + 2 * g + (j & 1); }
+__host__ __device__ constexpr int yfv2_s1x2_label_b(int s, int g, int j) {
+  // quads written for block B: [0] = held X[4k+2] of chunks 0..3, [1] = chunks 4,5 + A-output tile 0 elements 1,3,
+  // [2] = A-output tiles 1,2 elements 1,3;  held chunk c of lane group g is B-input 4c+g, A-output (mt, g, r odd) is
+  // B-input 24 + 8mt + 2g + (r-1)/2
+  const int v = 4 * s + j;                       // 0..11: the lane's v-th B-input value
+  return v < 6 ? 4 * v + g : 24 + 8 * ((v - 6) >> 1) + 2 * g + ((v - 6) & 1);
+}
+bool yfv2_s1x2_supported(int c2, int H, int W);
+bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s);   // a.img = first block's LDS image | second block's
 
 // ---- fused ShuffleV2 stride-2 block (yfv2_block.hip)
 struct BlockS2Args {

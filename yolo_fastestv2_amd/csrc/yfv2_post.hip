@@ -49,7 +49,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
 #pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
     const int c = c_lo + i;
-    lv[i] = cls[(size_t)(c < c_hi ? c : c_lo) * hw];
+    lv[i] = cls[(size_t)(c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw];   // masked slots re-read a valid class (fewer than 4 classes: quarters 1-3 are empty)
   }
   float m = -INFINITY;
 #pragma unroll
@@ -187,7 +187,7 @@ constexpr int NMS_MAX_DET = 300;   // utils/utils.py:243 (== YFV2_MAX_DET)
 
 template <bool COMPACT>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
-  __shared__ unsigned long long key[NMS_CAP];
+  __shared__ unsigned long long key[NMS_CAP], key2[NMS_CAP];   // key2: second exchange buffer of the sort
   __shared__ float bx1[NMS_CAP], by1[NMS_CAP], bx2[NMS_CAP], by2[NMS_CAP], area[NMS_CAP];
   __shared__ unsigned char supp[NMS_CAP];
   __shared__ unsigned char cls_of_row[NMS_CAP];
@@ -264,23 +264,45 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
     return;
   }
 
-  // ---- 2. sort (descending) on the next power of two >= n, zero keys pad the end
+  // ---- 2. sort (descending) on the next power of two >= n, zero keys pad the end.  Bitonic network with the keys in
+  // REGISTERS (thread t owns indices t and t + 1024): a compare-exchange distance below 64 is a lane shuffle inside the
+  // wave, distance 1024 is the thread's own second key, and only distances 64..512 go through LDS - 14 barriers for
+  // 2048 keys instead of 66, alternating two key buffers so that one barrier per LDS step is enough.
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
   for (int i = n + tid; i < np2; i += NMS_THREADS) key[i] = 0ull;
   __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += NMS_THREADS) {
-        const int l = i ^ j;
-        if (l > i) {
-          const unsigned long long x = key[i], y = key[l];
-          const bool desc = (i & k) == 0;
-          if (desc ? (x < y) : (x > y)) { key[i] = y; key[l] = x; }
+  {
+    static_assert(NMS_CAP == 2 * NMS_THREADS, "two keys per thread");
+    const int i0 = tid, i1 = tid + NMS_THREADS;
+    unsigned long long k0 = i0 < np2 ? key[i0] : 0ull, k1 = i1 < np2 ? key[i1] : 0ull;
+    auto cx = [](unsigned long long x, unsigned long long y, bool take_max) { return take_max == (x > y) ? x : y; };   // x != y or both zero
+    int pb = 0;
+    for (int k = 2; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const bool d0 = (i0 & k) == 0, d1 = (i1 & k) == 0;          // descending run?
+        if (j >= NMS_THREADS) {                                     // partner = this thread's other key (i0 < i1)
+          const unsigned long long hi = k0 > k1 ? k0 : k1, lo = k0 > k1 ? k1 : k0;
+          k0 = d0 ? hi : lo; k1 = d0 ? lo : hi;
+        } else if (j >= 64) {                                       // partner in another wave: through LDS
+          unsigned long long* buf = pb ? key2 : key;
+          buf[i0] = k0; buf[i1] = k1;
+          __syncthreads();
+          const unsigned long long y0 = buf[i0 ^ j], y1 = buf[i1 ^ j];
+          const bool low = (i0 & j) == 0;                           // same bit for i0 and i1 (j < 1024)
+          k0 = cx(k0, y0, low == d0); k1 = cx(k1, y1, low == d1);
+          pb ^= 1;
+        } else {                                                    // partner = lane ^ j of the same wave
+          const unsigned long long y0 = __shfl_xor(k0, j), y1 = __shfl_xor(k1, j);
+          const bool low = (i0 & j) == 0;
+          k0 = cx(k0, y0, low == d0); k1 = cx(k1, y1, low == d1);
         }
       }
-      __syncthreads();
     }
+    __syncthreads();                                                // readers of either buffer are done
+    if (i0 < np2) key[i0] = k0;
+    if (i1 < np2) key[i1] = k1;
+    __syncthreads();
   }
 
   // ---- 3. per-candidate geometry in sorted order
