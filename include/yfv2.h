@@ -18,7 +18,9 @@
  *     yfv2_debug_activation, which are measurement/debug helpers and say so.
  *   - all pointers named x / out6 / boxes / dets / idx / count are DEVICE
  *     pointers; weights passed to yfv2_load_weights are HOST pointers.
- *   - one handle per device, not thread-safe (one stream at a time).
+ *   - one handle per device, not thread-safe, and ONE STREAM AT A TIME: the handle's workspace (activations, logits
+ *     and candidate rows of yfv2_detect, the class-filter scratch of yfv2_nms) is shared by all calls on it, so calls
+ *     issued on different streams must be ordered by the caller (events); use one handle per concurrent stream.
  *   - there is no CPU fallback: if no gfx950 device is usable, yfv2_create
  *     fails with YFV2_ERR_DEVICE.
  */
@@ -140,11 +142,18 @@ YFV2_API int yfv2_resize_u8(yfv2_handle h, const uint8_t* src, int32_t B, int32_
  * int32, 1 where the reference's true_positives is 1.  Same walk as the reference: detections in their (score-
  * descending) order, best-IoU target over all of the image's targets (first on ties), IoU with the "+1 pixel"
  * convention in fp32, threshold compared in fp32, a target is matched once, stop when all targets are matched.
- * At most 1024 targets per image (YFV2_ERR_ARG otherwise; COCO's maximum is below 100).  Unlike the other entry points
- * this one waits for the stream before it returns (it reads that overflow flag back; its result is consumed on the host
- * by evaluation() anyway).  SURVEY.md section 8(f) row 2. */
+ * At most 1024 targets per image (YFV2_ERR_ARG otherwise; COCO's maximum is below 100).  B is not bound by max_batch
+ * (no workspace is involved).  Unlike the other entry points this one waits for the stream before it returns (it reads
+ * the overflow flag back); evaluation loops use the two-call form below instead.  SURVEY.md section 8(f) row 2. */
 YFV2_API int yfv2_batch_statistics(yfv2_handle h, const float* dets, const int32_t* count, int32_t B, const float* targets,
                                    int32_t T, float iou_threshold, int32_t* tp, void* stream);
+/* The same launch, enqueue only (no host synchronisation): an image with more than 1024 targets sets a sticky flag
+ * inside the handle (its own device word, not shared with any other entry point).  yfv2_batch_statistics_overflow
+ * waits for `stream`, returns that flag through *overflowed (1: at least one call since the last query produced an
+ * invalid tp row) and clears it - call it once after the last batch (utils.evaluation does). */
+YFV2_API int yfv2_batch_statistics_async(yfv2_handle h, const float* dets, const int32_t* count, int32_t B, const float* targets,
+                                         int32_t T, float iou_threshold, int32_t* tp, void* stream);
+YFV2_API int yfv2_batch_statistics_overflow(yfv2_handle h, int32_t* overflowed, void* stream);
 
 /* ---- introspection / measurement (bench.py, tests) ------------------------- */
 

@@ -78,7 +78,8 @@ struct yfv2_ctx {
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
   Buf logits[6];
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
-  int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries)
+  int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries), then one int32 of its own for the statistics overflow flag
+  int32_t* d_stats_flag = nullptr;  // = d_classes + 256
   long long* d_trace = nullptr;  // YFV2_TRACE=1: cycle stamps of the last fused s1 launch (debug)
   // which buffers hold the stage outputs of the last forward (for debug/parity)
   float* dbg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1023,8 +1024,12 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   yfv2_ctx* h = new yfv2_ctx();
   DeviceGuard guard(cfg->device);
   int rc = setup_ctx(h, cfg, rows, alloc_buf);
-  if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 256 * sizeof(int32_t)) != hipSuccess)
+  if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 257 * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, YFV2_ERR_DEVICE, "hipMalloc(class filter) failed");
+  if (rc == YFV2_OK) {
+    h->d_stats_flag = h->d_classes + 256;
+    if (hipMemset(h->d_stats_flag, 0, sizeof(int32_t)) != hipSuccess) rc = fail(h, YFV2_ERR_DEVICE, "hipMemset(statistics flag) failed");
+  }
   if (rc != YFV2_OK) {
     g_tls_error = h->err;
     yfv2_destroy(h);
@@ -1256,22 +1261,41 @@ int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres,
   return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
 }
 
-int yfv2_batch_statistics(yfv2_handle h, const float* dets, const int32_t* count, int32_t B, const float* targets, int32_t T,
-                          float iou_threshold, int32_t* tp, void* stream) {
-  int rc = check_call(h, B, false);
-  if (rc) return rc;
+// enqueue only: the overflow flag is sticky in the handle until yfv2_batch_statistics_overflow reads it
+int yfv2_batch_statistics_async(yfv2_handle h, const float* dets, const int32_t* count, int32_t B, const float* targets, int32_t T,
+                                float iou_threshold, int32_t* tp, void* stream) {
+  if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
+  if (B < 1) return fail(h, YFV2_ERR_BATCH, "yfv2_batch_statistics: B < 1");   // no workspace involved: B is not bound by max_batch
   if (!dets || !count || !tp || T < 0 || (T > 0 && !targets)) return fail(h, YFV2_ERR_ARG, "yfv2_batch_statistics: bad argument");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  HIP_TRY(h, hipMemsetAsync(h->d_classes, 0, sizeof(int32_t), s));   // reused as the overflow flag
   StatsArgs a{};
-  a.dets = dets; a.count = count; a.targets = targets; a.tp = tp; a.overflow = h->d_classes;
+  a.dets = dets; a.count = count; a.targets = targets; a.tp = tp; a.overflow = h->d_stats_flag;
   a.B = B; a.T = T; a.iou_thres = iou_threshold;
   yfv2_launch_stats(a, s);
   HIP_TRY(h, hipGetLastError());
+  return YFV2_OK;
+}
+
+int yfv2_batch_statistics_overflow(yfv2_handle h, int32_t* overflowed, void* stream) {
+  if (!h || !overflowed) return fail(h, YFV2_ERR_ARG, "yfv2_batch_statistics_overflow: null pointer");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
   int32_t over = 0;
-  HIP_TRY(h, hipMemcpyAsync(&over, h->d_classes, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(&over, h->d_stats_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemsetAsync(h->d_stats_flag, 0, sizeof(int32_t), s));
   HIP_TRY(h, hipStreamSynchronize(s));
+  *overflowed = over;
+  return YFV2_OK;
+}
+
+int yfv2_batch_statistics(yfv2_handle h, const float* dets, const int32_t* count, int32_t B, const float* targets, int32_t T,
+                          float iou_threshold, int32_t* tp, void* stream) {
+  int rc = yfv2_batch_statistics_async(h, dets, count, B, targets, T, iou_threshold, tp, stream);
+  if (rc) return rc;
+  int32_t over = 0;
+  rc = yfv2_batch_statistics_overflow(h, &over, stream);
+  if (rc) return rc;
   if (over) return fail(h, YFV2_ERR_ARG, "yfv2_batch_statistics: an image has more than 1024 targets");
   return YFV2_OK;
 }

@@ -417,12 +417,8 @@ static void launch_s1(const BlockS1Args& a, int blocks_per_cu, hipStream_t s) {
   int blocks = a.B * tiles;
   const int cap = 256 * blocks_per_cu;  // persistent: filters are staged once per workgroup
   if (blocks > cap) blocks = cap;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1_kernel<C2, THREADS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1_kernel<C2, THREADS>), lds_ok0);
   hipLaunchKernelGGL((block_s1_kernel<C2, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 
@@ -855,11 +851,8 @@ bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s) {
   const size_t pl = (((size_t)(a.H + 2) * (a.W + 1) + 1 + 15) & ~(size_t)15);
   const size_t lds = sizeof(float) * (size_t)(2 * (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) + 12 * pl * 4);
   const int blocks = a.B < 256 ? a.B : 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1x2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1x2_kernel<512>), lds_ok0);
   hipLaunchKernelGGL((block_s1x2_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
   return true;
 }
@@ -881,11 +874,8 @@ static void launch_s1w(const BlockS1Args& a, hipStream_t s) {
   const size_t pl = (((size_t)(a.H + 2) * (a.W + 1) + 1 + 15) & ~(size_t)15);
   const size_t lds = sizeof(float) * (size_t)(2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + 12 * pl * 4);
   const int blocks = a.B < 256 ? a.B : 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s1w_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1w_kernel<512>), lds_ok0);
   hipLaunchKernelGGL((block_s1w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
 }
 
@@ -1257,12 +1247,10 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
   const int tiles = (a.H / 2 + a.R - 1) / a.R;
   int blocks = a.B * tiles;
   if (blocks > 256) blocks = 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, false>), lds_ok0);
+  static std::atomic<unsigned long long> lds_ok1{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true>), lds_ok1);
   if (a.pp_in) hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true>), dim3(blocks), dim3(512), lds, s, a);
   else hipLaunchKernelGGL((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
 }
@@ -1482,12 +1470,8 @@ static void launch_tower2(const TowerArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)TW_WP_FL + (size_t)MH * TW_WH_FL + 25 * TW_KC * 16 + 5 * 96 +
                                       (size_t)16 * tw2_plane_slots(a.H, a.W));
   int blocks = a.B < 256 ? a.B : 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF>), lds_ok0);
   hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 

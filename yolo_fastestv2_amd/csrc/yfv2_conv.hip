@@ -247,12 +247,8 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   const int cap = lds > 64 * 1024 ? 256 : (lds > 32 * 1024 ? 512 : 1024);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  static bool attr_done = false;  // allow > 64 KiB dynamic LDS where needed
-  if (!attr_done && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
   hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 

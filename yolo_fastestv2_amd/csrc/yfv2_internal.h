@@ -15,6 +15,18 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 #endif
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-(function, device) attribute: raise it to the 160 KiB cap the first
+// time a function is launched on each device (`done` = the call site's bit mask of devices already served).
+#include <atomic>
+inline void yfv2_allow_full_lds(const void* fn, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+  const unsigned long long bit = 1ull << dev;
+  if (done.load(std::memory_order_relaxed) & bit) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.fetch_or(bit, std::memory_order_relaxed);
+}
+
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
   const void* x;       // fp32 (B,3,H,W) in [0,1], or (u8_in) uint8 (B,H,W,3) in 0..255

@@ -155,12 +155,10 @@ void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
   const int b0 = (a.fh[0] * a.fw[0] + DEC_CELLS - 1) / DEC_CELLS;
   const int b1 = (a.fh[1] * a.fw[1] + DEC_CELLS - 1) / DEC_CELLS;
   const size_t lds = (size_t)DEC_CELLS * 3 * (5 + a.classes) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<false>), lds_ok0);
+  static std::atomic<unsigned long long> lds_ok1{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<true>), lds_ok1);
   if (a.cand)
     hipLaunchKernelGGL(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), 0, s, a, b0, b1);
   else

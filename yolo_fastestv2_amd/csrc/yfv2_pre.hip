@@ -91,10 +91,7 @@ size_t yfv2_resize_lds_bytes(int SW, int W) { return 2 * (size_t)((SW * 3 + 6) &
 
 void yfv2_launch_resize(const ResizeArgs& a, hipStream_t s) {
   const size_t lds = yfv2_resize_lds_bytes(a.SW, a.W);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resize_u8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&resize_u8_kernel), lds_ok0);
   hipLaunchKernelGGL(resize_u8_kernel, dim3((unsigned)(a.B * a.H)), dim3(256), lds, s, a);
 }

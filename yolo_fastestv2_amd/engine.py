@@ -32,6 +32,7 @@ class Engine:
         self.height, self.width = int(height), int(width)
         self.classes, self.anchor_num = int(classes), int(anchor_num)
         self.anchors = [float(a) for a in (anchors if anchors is not None else [0.0] * 12)]
+        self._anchors_set = anchors is not None   # decode()/detect() refuse to run on the all-zero placeholder
         if len(self.anchors) != 12:
             raise ValueError("expected 12 anchor values (6 pairs), got %d" % len(self.anchors))
         self.max_batch = 0
@@ -102,6 +103,7 @@ class Engine:
             if len(anchors) != 12:
                 raise ValueError("expected 12 anchor values (6 pairs), got %d" % len(anchors))
             self.anchors = anchors
+        self._anchors_set = True
         check(_lib.lib().yfv2_set_anchors(self._h, (C.c_double * 12)(*self.anchors)), self._h)
 
     # ---- shapes ---------------------------------------------------------------------------
@@ -134,7 +136,13 @@ class Engine:
         check(fn(self._h, _ptr(x), B, ptrs, _stream(self.device)), self._h)
         return tuple(out)
 
+    def _need_anchors(self, what):
+        if not self._anchors_set:
+            raise RuntimeError("Engine.%s: anchors were never given (constructor `anchors=` or set_anchors(cfg['anchors'])); "
+                               "the all-zero placeholder would decode every box to zero size" % what)
+
     def decode(self, preds, out=None):
+        self._need_anchors("decode")
         preds = [p.contiguous() for p in preds]
         B = preds[0].shape[0]
         for p, s in zip(preds, self.logit_shapes(B)):
@@ -170,6 +178,7 @@ class Engine:
         return dets, idx, cnt
 
     def detect(self, x, conf_thres, iou_thres, out=None):
+        self._need_anchors("detect")
         x = self._check_x(x)
         B = x.shape[0]
         self.ensure_batch(B)
@@ -190,18 +199,26 @@ class Engine:
         check(_lib.lib().yfv2_resize_u8(self._h, _ptr(frames), B, sh, sw, _ptr(out), _stream(self.device)), self._h)
         return out
 
-    def batch_statistics(self, dets, cnt, targets, iou_threshold):
+    def batch_statistics(self, dets, cnt, targets, iou_threshold, sync=True):
         """True-positive flags (B, 300) int32 for the padded detections of nms()/detect() against targets (T,6)
-        [image index, label, x1, y1, x2, y2] - utils/utils.py:194-230 get_batch_statistics on the device."""
+        [image index, label, x1, y1, x2, y2] - utils/utils.py:194-230 get_batch_statistics on the device.
+        ``sync=False`` only enqueues (no host wait); call ``stats_overflowed()`` once after the last batch."""
         B = dets.shape[0]
         if tuple(dets.shape) != (B, MAX_DET, 6) or dets.dtype != torch.float32 or dets.device != self.device:
             raise ValueError("dets must be fp32 (B,%d,6) on %s" % (MAX_DET, self.device))
         targets = targets.to(self.device, torch.float32).reshape(-1, 6).contiguous()
-        self.ensure_batch(B)
         tp = torch.empty((B, MAX_DET), device=self.device, dtype=torch.int32)
-        check(_lib.lib().yfv2_batch_statistics(self._h, _ptr(dets.contiguous()), _ptr(cnt.contiguous()), B, _ptr(targets) if targets.numel() else None,
-                                               int(targets.shape[0]), float(iou_threshold), _ptr(tp), _stream(self.device)), self._h)
+        fn = _lib.lib().yfv2_batch_statistics if sync else _lib.lib().yfv2_batch_statistics_async
+        check(fn(self._h, _ptr(dets.contiguous()), _ptr(cnt.contiguous()), B, _ptr(targets) if targets.numel() else None,
+                 int(targets.shape[0]), float(iou_threshold), _ptr(tp), _stream(self.device)), self._h)
         return tp
+
+    def stats_overflowed(self):
+        """Waits for the stream; True if any batch_statistics(sync=False) call since the last query met an image with
+        more than 1024 targets (its flags are then invalid).  Clears the flag."""
+        over = C.c_int32(0)
+        check(_lib.lib().yfv2_batch_statistics_overflow(self._h, C.byref(over), _stream(self.device)), self._h)
+        return bool(over.value)
 
     # ---- introspection --------------------------------------------------------------------
     def stages(self):

@@ -86,6 +86,8 @@ class _Node(nn.Module):
 class Detector(nn.Module):
     def __init__(self, classes, anchor_num, load_param, export_onnx=False):
         super().__init__()
+        self._engines = {}      # (device, H, W) -> Engine
+        self._synced = {}       # engine key -> weight version token
         self.classes, self.anchor_num = int(classes), int(anchor_num)
         self.export_onnx = export_onnx
         for key, shape, kind in state_spec(self.classes, self.anchor_num):
@@ -125,12 +127,34 @@ class Detector(nn.Module):
                 print("  (%s not found: backbone keeps its random init)" % path)
         else:
             print("load param...")
-        self._engines = {}      # (device, H, W) -> Engine
-        self._synced = {}       # engine key -> weight version token
 
     # -- weights -> engine -----------------------------------------------------------------
+    # The engine holds a packed copy of the weights.  It is refreshed when (a) load_state_dict / .to() / .float() ... ran
+    # (the overrides below mark every engine stale), or (b) a parameter or buffer was modified in place through the
+    # tensor itself (optimizer steps, `p.mul_()`: the autograd version counter moves; checked per call on a cached
+    # tensor list, ~20 us).  Writes through `p.data` bypass that counter: call sync_weights() after such surgery.
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._synced.clear()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_tensors", None)
+        if "_synced" in self.__dict__:
+            self._synced.clear()
+        return out
+
+    def sync_weights(self):
+        """Force a re-upload on the next forward (needed only after edits through ``param.data``)."""
+        self.__dict__.pop("_tensors", None)
+        self._synced.clear()
+
     def _version_token(self):
-        return tuple((t._version, t.data_ptr()) for t in self.state_dict(keep_vars=True).values())
+        ts = self.__dict__.get("_tensors")
+        if ts is None:
+            ts = self.__dict__["_tensors"] = [t for t in self.state_dict(keep_vars=True).values() if t.is_floating_point()]
+        return tuple(t._version for t in ts)
 
     def engine_for(self, x):
         hh, ww = (int(x.shape[1]), int(x.shape[2])) if (x.dtype == torch.uint8 and x.shape[-1] == 3) else (int(x.shape[2]), int(x.shape[3]))

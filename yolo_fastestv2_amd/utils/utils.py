@@ -99,7 +99,7 @@ def get_batch_statistics(outputs, targets, iou_threshold, device=None):
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     B = len(outputs)
-    eng = get_engine(dev, 352, 352, 80, 3)   # the statistics kernel does not depend on the model configuration
+    eng = get_engine(dev, 32, 32, 1, 3)      # the statistics kernel uses no workspace: the smallest handle there is (a few KB)
     MAXD = 300
     dets = torch.zeros((B, MAXD, 6), dtype=torch.float32)
     cnt = torch.zeros((B,), dtype=torch.int32)
@@ -165,6 +165,7 @@ def evaluation(val_dataloader, cfg, model, device, conf_thres=0.01, nms_thresh=0
     if device.type != "cuda":
         raise RuntimeError("evaluation: no CPU path, pass the MI355X device")
     labels, kept = [], []
+    engines = set()
     scale = None
     for imgs, targets in val_dataloader:
         imgs = imgs.to(device)
@@ -184,12 +185,16 @@ def evaluation(val_dataloader, cfg, model, device, conf_thres=0.01, nms_thresh=0
         eng = model.engine_for(x)
         eng.set_anchors(cfg["anchors"])
         dets, _, cnt = eng.detect(x, conf_thres, nms_thresh)
-        tp = eng.batch_statistics(dets, cnt, targets, iou_thres)
+        tp = eng.batch_statistics(dets, cnt, targets, iou_thres, sync=False)   # enqueue only: nothing waits until the last line
+        engines.add(eng)
         live = torch.arange(dets.shape[1], device=device)[None, :] < cnt[:, None]      # image-major, rank order: the order
         kept.append((tp[live], dets[..., 4][live], dets[..., 5][live]))                 # sample_metrics is concatenated in
     if not kept:
         print("---- No detections over whole validation set ----")
         return None
+    for eng in engines:
+        if eng.stats_overflowed():
+            raise RuntimeError("evaluation: an image has more than 1024 targets (yfv2_batch_statistics limit)")
     tp = torch.cat([k[0] for k in kept]).cpu().numpy().astype(np.float64)
     conf = torch.cat([k[1] for k in kept]).cpu().numpy()
     cls = torch.cat([k[2] for k in kept]).cpu().numpy()
