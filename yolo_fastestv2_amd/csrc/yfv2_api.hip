@@ -81,6 +81,7 @@ struct yfv2_ctx {
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries), then one int32 of its own for the statistics overflow flag
   int32_t* d_stats_flag = nullptr;  // = d_classes + 256
   long long* d_trace = nullptr;  // YFV2_TRACE=1: cycle stamps of the last fused s1 launch (debug)
+  int trace_step = -1;           // YFV2_TRACE_STEP=i: only launch i of the plan writes stamps (towers: only then)
   // which buffers hold the stage outputs of the last forward (for debug/parity)
   float* dbg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t dbg_per_img[6] = {0, 0, 0, 0, 0, 0};
@@ -892,6 +893,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.img = params + st.img_off;
       a.has_head = st.has_head ? 1 : 0;
       a.nchw0 = nullptr; a.nchw1 = nullptr;
+      a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
       if (st.has_head) {
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
@@ -902,7 +904,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       BlockS1Args a = st.s1;
       a.B = B;
       a.img = params + st.img_off;
-      a.trace = nullptr;
+      a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
       if (!yfv2_launch_block_s1x2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no two-block kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_DWPW) {
@@ -926,7 +928,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       BlockS1Args a = st.s1;
       a.B = B;
       a.img = params + st.img_off;
-      a.trace = h->d_trace;
+      a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
       if (!yfv2_launch_block_s1(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused block kernel for step '" + st.name + "'");
     } else {
@@ -1036,7 +1038,7 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     return rc;
   }
   if (const char* tr = std::getenv("YFV2_TRACE"))
-    if (tr[0] == '1') { (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
+    if (tr[0] == '1') { if (const char* ts = std::getenv("YFV2_TRACE_STEP")) h->trace_step = std::atoi(ts); (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
   *out = h;
   return YFV2_OK;
 }

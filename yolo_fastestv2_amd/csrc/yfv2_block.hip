@@ -47,6 +47,8 @@ struct S1Cfg {
 };
 
 #define YFV2_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
+// per-wave stamps of workgroup 0 (YFV2_TRACE=1, tools/trace_waves.py): trace[64 + 32 * wave + i]
+#define YFV2_WSTAMP(i) do { if (a.trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.trace[64 + 32 * (threadIdx.x >> 6) + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 template <int C2, int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1w_kernel(BlockS1Args a) {
       *reinterpret_cast<f32x4*>(oimg + (size_t)pix * C + 4 * q) = (f32x4){st0[j][0], st0[j][2], st1[j][0], st1[j][2]};
     }
   };
+  YFV2_WSTAMP(0);
   stage_issue(blockIdx.x, (int)blockIdx.x < a.B);
 
   {  // prologue: the LDS image (same as block_s1_kernel<48>) in one coalesced 16-byte copy, all loads before the first store
@@ -504,9 +507,12 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1w_kernel(BlockS1Args a) {
   // tile t = wave + k * NW covers slots s_first + 16 t .. + 15
   const float* Tg = T1 + (size_t)g * PL * 4;              // plane of quad g; quad 4 s + g is 4 s planes further
 
+  YFV2_WSTAMP(1);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     stage_commit(b);
+    YFV2_WSTAMP(2);
     __syncthreads();
+    YFV2_WSTAMP(3);
 
     // ================= phase A: pw1 (+BN+ReLU) in place, a wave reads and rewrites only its own tiles' slots
     {
@@ -561,7 +567,9 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1w_kernel(BlockS1Args a) {
         for (int s2 = 0; s2 < KC; ++s2) bf[s2] = bn[s2];
       }
     }
+    YFV2_WSTAMP(4);
     __syncthreads();  // phase B reads the neighbours' tiles
+    YFV2_WSTAMP(5);
 
     // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
     for (int t = wave; 16 * t < n_slots; t += NW) {
@@ -617,8 +625,10 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1w_kernel(BlockS1Args a) {
         }
       }
     }
+    YFV2_WSTAMP(6);
     stage_issue(b + gridDim.x, b + (int)gridDim.x < a.B);  // next image: in flight across the barrier
     __syncthreads();  // T1 is rewritten by the next image's stage_commit
+    YFV2_WSTAMP(7);
   }
 }
 
@@ -656,6 +666,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
   const int s_first = RP + 1;
   const int n_slots = (H - 1) * RP + W;                   // <= 16 * NT * NW (launcher)
 
+  YFV2_WSTAMP(0);
   {  // prologue: both blocks' LDS images in one coalesced copy
     const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
@@ -669,6 +680,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
   }
   for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
   __syncthreads();
+  YFV2_WSTAMP(1);
 
   // this lane's slot in each of its wave's tiles (tile nt of the wave = wave + NW * nt), fixed for every image
   int sl[NT], pix[NT];
@@ -796,12 +808,18 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
         if (real[nt]) zimg[(size_t)pix[nt] * C + 4 * c + g] = xq[c][0];          // X[16 c + 4 g] -> Z[4 c + g]
       }
     }
+    YFV2_WSTAMP(2);
     __syncthreads();
+    YFV2_WSTAMP(3);
     phase_a(lds);
+    YFV2_WSTAMP(4);
     __syncthreads();
+    YFV2_WSTAMP(5);
     f32x4 bo[KC][NT];
     phase_b(lds, bo);
+    YFV2_WSTAMP(6);
     __syncthreads();                                      // every window read of the first block is done
+    YFV2_WSTAMP(7);
     // ---- the second block's branch input into the tile; the first block's even outputs pass straight to Z
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -821,17 +839,24 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
         }
       }
     }
+    YFV2_WSTAMP(8);
     __syncthreads();
+    YFV2_WSTAMP(9);
     phase_a(lds + IMG_FL);
+    YFV2_WSTAMP(10);
     __syncthreads();
+    YFV2_WSTAMP(11);
     phase_b(lds + IMG_FL, bo);
+    YFV2_WSTAMP(12);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       if (real[nt]) {
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zimg + (size_t)pix[nt] * C + C2 + 16 * mt + 4 * g) = bo[mt][nt];
       }
+    YFV2_WSTAMP(13);
     __syncthreads();                                      // the tile is rewritten by the next image's load
+    YFV2_WSTAMP(14);
   }
 }
 
@@ -1297,6 +1322,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
   const int RP = tw2_row_pitch(W), PL = tw2_plane_slots(H, W);   // row pitch / plane size in 16-byte slots
   const int tin_fl = 4 * PL * 4;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  YFV2_WSTAMP(0);
 
   // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
   // yfv2_load_weights) is one straight coalesced 16-byte copy
@@ -1313,6 +1339,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
   }
   for (int i = tid; i < tin_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(TIN)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the 2-pixel halo stays zero
   __syncthreads();
+  YFV2_WSTAMP(1);
 
   // this wave's pixel tiles (fixed for every image)
   int base[NT], opix[NT];
@@ -1367,6 +1394,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
         if (s_src[j] >= 0) *reinterpret_cast<f32x4*>(TIN + s_dst[j]) = pre[j];
       if (s + 1 < KC) stage_load(img, s + 1, pre);  // flies during this chunk's compute
       __syncthreads();
+      YFV2_WSTAMP(2 + 3 * s);
       const int cb = 16 * s + 4 * g;
       f32x4 d[NT];
 #pragma unroll
@@ -1400,6 +1428,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) afP[mt] = *reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
       __builtin_amdgcn_sched_barrier(0);
+      YFV2_WSTAMP(3 + 3 * s);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1407,6 +1436,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afP[mt][j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
+      YFV2_WSTAMP(4 + 3 * s);
     }
     // pointwise BN (no ReLU: fpn.py:16-17,23-24)
 #pragma unroll
@@ -1418,6 +1448,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[mt][nt][k] = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
     }
+    YFV2_WSTAMP(17);
     if constexpr (MH == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -1462,6 +1493,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
         }
       }
     }
+    YFV2_WSTAMP(18);
   }
 }
 

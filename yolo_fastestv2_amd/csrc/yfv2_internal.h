@@ -170,6 +170,7 @@ struct TowerArgs {
   int mh, split;     // co < split -> nchw0[b][co][hw], else nchw1[b][co-split][hw]
   float* nchw0; float* nchw1;
   int B, H, W;
+  long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (or null)
 };
 
 // ---- decode (handel_preds) and NMS
