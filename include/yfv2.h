@@ -187,6 +187,9 @@ YFV2_API int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_de
  * the launch's name; returns the number of floats copied or a negative error code. */
 YFV2_API int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t step, char* name,
                                        int32_t name_cap, float* dst, int64_t cap);
+/* Host-only test hook: the channel order in which that plan stores stage 3's output C2 (label[k] = logical channel at
+ * NHWC position k, 96 entries); returns 1 if the plan permutes (chain kernel), 0 for plain NHWC, negative on error. */
+YFV2_API int yfv2_debug_plan_c2_label(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* label);
 
 #ifdef __cplusplus
 }

@@ -366,11 +366,13 @@ def test_other_input_size_320(yfv2, dev):
         assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)) and np.array_equal(idx[b].numpy(), o_idx[b])
 
 
-@pytest.mark.parametrize("env", [{"YFV2_S2PX": "0"}, {"YFV2_FUSED": "0"}], ids=["stage2-on-LDS-kernels", "layer-by-layer"])
+@pytest.mark.parametrize("env", [{"YFV2_S2PX": "0"}, {"YFV2_FUSED": "0"}, {"YFV2_S1CHAIN": "0"}, {"YFV2_S1CHAIN": "0", "YFV2_S1X2": "0"},
+                                 {"YFV2_S1CHAIN": "0", "YFV2_S1X2": "0", "YFV2_S1W": "0", "YFV2_DWPW": "0"}],
+                         ids=["stage2-on-LDS-kernels", "layer-by-layer", "stage3-as-pairs", "stage3-single-blocks", "round-1-kernels"])
 def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
-    """The two fallback launch plans (stage 2 on the LDS kernels / everything layer by layer, both NHWC) are what
-    runs for shapes the lane-per-pixel or fused kernels do not cover: same logits as the oracle, and the same
-    survivors as the default plan."""
+    """The fallback launch plans (stage 2 on the LDS kernels / everything layer by layer / stage 3 as pairs of blocks or as
+    single blocks instead of the seven-block chain / the round-1 kernel set) are what runs for shapes the newer kernels do
+    not cover, and what the A/B switches select: same logits as the oracle."""
     x = (torch.from_numpy(images_u8[:3]).float() / 255.0)
     ref = oracle.forward(coco_weights, x)
     sd = {k: torch.as_tensor(np.asarray(v)) for k, v in coco_weights.items()}
@@ -386,7 +388,10 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
             else:
                 os.environ[k] = v
     names = [s["name"] for s in eng.stages()]
-    assert not any("lane-per-pixel" in n for n in names), names
+    if "YFV2_S1CHAIN" in env:
+        assert not any("chain of" in n for n in names), names
+    else:
+        assert not any("lane-per-pixel" in n for n in names), names
     got = eng.forward(x.to(dev))
     for g, r, k in zip(got, ref, LOGIT_KEYS):
         err = float((g.cpu() - r).abs().max())

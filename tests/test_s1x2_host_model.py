@@ -106,7 +106,8 @@ def _kernel_model(x, im):
     return z
 
 
-def test_two_block_step_host_packing_and_index_algebra():
+def test_two_block_step_host_packing_and_index_algebra(monkeypatch):
+    monkeypatch.setenv("YFV2_S1CHAIN", "0")   # the plan without the seven-block chain: pairs of blocks
     w = yfv2.random_state_dict(5)
     im, name = _plan_image(w, "stage3.1 + 2 two fused s1 blocks")
     if im is None:
@@ -120,7 +121,8 @@ def test_two_block_step_host_packing_and_index_algebra():
     assert err <= 1e-4 * max(1.0, np.abs(ref).max()), "two-block dataflow model vs oracle: max abs err %g" % err
 
 
-def test_fused_depthwise_pointwise_step_host_packing():
+def test_fused_depthwise_pointwise_step_host_packing(monkeypatch):
+    monkeypatch.setenv("YFV2_S1CHAIN", "0")   # plain NHWC input to the 96 -> 192 block (the chain permutes C2, tests/test_s1chain_host_model.py)
     """dwpw_s2_kernel's image (pointwise fragments | depthwise taps [9][C] | dw scale, shift | pw scale, shift) for the two
     branch tails of the 96 -> 192 block: a numpy model of dw3x3 s2 + BN -> pw + BN + ReLU reading that image, against the
     oracle's layers."""

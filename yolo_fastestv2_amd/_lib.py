@@ -57,6 +57,7 @@ _PROTOTYPES = {
     "yfv2_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "yfv2_debug_plan_dryrun": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "yfv2_debug_plan_image": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "yfv2_debug_plan_c2_label": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "yfv2_num_rows": (C.c_int32, [C.c_void_p]),
     "yfv2_num_stages": (C.c_int32, [C.c_void_p]),
     "yfv2_stage_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),

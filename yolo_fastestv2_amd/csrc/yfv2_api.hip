@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_DWPW = 9, STEP_S1X2 = 10 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_DWPW = 9, STEP_S1X2 = 10, STEP_S1CHAIN = 11 };
 
 struct Step {
   int kind = 0;
@@ -76,6 +76,8 @@ struct yfv2_ctx {
   bool stem_pp = false;     // the stem writes pair planes [12][H/4][W/4][2] (consumed by s2px_kernel)
   int s2_label[48] = {0};   // logical channel stored in slot 2*pair + element
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
+  bool c2_permuted = false; // stage 3's output (C2) is stored in the chain kernel's order:
+  int c2_label[96] = {0};   //   physical channel position k holds logical channel c2_label[k]
   Buf logits[6];
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries), then one int32 of its own for the statistics overflow flag
@@ -363,6 +365,17 @@ struct WeightPacker {
       for (int k = 0; k < ci; ++k) blob[g.w + (size_t)r * ci + k] = blob[f.w + (size_t)r * ci + label[k]];
     return g;
   }
+  // copy with the OUTPUT channels re-ordered: row r (and its BN scale / shift) takes logical output channel label[r]
+  Folded permuted_pw_outputs(const Folded& f, int co, int ci, const int* label) {
+    Folded g;
+    g.w = reserve((size_t)co * ci); g.scale = reserve(co); g.shift = reserve(co);
+    for (int r = 0; r < co; ++r) {
+      for (int k = 0; k < ci; ++k) blob[g.w + (size_t)r * ci + k] = blob[f.w + (size_t)label[r] * ci + k];
+      blob[g.scale + r] = blob[f.scale + label[r]];
+      blob[g.shift + r] = blob[f.shift + label[r]];
+    }
+    return g;
+  }
   Folded permuted_dw_channels(const Folded& f, int c, int kk, const int* label) {
     Folded g;
     g.w = reserve((size_t)c * kk); g.scale = reserve(c); g.shift = reserve(c);
@@ -460,8 +473,9 @@ struct PlanBuilder {
   // ShuffleV2Block stride 2 (shufflenetv2.py:19-44,52-55): out = cat(proj(x), main(x))
   // pp_label != nullptr: the input is stage 2's pair-plane layout (slot k holds logical channel pp_label[k],
   // pair p lives in buffer pp_buf[p]); only the fused kernel reads it
+  // in_label != nullptr: the NHWC input holds logical channel in_label[k] at position k (stage 3 written by the chain kernel)
   void block_s2(const std::string& p, int cin, int H, int W, const Buf& x, const Buf& y, const int* pp_label = nullptr,
-                const int* pp_buf = nullptr, long long pp_bufstride = 0) {
+                const int* pp_buf = nullptr, long long pp_bufstride = 0, const int* in_label = nullptr) {
     Folded f;
     const int oh = H / 2, ow = W / 2, co = 2 * cin;
     const char* env = std::getenv("YFV2_FUSED");
@@ -512,8 +526,10 @@ struct PlanBuilder {
       Folded fd, fp;
       ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fd);
       ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &fp);
+      if (in_label && ok) { fd = wp.permuted_dw_channels(fd, cin, 9, in_label); fp = wp.permuted_pw_inputs(fp, cin, cin, in_label); }
       add_dwpw(p + ".proj: dw3x3s2+bn -> pw+bn+relu", x.p, 0, fd, fp);
       ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", cin, cin, &f);
+      if (in_label && ok) f = wp.permuted_pw_inputs(f, cin, cin, in_label);
       add_pw(p + ".main.pw1+bn+relu", cin, PW_PLAIN, cin, H * W, x.p, cin, 0, h->t1.p, cin, 0, true, f);
       ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", cin, 3, &fd);
       ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", cin, cin, &fp);
@@ -521,10 +537,13 @@ struct PlanBuilder {
       return;
     }
     ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &f);
+    if (in_label && ok) f = wp.permuted_dw_channels(f, cin, 9, in_label);
     add_dw(p + ".proj.dw3x3s2+bn", 3, 2, cin, H, W, x.p, cin, h->t3.p, cin, false, f);
     ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &f);
+    if (in_label && ok) f = wp.permuted_pw_inputs(f, cin, cin, in_label);
     add_pw(p + ".proj.pw+bn+relu", cin, PW_PLAIN, cin, oh * ow, h->t3.p, cin, 0, y.p, co, 0, true, f);
     ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", cin, cin, &f);
+    if (in_label && ok) f = wp.permuted_pw_inputs(f, cin, cin, in_label);
     add_pw(p + ".main.pw1+bn+relu", cin, PW_PLAIN, cin, H * W, x.p, cin, 0, h->t1.p, cin, 0, true, f);
     ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", cin, 3, &f);
     add_dw(p + ".main.dw3x3s2+bn", 3, 2, cin, H, W, h->t1.p, cin, h->t2.p, cin, false, f);
@@ -662,6 +681,151 @@ struct PlanBuilder {
     h->plan.push_back(s);
   }
 
+
+  // ---- a chain of stride-1 blocks as ONE launch (block_s1chain_kernel, yfv2_block.hip).  The kernel moves data in a
+  // fixed, lane-uniform way (pixel slot owned by the 4 lanes g of a 16-lane row; per block and lane: accumulator elements
+  // 1, 3 -> next tile, element 0 -> held one block, element 2 -> parked in Z; next tile quads = (held 3 + parked 1 |
+  // parked 2 + fresh 2 | fresh 4)); this planner decides which LOGICAL channel each of those positions carries so that
+  // the whole thing is the reference's channel_shuffle / pass-through / cat chain (shufflenetv2.py:48-51,57-63):
+  //   logical activation A_k (96 channels) before block k:  branch input i = A_k[2i+1],  A_{k+1} = [A_k[0::2], F_k]
+  // A fresh output F_k[j] (index 48 + j in A_{k+1}) becomes a branch input after L blocks, L = 1 + trailing zeros of its
+  // index: odd j at once (24 values -> elements 1, 3), j = 2 mod 4 after one pass (12 -> element 0), j = 0 mod 4 later
+  // (12 -> element 2, parked).  X[2i+1] feed block 1 from the load, X[4i+2] are held for block 2, X[4i] stay in memory.
+  // Outputs: the blocks' images (pw1 input columns / pw2 output rows permuted, tables PS / PL appended) and
+  // z_label[pos] = logical channel of the chain's output stored at Z position pos.
+  struct ChainLoc { int kind = 0, blk = 0, mt = 0, g = 0, e = 0, off = 0; };   // kind 0: X[off], 1: accumulator of block blk, 2: parked at Z[off]
+  void s1chain_block(const std::vector<std::string>& names, int c, int H, int W, const Buf& x, const Buf& y, int* z_label) {
+    const int c2 = c / 2, NB = (int)names.size();
+    std::vector<Folded> f1(NB), fd(NB), f2(NB);
+    for (int k = 0; k < NB; ++k) {
+      ok &= wp.pw(names[k] + ".branch_main.0", names[k] + ".branch_main.1", c2, c2, &f1[k]);
+      ok &= wp.dw(names[k] + ".branch_main.3", names[k] + ".branch_main.4", c2, 3, &fd[k]);
+      ok &= wp.pw(names[k] + ".branch_main.5", names[k] + ".branch_main.6", c2, c2, &f2[k]);
+    }
+    std::vector<float> im;
+    if (ok && c2 == 48 && NB >= 2) {
+      std::vector<ChainLoc> act(96);                     // where logical channel o of the current activation lives
+      for (int o = 0; o < 96; ++o) { act[o].kind = 0; act[o].off = o; }
+      int next_final = 60, next_temp = 0;                // Z positions: [60, 95) parked survivors, [0, 60) parked temporaries
+      auto tile_of_fresh = [](int mt, int e) {           // accumulator (mt, element 1 | 3) -> tile (quad j, element)
+        const int hi = e == 3 ? 1 : 0;
+        if (mt == 0) return std::make_pair(1, 2 + hi);
+        if (mt == 1) return std::make_pair(2, 0 + hi);
+        return std::make_pair(2, 2 + hi);
+      };
+      std::vector<std::vector<int>> tables(NB, std::vector<int>(24, 0));   // per block: PS[mt][g] | PLnext[i][g]
+      for (int k = 0; k < NB; ++k) {
+        // ---- where does branch input i of this block sit in the tile?  label[physical column 16 j + 4 g + e] = i
+        int label[48];
+        for (int q = 0; q < 48; ++q) label[q] = -1;
+        int parked_n = 0;
+        for (int i = 0; i < 48; ++i) {
+          const ChainLoc& L = act[2 * i + 1];
+          int j = -1, g = -1, e = -1;
+          if (k == 0) {                                   // loaded from X: quad cq = off / 16, lane group, element 1 | 3
+            if (L.kind != 0 || !(L.off & 1)) { ok = false; break; }
+            const int cq = L.off / 16; g = (L.off % 16) / 4;
+            j = cq / 2; e = (cq & 1) * 2 + ((L.off & 3) == 3 ? 1 : 0);
+          } else if (L.kind == 1 && L.blk == k - 1 && (L.e == 1 || L.e == 3)) {   // fresh output of the previous block
+            const auto t = tile_of_fresh(L.mt, L.e); j = t.first; e = t.second; g = L.g;
+          } else if (k == 1 && L.kind == 0 && (L.off & 3) == 2) {                  // X element 2, held since the load
+            const int cq = L.off / 16; g = (L.off % 16) / 4;
+            if (cq < 4) { j = 0; e = cq; } else { j = 1; e = cq - 4; }
+          } else if (k >= 2 && L.kind == 1 && L.blk == k - 2 && L.e == 0) {        // element 0 of the block before the previous one
+            j = 0; g = L.g; e = L.mt;
+          } else if (k >= 2 && (L.kind == 2 || (L.kind == 0 && (L.off & 3) == 0 && L.off != 0))) {   // parked: lane group / index in arrival order
+            if (parked_n >= 12) { ok = false; break; }
+            g = parked_n / 3; const int pi = parked_n % 3; ++parked_n;
+            if (pi == 0) { j = 0; e = 3; } else { j = 1; e = pi - 1; }
+            tables[k - 1][12 + pi * 4 + g] = L.kind == 0 ? (128 | L.off) : L.off;   // loaded during block k-1's phase B
+          } else { ok = false; break; }
+          if (label[16 * j + 4 * g + e] != -1) { ok = false; break; }
+          label[16 * j + 4 * g + e] = i;
+        }
+        if (!ok) break;
+        if (k >= 2 && parked_n != 12) { ok = false; break; }
+        for (int q = 0; q < 48; ++q) if (label[q] < 0) { ok = false; }
+        if (!ok) break;
+        // ---- which logical fresh channel lands in accumulator (mt, g, e)?  rowlab[16 mt + 4 g + e] = j
+        int rowlab[48];
+        if (k == NB - 1) {
+          for (int q = 0; q < 48; ++q) rowlab[q] = q;   // last block: natural order (Z[0..47] = logical 48..95)
+        } else {
+          int n13 = 0, n0 = 0, n2 = 0;
+          for (int j = 0; j < 48; ++j) {
+            int slot, e;
+            if (j & 1) { slot = n13 / 2; e = (n13 & 1) ? 3 : 1; ++n13; }
+            else if ((j & 3) == 2) { slot = n0++; e = 0; }
+            else { slot = n2++; e = 2; }
+            rowlab[16 * (slot / 4) + 4 * (slot % 4) + e] = j;   // slot = 4 mt + g
+          }
+        }
+        const Folded f1k = wp.permuted_pw_inputs(f1[k], c2, c2, label);
+        const Folded f2k = wp.permuted_pw_outputs(f2[k], c2, c2, rowlab);
+        // ---- next activation; park positions of the element-2 values
+        std::vector<ChainLoc> nxt(96);
+        for (int i = 0; i < 48; ++i) nxt[i] = act[2 * i];
+        for (int q = 0; q < 48; ++q) {
+          const int mt = q / 16, g = (q % 16) / 4, e = q % 4, j = rowlab[q];
+          ChainLoc L; L.kind = 1; L.blk = k; L.mt = mt; L.g = g; L.e = e;
+          if (k < NB - 1 && e == 2) {                   // parked: survives the chain iff it is not consumed by a later block
+            int idx = 48 + j, steps = 0;
+            while (!(idx & 1) && idx != 0) { idx >>= 1; ++steps; }   // consumed as branch input of block k + 1 + steps
+            const bool survives = (k + 1 + steps) > NB - 1;
+            L.kind = 2;
+            L.off = survives ? next_final++ : next_temp++;
+            if (next_final > 95 || next_temp > 60) { ok = false; }
+            tables[k][0 * 12 + mt * 4 + g] = L.off;
+          }
+          nxt[48 + j] = L;
+        }
+        act.swap(nxt);
+        wp.append_s1(im, f1k, fd[k], f2k, c2);
+        for (int t = 0; t < 32; ++t) {                  // int tables as raw bits behind the BN vectors
+          float fbits; const int v = t < 24 ? tables[k][t] : 0;
+          std::memcpy(&fbits, &v, sizeof(float));
+          im.push_back(fbits);
+        }
+      }
+      // the PL entries were written into tables[k-1] AFTER image k-1 was appended: patch them in place
+      if (ok) {
+        const size_t per = im.size() / NB;
+        for (int k = 0; k < NB; ++k)
+          for (int t = 12; t < 24; ++t) {
+            float fbits; const int v = tables[k][t];
+            std::memcpy(&fbits, &v, sizeof(float));
+            im[(size_t)k * per + per - 32 + t] = fbits;
+          }
+        // ---- where the chain's output lives in Z
+        for (int pos = 0; pos < 96; ++pos) z_label[pos] = -1;
+        for (int o = 0; o < 96; ++o) {
+          const ChainLoc& L = act[o];
+          int pos = -1;
+          if (L.kind == 0 && L.off == 0) pos = 95;                                    // X[0]: copied at load time (CH_X0_POS)
+          else if (L.kind == 1 && L.blk == NB - 1) pos = 16 * L.mt + 4 * L.g + L.e;   // last block's accumulators
+          else if (L.kind == 1 && L.blk == NB - 2 && L.e == 0) pos = 48 + 3 * L.g + L.mt;   // held elements of the block before
+          else if (L.kind == 2 && L.off >= 60) pos = L.off;
+          if (pos < 0 || z_label[pos] != -1) { ok = false; break; }
+          z_label[pos] = o;
+        }
+        if ((int)per != yfv2_s1chain_image_floats()) ok = false;
+      }
+    } else {
+      ok = false;
+    }
+    Step s;
+    s.kind = STEP_S1CHAIN;
+    s.c2 = c2;
+    s.s1.in = x.p; s.s1.out = y.p;
+    s.s1.H = H; s.s1.W = W; s.s1.R = H; s.s1.nblk = NB;
+    s.img_off = wp.put(im);
+    s.name = names.front() + " .. " + names.back().substr(names.back().rfind('.') + 1) + " chain of " + std::to_string(NB) +
+             " fused s1 blocks in one launch (activations between them stay on chip)";
+    s.flops = NB * 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
+    s.bytes = NB * 4.0 * H * W * (2.0 * c);   // per-layer accounting: every block reads and writes c channels
+    h->plan.push_back(s);
+  }
+
   void block_s1(const std::string& p, int c, int H, int W, const Buf& x, const Buf& y) {
     Folded f;
     const int c2 = c / 2;
@@ -788,6 +952,7 @@ struct PlanBuilder {
         if (i == 0) {
           if (use_px) s2px_block(p, hh, ww);
           else if (px_pending) block_s2(p, cin, hh, ww, h->s2pp, *y, L2.label, L2.buf, pp_bufstride);
+          else if (si == 2 && h->c2_permuted) block_s2(p, cin, hh, ww, *x, *y, nullptr, nullptr, 0, h->c2_label);
           else block_s2(p, cin, hh, ww, *x, *y);
           px_pending = false;
           hh /= 2; ww /= 2;
@@ -797,6 +962,13 @@ struct PlanBuilder {
           }
         } else if (use_px) {
           s1px_block(p, hh, ww, L2, pp_bufstride);
+        } else if (const char* envf3 = std::getenv("YFV2_FUSED"); !(envf3 && envf3[0] == '0') && i == 1 && repeats[si] == 8 &&
+                   yfv2_s1chain_supported(cout / 2, hh, ww) && yfv2_block_s1_rows(cout / 2, hh, ww) == hh) {
+          std::vector<std::string> names;
+          for (int q = 1; q < repeats[si]; ++q) names.push_back("backbone.stage" + std::to_string(si + 2) + "." + std::to_string(q));
+          s1chain_block(names, cout, hh, ww, *x, *y, h->c2_label);     // blocks 1..7 of the stage as one launch
+          h->c2_permuted = ok;
+          i = repeats[si] - 1;
         } else if (const char* envf2 = std::getenv("YFV2_FUSED"); !(envf2 && envf2[0] == '0') && i + 1 < repeats[si] &&
                    yfv2_s1x2_supported(cout / 2, hh, ww) && yfv2_block_s1_rows(cout / 2, hh, ww) == hh) {
           const std::string pnext = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i + 1);
@@ -827,6 +999,12 @@ struct PlanBuilder {
     ok &= wp.pw("fpn.conv1x1_3.0", "fpn.conv1x1_3.1", 72, 192, &f);
     add_pw("fpn.conv1x1_3 pw192->72+bn+relu", 192, PW_PLAIN, 72, h3 * w3, c3->p, 192, 0, h->f3.p, 72, 0, true, f);
     ok &= wp.pw("fpn.conv1x1_2.0", "fpn.conv1x1_2.1", 72, 288, &f);
+    if (h->c2_permuted && ok) {   // columns 192.. read C2 in the chain kernel's channel order
+      int lab[288];
+      for (int k = 0; k < 192; ++k) lab[k] = k;
+      for (int k = 0; k < 96; ++k) lab[192 + k] = 192 + h->c2_label[k];
+      f = wp.permuted_pw_inputs(f, 72, 288, lab);
+    }
     {
       Step& s = add_pw("fpn.conv1x1_2 up2x(C3)+cat(C2)+pw288->72+bn+relu", 288, PW_FPN, 72, h2 * w2, c3->p, 192, 0,
                        h->f2.p, 72, 0, true, f);
@@ -907,6 +1085,13 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
       if (!yfv2_launch_block_s1x2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no two-block kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_S1CHAIN) {
+      BlockS1Args a = st.s1;
+      a.B = B;
+      a.img = params + st.img_off;
+      a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
+      if (!yfv2_launch_block_s1chain(a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no chain kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_DWPW) {
       DwPwArgs a = st.dwpw;
       a.B = B;
@@ -1104,6 +1289,31 @@ int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* te
   return cnt;
 }
 
+// Host-only test hook: the channel order in which the plan stores stage 3's output (C2).  label[k] = logical channel at
+// physical position k; returns 1 if the plan permutes (chain kernel), 0 if C2 is plain NHWC, or a negative error code.
+int yfv2_debug_plan_c2_label(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* label) {
+  if (!cfg || !tensors || n <= 0 || !label) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_c2_label: bad argument");
+  int rows = 0;
+  if (int rc = check_config(cfg, &rows)) return rc;
+  yfv2_ctx ctx;
+  uintptr_t next = 0x100000000ull;
+  auto fake = [&](yfv2_ctx* hh, Buf* b, size_t per_img) {
+    b->per_img = per_img;
+    b->p = reinterpret_cast<float*>(next);
+    next += (per_img * sizeof(float) * (size_t)hh->cfg.max_batch + 4095) & ~(uintptr_t)4095;
+    return (int)YFV2_OK;
+  };
+  setup_ctx(&ctx, cfg, rows, fake);
+  WeightPacker wp;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
+  PlanBuilder pb{&ctx, wp};
+  pb.build();
+  if (!pb.ok || !wp.missing.empty()) return fail(nullptr, YFV2_ERR_WEIGHTS, wp.missing.empty() ? "weight packing failed" : wp.missing);
+  for (int k = 0; k < 96; ++k) label[k] = ctx.c2_permuted ? ctx.c2_label[k] : k;
+  return ctx.c2_permuted ? 1 : 0;
+}
+
 void yfv2_destroy(yfv2_handle h) {
   if (!h) return;
   DeviceGuard guard(h->device);
@@ -1127,6 +1337,7 @@ int yfv2_load_weights(yfv2_handle h, const yfv2_tensor_desc* tensors, int32_t n)
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
   h->plan.clear();
+  h->c2_permuted = false;
   PlanBuilder pb{h, wp};
   pb.build();
   if (!pb.ok || !wp.missing.empty()) {
@@ -1416,6 +1627,14 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
       hipMemcpy(host_dst, h->dbg[which], (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
     fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");
     return YFV2_ERR_DEVICE;
+  }
+  if (which == 2 && h->c2_permuted) {   // stage 3 lives in the chain kernel's channel order: back to logical NHWC
+    float tmp[96];
+    for (int64_t px = 0; px < n / 96; ++px) {
+      float* row = host_dst + px * 96;
+      for (int k = 0; k < 96; ++k) tmp[h->c2_label[k]] = row[k];
+      std::memcpy(row, tmp, sizeof(tmp));
+    }
   }
   return n;
 }

@@ -436,7 +436,7 @@ static void launch_s1(const BlockS1Args& a, int blocks_per_cu, hipStream_t s) {
 // SQ_LDS_BANK_CONFLICT = 34 % of its LDS-active cycles), and a 22x22 image is 32 tiles in BOTH phases = four full
 // rounds of the 8 waves (the pixel tiling needs 33 in phase A: a fifth round for one tile).
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 2) void block_s1w_kernel(BlockS1Args a) {
+__global__ __launch_bounds__(THREADS) void block_s1w_kernel(BlockS1Args a) {
   constexpr int C2 = 48;
   using Cfg = S1Cfg<C2>;
   constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1w_kernel(BlockS1Args a) {
 
   // ---- staging: eight consecutive lanes take eight consecutive pixels of one channel quad (ds_write_b128 is serviced in
   // 8-lane groups), the next 8-lane group the next quad: a wave reads 8 pixels x 8 quads x 32 bytes
-  constexpr int MAXP = 12;                                // ceil(ceil(484 / 8) * 8 * 12 / 512)
+  constexpr int MAXP = 12 * 512 / THREADS;                // ceil(ceil(484 / 8) * 8 * 12 / THREADS)
   const int npx8 = (HW + 7) & ~7;
   f32x4 st0[MAXP], st1[MAXP];
   auto stage_issue = [&](int b_, bool active) {
@@ -860,6 +860,313 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
   }
 }
 
+// ============================================================================
+// A CHAIN of stride-1 blocks in one launch (C2 = 48, whole image, plane-per-quad tile): stage 3's blocks 1..7
+// ============================================================================
+// Reference: N consecutive ShuffleV2Block(stride 1) (shufflenetv2.py:19-32,48-51,57-63).  Per image the chain reads its
+// input X once and writes its output Z once; everything in between stays on the chip or in a few parked dwords per pixel:
+//   * the 48 channels that go through a block's branch live in the LDS tile (as in block_s1w / block_s1x2);
+//   * a value that passes k blocks before it becomes a branch input is, by the time it is needed,
+//       k = 0  a fresh branch output picked straight out of the accumulators (elements 1, 3 of every quad),
+//       k = 1  three registers per pixel slot (elements 0: held for one block),
+//       k >= 2 "parked": twelve values per pixel and block (elements 2) are stored as single dwords into Z - which is
+//              free until the very end - and three of them are loaded back per lane right before their block; the quarter
+//              of X that passes two or more blocks (X[4k]) is never loaded up front, it waits in X for the same loads;
+//   * which logical channel sits in which lane / element / tile position / Z position is decided on the host
+//     (PlanBuilder::s1chain_block): it permutes the input columns of every pw1 and the output rows of every pw2 so that
+//     the kernel's fixed, lane-uniform data movement below is the reference's channel_shuffle; the two per-block tables
+//     (where to park, what to load back) ride at the end of each block's LDS image, and the consumers of the stage's
+//     output read Z through the channel permutation the plan reports.
+// Per block image: W1 | W2 | dw taps | 6 BN vectors (block_s1_kernel's image) | int tables PS[3][4], PL[3][4] (+8 pad);
+// two image buffers alternate, the image after next is fetched during phase B.
+constexpr int CH_TBL_FL = 32;
+constexpr int CH_IMG_FL = 2 * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + CH_TBL_FL;
+constexpr int CH_X0_POS = 95;       // Z position of X[0], the one channel that passes every block
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a) {
+  constexpr int C2 = 48;
+  using Cfg = S1Cfg<C2>;
+  constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2, NT = 4;
+  constexpr int NW = THREADS / 64;
+  constexpr int N4 = CH_IMG_FL / 4, NIT = (N4 + THREADS - 1) / THREADS;   // float4 per image, per thread
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* T1 = lds + 2 * CH_IMG_FL;
+  const int H = a.H, W = a.W, HW = H * W, NB = a.nblk;
+  const int RP = W + 1;
+  const int PL = ((H + 2) * RP + 1 + 15) & ~15;
+  const float invRP = 1.0f / (float)RP;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int s_first = RP + 1;
+  const int n_slots = (H - 1) * RP + W;                   // <= 16 * NT * NW (launcher)
+  YFV2_WSTAMP(0);
+
+  for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
+
+  int sl[NT], pix[NT];
+  bool valid[NT], real[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int q = 16 * (wave + NW * nt) + p;
+    valid[nt] = q < n_slots;
+    sl[nt] = s_first + (valid[nt] ? q : n_slots - 1);
+    const int r1 = yfv2_fdiv(sl[nt], invRP), xs = sl[nt] - r1 * RP;
+    real[nt] = valid[nt] && xs >= 1;                      // column 0 of a haloed row is the shared zero column
+    pix[nt] = (r1 - 1) * W + (xs - 1);
+  }
+  float* Tg = T1 + (size_t)g * PL * 4;                    // plane of quad g; quad 4 s + g is 4 s planes further
+
+  auto phase_a = [&](const float* IM) {
+    const float* W1 = IM;
+    const float* CS = IM + 2 * Cfg::W_FL + Cfg::DW_FL;
+    f32x4 sc1[KC], sh1[KC], aw[KC][KC];
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt) {
+      sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
+      sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
+      f32x4 bf[KC];
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + sl[nt]) * 4);
+      f32x4 acc[KC];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
+      if (valid[nt]) {
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          f32x4 y;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
+            y[c] = (real[nt] && uu > 0.f) ? uu : 0.f;     // the zero column stays zero (depthwise padding)
+          }
+          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + sl[nt]) * 4) = y;
+        }
+      }
+    }
+  };
+  auto phase_b = [&](const float* IM, f32x4 (&bo)[KC][NT]) {
+    const float* W2 = IM + Cfg::W_FL;
+    const float* WD = IM + 2 * Cfg::W_FL;
+    const float* CS = WD + Cfg::DW_FL;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
+      const float* win0 = Tg + (size_t)(sl[nt] - RP - 1) * 4;
+#pragma unroll 1
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        f32x4 lsc, lsh, win[9], af[KC];
+        lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+        lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const f32x4 wl = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);   // taps: read as the FMAs go (register budget)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[c], d[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], bo[mt][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = __builtin_fmaf(bo[mt][nt][k], sc[k], sh[k]);
+          bo[mt][nt][k] = u > 0.f ? u : 0.f;
+        }
+      }
+    }
+  };
+  // the three quads of the next block's branch input (planes g, 4 + g, 8 + g) at this lane's slots
+  auto write_tile = [&](int nt, f32x4 q0, f32x4 q1, f32x4 q2) {
+    if (!real[nt]) { q0 = (f32x4){0.f, 0.f, 0.f, 0.f}; q1 = q0; q2 = q0; }   // halo slots stay the zero column
+    *reinterpret_cast<f32x4*>(T1 + ((size_t)(0 + g) * PL + sl[nt]) * 4) = q0;
+    *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 + g) * PL + sl[nt]) * 4) = q1;
+    *reinterpret_cast<f32x4*>(T1 + ((size_t)(8 + g) * PL + sl[nt]) * 4) = q2;
+  };
+  auto tbl = [&](const float* IM, int which, int i) {     // PS (which = 0) / PL (which = 1) entry i of this lane group
+    return reinterpret_cast<const int*>(IM + 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL)[which * 12 + i * 4 + g];
+  };
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float* ximg = a.in + (size_t)b * HW * C;
+    float* zimg = a.out + (size_t)b * HW * C;
+    // ---- images of blocks 0 and 1, and X: element 0 of every quad (X[4k], passes at least two blocks) is left in memory
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+      f32x4 tmp[2 * NIT];
+#pragma unroll
+      for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < 2 * N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; if (i < 2 * N4) reinterpret_cast<f32x4*>(lds)[i] = tmp[k]; }
+    }
+    float hold2[6][NT];                                   // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 xq[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        xq[c] = real[nt] ? *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (valid[nt]) {
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * j + g) * PL + sl[nt]) * 4) = (f32x4){xq[2 * j][1], xq[2 * j][3], xq[2 * j + 1][1], xq[2 * j + 1][3]};
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) hold2[c][nt] = xq[c][2];
+      if (real[nt] && g == 0) zimg[(size_t)pix[nt] * C + CH_X0_POS] = xq[0][0];
+    }
+    YFV2_WSTAMP(1);
+    __syncthreads();
+    YFV2_WSTAMP(2);
+
+    // ---- first block (peeled: its exchange draws on X's held elements)
+    f32x4 bo[KC][NT];
+    float Hd[KC][NT];                                     // element 0 of every accumulator quad: branch input of the block after next
+    phase_a(lds);
+    YFV2_WSTAMP(3);
+    __syncthreads();
+    phase_b(lds, bo);
+    YFV2_WSTAMP(4);
+    __syncthreads();                                      // every window read of this block is done
+    if (NB == 1) {
+      // degenerate chain: a single block (not used by the plan; kept so that any NB >= 1 is defined)
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (valid[nt] && NB > 1) {
+        write_tile(nt, (f32x4){hold2[0][nt], hold2[1][nt], hold2[2][nt], hold2[3][nt]},
+                   (f32x4){hold2[4][nt], hold2[5][nt], bo[0][nt][1], bo[0][nt][3]},
+                   (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
+        if (real[nt]) {
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) zimg[(size_t)pix[nt] * C + tbl(lds, 0, mt)] = bo[mt][nt][2];
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
+    }
+    __syncthreads();
+    YFV2_WSTAMP(5);
+
+    // ---- blocks 1 .. NB-1
+#pragma unroll 1
+    for (int kb = 1; kb < NB; ++kb) {
+      const float* IM = lds + (kb & 1) * CH_IMG_FL;
+      float* IMN = lds + ((kb + 1) & 1) * CH_IMG_FL;
+      const bool more = kb + 1 < NB;
+      {
+        // the image after this one travels during phase A into the buffer the previous block has left
+        f32x4 nimg[NIT];
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.img + (size_t)(kb + 1) * CH_IMG_FL);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; nimg[k] = (more && i < N4) ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        phase_a(IM);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (more && i < N4) reinterpret_cast<f32x4*>(IMN)[i] = nimg[k]; }
+      }
+      if (kb == 1) YFV2_WSTAMP(6);
+      // the parked values of the next block travel during phase B
+      float plv[3][NT];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int e = tbl(IM, 1, i);
+        const float* base = (e & 128) ? ximg : zimg;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) plv[i][nt] = (more && real[nt]) ? base[(size_t)pix[nt] * C + (e & 127)] : 0.f;
+      }
+      __syncthreads();
+      phase_b(IM, bo);
+      if (kb == 1) YFV2_WSTAMP(7);
+      if (more) {
+        __syncthreads();                                  // every window read of this block is done
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (valid[nt]) {
+            write_tile(nt, (f32x4){Hd[0][nt], Hd[1][nt], Hd[2][nt], plv[0][nt]},
+                       (f32x4){plv[1][nt], plv[2][nt], bo[0][nt][1], bo[0][nt][3]},
+                       (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
+            if (real[nt]) {
+#pragma unroll
+              for (int mt = 0; mt < KC; ++mt) zimg[(size_t)pix[nt] * C + tbl(IM, 0, mt)] = bo[mt][nt][2];
+            }
+          }
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
+        }
+        __syncthreads();
+        if (kb == 1) YFV2_WSTAMP(8);
+      }
+    }
+    YFV2_WSTAMP(9);
+    // ---- the last block's output in accumulator order, the held elements of the block before it behind them
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      if (real[nt]) {
+        float* zp = zimg + (size_t)pix[nt] * C;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zp + 16 * mt + 4 * g) = bo[mt][nt];
+        if (NB > 1) {
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) zp[C2 + 3 * g + mt] = Hd[mt][nt];
+        }
+      }
+    YFV2_WSTAMP(10);
+    __syncthreads();                                      // tile and image buffers are rewritten by the next image
+  }
+}
+
+static long s1chain_lds_floats(int H, int W) {
+  const long pl = (((long)(H + 2) * (W + 1) + 1 + 15) & ~15L);
+  return 2L * CH_IMG_FL + 12L * pl * 4;
+}
+
+int yfv2_s1chain_image_floats() { return CH_IMG_FL; }
+
+bool yfv2_s1chain_supported(int c2, int H, int W) {
+  if (c2 != 48) return false;
+  if ((H - 1) * (W + 1) + W > 16 * 4 * 8) return false;   // slots <= 4 tiles x 8 waves
+  if (s1chain_lds_floats(H, W) * 4 > 160 * 1024) return false;
+  const char* env = std::getenv("YFV2_S1CHAIN");
+  return !(env && env[0] == '0');
+}
+
+bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s) {
+  if (!yfv2_s1chain_supported(48, a.H, a.W) || a.nblk < 2) return false;
+  const size_t lds = sizeof(float) * (size_t)s1chain_lds_floats(a.H, a.W);
+  const int blocks = a.B < 256 ? a.B : 256;
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain_kernel<512>), lds_ok0);
+  hipLaunchKernelGGL((block_s1chain_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  return true;
+}
+
 bool yfv2_s1x2_supported(int c2, int H, int W) {
   if (c2 != 48) return false;
   if ((H - 1) * (W + 1) + W > 16 * 4 * 8) return false;   // slots <= 4 tiles x 8 waves
@@ -899,7 +1206,13 @@ static void launch_s1w(const BlockS1Args& a, hipStream_t s) {
   const size_t pl = (((size_t)(a.H + 2) * (a.W + 1) + 1 + 15) & ~(size_t)15);
   const size_t lds = sizeof(float) * (size_t)(2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + 12 * pl * 4);
   const int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0};
+  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
+  static const bool wide = [] { const char* e = std::getenv("YFV2_S1W_T"); return e && std::atoi(e) == 1024; }();   // A/B: 16 waves, 2 tiles each
+  if (wide) {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1w_kernel<1024>), lds_ok1);
+    hipLaunchKernelGGL((block_s1w_kernel<1024>), dim3(blocks), dim3(1024), lds, s, a);
+    return;
+  }
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1w_kernel<512>), lds_ok0);
   hipLaunchKernelGGL((block_s1w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
 }

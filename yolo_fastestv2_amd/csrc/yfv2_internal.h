@@ -96,6 +96,7 @@ struct BlockS1Args {
   long long* trace;  // debug: workgroup 0 / thread 0 writes s_memtime stamps at phase boundaries (or null)
   int B, H, W;
   int R;             // rows per work item (H % R == 0)
+  int nblk;          // block_s1chain_kernel: blocks in the chain (img = their images back to back)
 };
 
 // two consecutive stride-1 blocks in one launch (block_s1x2_kernel, C2 = 48): logical branch-input channel held at
@@ -110,6 +111,11 @@ __host__ __device__ constexpr int yfv2_s1x2_label_b(int s, int g, int j) {
   return v < 6 ? 4 * v + g : 24 + 8 * ((v - 6) >> 1) + 2 * g + ((v - 6) & 1);
 }
 bool yfv2_s1x2_supported(int c2, int H, int W);
+// chain of N stride-1 blocks in one launch (block_s1chain_kernel, C2 = 48); see PlanBuilder::s1chain_block for the
+// channel bookkeeping shared by host and kernel
+bool yfv2_s1chain_supported(int c2, int H, int W);
+int yfv2_s1chain_image_floats();                                    // floats per block image (incl. the two int tables)
+bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s);
 bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s);   // a.img = first block's LDS image | second block's
 
 // ---- fused ShuffleV2 stride-2 block (yfv2_block.hip)
