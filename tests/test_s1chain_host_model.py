@@ -16,9 +16,8 @@ from yolo_fastestv2_amd import _lib
 from yolo_fastestv2_amd._lib import Config, TensorDesc
 
 KC, C2, NB = 3, 48, 7
-W_FL, DW_FL, CST_FL, TBL_FL = KC * KC * 256, 9 * KC * 16, 6 * KC * 16, 32
+W_FL, DW_FL, CST_FL, TBL_FL = KC * KC * 256, 9 * KC * 16, 6 * KC * 16, 64
 IMG_FL = 2 * W_FL + DW_FL + CST_FL + TBL_FL
-X0_POS = 95
 
 
 def _descs(w):
@@ -78,7 +77,7 @@ def _branch(tile_phys, im):
 
 def _tables(im):
     t = im[2 * W_FL + DW_FL + CST_FL:IMG_FL].view(np.int32)
-    return t[:12].reshape(3, 4), t[12:24].reshape(3, 4)       # PS[mt][g], PL[i][g]
+    return t[:12].reshape(3, 4), t[12:36].reshape(6, 4)       # PS[mt][g] (park positions of elements 2), XS[c][g] (block 0: of X[16 c + 4 g])
 
 
 def _kernel_model(x, images):
@@ -94,7 +93,11 @@ def _kernel_model(x, images):
             tile[..., 16 * j + 4 * g + 2] = xq[:, :, 2 * j + 1, g, 1]
             tile[..., 16 * j + 4 * g + 3] = xq[:, :, 2 * j + 1, g, 3]
     hold2 = xq[:, :, :, :, 2].copy()                   # [c][g]
-    z[..., X0_POS] = xq[:, :, 0, 0, 0]
+    ps, xs = _tables(images[0])
+    for c in range(6):
+        for g in range(4):
+            assert np.isnan(z[..., xs[c, g]]).all(), "two X values parked at one Z position"
+            z[..., xs[c, g]] = xq[:, :, c, g, 0]
 
     def fresh_quads(bo, g):
         return ([None, None, bo[:, :, 0, g, 1], bo[:, :, 0, g, 3]], [bo[:, :, 1, g, 1], bo[:, :, 1, g, 3], bo[:, :, 2, g, 1], bo[:, :, 2, g, 3]])
@@ -120,15 +123,13 @@ def _kernel_model(x, images):
     tile = tile_n
     for kb in range(1, NB):
         im = images[kb]
-        ps, pl = _tables(im)
+        ps, _ = _tables(im)
         more = kb + 1 < NB
         plv = np.zeros((H, W, 3, 4), np.float32)
-        if more:
+        if more:                                       # the next block's twelve parked inputs: group kb - 1 of Z, three per lane group
             for i in range(3):
                 for g in range(4):
-                    e = int(pl[i, g])
-                    src = x if (e & 128) else z
-                    plv[:, :, i, g] = src[..., e & 127]
+                    plv[:, :, i, g] = z[..., 12 * (kb - 1) + 3 * g + i]
             assert not np.isnan(plv).any(), "block %d loads back a Z position nobody has written yet" % (kb + 1)
         bo = _branch(tile, im)
         if more:

@@ -693,7 +693,7 @@ struct PlanBuilder {
   // (12 -> element 2, parked).  X[2i+1] feed block 1 from the load, X[4i+2] are held for block 2, X[4i] stay in memory.
   // Outputs: the blocks' images (pw1 input columns / pw2 output rows permuted, tables PS / PL appended) and
   // z_label[pos] = logical channel of the chain's output stored at Z position pos.
-  struct ChainLoc { int kind = 0, blk = 0, mt = 0, g = 0, e = 0, off = 0; };   // kind 0: X[off], 1: accumulator of block blk, 2: parked at Z[off]
+  struct ChainLoc { int kind = 0, blk = 0, mt = 0, g = 0, e = 0, off = 0; };   // kind 0: X[off] (loaded up front), 1: accumulator of block blk, 2: parked at Z[off]
   void s1chain_block(const std::vector<std::string>& names, int c, int H, int W, const Buf& x, const Buf& y, int* z_label) {
     const int c2 = c / 2, NB = (int)names.size();
     std::vector<Folded> f1(NB), fd(NB), f2(NB);
@@ -703,18 +703,36 @@ struct PlanBuilder {
       ok &= wp.pw(names[k] + ".branch_main.5", names[k] + ".branch_main.6", c2, c2, &f2[k]);
     }
     std::vector<float> im;
-    if (ok && c2 == 48 && NB >= 2) {
+    if (ok && c2 == 48 && NB >= 3 && NB <= 7) {
+      // Z positions: [12 (k - 2), + 12) = the parked inputs of block k (k = 2 .. NB-1; all of it below 60 and free until
+      // the final stores), [60, 96) = parked values no block consumes (they are already where the output wants them)
+      std::vector<int> group_n(NB, 0);
+      int next_final = 60;
+      auto park = [&](int idx_next /* index in the activation that enters block kn */, int kn) {
+        int steps = 0;
+        while (!(idx_next & 1) && idx_next != 0) { idx_next >>= 1; ++steps; }
+        const int kc = kn + steps;                        // consumed as a branch input of block kc
+        if (idx_next == 0 || kc > NB - 1) return next_final < 96 ? next_final++ : (ok = false, 0);
+        if (kc < 2 || group_n[kc] >= 12) { ok = false; return 0; }
+        return 12 * (kc - 2) + group_n[kc]++;
+      };
       std::vector<ChainLoc> act(96);                     // where logical channel o of the current activation lives
-      for (int o = 0; o < 96; ++o) { act[o].kind = 0; act[o].off = o; }
-      int next_final = 60, next_temp = 0;                // Z positions: [60, 95) parked survivors, [0, 60) parked temporaries
+      std::vector<std::vector<int>> tables(NB, std::vector<int>(36, 0));   // per block: PS[mt][g] | (block 0) XS[c][g]
+      for (int o = 0; o < 96; ++o) {
+        act[o].kind = 0; act[o].off = o;
+        if ((o & 3) == 0) {                               // X[16 cq + 4 g]: parked at load time
+          act[o].kind = 2;
+          act[o].off = o == 0 ? 95 : park(o, 0);          // X[0] passes every block: Z[95]
+          tables[0][12 + (o / 16) * 4 + (o % 16) / 4] = act[o].off;
+        }
+      }
       auto tile_of_fresh = [](int mt, int e) {           // accumulator (mt, element 1 | 3) -> tile (quad j, element)
         const int hi = e == 3 ? 1 : 0;
         if (mt == 0) return std::make_pair(1, 2 + hi);
         if (mt == 1) return std::make_pair(2, 0 + hi);
         return std::make_pair(2, 2 + hi);
       };
-      std::vector<std::vector<int>> tables(NB, std::vector<int>(24, 0));   // per block: PS[mt][g] | PLnext[i][g]
-      for (int k = 0; k < NB; ++k) {
+      for (int k = 0; k < NB && ok; ++k) {
         // ---- where does branch input i of this block sit in the tile?  label[physical column 16 j + 4 g + e] = i
         int label[48];
         for (int q = 0; q < 48; ++q) label[q] = -1;
@@ -733,18 +751,17 @@ struct PlanBuilder {
             if (cq < 4) { j = 0; e = cq; } else { j = 1; e = cq - 4; }
           } else if (k >= 2 && L.kind == 1 && L.blk == k - 2 && L.e == 0) {        // element 0 of the block before the previous one
             j = 0; g = L.g; e = L.mt;
-          } else if (k >= 2 && (L.kind == 2 || (L.kind == 0 && (L.off & 3) == 0 && L.off != 0))) {   // parked: lane group / index in arrival order
-            if (parked_n >= 12) { ok = false; break; }
-            g = parked_n / 3; const int pi = parked_n % 3; ++parked_n;
+          } else if (k >= 2 && L.kind == 2 && L.off >= 12 * (k - 2) && L.off < 12 * (k - 2) + 12) {   // parked in this block's group
+            const int n = L.off - 12 * (k - 2), pi = n % 3;
+            g = n / 3; ++parked_n;
             if (pi == 0) { j = 0; e = 3; } else { j = 1; e = pi - 1; }
-            tables[k - 1][12 + pi * 4 + g] = L.kind == 0 ? (128 | L.off) : L.off;   // loaded during block k-1's phase B
           } else { ok = false; break; }
           if (label[16 * j + 4 * g + e] != -1) { ok = false; break; }
           label[16 * j + 4 * g + e] = i;
         }
         if (!ok) break;
         if (k >= 2 && parked_n != 12) { ok = false; break; }
-        for (int q = 0; q < 48; ++q) if (label[q] < 0) { ok = false; }
+        for (int q = 0; q < 48; ++q) if (label[q] < 0) ok = false;
         if (!ok) break;
         // ---- which logical fresh channel lands in accumulator (mt, g, e)?  rowlab[16 mt + 4 g + e] = j
         int rowlab[48];
@@ -768,47 +785,35 @@ struct PlanBuilder {
         for (int q = 0; q < 48; ++q) {
           const int mt = q / 16, g = (q % 16) / 4, e = q % 4, j = rowlab[q];
           ChainLoc L; L.kind = 1; L.blk = k; L.mt = mt; L.g = g; L.e = e;
-          if (k < NB - 1 && e == 2) {                   // parked: survives the chain iff it is not consumed by a later block
-            int idx = 48 + j, steps = 0;
-            while (!(idx & 1) && idx != 0) { idx >>= 1; ++steps; }   // consumed as branch input of block k + 1 + steps
-            const bool survives = (k + 1 + steps) > NB - 1;
+          if (k < NB - 1 && e == 2) {
             L.kind = 2;
-            L.off = survives ? next_final++ : next_temp++;
-            if (next_final > 95 || next_temp > 60) { ok = false; }
-            tables[k][0 * 12 + mt * 4 + g] = L.off;
+            L.off = park(48 + j, k + 1);
+            tables[k][mt * 4 + g] = L.off;
           }
           nxt[48 + j] = L;
         }
         act.swap(nxt);
         wp.append_s1(im, f1k, fd[k], f2k, c2);
-        for (int t = 0; t < 32; ++t) {                  // int tables as raw bits behind the BN vectors
-          float fbits; const int v = t < 24 ? tables[k][t] : 0;
+        for (int t = 0; t < 64; ++t) {                  // int tables as raw bits behind the BN vectors
+          float fbits; const int v = t < 36 ? tables[k][t] : 0;
           std::memcpy(&fbits, &v, sizeof(float));
           im.push_back(fbits);
         }
       }
-      // the PL entries were written into tables[k-1] AFTER image k-1 was appended: patch them in place
       if (ok) {
-        const size_t per = im.size() / NB;
-        for (int k = 0; k < NB; ++k)
-          for (int t = 12; t < 24; ++t) {
-            float fbits; const int v = tables[k][t];
-            std::memcpy(&fbits, &v, sizeof(float));
-            im[(size_t)k * per + per - 32 + t] = fbits;
-          }
+        for (int k = 2; k < NB; ++k) if (group_n[k] != 12) ok = false;
         // ---- where the chain's output lives in Z
         for (int pos = 0; pos < 96; ++pos) z_label[pos] = -1;
-        for (int o = 0; o < 96; ++o) {
+        for (int o = 0; o < 96 && ok; ++o) {
           const ChainLoc& L = act[o];
           int pos = -1;
-          if (L.kind == 0 && L.off == 0) pos = 95;                                    // X[0]: copied at load time (CH_X0_POS)
-          else if (L.kind == 1 && L.blk == NB - 1) pos = 16 * L.mt + 4 * L.g + L.e;   // last block's accumulators
-          else if (L.kind == 1 && L.blk == NB - 2 && L.e == 0) pos = 48 + 3 * L.g + L.mt;   // held elements of the block before
+          if (L.kind == 1 && L.blk == NB - 1) pos = 16 * L.mt + 4 * L.g + L.e;               // last block's accumulators
+          else if (L.kind == 1 && L.blk == NB - 2 && L.e == 0) pos = 48 + 3 * L.g + L.mt;    // held elements of the block before
           else if (L.kind == 2 && L.off >= 60) pos = L.off;
           if (pos < 0 || z_label[pos] != -1) { ok = false; break; }
           z_label[pos] = o;
         }
-        if ((int)per != yfv2_s1chain_image_floats()) ok = false;
+        if ((int)(im.size() / NB) != yfv2_s1chain_image_floats()) ok = false;
       }
     } else {
       ok = false;

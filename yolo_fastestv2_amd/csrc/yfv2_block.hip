@@ -868,20 +868,20 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
 //   * the 48 channels that go through a block's branch live in the LDS tile (as in block_s1w / block_s1x2);
 //   * a value that passes k blocks before it becomes a branch input is, by the time it is needed,
 //       k = 0  a fresh branch output picked straight out of the accumulators (elements 1, 3 of every quad),
-//       k = 1  three registers per pixel slot (elements 0: held for one block),
-//       k >= 2 "parked": twelve values per pixel and block (elements 2) are stored as single dwords into Z - which is
-//              free until the very end - and three of them are loaded back per lane right before their block; the quarter
-//              of X that passes two or more blocks (X[4k]) is never loaded up front, it waits in X for the same loads;
+//       k = 1  three registers per pixel slot (elements 0: held for one block; X[4i+2] for the second block),
+//       k >= 2 "parked": elements 2 (twelve values per pixel and block) and X[4i] are stored as single dwords into Z -
+//              which is free until the very end - GROUPED BY THE BLOCK THAT CONSUMES THEM: Z[12 (k - 2) .. + 11] holds
+//              the twelve parked inputs of block k, so that each lane fetches its three with one 12-byte load during
+//              the phase A of the block before; values no block of the chain consumes are parked at their final place;
 //   * which logical channel sits in which lane / element / tile position / Z position is decided on the host
 //     (PlanBuilder::s1chain_block): it permutes the input columns of every pw1 and the output rows of every pw2 so that
-//     the kernel's fixed, lane-uniform data movement below is the reference's channel_shuffle; the two per-block tables
-//     (where to park, what to load back) ride at the end of each block's LDS image, and the consumers of the stage's
-//     output read Z through the channel permutation the plan reports.
-// Per block image: W1 | W2 | dw taps | 6 BN vectors (block_s1_kernel's image) | int tables PS[3][4], PL[3][4] (+8 pad);
-// two image buffers alternate, the image after next is fetched during phase B.
-constexpr int CH_TBL_FL = 32;
+//     the kernel's fixed, lane-uniform data movement below is the reference's channel_shuffle; the park positions ride
+//     at the end of each block's LDS image, and the consumers of the stage's output read Z through the channel
+//     permutation the plan reports.
+// Per block image: W1 | W2 | dw taps | 6 BN vectors (block_s1_kernel's image) | int tables PS[3][4], XS[6][4] (+ pad);
+// two image buffers alternate, the image after next is fetched during phase A.
+constexpr int CH_TBL_FL = 64;
 constexpr int CH_IMG_FL = 2 * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + CH_TBL_FL;
-constexpr int CH_X0_POS = 95;       // Z position of X[0], the one channel that passes every block
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a) {
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
     sl[nt] = s_first + (valid[nt] ? q : n_slots - 1);
     const int r1 = yfv2_fdiv(sl[nt], invRP), xs = sl[nt] - r1 * RP;
     real[nt] = valid[nt] && xs >= 1;                      // column 0 of a haloed row is the shared zero column
-    pix[nt] = (r1 - 1) * W + (xs - 1);
+    pix[nt] = real[nt] ? (r1 - 1) * W + (xs - 1) : 0;
   }
   float* Tg = T1 + (size_t)g * PL * 4;                    // plane of quad g; quad 4 s + g is 4 s planes further
 
@@ -969,7 +969,9 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
 #pragma unroll 1
       for (int s = 0; s < KC; ++s) {
         const int cb = 16 * s + 4 * g;
-        f32x4 lsc, lsh, win[9], af[KC];
+        f32x4 wl[9], lsc, lsh, win[9], af[KC];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
         lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
         lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
 #pragma unroll
@@ -979,11 +981,9 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
         __builtin_amdgcn_sched_barrier(0);
         f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const f32x4 wl = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);   // taps: read as the FMAs go (register budget)
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[c], d[c]);
-        }
+          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
 #pragma unroll
@@ -1010,63 +1010,73 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
     *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 + g) * PL + sl[nt]) * 4) = q1;
     *reinterpret_cast<f32x4*>(T1 + ((size_t)(8 + g) * PL + sl[nt]) * 4) = q2;
   };
-  auto tbl = [&](const float* IM, int which, int i) {     // PS (which = 0) / PL (which = 1) entry i of this lane group
-    return reinterpret_cast<const int*>(IM + 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL)[which * 12 + i * 4 + g];
+  auto tbl = [&](const float* IM, int i) {                // entry i of this lane group: PS[mt] = 0..2, XS[c] = 3..8
+    return reinterpret_cast<const int*>(IM + 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL)[i * 4 + g];
   };
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const float* ximg = a.in + (size_t)b * HW * C;
     float* zimg = a.out + (size_t)b * HW * C;
-    // ---- images of blocks 0 and 1, and X: element 0 of every quad (X[4k], passes at least two blocks) is left in memory
+    // ---- everything this image needs from memory up front is requested at once: the images of blocks 0 and 1, and X
+    float hold2[6][NT];                                   // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
     {
+      f32x4 tmp[2 * NIT], xq[NT][6];
       const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-      f32x4 tmp[2 * NIT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          xq[nt][c] = *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g);   // halo slots read pixel 0 and are zeroed below
 #pragma unroll
       for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < 2 * N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      __builtin_amdgcn_sched_barrier(0);                  // all requests are out before the first use
 #pragma unroll
       for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; if (i < 2 * N4) reinterpret_cast<f32x4*>(lds)[i] = tmp[k]; }
-    }
-    float hold2[6][NT];                                   // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 xq[6];
+      for (int nt = 0; nt < NT; ++nt) {
+        if (!real[nt]) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c)
-        xq[c] = real[nt] ? *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (valid[nt]) {
+          for (int c = 0; c < 6; ++c) xq[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (valid[nt]) {
 #pragma unroll
-        for (int j = 0; j < KC; ++j)
-          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * j + g) * PL + sl[nt]) * 4) = (f32x4){xq[2 * j][1], xq[2 * j][3], xq[2 * j + 1][1], xq[2 * j + 1][3]};
+          for (int j = 0; j < KC; ++j)
+            *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * j + g) * PL + sl[nt]) * 4) = (f32x4){xq[nt][2 * j][1], xq[nt][2 * j][3], xq[nt][2 * j + 1][1], xq[nt][2 * j + 1][3]};
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) hold2[c][nt] = xq[nt][c][2];
       }
+      __syncthreads();                                    // image 0 (with its XS table) is in LDS
+      // X[16 c + 4 g] pass at least two blocks: parked into the group of the block that consumes them
 #pragma unroll
-      for (int c = 0; c < 6; ++c) hold2[c][nt] = xq[c][2];
-      if (real[nt] && g == 0) zimg[(size_t)pix[nt] * C + CH_X0_POS] = xq[0][0];
+      for (int c = 0; c < 6; ++c) {
+        const int pos = tbl(lds, 3 + c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (real[nt]) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
+      }
     }
     YFV2_WSTAMP(1);
-    __syncthreads();
-    YFV2_WSTAMP(2);
 
     // ---- first block (peeled: its exchange draws on X's held elements)
     f32x4 bo[KC][NT];
     float Hd[KC][NT];                                     // element 0 of every accumulator quad: branch input of the block after next
     phase_a(lds);
-    YFV2_WSTAMP(3);
+    YFV2_WSTAMP(2);
     __syncthreads();
+    YFV2_WSTAMP(3);
     phase_b(lds, bo);
     YFV2_WSTAMP(4);
     __syncthreads();                                      // every window read of this block is done
-    if (NB == 1) {
-      // degenerate chain: a single block (not used by the plan; kept so that any NB >= 1 is defined)
-    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if (valid[nt] && NB > 1) {
+      if (valid[nt]) {
         write_tile(nt, (f32x4){hold2[0][nt], hold2[1][nt], hold2[2][nt], hold2[3][nt]},
                    (f32x4){hold2[4][nt], hold2[5][nt], bo[0][nt][1], bo[0][nt][3]},
                    (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
         if (real[nt]) {
 #pragma unroll
-          for (int mt = 0; mt < KC; ++mt) zimg[(size_t)pix[nt] * C + tbl(lds, 0, mt)] = bo[mt][nt][2];
+          for (int mt = 0; mt < KC; ++mt) zimg[(size_t)pix[nt] * C + tbl(lds, mt)] = bo[mt][nt][2];
         }
       }
 #pragma unroll
@@ -1081,29 +1091,31 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
       const float* IM = lds + (kb & 1) * CH_IMG_FL;
       float* IMN = lds + ((kb + 1) & 1) * CH_IMG_FL;
       const bool more = kb + 1 < NB;
+      float plv[3][NT];
       {
-        // the image after this one travels during phase A into the buffer the previous block has left
+        // requested before phase A, used after it: the image after this one (into the buffer the previous block has
+        // left) and the three parked inputs of the next block (group kb - 1 of Z: parked two or more blocks ago)
         f32x4 nimg[NIT];
         const f32x4* src = reinterpret_cast<const f32x4*>(a.img + (size_t)(kb + 1) * CH_IMG_FL);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; nimg[k] = (more && i < N4) ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float* zp = zimg + (size_t)pix[nt] * C + 12 * (kb - 1) + 3 * g;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) plv[i][nt] = zp[i];   // (halo slots: pixel 0's values, zeroed by write_tile; last block: unused)
+        }
+        __builtin_amdgcn_sched_barrier(0);
         phase_a(IM);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (more && i < N4) reinterpret_cast<f32x4*>(IMN)[i] = nimg[k]; }
       }
       if (kb == 1) YFV2_WSTAMP(6);
-      // the parked values of the next block travel during phase B
-      float plv[3][NT];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int e = tbl(IM, 1, i);
-        const float* base = (e & 128) ? ximg : zimg;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) plv[i][nt] = (more && real[nt]) ? base[(size_t)pix[nt] * C + (e & 127)] : 0.f;
-      }
       __syncthreads();
-      phase_b(IM, bo);
       if (kb == 1) YFV2_WSTAMP(7);
+      phase_b(IM, bo);
+      if (kb == 1) YFV2_WSTAMP(8);
       if (more) {
         __syncthreads();                                  // every window read of this block is done
 #pragma unroll
@@ -1114,17 +1126,17 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
                        (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
             if (real[nt]) {
 #pragma unroll
-              for (int mt = 0; mt < KC; ++mt) zimg[(size_t)pix[nt] * C + tbl(IM, 0, mt)] = bo[mt][nt][2];
+              for (int mt = 0; mt < KC; ++mt) zimg[(size_t)pix[nt] * C + tbl(IM, mt)] = bo[mt][nt][2];
             }
           }
 #pragma unroll
           for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
         }
         __syncthreads();
-        if (kb == 1) YFV2_WSTAMP(8);
+        if (kb == 1) YFV2_WSTAMP(9);
       }
     }
-    YFV2_WSTAMP(9);
+    YFV2_WSTAMP(10);
     // ---- the last block's output in accumulator order, the held elements of the block before it behind them
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -1132,12 +1144,10 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
         float* zp = zimg + (size_t)pix[nt] * C;
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zp + 16 * mt + 4 * g) = bo[mt][nt];
-        if (NB > 1) {
 #pragma unroll
-          for (int mt = 0; mt < KC; ++mt) zp[C2 + 3 * g + mt] = Hd[mt][nt];
-        }
+        for (int mt = 0; mt < KC; ++mt) zp[C2 + 3 * g + mt] = Hd[mt][nt];
       }
-    YFV2_WSTAMP(10);
+    YFV2_WSTAMP(11);
     __syncthreads();                                      // tile and image buffers are rewritten by the next image
   }
 }
