@@ -80,6 +80,13 @@ def _tables(im):
     return t[:12].reshape(3, 4), t[12:36].reshape(6, 4)       # PS[mt][g] (park positions of elements 2), XS[c][g] (block 0: of X[16 c + 4 g])
 
 
+def _park(z, ps, g, mt, v):
+    """elements 2: lane groups 0..2 one 12-byte store at PS[0][g], lane group 3 three dwords at PS[0..2][3]"""
+    pos = ps[0, g] + mt if g < 3 else ps[mt, 3]
+    assert pos == ps[mt, g], "park table: lane group %d's run is not consecutive" % g
+    z[..., pos] = v
+
+
 def _kernel_model(x, images):
     """x: (H, W, 96) -> Z: (H, W, 96) in the kernel's physical order, following block_s1chain_kernel lane group by lane group"""
     H, W, _ = x.shape
@@ -96,8 +103,10 @@ def _kernel_model(x, images):
     ps, xs = _tables(images[0])
     for c in range(6):
         for g in range(4):
-            assert np.isnan(z[..., xs[c, g]]).all(), "two X values parked at one Z position"
-            z[..., xs[c, g]] = xq[:, :, c, g, 0]
+            pos = xs[c, 0] if g == 0 else xs[3 * (c // 3), g] + c % 3      # lane groups 1..3: two 12-byte runs
+            assert pos == xs[c, g], "X park table: a run of lane group %d is not consecutive" % g
+            assert np.isnan(z[..., pos]).all(), "two X values parked at one Z position"
+            z[..., pos] = xq[:, :, c, g, 0]
 
     def fresh_quads(bo, g):
         return ([None, None, bo[:, :, 0, g, 1], bo[:, :, 0, g, 3]], [bo[:, :, 1, g, 1], bo[:, :, 1, g, 3], bo[:, :, 2, g, 1], bo[:, :, 2, g, 3]])
@@ -118,7 +127,7 @@ def _kernel_model(x, images):
         q1[0], q1[1] = hold2[:, :, 4, g], hold2[:, :, 5, g]
         put(tile_n, g, [hold2[:, :, c, g] for c in range(4)], q1, q2)
         for mt in range(3):
-            z[..., ps[mt, g]] = bo[:, :, mt, g, 2]
+            _park(z, ps, g, mt, bo[:, :, mt, g, 2])
             hd[:, :, mt, g] = bo[:, :, mt, g, 0]
     tile = tile_n
     for kb in range(1, NB):
@@ -140,7 +149,7 @@ def _kernel_model(x, images):
                 put(tile_n, g, [hd[:, :, 0, g], hd[:, :, 1, g], hd[:, :, 2, g], plv[:, :, 0, g]], q1, q2)
             for g in range(4):
                 for mt in range(3):
-                    z[..., ps[mt, g]] = bo[:, :, mt, g, 2]
+                    _park(z, ps, g, mt, bo[:, :, mt, g, 2])
             hd = bo[:, :, :, :, 0].copy()
             tile = tile_n
     for g in range(4):

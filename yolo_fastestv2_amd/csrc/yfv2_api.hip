@@ -708,22 +708,46 @@ struct PlanBuilder {
       // the final stores), [60, 96) = parked values no block consumes (they are already where the output wants them)
       std::vector<int> group_n(NB, 0);
       int next_final = 60;
-      auto park = [&](int idx_next /* index in the activation that enters block kn */, int kn) {
+      // consumer of the value that has index idx in the activation entering block kn: the block that takes it as a
+      // branch input, or NB if it survives the chain
+      auto consumer = [&](int idx, int kn) {
         int steps = 0;
-        while (!(idx_next & 1) && idx_next != 0) { idx_next >>= 1; ++steps; }
-        const int kc = kn + steps;                        // consumed as a branch input of block kc
-        if (idx_next == 0 || kc > NB - 1) return next_final < 96 ? next_final++ : (ok = false, 0);
-        if (kc < 2 || group_n[kc] >= 12) { ok = false; return 0; }
-        return 12 * (kc - 2) + group_n[kc]++;
+        while (!(idx & 1) && idx != 0) { idx >>= 1; ++steps; }
+        return (idx == 0 || kn + steps > NB - 1) ? NB : kn + steps;
+      };
+      // n consecutive Z positions for values with consumer kc
+      auto park_slots = [&](int kc, int n) {
+        if (kc >= NB) { const int p0 = next_final; next_final += n; if (next_final > 96) ok = false; return p0; }
+        if (kc < 2 || group_n[kc] + n > 12) { ok = false; return 0; }
+        const int p0 = 12 * (kc - 2) + group_n[kc];
+        group_n[kc] += n;
+        return p0;
       };
       std::vector<ChainLoc> act(96);                     // where logical channel o of the current activation lives
-      std::vector<std::vector<int>> tables(NB, std::vector<int>(36, 0));   // per block: PS[mt][g] | (block 0) XS[c][g]
-      for (int o = 0; o < 96; ++o) {
-        act[o].kind = 0; act[o].off = o;
-        if ((o & 3) == 0) {                               // X[16 cq + 4 g]: parked at load time
-          act[o].kind = 2;
-          act[o].off = o == 0 ? 95 : park(o, 0);          // X[0] passes every block: Z[95]
-          tables[0][12 + (o / 16) * 4 + (o % 16) / 4] = act[o].off;
+      std::vector<std::vector<int>> tables(NB, std::vector<int>(36, 0));   // per block: PS[i][g] | (block 0) XS[c][g]
+      for (int o = 0; o < 96; ++o) { act[o].kind = 0; act[o].off = o; }
+      // X[16 cq + 4 g] are parked at load time.  Lane groups 1..3: the kernel stores (cq = 0,1,2) and (cq = 3,4,5) as two
+      // 12-byte runs, so each triple must share a consumer; lane group 0: six single dwords (X[0] passes every block: Z[95])
+      for (int g = 0; g < 4 && ok; ++g) {
+        if (g == 0) {
+          for (int cq = 0; cq < 6; ++cq) {
+            const int o = 16 * cq;
+            act[o].kind = 2;
+            act[o].off = o == 0 ? 95 : park_slots(consumer(o, 0), 1);
+            tables[0][12 + cq * 4 + 0] = act[o].off;
+          }
+          if (next_final > 95) ok = false;                // Z[95] is X[0]'s
+        } else {
+          for (int t = 0; t < 2; ++t) {
+            const int kc = consumer(16 * (3 * t) + 4 * g, 0);
+            for (int i = 1; i < 3; ++i) if (consumer(16 * (3 * t + i) + 4 * g, 0) != kc) ok = false;
+            const int p0 = park_slots(kc, 3);
+            for (int i = 0; i < 3; ++i) {
+              const int o = 16 * (3 * t + i) + 4 * g;
+              act[o].kind = 2; act[o].off = p0 + i;
+              tables[0][12 + (3 * t + i) * 4 + g] = p0 + i;
+            }
+          }
         }
       }
       auto tile_of_fresh = [](int mt, int e) {           // accumulator (mt, element 1 | 3) -> tile (quad j, element)
@@ -768,26 +792,45 @@ struct PlanBuilder {
         if (k == NB - 1) {
           for (int q = 0; q < 48; ++q) rowlab[q] = q;   // last block: natural order (Z[0..47] = logical 48..95)
         } else {
-          int n13 = 0, n0 = 0, n2 = 0;
+          int n13 = 0, n0 = 0;
           for (int j = 0; j < 48; ++j) {
+            if ((j & 3) == 0) continue;
             int slot, e;
             if (j & 1) { slot = n13 / 2; e = (n13 & 1) ? 3 : 1; ++n13; }
-            else if ((j & 3) == 2) { slot = n0++; e = 0; }
-            else { slot = n2++; e = 2; }
+            else { slot = n0++; e = 0; }
             rowlab[16 * (slot / 4) + 4 * (slot % 4) + e] = j;   // slot = 4 mt + g
           }
+          // the twelve j = 0 mod 4 go to elements 2: lane groups 0..2 get three values with ONE consumer each (the kernel
+          // parks them with one 12-byte store), lane group 3 takes whatever is left (three dwords)
+          std::vector<std::vector<int>> by_consumer(NB + 1);
+          for (int j = 0; j < 48; j += 4) by_consumer[consumer(48 + j, k + 1)].push_back(j);
+          std::vector<std::vector<int>> triples;
+          std::vector<int> left;
+          for (auto& v : by_consumer) {
+            size_t t = 0;
+            for (; t + 3 <= v.size(); t += 3) triples.push_back({v[t], v[t + 1], v[t + 2]});
+            for (; t < v.size(); ++t) left.push_back(v[t]);
+          }
+          while (triples.size() > 3) { for (int q : triples.back()) left.push_back(q); triples.pop_back(); }
+          if (triples.size() != 3 || left.size() != 3) { ok = false; break; }
+          for (int g = 0; g < 3; ++g)
+            for (int mt = 0; mt < 3; ++mt) rowlab[16 * mt + 4 * g + 2] = triples[g][mt];
+          for (int mt = 0; mt < 3; ++mt) rowlab[16 * mt + 4 * 3 + 2] = left[mt];
         }
         const Folded f1k = wp.permuted_pw_inputs(f1[k], c2, c2, label);
         const Folded f2k = wp.permuted_pw_outputs(f2[k], c2, c2, rowlab);
         // ---- next activation; park positions of the element-2 values
         std::vector<ChainLoc> nxt(96);
         for (int i = 0; i < 48; ++i) nxt[i] = act[2 * i];
+        int trip_base[3] = {0, 0, 0};
+        if (k < NB - 1)
+          for (int g = 0; g < 3; ++g) trip_base[g] = park_slots(consumer(48 + rowlab[4 * g + 2], k + 1), 3);   // its three share the consumer
         for (int q = 0; q < 48; ++q) {
           const int mt = q / 16, g = (q % 16) / 4, e = q % 4, j = rowlab[q];
           ChainLoc L; L.kind = 1; L.blk = k; L.mt = mt; L.g = g; L.e = e;
           if (k < NB - 1 && e == 2) {
             L.kind = 2;
-            L.off = park(48 + j, k + 1);
+            L.off = g < 3 ? trip_base[g] + mt : park_slots(consumer(48 + j, k + 1), 1);
             tables[k][mt * 4 + g] = L.off;
           }
           nxt[48 + j] = L;

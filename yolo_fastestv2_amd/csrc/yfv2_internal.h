@@ -6,6 +6,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));   // three floats at any dword address (global_load/store_dwordx3)
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
