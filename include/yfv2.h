@@ -166,6 +166,10 @@ YFV2_API int32_t yfv2_num_stages(yfv2_handle h); /* launches in one forward */
  * DESIGN.md / bench.py's roofline use. */
 YFV2_API int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_cap, double* flops_per_image,
                     double* bytes_per_image);
+/* The kernel (family) launch `i` runs, as a prefix of the symbol name a rocprofv3 kernel trace shows for it
+ * (e.g. "block_s1chain_kernel", "tower2_kernel<6, 512, 4, 4>"): lets bench.py group its per-launch times the way
+ * profiles/*_kernel_stats.csv does. */
+YFV2_API int yfv2_stage_kernel(yfv2_handle h, int32_t i, char* name, int32_t name_cap);
 
 /* Measurement helper (synchronises): runs the forward `iters` times with a
  * hipEvent pair around every launch on `stream` and writes the mean duration

@@ -305,28 +305,79 @@ def _batch_from_reference_images(images_u8, n, seed):
     return torch.stack(out)
 
 
-def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, images_u8, coco_weights):
-    """BASELINE config 3: batch 256, COCO weights, forward + decode + NMS at the test.py thresholds.
-    Without COCO val the mAP check is detection-set parity: the GPU survivors must equal the CPU
-    oracle's; a mismatch is tolerated only for candidates sitting within 1e-4 of the confidence
-    threshold (fp32 noise between two valid executions decides those either way)."""
+def _xyxy_cls(dec_row_set):
+    """(n, 85) decoded rows -> xyxy boxes (+ class * 4096 offset, utils.py:283-285), conf, class, as the reference's NMS sees them"""
+    d = dec_row_set.astype(np.float32)
+    p = d[:, 5:] * d[:, 4:5]
+    conf, cls = p.max(1), p.argmax(1)
+    half_w, half_h = d[:, 2] / np.float32(2), d[:, 3] / np.float32(2)
+    box = np.stack([d[:, 0] - half_w, d[:, 1] - half_h, d[:, 0] + half_w, d[:, 1] + half_h], 1) + (cls * 4096).astype(np.float32)[:, None]
+    return box, conf, cls
+
+
+def _unexplained(o_dec_img, differing, thr, iou_thr):
+    """Survivor differences between two valid fp32 executions are legitimate only where a decision sits on a margin
+    (reference-vs-reference noise is ~1e-6 on scores): the candidate's obj / conf within 1e-4 of the
+    threshold, or - for a suppression decision - an overlapping same-class candidate whose IoU with it is within 2e-3 of
+    the NMS threshold, or whose conf is within 1e-5 of its own (visiting order).  Returns the rows nothing explains."""
+    if not differing:
+        return []
+    obj = o_dec_img[:, 4]
+    cand = np.flatnonzero(obj > thr - 1e-4)
+    box, conf, cls = _xyxy_cls(o_dec_img[cand])
+    where = {int(n): k for k, n in enumerate(cand)}
+    area = (box[:, 2] - box[:, 0]) * (box[:, 3] - box[:, 1])
+    bad = []
+    for n in differing:
+        k = where.get(int(n))
+        if k is None:                                   # objectness clearly below the threshold: nobody may keep this row
+            bad.append(int(n))
+            continue
+        if abs(float(obj[n]) - thr) < 1e-4 or abs(float(conf[k]) - thr) < 1e-4:
+            continue
+        iw = np.clip(np.minimum(box[:, 2], box[k, 2]) - np.maximum(box[:, 0], box[k, 0]), 0, None)
+        ih = np.clip(np.minimum(box[:, 3], box[k, 3]) - np.maximum(box[:, 1], box[k, 1]), 0, None)
+        iou = iw * ih / (area + area[k] - iw * ih + 1e-30)
+        near_iou = np.abs(iou - iou_thr) < 2e-3
+        tie = (np.abs(conf - conf[k]) < 1e-5) & (iou > iou_thr - 2e-3)
+        near_iou[k] = tie[k] = False
+        # a neighbour that is itself on a margin can flip this one (chains of suppression): look one step out
+        flip = near_iou | tie
+        if not flip.any():
+            second = iou > iou_thr - 2e-3
+            second[k] = False
+            for m in np.flatnonzero(second):
+                iw2 = np.clip(np.minimum(box[:, 2], box[m, 2]) - np.maximum(box[:, 0], box[m, 0]), 0, None)
+                ih2 = np.clip(np.minimum(box[:, 3], box[m, 3]) - np.maximum(box[:, 1], box[m, 1]), 0, None)
+                iou2 = iw2 * ih2 / (area + area[m] - iw2 * ih2 + 1e-30)
+                t2 = (np.abs(iou2 - iou_thr) < 2e-3) | ((np.abs(conf - conf[m]) < 1e-5) & (iou2 > iou_thr - 2e-3))
+                t2[m] = False
+                if t2.any() or abs(float(conf[m]) - thr) < 1e-4:
+                    flip[m] = True
+                    break
+        if not flip.any():
+            bad.append(int(n))
+    return bad
+
+
+@pytest.mark.parametrize("conf_thres", [0.3, 0.01], ids=["test.py-0.3", "evaluation-0.01"])
+def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, images_u8, coco_weights, conf_thres):
+    """BASELINE config 3: batch 256, COCO weights, forward + decode + NMS at the test.py thresholds (0.3 / 0.4) and at
+    evaluation()'s (0.01 / 0.4).  Without COCO val the mAP check is detection-set parity: the GPU survivors must equal the
+    CPU oracle's.  A difference is accepted ONLY where `_unexplained` finds the decision on a numerical margin; the count of
+    unexplained differences must be zero (printed with -s), and the rows of common survivors must agree to tolerance."""
     x = _batch_from_reference_images(images_u8, 256, seed=3)
     eng = model.engine_for(x.to(dev))
     eng.set_anchors(cfg["anchors"])
-    rows, idx = yfv2.unpack_detections(*eng.detect(x.to(dev), 0.3, 0.4))
-    _, o_dec, (o_rows, o_idx) = oracle.detect(coco_weights, x, cfg["anchors"], cfg["height"], 0.3, 0.4)
+    rows, idx = yfv2.unpack_detections(*eng.detect(x.to(dev), conf_thres, 0.4))
+    _, o_dec, (o_rows, o_idx) = oracle.detect(coco_weights, x, cfg["anchors"], cfg["height"], conf_thres, 0.4)
     n_det = sum(len(i) for i in o_idx)
     assert n_det > 500, "the synthetic batch must contain real detections (got %d)" % n_det
-    bad = 0
+    n_diff, bad = 0, []
     for b in range(256):
         got, ref = set(idx[b].tolist()), set(int(v) for v in o_idx[b])
-        for n in got ^ ref:  # every disagreement must be a threshold-margin case
-            obj = float(o_dec[b, n, 4])
-            conf = float((o_dec[b, n, 5:] * o_dec[b, n, 4]).max())
-            near = min(abs(obj - 0.3), abs(conf - 0.3)) < 1e-4
-            if not near:
-                # or suppressed/kept by an IoU within 1e-3 of 0.4: count, do not fail on a handful
-                bad += 1
+        n_diff += len(got ^ ref)
+        bad += [(b, n) for n in _unexplained(o_dec[b], sorted(got ^ ref), conf_thres, 0.4)]
         common = sorted(got & ref)
         if common:
             gi = {int(n): k for k, n in enumerate(idx[b].tolist())}
@@ -335,7 +386,11 @@ def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, imag
             r = o_rows[b][[ri[n] for n in common]]
             assert (np.abs(g[:, :4] - r[:, :4]) <= BOX_RTOL * np.maximum(1, np.abs(r[:, :4]))).all()
             assert np.abs(g[:, 4] - r[:, 4]).max() <= SCORE_ATOL and np.array_equal(g[:, 5], r[:, 5])
-    assert bad <= max(2, n_det // 500), "%d unexplained survivor differences out of %d detections" % (bad, n_det)
+    print("conf %.2f: %d oracle detections, %d survivor differences, %d unexplained" % (conf_thres, n_det, n_diff, len(bad)))
+    assert not bad, "%d unexplained survivor differences out of %d detections (%d on numerical margins): %s" % (
+        len(bad), n_det, n_diff - len(bad), bad[:8])
+    if conf_thres == 0.3:
+        assert n_diff <= 2, "at the test.py thresholds the margins are wide (SURVEY.md App. D): %d differences" % n_diff
 
 
 def test_other_input_size_320(yfv2, dev):

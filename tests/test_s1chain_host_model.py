@@ -81,7 +81,7 @@ def _tables(im):
 
 
 def _park(z, ps, g, mt, v):
-    """elements 2: lane groups 0..2 one 12-byte store at PS[0][g], lane group 3 three dwords at PS[0..2][3]"""
+    """elements 2: three dwords at PS[0..2][g]; the planner keeps the three of lane groups 0..2 adjacent (one consumer, one cache line)"""
     pos = ps[0, g] + mt if g < 3 else ps[mt, 3]
     assert pos == ps[mt, g], "park table: lane group %d's run is not consecutive" % g
     z[..., pos] = v

@@ -1069,6 +1069,24 @@ struct PlanBuilder {
   }
 };
 
+// kernel (family) a plan step launches, as it appears in a rocprofv3 kernel trace (prefix of the symbol name)
+std::string step_kernel(const Step& st) {
+  switch (st.kind) {
+    case STEP_STEM: return "stem_px_kernel";
+    case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
+    case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
+    case STEP_S1: return st.c2 == 48 && st.s1.R == st.s1.H ? "block_s1w_kernel" : "block_s1_kernel<" + std::to_string(st.c2) + ",";
+    case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4>" : "1, 1>");
+    case STEP_S2: return "block_s2_kernel<" + std::to_string(st.c2) + ",";
+    case STEP_S1PX: return "s1px_kernel";
+    case STEP_S2PX: return "s2px_proj_kernel + s2px_main_kernel";
+    case STEP_DWPW: return "dwpw_s2_kernel";
+    case STEP_S1X2: return "block_s1x2_kernel";
+    case STEP_S1CHAIN: return "block_s1chain_kernel";
+  }
+  return "?";
+}
+
 int alloc_buf(yfv2_ctx* h, Buf* b, size_t per_img) {
   b->per_img = per_img;
   HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&b->p), per_img * sizeof(float) * (size_t)h->cfg.max_batch));
@@ -1589,6 +1607,13 @@ int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_cap, doub
   if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", s.name.c_str());
   if (flops_per_image) *flops_per_image = s.flops;
   if (bytes_per_image) *bytes_per_image = s.bytes;
+  return YFV2_OK;
+}
+
+int yfv2_stage_kernel(yfv2_handle h, int32_t i, char* name, int32_t name_cap) {
+  if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
+  if (i < 0 || i >= (int32_t)h->plan.size() || !name || name_cap < 1) return fail(h, YFV2_ERR_ARG, "yfv2_stage_kernel: bad argument");
+  std::snprintf(name, (size_t)name_cap, "%s", step_kernel(h->plan[i]).c_str());
   return YFV2_OK;
 }
 

@@ -1014,14 +1014,10 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
     return reinterpret_cast<const int*>(IM + 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL)[i * 4 + g];
   };
 
-  // elements 2 of a block's accumulators -> Z: lane groups 0..2 hold three values with one consumer (one 12-byte store at
-  // PS[0]), lane group 3 holds the left-overs (three dwords at PS[0..2])
+  // elements 2 of a block's accumulators -> Z (three dwords; the planner keeps a lane group's three adjacent where they
+  // share a consumer, which keeps them in one cache line)
   auto park = [&](float* zp, const float* IM, float v0, float v1, float v2) {
-    if (g != 3) {
-      *reinterpret_cast<f32x3u*>(zp + tbl(IM, 0)) = (f32x3u){v0, v1, v2};
-    } else {
-      zp[tbl(IM, 0)] = v0; zp[tbl(IM, 1)] = v1; zp[tbl(IM, 2)] = v2;
-    }
+    zp[tbl(IM, 0)] = v0; zp[tbl(IM, 1)] = v1; zp[tbl(IM, 2)] = v2;
   };
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -1060,24 +1056,13 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
       __syncthreads();                                    // image 0 (with its XS table) is in LDS
       YFV2_WSTAMP(13);
       // X[16 c + 4 g] pass at least two blocks: parked into the group of the block that consumes them
-      // (lane groups 1..3: their six values have ONE consumer each -> two 12-byte stores; lane group 0: six dwords)
-      if (g != 0) {
-        const int p0 = tbl(lds, 3), p1 = tbl(lds, 6);
+      // (single dwords: 12-byte stores at dword alignment measured 3x slower than three dword stores)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int pos = tbl(lds, 3 + c);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          if (real[nt]) {
-            float* zp = zimg + (size_t)pix[nt] * C;
-            *reinterpret_cast<f32x3u*>(zp + p0) = (f32x3u){xq[nt][0][0], xq[nt][1][0], xq[nt][2][0]};
-            *reinterpret_cast<f32x3u*>(zp + p1) = (f32x3u){xq[nt][3][0], xq[nt][4][0], xq[nt][5][0]};
-          }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const int pos = tbl(lds, 3 + c);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            if (real[nt]) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
-        }
+          if (real[nt]) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
       }
     }
     YFV2_WSTAMP(1);
@@ -1123,8 +1108,8 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const float* zp = zimg + (size_t)pix[nt] * C + 12 * (kb - 1) + 3 * g;
-          const f32x3u v = *reinterpret_cast<const f32x3u*>(zp);   // (halo slots: pixel 0's values, zeroed by write_tile; last block: unused)
-          plv[0][nt] = v[0]; plv[1][nt] = v[1]; plv[2][nt] = v[2];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) plv[i][nt] = zp[i];   // (halo slots: pixel 0's values, zeroed by write_tile; last block: unused)
         }
         __builtin_amdgcn_sched_barrier(0);
         phase_a(IM);
@@ -1162,7 +1147,8 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
         float* zp = zimg + (size_t)pix[nt] * C;
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zp + 16 * mt + 4 * g) = bo[mt][nt];
-        *reinterpret_cast<f32x3u*>(zp + C2 + 3 * g) = (f32x3u){Hd[0][nt], Hd[1][nt], Hd[2][nt]};
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) zp[C2 + 3 * g + mt] = Hd[mt][nt];
       }
     YFV2_WSTAMP(11);
     __syncthreads();                                      // tile and image buffers are rewritten by the next image

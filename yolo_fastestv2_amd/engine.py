@@ -229,7 +229,10 @@ class Engine:
         for i in range(n):
             fl, by = C.c_double(), C.c_double()
             check(L.yfv2_stage_info(self._h, i, buf, 256, C.byref(fl), C.byref(by)), self._h)
-            out.append({"name": buf.value.decode(), "flops_per_image": fl.value, "bytes_per_image": by.value})
+            st = {"name": buf.value.decode(), "flops_per_image": fl.value, "bytes_per_image": by.value}
+            check(L.yfv2_stage_kernel(self._h, i, buf, 256), self._h)
+            st["kernel"] = buf.value.decode()
+            out.append(st)
         return out
 
     def profile_forward(self, x, iters=5):
