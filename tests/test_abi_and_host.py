@@ -150,6 +150,50 @@ def test_gather_detections_world_size_2_gloo(tmp_path):
         assert p.returncode == 0 and "rank %d ok" % r in o, o
 
 
+def test_detect_sharded_world_size_2_gloo_reassembles_the_single_rank_result(tmp_path):
+    """SURVEY.md 8(e) end to end on CPU: the batch is split with shard_range, every rank runs `detect` on ITS images only
+    (a stand-in engine whose detections are a deterministic function of each image, so a wrong split, order or padding
+    shows), detect_sharded gathers - every rank must hold exactly what one rank computes on the whole batch.  Also the
+    debug mode that gathers the decoded tensor."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from yolo_fastestv2_amd import detect_sharded, gather_decoded, shard_range
+
+        class FakeEngine:                     # same call shape as Engine.detect
+            def detect(self, x, conf_thres, iou_thres, out=None):
+                B = x.shape[0]
+                s = x.reshape(B, -1).double().sum(1)                      # a fingerprint of each image
+                cnt = (s * 7).long().remainder(300).to(torch.int32)
+                k = torch.arange(300)[None, :, None].double()
+                dets = ((s[:, None, None] + k) * torch.arange(1, 7)[None, None, :]).float() * float(conf_thres + iou_thres)
+                idx = ((s[:, None] * 13).long() + torch.arange(300)[None]).remainder(1815).to(torch.int32)
+                live = torch.arange(300)[None] < cnt[:, None]
+                return dets * live[..., None], idx * live, cnt
+
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        g = torch.Generator().manual_seed(5)
+        x_all = torch.rand(8, 3, 32, 32, generator=g)                    # every rank builds the same global batch
+        lo, hi = shard_range(x_all.shape[0], rank, world)
+        eng = FakeEngine()
+        d, i, c = detect_sharded(eng, x_all[lo:hi], 0.3, 0.4)
+        D, I, C = eng.detect(x_all, 0.3, 0.4)
+        assert d.shape == D.shape and torch.equal(d, D) and torch.equal(i, I) and torch.equal(c, C), rank
+        dec_all = torch.rand(8, 60, 85, generator=g)
+        assert torch.equal(gather_decoded(dec_all[lo:hi].clone()), dec_all), rank
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in o, o
+
+
 def test_gather_is_identity_without_process_group():
     from yolo_fastestv2_amd import gather_detections
     d, i, c = torch.rand(2, 300, 6), torch.zeros(2, 300, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)

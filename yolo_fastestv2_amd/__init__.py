@@ -17,7 +17,7 @@ from .model.detector import Detector  # noqa: F401
 from .utils.utils import (ap_per_class, compute_ap, evaluation, get_batch_statistics, handel_preds, load_datafile,  # noqa: F401
                           nms_with_indices, non_max_suppression)
 from .weights import export_weights, random_state_dict  # noqa: F401
-from .sharded import detect_sharded, gather_detections, shard_range  # noqa: F401
+from .sharded import detect_sharded, gather_decoded, gather_detections, shard_range  # noqa: F401
 
 
 def install(reference_detector_module=None, reference_utils_module=None):

@@ -33,6 +33,20 @@ def gather_detections(dets, idx, cnt, group=None, force=False):
     return tuple(out)
 
 
+def gather_decoded(decoded, group=None, force=False):
+    """Debug / parity mode (BASELINE.json's wording "all-gather of decoded boxes"): all-gather the
+    per-rank decoded tensor (B_local, rows, 5+classes) -> (W*B_local, rows, 5+classes) on every rank.  158 MB per rank at
+    256 images - about a millisecond per xGMI link, comparable to the whole forward - which is why the product path
+    (``detect_sharded``) gathers the 8.4 KB/image padded detections instead."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return decoded
+    W = dist.get_world_size(group)
+    decoded = decoded.contiguous()
+    g = torch.empty((W * decoded.shape[0],) + tuple(decoded.shape[1:]), dtype=decoded.dtype, device=decoded.device)
+    dist.all_gather_into_tensor(g, decoded, group=group)
+    return g
+
+
 def detect_sharded(engine, x_local, conf_thres, iou_thres, group=None, out=None):
     """This rank's shard through forward+decode+NMS, then the all-gather.
     Every rank must pass the same local batch size (pad the last shard)."""
