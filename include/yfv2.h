@@ -155,6 +155,19 @@ YFV2_API int yfv2_batch_statistics_async(yfv2_handle h, const float* dets, const
                                          int32_t T, float iou_threshold, int32_t* tp, void* stream);
 YFV2_API int yfv2_batch_statistics_overflow(yfv2_handle h, int32_t* overflowed, void* stream);
 
+/* replaces: utils/loss.py:130-208 compute_loss (with build_target :53-124 and bbox_iou(CIoU) :8-51) and, when grad6 is
+ * not NULL, what autograd derives from it: the gradient of the TOTAL loss w.r.t. each of the six logit maps (same
+ * shapes as out6; device pointers; overwritten).  SURVEY.md section 8(f) row 3, first slice - the loss end of the
+ * training path (train.py:105-108); train-mode forward and the convolutions' backward are not implemented.
+ *   out6     the six NCHW logit maps of yfv2_forward (B images)
+ *   targets  (T, 6) fp32 device rows [image index in the batch, class, cx, cy, w, h], box normalised to [0, 1]: the tensor
+ *            the reference's collate_fn builds (utils/datasets.py:12-22); T may be 0
+ *   losses   device float[4]: lbox (x3.2), lobj (x64), lcls (x32) and their sum, the 4-tuple compute_loss returns
+ * Uses the handle's anchors (yfv2_set_anchors) as float64 like the reference.  Work is enqueued on `stream`; the
+ * handle's loss workspace grows (one device synchronisation) when T exceeds what earlier calls needed. */
+YFV2_API int yfv2_loss(yfv2_handle h, const float* const out6[6], int32_t B, const float* targets, int32_t T, float* losses,
+                       float* const grad6[6], void* stream);
+
 /* ---- introspection / measurement (bench.py, tests) ------------------------- */
 
 YFV2_API int32_t yfv2_num_rows(yfv2_handle h);   /* 1815 for 352x352, A=3 */
@@ -168,7 +181,7 @@ YFV2_API int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_
                     double* bytes_per_image);
 /* The kernel (family) launch `i` runs, as a prefix of the symbol name a rocprofv3 kernel trace shows for it
  * (e.g. "block_s1chain_kernel", "tower2_kernel<6, 512, 4, 4>"): lets bench.py group its per-launch times the way
- * profiles/*_kernel_stats.csv does. */
+ * the kernel-stats tables under profiles/ do. */
 YFV2_API int yfv2_stage_kernel(yfv2_handle h, int32_t i, char* name, int32_t name_cap);
 
 /* Measurement helper (synchronises): runs the forward `iters` times with a

@@ -20,6 +20,8 @@ Outputs (all small, committed):
                        -> reference non_max_suppression rows
   golden_stats.npz     NMS rows of the stress set + synthetic targets -> reference get_batch_statistics
   golden_ap.npz        synthetic detection statistics -> reference ap_per_class (python make_golden.py ap)
+  golden_loss.npz      seeded logits + targets -> reference utils/loss.py compute_loss values and its autograd
+                       gradients w.r.t. the six logit maps (python make_golden.py loss)
 
 usage: PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -254,8 +256,80 @@ def make_ap_golden():
     np.savez_compressed(os.path.join(HERE, "golden_ap.npz"), **out)
 
 
+LOSS_CASES = ((80, 2, 4, 0), (80, 3, 40, 1), (20, 2, 25, 2), (1, 2, 9, 3), (80, 2, 0, 4), (80, 4, 120, 5))   # classes, batch, labels, seed
+
+
+def loss_case_inputs(classes, B, T, seed):
+    """Deterministic logits and labels of one loss case (numpy PCG64: reproducible without storing the logits).
+    Labels: [image, class, cx, cy, w, h] normalised; some are pushed to the image border and to extreme sizes so that
+    the anchor-ratio test and the neighbour-cell offsets (utils/loss.py:93-107) see every branch."""
+    rng = np.random.default_rng(1000 + seed)
+    shapes = [(B, 12, 22, 22), (B, 3, 22, 22), (B, classes, 22, 22), (B, 12, 11, 11), (B, 3, 11, 11), (B, classes, 11, 11)]
+    preds = [(rng.standard_normal(sh) * 2).astype(np.float32) for sh in shapes]
+    t = rng.random((T, 6)).astype(np.float32)
+    if T:
+        t[:, 0] = rng.integers(0, B, T)
+        t[:, 1] = rng.integers(0, classes, T)
+        t[:, 4:6] = t[:, 4:6] * 0.6 + 0.01
+        edge = rng.random(T) < 0.25
+        t[edge, 2] = np.where(rng.random(edge.sum()) < 0.5, 0.004, 0.997).astype(np.float32)
+        t[rng.random(T) < 0.15, 4:6] = 0.9
+    return preds, t
+
+
+def make_loss_golden():
+    """golden_loss.npz: the reference's own utils/loss.py compute_loss (imported from /root/reference, executed with ONE
+    shim: Tensor.clamp_ accepts the float-tensor bounds of utils/loss.py:119 on an int64 tensor by taking int() of them -
+    the line is otherwise a TypeError on this torch) on seeded logits and labels: the four loss values and
+    its autograd gradients w.r.t. the six logit maps (objectness maps dense, the others as (index, value) of their
+    non-zeros).  The oracle's restatement must reproduce all of it exactly."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_loss", os.path.join(REF, "utils", "loss.py"))
+    L = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(L)
+    orig = torch.Tensor.clamp_
+
+    def clamp_(self, mn=None, mx=None):
+        fix = lambda v: int(v) if (torch.is_tensor(v) and not self.is_floating_point()) else v  # noqa: E731
+        return orig(self, fix(mn), fix(mx))
+    torch.Tensor.clamp_ = clamp_
+    anchors = [float(a) for a in np.load(os.path.join(HERE, "cfg_coco.npz"))["anchors"]]
+    out = {"n": np.asarray(len(LOSS_CASES)), "cases": np.asarray(LOSS_CASES, np.int64)}
+    try:
+        for ci, (classes, B, T, seed) in enumerate(LOSS_CASES):
+            preds, t = loss_case_inputs(classes, B, T, seed)
+            cfg = {"anchor_num": 3, "classes": classes, "width": 352, "height": 352, "anchors": anchors}
+            p1 = [torch.from_numpy(p.copy()).requires_grad_() for p in preds]
+            p2 = [torch.from_numpy(p.copy()).requires_grad_() for p in preds]
+            ref = L.compute_loss(p1, torch.from_numpy(t), cfg, torch.device("cpu"))
+            ref[3].backward()
+            mine = oracle.compute_loss(p2, torch.from_numpy(t), anchors, classes)
+            mine[3].backward()
+            for a, b in zip(ref, mine):
+                assert float(a) == float(b), "oracle compute_loss != reference compute_loss"
+            for a, b in zip(p1, p2):
+                ga = a.grad if a.grad is not None else torch.zeros_like(a)
+                gb = b.grad if b.grad is not None else torch.zeros_like(b)
+                assert torch.equal(ga, gb), "oracle gradients != reference autograd gradients"
+            out["targets%d" % ci] = t
+            out["loss%d" % ci] = np.asarray([float(v) for v in ref], np.float32)
+            for k, p in enumerate(p1):
+                g = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().reshape(-1)
+                if k % 3 == 1:
+                    out["grad%d_%d" % (ci, k)] = g
+                else:
+                    nz = np.flatnonzero(g)
+                    out["grad%d_%d_idx" % (ci, k)], out["grad%d_%d_val" % (ci, k)] = nz.astype(np.int64), g[nz]
+            print("loss case", ci, (classes, B, T), [float(v) for v in ref])
+    finally:
+        torch.Tensor.clamp_ = orig
+    np.savez_compressed(os.path.join(HERE, "golden_loss.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "ap":
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":
+        make_loss_golden()    # only golden_loss.npz
+    elif len(sys.argv) > 1 and sys.argv[1] == "ap":
         make_ap_golden()      # only golden_ap.npz (the other files are left as committed)
     else:
         main()

@@ -54,6 +54,7 @@ _PROTOTYPES = {
     "yfv2_batch_statistics_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                               C.c_void_p, C.c_void_p]),
     "yfv2_batch_statistics_overflow": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "yfv2_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "yfv2_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "yfv2_debug_plan_dryrun": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "yfv2_debug_plan_image": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64]),

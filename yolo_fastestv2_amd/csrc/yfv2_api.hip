@@ -82,6 +82,10 @@ struct yfv2_ctx {
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries), then one int32 of its own for the statistics overflow flag
   int32_t* d_stats_flag = nullptr;  // = d_classes + 256
+  // training-loss workspace (yfv2_loss): match slots for loss_cap labels, objectness target maps for max_batch images,
+  // counters and float64 sums; grown on demand (a growth waits for the device)
+  void* d_loss_ws = nullptr;
+  size_t loss_ws_bytes = 0;
   long long* d_trace = nullptr;  // YFV2_TRACE=1: cycle stamps of the last fused s1 launch (debug)
   int trace_step = -1;           // YFV2_TRACE_STEP=i: only launch i of the plan writes stamps (towers: only then)
   // which buffers hold the stage outputs of the last forward (for debug/parity)
@@ -1391,6 +1395,7 @@ void yfv2_destroy(yfv2_handle h) {
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
   free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);
+  if (h->d_loss_ws) (void)hipFree(h->d_loss_ws);
   if (h->d_params) (void)hipFree(h->d_params);
   delete h;
 }
@@ -1576,6 +1581,56 @@ int yfv2_batch_statistics(yfv2_handle h, const float* dets, const int32_t* count
   rc = yfv2_batch_statistics_overflow(h, &over, stream);
   if (rc) return rc;
   if (over) return fail(h, YFV2_ERR_ARG, "yfv2_batch_statistics: an image has more than 1024 targets");
+  return YFV2_OK;
+}
+
+int yfv2_loss(yfv2_handle h, const float* const out6[6], int32_t B, const float* targets, int32_t T, float* losses,
+              float* const grad6[6], void* stream) {
+  int rc = check_call(h, B, false);
+  if (rc) return rc;
+  if (!out6 || !losses || T < 0 || (T > 0 && !targets)) return fail(h, YFV2_ERR_ARG, "yfv2_loss: bad argument");
+  for (int i = 0; i < 6; ++i)
+    if (!out6[i] || (grad6 && !grad6[i])) return fail(h, YFV2_ERR_ARG, "yfv2_loss: null logit / gradient tensor");
+  if (T > (1 << 20)) return fail(h, YFV2_ERR_ARG, "yfv2_loss: more than 2^20 labels in one batch");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t A = (size_t)h->cfg.anchor_num;
+  const size_t cells0 = (size_t)B * A * h->fh[0] * h->fw[0], cells1 = (size_t)B * A * h->fh[1] * h->fw[1];
+  // layout: [sums 6 doubles][nb 2 ints + pad][tobj0][tobj1][pad][matches]
+  const size_t off_nb = 6 * sizeof(double), off_t0 = off_nb + 16, off_t1 = off_t0 + cells0;
+  const size_t zero_bytes = (off_t1 + cells1 + 15) & ~(size_t)15;
+  const size_t need = zero_bytes + sizeof(LossMatch) * (size_t)(2 * 5 * 3) * (size_t)(T > 0 ? T : 1);
+  if (need > h->loss_ws_bytes) {
+    HIP_TRY(h, hipDeviceSynchronize());               // an earlier yfv2_loss may still be using the old block
+    if (h->d_loss_ws) { (void)hipFree(h->d_loss_ws); h->d_loss_ws = nullptr; h->loss_ws_bytes = 0; }
+    const size_t cap = need + need / 2;
+    HIP_TRY(h, hipMalloc(&h->d_loss_ws, cap));
+    h->loss_ws_bytes = cap;
+  }
+  char* ws = static_cast<char*>(h->d_loss_ws);
+  HIP_TRY(h, hipMemsetAsync(ws, 0, zero_bytes, s));
+  LossArgs a{};
+  for (int l = 0; l < 2; ++l) {
+    a.reg[l] = out6[3 * l]; a.obj[l] = out6[3 * l + 1]; a.cls[l] = out6[3 * l + 2];
+    a.grad_reg[l] = grad6 ? grad6[3 * l] : nullptr; a.grad_obj[l] = grad6 ? grad6[3 * l + 1] : nullptr; a.grad_cls[l] = grad6 ? grad6[3 * l + 2] : nullptr;
+    a.fh[l] = h->fh[l]; a.fw[l] = h->fw[l];
+    a.stride[l] = (double)h->cfg.width / (double)h->fw[l];        // utils/loss.py:82
+    if (grad6) {                                                   // reg / cls gradients are accumulated with atomics: start from zero
+      HIP_TRY(h, hipMemsetAsync(grad6[3 * l], 0, sizeof(float) * (size_t)B * 4 * A * h->fh[l] * h->fw[l], s));
+      HIP_TRY(h, hipMemsetAsync(grad6[3 * l + 2], 0, sizeof(float) * (size_t)B * h->cfg.classes * h->fh[l] * h->fw[l], s));
+    }
+  }
+  for (int i = 0; i < 12; ++i) a.anchors[i] = h->cfg.anchors[i];
+  a.targets = targets;
+  a.sums = reinterpret_cast<double*>(ws);
+  a.nb = reinterpret_cast<int*>(ws + off_nb);
+  a.tobj[0] = reinterpret_cast<unsigned char*>(ws + off_t0);
+  a.tobj[1] = reinterpret_cast<unsigned char*>(ws + off_t1);
+  a.matches = reinterpret_cast<LossMatch*>(ws + zero_bytes);
+  a.losses = losses;
+  a.B = B; a.T = T; a.classes = h->cfg.classes;
+  yfv2_launch_loss(a, s);
+  HIP_TRY(h, hipGetLastError());
   return YFV2_OK;
 }
 

@@ -231,6 +231,27 @@ struct StatsArgs {
 };
 constexpr int STATS_MAX_TARGETS = 1024;
 void yfv2_launch_stats(const StatsArgs& a, hipStream_t s);
+// ---- training loss and its gradient w.r.t. the logits (yfv2_loss.hip; utils/loss.py:8-208)
+struct LossMatch {            // one (scale, offset candidate, anchor, label) slot of build_target
+  int valid, b, a, gj, gi, cls;
+  float tb[4];                // target box: (gx - cell x, gy - cell y, gw, gh) in grid units, fp32
+  double aw, ah;              // anchor / stride, float64
+};
+struct LossArgs {
+  const float* reg[2]; const float* obj[2]; const float* cls[2];   // the six logit maps (NCHW)
+  float* grad_reg[2]; float* grad_obj[2]; float* grad_cls[2];      // d total / d logits (all null: forward only); reg / cls pre-zeroed
+  const float* targets;       // (T, 6) image, class, cx, cy, w, h (normalised), device
+  LossMatch* matches;         // 2 * 5 * 3 * T slots
+  unsigned char* tobj[2];     // objectness targets (B, 3, H, W), pre-zeroed
+  int* nb;                    // matches per scale [2], pre-zeroed
+  double* sums;               // per scale: sum(1 - ciou), sum(objectness BCE), sum(class CE)  [2][3], pre-zeroed
+  float* losses;              // out: lbox, lobj, lcls, total
+  int B, T, classes;
+  int fh[2], fw[2];
+  double stride[2];           // cfg.width / fw
+  double anchors[12];
+};
+void yfv2_launch_loss(const LossArgs& a, hipStream_t s);
 // ---- pre-process: bilinear resize of uint8 HWC frames (yfv2_pre.hip)
 struct ResizeArgs {
   const unsigned char* src;  // (B, SH, SW, 3)

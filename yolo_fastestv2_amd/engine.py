@@ -213,6 +213,25 @@ class Engine:
                  int(targets.shape[0]), float(iou_threshold), _ptr(tp), _stream(self.device)), self._h)
         return tp
 
+    def loss(self, preds, targets, want_grad=False):
+        """utils/loss.py:130-208 compute_loss on the device: (losses, grads) with losses a float32 (4,) device tensor
+        [lbox, lobj, lcls, total] and grads the gradients of `total` w.r.t. the six logit maps (None unless want_grad)."""
+        self._need_anchors("loss")
+        preds = [p.detach().contiguous() for p in preds]
+        B = preds[0].shape[0]
+        for p, s in zip(preds, self.logit_shapes(B)):
+            if tuple(p.shape) != s or p.dtype != torch.float32 or p.device != self.device:
+                raise ValueError("logit tensor %s %s on %s, expected fp32 %s on %s" % (p.dtype, tuple(p.shape), p.device, s, self.device))
+        self.ensure_batch(B)
+        targets = torch.as_tensor(targets).to(self.device, torch.float32).reshape(-1, 6).contiguous()
+        losses = torch.empty(4, device=self.device, dtype=torch.float32)
+        grads = [torch.empty_like(p) for p in preds] if want_grad else None
+        ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in preds])
+        gptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in grads]) if want_grad else None
+        check(_lib.lib().yfv2_loss(self._h, ptrs, B, _ptr(targets) if targets.numel() else None, int(targets.shape[0]), _ptr(losses),
+                                   gptrs, _stream(self.device)), self._h)
+        return losses, grads
+
     def stats_overflowed(self):
         """Waits for the stream; True if any batch_statistics(sync=False) call since the last query met an image with
         more than 1024 targets (its flags are then invalid).  Clears the flag."""
