@@ -57,7 +57,9 @@ def test_oracle_build_target_edge_cases(cfg):
     far = oracle.build_target(shapes, np.asarray([[0, 1, 0.5, 0.5, 0.001, 0.001]], np.float32), cfg["anchors"])
     assert all(len(s[0]) == 0 for s in far)               # 0.02 x 0.02 cells: ratio to every anchor > 2
     corner = oracle.build_target(shapes, np.asarray([[0, 1, 0.999, 0.001, 0.1, 0.15]], np.float32), cfg["anchors"])
-    assert len(corner[0][0]) >= 2                         # stride 16: the centre cell and at least one neighbour
+    assert len(corner[0][0]) == 1                         # stride 16: the corner cell only - both neighbour tests fail at the border (:104-105)
+    inner = oracle.build_target(shapes, np.asarray([[0, 1, 0.52, 0.48, 0.1, 0.15]], np.float32), cfg["anchors"])
+    assert len(inner[0][0]) == 3                          # centre + one horizontal + one vertical neighbour
     for (b, a, gj, gi, tb, an, c), (h, w) in zip(corner, shapes):
         if len(b):
             assert 0 <= int(gi.min()) and int(gi.max()) <= w - 1 and 0 <= int(gj.min()) and int(gj.max()) <= h - 1
