@@ -1633,7 +1633,7 @@ bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
 __host__ __device__ constexpr int tw2_row_pitch(int W) { return W + 16; }                                        // 16-byte slots
 __host__ __device__ constexpr int tw2_plane_slots(int H, int W) { return ((H + 4) * tw2_row_pitch(W) + 15) & ~15; }
 
-template <int MH, int THREADS, int NT, int NPF>
+template <int MH, int THREADS, int NT, int NPF, bool BF6>
 __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
   constexpr int KC = TW_KC, C = TW_C;
   constexpr int NW = THREADS / 64;
@@ -1750,6 +1750,24 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
           const float u = __builtin_fmaf(d[nt][k], sc[k], sh[k]);  // channels >= 72: sc = sh = 0 -> 0
           bfr[nt][k] = (cb < C && u > 0.f) ? u : 0.f;
         }
+      if constexpr (BF6) {
+        // bf16x6 (yfv2_internal.h): the depthwise result is split once per pixel tile, each filter fragment once per
+        // output-channel tile; three MFMAs per (mt, nt) - the NT accumulators of one mt are independent of each other
+        Bf3B b3[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b3[nt] = yfv2_split_b(bfr[nt]);
+        YFV2_WSTAMP(3 + 3 * s);
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const Bf3A a3 = yfv2_split_a(*reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = yfv2_mfma6_step<0>(a3, b3[nt], acc[mt][nt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = yfv2_mfma6_step<1>(a3, b3[nt], acc[mt][nt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = yfv2_mfma6_step<2>(a3, b3[nt], acc[mt][nt]);
+        }
+      } else {
       f32x4 afP[KC];
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) afP[mt] = *reinterpret_cast<const f32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
@@ -1762,6 +1780,7 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afP[mt][j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
+      }
       YFV2_WSTAMP(4 + 3 * s);
     }
     // pointwise BN (no ReLU: fpn.py:16-17,23-24)
@@ -1785,35 +1804,66 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
           if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
       }
     } else {
+      // chained output conv: the BN'd accumulator tile s IS the B fragment of chunk s.  Output-channel tiles in pairs, so
+      // that (bf16x6) one split of a B fragment feeds two tiles' MFMAs
+      constexpr int MP = MH >= 2 ? 2 : 1;
 #pragma unroll 1
-      for (int m = 0; m < MH; ++m) {
-        f32x4 hacc[NT];
+      for (int m0 = 0; m0 < MH; m0 += MP) {
+        f32x4 hacc[MP][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 afH[KC];
+        for (int q = 0; q < MP; ++q)
 #pragma unroll
-        for (int s = 0; s < KC; ++s) afH[s] = *reinterpret_cast<const f32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int nt = 0; nt < NT; ++nt) hacc[q][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF6) {
 #pragma unroll
-        for (int s = 0; s < KC; ++s)
+          for (int s = 0; s < KC; ++s) {
+            Bf3A a3[MP];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+            for (int q = 0; q < MP; ++q) a3[q] = yfv2_split_a(*reinterpret_cast<const f32x4*>(WH + (((m0 + q) * KC + s) * 64 + lane) * 4));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              hacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afH[s][j], acc[s][nt][j], hacc[nt], 0, 0, 0);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 4 * 96 + 16 * m + 4 * g);
+            for (int nt = 0; nt < NT; ++nt) {
+              const Bf3B b3 = yfv2_split_b(acc[s][nt]);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (!pv[nt]) continue;
+              for (int q = 0; q < MP; ++q) hacc[q][nt] = yfv2_mfma6_step<0>(a3[q], b3, hacc[q][nt]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = 16 * m + 4 * g + r;
-            if (co < a.mh) {
-              const float y = hacc[nt][r] + bias[r];
-              if (co < a.split)
-                a.nchw0[((size_t)b * a.split + co) * HW + opix[nt]] = y;
-              else
-                a.nchw1[((size_t)b * (a.mh - a.split) + (co - a.split)) * HW + opix[nt]] = y;
+              for (int q = 0; q < MP; ++q) hacc[q][nt] = yfv2_mfma6_step<1>(a3[q], b3, hacc[q][nt]);
+#pragma unroll
+              for (int q = 0; q < MP; ++q) hacc[q][nt] = yfv2_mfma6_step<2>(a3[q], b3, hacc[q][nt]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < MP; ++q) {
+            f32x4 afH[KC];
+#pragma unroll
+            for (int s = 0; s < KC; ++s) afH[s] = *reinterpret_cast<const f32x4*>(WH + (((m0 + q) * KC + s) * 64 + lane) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KC; ++s)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  hacc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afH[s][j], acc[s][nt][j], hacc[q][nt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < MP; ++q) {
+          const int m = m0 + q;
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 4 * 96 + 16 * m + 4 * g);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (!pv[nt]) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = 16 * m + 4 * g + r;
+              if (co < a.mh) {
+                const float y = hacc[q][nt][r] + bias[r];
+                if (co < a.split)
+                  a.nchw0[((size_t)b * a.split + co) * HW + opix[nt]] = y;
+                else
+                  a.nchw1[((size_t)b * (a.mh - a.split) + (co - a.split)) * HW + opix[nt]] = y;
+              }
             }
           }
         }
@@ -1828,9 +1878,14 @@ static void launch_tower2(const TowerArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)TW_WP_FL + (size_t)MH * TW_WH_FL + 25 * TW_KC * 16 + 5 * 96 +
                                       (size_t)16 * tw2_plane_slots(a.H, a.W));
   int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF>), lds_ok0);
-  hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF>), dim3(blocks), dim3(THREADS), lds, s, a);
+  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
+  if (yfv2_use_bf6()) {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF, true>), lds_ok1);
+    hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF, true>), dim3(blocks), dim3(THREADS), lds, s, a);
+    return;
+  }
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF, false>), lds_ok0);
+  hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF, false>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 
 bool yfv2_tower2_supported(int H, int W) { return H * W <= 16 * 4 * 8; }

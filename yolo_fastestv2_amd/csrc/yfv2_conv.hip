@@ -12,6 +12,8 @@
 // contiguous) so that a 16-lane group reads one pixel's channel quad per lane
 // and stores are 16 B per lane; the API surface stays NCHW (input image and the
 // six logit maps).
+#include <cstdlib>
+
 #include "yfv2_internal.h"
 
 // ============================================================================
@@ -36,7 +38,7 @@
 //               [0,192) gathered from C3 at (y/2, x/2), [192,288) from C2
 //   PW_HEAD     the three biased output convs (detector.py:17-19,25-31): stores
 //               NCHW logits into two destination tensors split at `split`
-template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
+template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false, bool BF6 = false>
 __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   constexpr int K16 = K / 16;
   constexpr int KT = K % 16;
@@ -112,6 +114,15 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
         }
         // all MT filter fragments of the chunk first (distinct registers), then MT*NT independent
         // MFMA chains interleaved - no LDS wait between MFMAs
+        if constexpr (BF6) {
+          Bf3A a3[MT];
+          Bf3B b3[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a3[mt] = yfv2_split_a(*reinterpret_cast<const f32x4*>(wl + ((mt * K16 + s) * 64 + lane) * 4));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b3[nt] = yfv2_split_b(bcur[nt]);
+          yfv2_mfma6_tiles<MT, NT>(a3, b3, acc);
+        } else {
         f32x4 afs[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + ((mt * K16 + s) * 64 + lane) * 4);
@@ -123,6 +134,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afs[mt][j], bcur[nt][j], acc[mt][nt], 0, 0, 0);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
       }
@@ -172,6 +184,15 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 
 #pragma unroll
     for (int s = 0; s < K16; ++s) {
+      if constexpr (BF6) {
+        Bf3A a3[MT];
+        Bf3B b3[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a3[mt] = yfv2_split_a(*reinterpret_cast<const f32x4*>(wl + ((mt * K16 + s) * 64 + lane) * 4));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b3[nt] = yfv2_split_b(bf[nt][s]);
+        yfv2_mfma6_tiles<MT, NT>(a3, b3, acc);
+      } else {
       f32x4 afs[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) afs[mt] = *reinterpret_cast<const f32x4*>(wl + ((mt * K16 + s) * 64 + lane) * 4);
@@ -183,8 +204,21 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afs[mt][j], bf[nt][s][j], acc[mt][nt], 0, 0, 0);
+      }
     }
     if constexpr (KT) {  // 8-channel tail: group g owns channels 16*K16 + 2g, +1
+      if constexpr (BF6) {   // as a chunk whose elements 2, 3 are zero
+        Bf3A a3[MT];
+        Bf3B b3[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x2 af = *reinterpret_cast<const f32x2*>(wl + FRAG_FL + (mt * 64 + lane) * 2);
+          a3[mt] = yfv2_split_a((f32x4){af[0], af[1], 0.f, 0.f});
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b3[nt] = yfv2_split_b((f32x4){bt[nt][0], bt[nt][1], 0.f, 0.f});
+        yfv2_mfma6_tiles<MT, NT>(a3, b3, acc);
+      } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const f32x2 af = *reinterpret_cast<const f32x2*>(wl + FRAG_FL + (mt * 64 + lane) * 2);
@@ -193,6 +227,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bt[nt][j], acc[mt][nt], 0, 0, 0);
+      }
       }
     }
 
@@ -237,6 +272,12 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   }
 }
 
+// YFV2_BF6=0 selects the fp32 MFMA (v_mfma_f32_16x16x4_f32) in every kernel that has the bf16x6 form (A/B switch)
+bool yfv2_use_bf6() {
+  static const bool on = [] { const char* e = std::getenv("YFV2_BF6"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
 static void pw_launch(const PwArgs& a, hipStream_t s) {
   const size_t lds = (size_t)MT * 16 * K * sizeof(float);   // K/16 fragments of 256 floats + (K%16 == 8) 128 per M tile
@@ -247,7 +288,15 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   const int cap = lds > 64 * 1024 ? 256 : (lds > 32 * 1024 ? 512 : 1024);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  static std::atomic<unsigned long long> lds_ok0{0};
+  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
+  // bf16x6 for the instantiations the default plans use (the streamed large-K forms and the small biased heads); the fully
+  // unrolled 6-tile forms of the layer-by-layer fallback would spill with the split operands and stay on the fp32 MFMA
+  constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
+  if constexpr (kBf6) if (yfv2_use_bf6()) {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), lds_ok1);
+    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), dim3(blocks), dim3(THREADS), lds, s, a);
+    return;
+  }
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
   hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
@@ -264,7 +313,7 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
   if (mode == PW_PLAIN) {
     if (K == 24 && MT == 2) { pw_launch<24, 2, 4, PW_PLAIN>(a, s); return true; }
     if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_PLAIN>(a, s); return true; }
-    if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_PLAIN>(a, s); return true; }
+    if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_PLAIN, 256, true>(a, s); return true; }
     if (K == 72 && MT == 5) { pw_launch<72, 5, 2, PW_PLAIN>(a, s); return true; }
     if (K == 192 && MT == 5) { pw_launch<192, 5, 2, PW_PLAIN, 512, true>(a, s); return true; }
   } else if (mode == PW_SHUFFLE) {

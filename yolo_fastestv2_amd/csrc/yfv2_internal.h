@@ -28,6 +28,71 @@ inline void yfv2_allow_full_lds(const void* fn, std::atomic<unsigned long long>&
   done.fetch_or(bit, std::memory_order_relaxed);
 }
 
+// ---- fp32 pointwise convs on the bf16 matrix cores ("bf16x6")
+// gfx950's fp32 MFMA runs at the fp32 VECTOR rate (16x16x4: 32 cycles per 1024 MACs per SIMD); its bf16 MFMA is 16x
+// faster (16x16x32: ~17 cycles per 8192 MACs).  An fp32 value is EXACTLY the sum of three bf16 terms (truncation: 8 + 8 + 8
+// significant bits), so w * x = sum of nine bf16 x bf16 products, each exact in fp32; the six largest (everything above
+// 2^-23 of |w x|, i.e. below one fp32 rounding of the product) are accumulated in fp32 by three MFMAs whose eight k-slots
+// per lane group are the lane's 4 channels x 2 terms:
+//     A {w.hi, w.hi} x B {x.hi, x.mid}      A {w.mid, w.mid} x B {x.hi, x.mid}      A {w.hi, w.lo} x B {x.lo, x.hi}
+// Same fragment maps as v_mfma_f32_16x16x4_f32 (A lane l: row l&15; B lane l: pixel l&15; lane group l>>4 owns 4 channels of
+// the 16-channel chunk; D lane l reg r: row 4(l>>4)+r, column l&15), so it drops into the existing loops: split the A
+// fragment once per (tile of output channels, chunk), the B fragment once per (pixel tile, chunk), then mfma6().
+// Measured (tools/ubench/bf16x6.hip, K = 192, 5 x 2 tiles): max error vs float64 7.1e-6 against 8.6e-6 for the fp32 MFMA on
+// the same data; 30 MFMAs in ~520 cycles against 40 in 1280; the whole network's logits: 1.39e-5 vs 1.41e-5 from float64.
+#ifdef __HIPCC__
+typedef __bf16 yfv2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct Bf3A { u32x4 hh, mm, hl; };   // {hi,hi}, {mid,mid}, {hi,lo}
+struct Bf3B { u32x4 hm, lh; };       // {hi,mid}, {lo,hi}
+__device__ __forceinline__ unsigned yfv2_pack_hi16(float a, float b) {   // high halves of a (low 16 bits) and b (high 16 bits): two truncated bf16
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+__device__ __forceinline__ float yfv2_trunc_bf16(float a) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xffff0000u); }
+__device__ __forceinline__ void yfv2_split3(f32x4 v, unsigned (&h)[2], unsigned (&m)[2], unsigned (&l)[2]) {
+  float r1[4], r2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { r1[c] = v[c] - yfv2_trunc_bf16(v[c]); r2[c] = r1[c] - yfv2_trunc_bf16(r1[c]); }   // exact subtractions
+  h[0] = yfv2_pack_hi16(v[0], v[1]); h[1] = yfv2_pack_hi16(v[2], v[3]);
+  m[0] = yfv2_pack_hi16(r1[0], r1[1]); m[1] = yfv2_pack_hi16(r1[2], r1[3]);
+  l[0] = yfv2_pack_hi16(r2[0], r2[1]); l[1] = yfv2_pack_hi16(r2[2], r2[3]);
+}
+__device__ __forceinline__ Bf3A yfv2_split_a(f32x4 w) {
+  unsigned h[2], m[2], l[2];
+  yfv2_split3(w, h, m, l);
+  return {(u32x4){h[0], h[1], h[0], h[1]}, (u32x4){m[0], m[1], m[0], m[1]}, (u32x4){h[0], h[1], l[0], l[1]}};
+}
+__device__ __forceinline__ Bf3B yfv2_split_b(f32x4 x) {
+  unsigned h[2], m[2], l[2];
+  yfv2_split3(x, h, m, l);
+  return {(u32x4){h[0], h[1], m[0], m[1]}, (u32x4){l[0], l[1], h[0], h[1]}};
+}
+// one of the three MFMAs (k = 0: the small terms, 1: w.mid, 2: w.hi): call sites run k outermost over their independent
+// accumulators so that no MFMA waits for the one before it
+template <int k>
+__device__ __forceinline__ f32x4 yfv2_mfma6_step(const Bf3A& a, const Bf3B& b, f32x4 acc) {
+  if constexpr (k == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(yfv2_bf16x8, a.hl), __builtin_bit_cast(yfv2_bf16x8, b.lh), acc, 0, 0, 0);
+  else if constexpr (k == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(yfv2_bf16x8, a.mm), __builtin_bit_cast(yfv2_bf16x8, b.hm), acc, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(yfv2_bf16x8, a.hh), __builtin_bit_cast(yfv2_bf16x8, b.hm), acc, 0, 0, 0);
+}
+// acc[mt][nt] += A[mt] x B[nt] for all tiles of a 16-channel chunk
+template <int MT_, int NT_>
+__device__ __forceinline__ void yfv2_mfma6_tiles(const Bf3A (&a)[MT_], const Bf3B (&b)[NT_], f32x4 (&acc)[MT_][NT_]) {
+#pragma unroll
+  for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = yfv2_mfma6_step<0>(a[mt], b[nt], acc[mt][nt]);
+#pragma unroll
+  for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = yfv2_mfma6_step<1>(a[mt], b[nt], acc[mt][nt]);
+#pragma unroll
+  for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = yfv2_mfma6_step<2>(a[mt], b[nt], acc[mt][nt]);
+}
+#endif
+
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
   const void* x;       // fp32 (B,3,H,W) in [0,1], or (u8_in) uint8 (B,H,W,3) in 0..255
@@ -207,6 +272,7 @@ struct NmsArgs {
   double iou_thres;
 };
 
+bool yfv2_use_bf6();   // YFV2_BF6=0: fp32 MFMA everywhere (A/B switch), default: bf16x6 where implemented
 // launchers (defined next to the kernels)
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
 // K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
