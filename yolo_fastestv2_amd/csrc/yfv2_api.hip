@@ -238,11 +238,10 @@ struct WeightPacker {
     return off;
   }
   // pw_kernel: filter fragments [MT][K/16][64 lanes][4] (+ an 8-channel tail [MT][64 lanes][2]), scale[MT*16], shift[MT*16]
-  size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */, bool presplit = false) {
+  size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */) {
     const int rows = MT * 16, K16 = K / 16;
     std::vector<float> im;
-    if (presplit) push_frag_bf3(im, &blob[f.w], M, K, MT, K16);
-    else push_frag(im, &blob[f.w], M, K, MT, K16);
+    push_frag(im, &blob[f.w], M, K, MT, K16);
     if (K % 16)
       for (int mt = 0; mt < MT; ++mt)
         for (int l = 0; l < 64; ++l)
@@ -253,26 +252,6 @@ struct WeightPacker {
     push_vec(im, &blob[f.scale], M, rows);
     push_vec(im, &blob[f.shift], M, rows);
     return put(im);
-  }
-  // the same fragments split for the bf16 matrix cores (yfv2_internal.h, bf16x6): per lane {hi01 hi23 lo01 lo23 mid01 mid23},
-  // every fp32 weight = hi + mid + lo exactly, each term a truncated bf16, two terms per dword (element 0 in the low half)
-  static void push_frag_bf3(std::vector<float>& im, const float* w, int M, int K, int MT, int KC) {
-    auto top = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u >> 16; };
-    auto val = [](uint32_t h) { uint32_t u = h << 16; float v; std::memcpy(&v, &u, 4); return v; };
-    for (int mt = 0; mt < MT; ++mt)
-      for (int s = 0; s < KC; ++s)
-        for (int l = 0; l < 64; ++l) {
-          uint32_t hi[4], mid[4], lo[4];
-          for (int j = 0; j < 4; ++j) {
-            const int r = 16 * mt + (l & 15), c = 16 * s + 4 * (l >> 4) + j;
-            const float v = (r < M && c < K) ? w[(size_t)r * K + c] : 0.f;
-            hi[j] = top(v); const float r1 = v - val(hi[j]);
-            mid[j] = top(r1); const float r2 = r1 - val(mid[j]);
-            lo[j] = top(r2);
-          }
-          const uint32_t d[6] = {hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, mid[0] | mid[1] << 16, mid[2] | mid[3] << 16};
-          for (uint32_t q : d) { float fb; std::memcpy(&fb, &q, 4); im.push_back(fb); }
-        }
   }
   // dwpw_s2_kernel<C>: pw fragments | dw taps [9][C] | dw scale, shift | pw scale, shift
   size_t image_dwpw(const Folded& fd, const Folded& fp, int C) {
@@ -469,7 +448,7 @@ struct PlanBuilder {
     s.pw.H = 0; s.pw.W = 0; s.pw.HW = px;
     s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0;
     s.px_per_img = px;
-    s.img_off = wp.image_pw(f, M, K, yfv2_pw_tiles(K, mode, M), yfv2_pw_presplit(K, mode));
+    s.img_off = wp.image_pw(f, M, K, yfv2_pw_tiles(K, mode, M));
     s.name = name;
     s.flops = 2.0 * px * K * M;
     s.bytes = 4.0 * px * (K + M);

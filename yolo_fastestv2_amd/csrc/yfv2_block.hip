@@ -883,12 +883,9 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
 constexpr int CH_TBL_FL = 64;
 constexpr int CH_IMG_FL = 2 * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + CH_TBL_FL;
 
-template <int THREADS, bool BF6>
+template <int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a) {
   constexpr int C2 = 48;
-  // pw1 stays on the fp32 MFMA: its nine split fragments (108 registers) spill, and splitting per tile is VALU-bound;
-  // pw2 (phase B, chunk-outer: one split per chunk serves the wave's four tiles) runs bf16x6
-  constexpr bool BF6_PHASE_A = false;
   using Cfg = S1Cfg<C2>;
   constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2, NT = 4;
   constexpr int NW = THREADS / 64;
@@ -922,13 +919,29 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
   auto phase_a = [&](const float* IM) {
     const float* W1 = IM;
     const float* CS = IM + 2 * Cfg::W_FL + Cfg::DW_FL;
-    f32x4 sc1[KC], sh1[KC];
+    f32x4 sc1[KC], sh1[KC], aw[KC][KC];
 #pragma unroll
     for (int mt = 0; mt < KC; ++mt) {
       sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
       sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
     }
-    auto epilogue = [&](int nt, f32x4 (&acc)[KC]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
+      f32x4 bf[KC];
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + sl[nt]) * 4);
+      f32x4 acc[KC];
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < KC; ++s2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
       if (valid[nt]) {
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) {
@@ -941,57 +954,6 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
           *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + sl[nt]) * 4) = y;
         }
       }
-    };
-    if constexpr (BF6 && BF6_PHASE_A) {
-      // bf16x6 (yfv2_internal.h): the nine filter fragments are split once per block and stay in registers as operand quads
-      Bf3A aw3[KC][KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) aw3[mt][s2] = yfv2_split_a(*reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4));
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
-        Bf3B b3[KC];
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) b3[s2] = yfv2_split_b(*reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + sl[nt]) * 4));
-        f32x4 acc[KC];
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) {
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) acc[mt] = yfv2_mfma6_step<0>(aw3[mt][s2], b3[s2], acc[mt]);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) acc[mt] = yfv2_mfma6_step<1>(aw3[mt][s2], b3[s2], acc[mt]);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) acc[mt] = yfv2_mfma6_step<2>(aw3[mt][s2], b3[s2], acc[mt]);
-        }
-        epilogue(nt, acc);
-      }
-    } else {
-      f32x4 aw[KC][KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
-        f32x4 bf[KC];
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + sl[nt]) * 4);
-        f32x4 acc[KC];
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
-        epilogue(nt, acc);
-      }
     }
   };
   auto phase_b = [&](const float* IM, f32x4 (&bo)[KC][NT]) {
@@ -999,48 +961,9 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
     const float* WD = IM + 2 * Cfg::W_FL;
     const float* CS = WD + Cfg::DW_FL;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (BF6) {
-      // chunk-outer: the chunk's taps, BN constants and (split) pw2 fragments are fetched once and serve the wave's 4 tiles
-#pragma unroll 1
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        f32x4 wl[9], lsc, lsh;
-        Bf3A a3[KC];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-        lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-        lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) a3[mt] = yfv2_split_a(*reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (16 * (wave + NW * nt) >= n_slots) continue;   // wave-uniform
-          const float* win0 = Tg + (size_t)(sl[nt] - RP - 1) * 4;
-          f32x4 win[9];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
-          f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
-#pragma unroll
-          for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
-          const Bf3B b3 = yfv2_split_b(bfr);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = yfv2_mfma6_step<0>(a3[mt], b3, bo[mt][nt]);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = yfv2_mfma6_step<1>(a3[mt], b3, bo[mt][nt]);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = yfv2_mfma6_step<2>(a3[mt], b3, bo[mt][nt]);
-        }
-      }
-    } else {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
       if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
       const float* win0 = Tg + (size_t)(sl[nt] - RP - 1) * 4;
 #pragma unroll 1
@@ -1068,11 +991,6 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
 #pragma unroll
           for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], bo[mt][nt], 0, 0, 0);
       }
-    }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
@@ -1105,12 +1023,10 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const float* ximg = a.in + (size_t)b * HW * C;
     float* zimg = a.out + (size_t)b * HW * C;
-    // ---- everything this image needs from memory up front is requested at once: the images of blocks 0 and 1, X, and
-    // (straight from the image in global memory, so that no barrier separates them from the loads) block 0's XS table
+    // ---- everything this image needs from memory up front is requested at once: the images of blocks 0 and 1, and X
     float hold2[6][NT];                                   // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
     {
       f32x4 tmp[2 * NIT], xq[NT][6];
-      int xs[6];
       const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -1119,8 +1035,6 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
           xq[nt][c] = *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g);   // halo slots read pixel 0 and are zeroed below
 #pragma unroll
       for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < 2 * N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) xs[c] = reinterpret_cast<const int*>(a.img + 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL)[(3 + c) * 4 + g];
       __builtin_amdgcn_sched_barrier(0);                  // all requests are out before the first use
 #pragma unroll
       for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; if (i < 2 * N4) reinterpret_cast<f32x4*>(lds)[i] = tmp[k]; }
@@ -1137,16 +1051,19 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) hold2[c][nt] = xq[nt][c][2];
-        // X[16 c + 4 g] pass at least two blocks: parked into the group of the block that consumes them (single dwords:
-        // 12-byte stores at dword alignment measured 3x slower than three dword stores)
-        if (real[nt]) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) zimg[(size_t)pix[nt] * C + xs[c]] = xq[nt][c][0];
-        }
       }
       YFV2_WSTAMP(12);
-      __syncthreads();                                    // images 0, 1 and the tile are in LDS
+      __syncthreads();                                    // image 0 (with its XS table) is in LDS
       YFV2_WSTAMP(13);
+      // X[16 c + 4 g] pass at least two blocks: parked into the group of the block that consumes them
+      // (single dwords: 12-byte stores at dword alignment measured 3x slower than three dword stores)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int pos = tbl(lds, 3 + c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (real[nt]) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
+      }
     }
     YFV2_WSTAMP(1);
 
@@ -1257,18 +1174,9 @@ bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s) {
   if (!yfv2_s1chain_supported(48, a.H, a.W) || a.nblk < 2) return false;
   const size_t lds = sizeof(float) * (size_t)s1chain_lds_floats(a.H, a.W);
   const int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
-  // pw2 on the bf16 matrix cores (bf16x6) is opt-in here: phase B itself drops from 15.3 k to 10.4 k cycles per block, but the
-  // split operands push the kernel over 256 registers and the spills land in phase A and the exchange (13.4 k -> 25.6 k,
-  // 9.7 k -> 22.8 k): 192-198 us against 167-168 us in a same-box A/B.  Needs pre-split filters in LDS to pay off.
-  static const bool bf6 = [] { const char* e = std::getenv("YFV2_BF6_CHAIN"); return e && e[0] == '1'; }();
-  if (bf6) {
-    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain_kernel<512, true>), lds_ok1);
-    hipLaunchKernelGGL((block_s1chain_kernel<512, true>), dim3(blocks), dim3(512), lds, s, a);
-    return true;
-  }
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain_kernel<512, false>), lds_ok0);
-  hipLaunchKernelGGL((block_s1chain_kernel<512, false>), dim3(blocks), dim3(512), lds, s, a);
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain_kernel<512>), lds_ok0);
+  hipLaunchKernelGGL((block_s1chain_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
   return true;
 }
 

@@ -47,10 +47,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   // W[16mt + (l&15)][16s + 4(l>>4) .. +3] - the 64 lanes of a fragment read touch 64 consecutive 16-byte slots, no bank
   // conflicts whatever 16-lane groups the hardware forms (a row-padded [M][K+4] image collides 5-7 slots per group);
   // an 8-channel tail is MT fragments of 8 bytes per lane behind them
-  // BF6 streamed forms (yfv2_pw_presplit): the host has already split the filter - 6 dwords per lane and fragment
-  // {hi01 hi23 | lo01 lo23 | mid01 mid23} (packed bf16 pairs) instead of 4 floats
-  constexpr bool PRESPLIT = BF6 && STREAM;
-  constexpr int FRAG_FL = MT * K16 * (PRESPLIT ? 384 : 256);
+  constexpr int FRAG_FL = MT * K16 * 256;
   constexpr int FILT_FL = FRAG_FL + (KT ? MT * 128 : 0);
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x;
@@ -121,12 +118,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
           Bf3A a3[MT];
           Bf3B b3[NT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const unsigned* fr = reinterpret_cast<const unsigned*>(wl) + ((mt * K16 + s) * 64 + lane) * 6;
-            const u32x4 hl = *reinterpret_cast<const u32x4*>(fr);          // hi01 hi23 lo01 lo23
-            const u32x2 m = *reinterpret_cast<const u32x2*>(fr + 4);       // mid01 mid23
-            a3[mt] = {(u32x4){hl[0], hl[1], hl[0], hl[1]}, (u32x4){m[0], m[1], m[0], m[1]}, hl};
-          }
+          for (int mt = 0; mt < MT; ++mt) a3[mt] = yfv2_split_a(*reinterpret_cast<const f32x4*>(wl + ((mt * K16 + s) * 64 + lane) * 4));
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) b3[nt] = yfv2_split_b(bcur[nt]);
           yfv2_mfma6_tiles<MT, NT>(a3, b3, acc);
@@ -288,10 +280,7 @@ bool yfv2_use_bf6() {
 
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
 static void pw_launch(const PwArgs& a, hipStream_t s) {
-  constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
-  const bool bf6 = kBf6 && yfv2_use_bf6();
-  // K/16 fragments of 256 floats + (K%16 == 8) 128 per M tile; the pre-split image of a bf16x6 streamed form is 1.5x
-  const size_t lds = (size_t)MT * 16 * K * sizeof(float) * ((bf6 && STREAM) ? 3 : 2) / 2;
+  const size_t lds = (size_t)MT * 16 * K * sizeof(float);   // K/16 fragments of 256 floats + (K%16 == 8) 128 per M tile
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
   int blocks = (n_super + THREADS / 64 - 1) / (THREADS / 64);
   // persistent-ish grid: enough blocks to fill 256 CUs a few times over, few
@@ -302,18 +291,14 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
   // bf16x6 for the instantiations the default plans use (the streamed large-K forms and the small biased heads); the fully
   // unrolled 6-tile forms of the layer-by-layer fallback would spill with the split operands and stay on the fp32 MFMA
-  if constexpr (kBf6) if (bf6) {
+  constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
+  if constexpr (kBf6) if (yfv2_use_bf6()) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), lds_ok1);
     hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), dim3(blocks), dim3(THREADS), lds, s, a);
     return;
   }
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
   hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
-}
-
-// does yfv2_launch_pw run (K, mode) as a bf16x6 streamed form, i.e. does it expect the pre-split filter image?
-bool yfv2_pw_presplit(int K, int mode) {
-  return yfv2_use_bf6() && ((mode == PW_PLAIN && (K == 96 || K == 192)) || (mode == PW_FPN && K == 288));
 }
 
 // M tiles of the instantiation yfv2_launch_pw picks: the host packs the filter image for exactly that many

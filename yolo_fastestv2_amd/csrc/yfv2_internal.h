@@ -277,8 +277,7 @@ bool yfv2_use_bf6();   // YFV2_BF6=0: fp32 MFMA everywhere (A/B switch), default
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
 // K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
-int yfv2_pw_tiles(int K, int mode, int M);
-bool yfv2_pw_presplit(int K, int mode);      // the launch expects WeightPacker::image_pw's pre-split (bf16x6) filter fragments   // M tiles of the kernel instantiation yfv2_launch_pw uses (the host packs for that many)
+int yfv2_pw_tiles(int K, int mode, int M);   // M tiles of the kernel instantiation yfv2_launch_pw uses (the host packs for that many)
 bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
 int yfv2_block_s1_rows(int c2, int H, int W);
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
