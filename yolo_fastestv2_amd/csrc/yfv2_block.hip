@@ -1754,8 +1754,12 @@ __global__ __launch_bounds__(THREADS) void tower2_kernel(TowerArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(trow + base[nt] + kx * 4);
+            if constexpr (BF6) {
+              d[nt] = __builtin_elementwise_fma(v, w, d[nt]);   // two v_pk_fma_f32: with the pointwise on the bf16 pipe the fp32 datapath is the depthwise's alone
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[nt][k] = __builtin_fmaf(v[k], w[k], d[nt][k]);
+              for (int k = 0; k < 4; ++k) d[nt][k] = __builtin_fmaf(v[k], w[k], d[nt][k]);
+            }
           }
         }
       }
