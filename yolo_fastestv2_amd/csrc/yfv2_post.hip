@@ -207,18 +207,32 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   // maximum of fl32(cls_j*obj), and a 4-step xor-shuffle picks the group's maximum with
   // the LOWEST class index among equals (= torch.max's first-index rule, utils.py:267).
   if constexpr (COMPACT) {
-    for (int n = tid; n < a.rows; n += NMS_THREADS) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(img + (size_t)n * 8 + 4);  // obj, conf, cls
-      if (t[0] > ct && t[1] > ct) {
-        const int slot = atomicAdd(&n_cand, 1);
+    // (one LDS atomic per WAVE, not per candidate: with every row a candidate - the bench's random weights - 1815
+    // atomics on one word serialise into tens of microseconds)
+    for (int n0 = 0; n0 < a.rows; n0 += NMS_THREADS) {
+      const int n = n0 + tid;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (n < a.rows) t = *reinterpret_cast<const f32x4*>(img + (size_t)n * 8 + 4);  // obj, conf, cls
+      const bool pass = n < a.rows && t[0] > ct && t[1] > ct;
+      const unsigned long long m = __ballot(pass);
+      int base = 0;
+      if ((tid & 63) == 0 && m) base = atomicAdd(&n_cand, (int)__popcll(m));
+      base = __shfl(base, 0);
+      if (pass) {
+        const int slot = base + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
         key[slot] = ((unsigned long long)__float_as_uint(t[1]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
         cls_of_row[n] = (unsigned char)(int)t[2];
       }
     }
   } else {
-  for (int n = tid; n < a.rows; n += NMS_THREADS) {
-      const float obj = img[(size_t)n * rowlen + 4];
-      if (obj > ct) cand_row[atomicAdd(&n_obj, 1)] = (unsigned short)n;
+    for (int n0 = 0; n0 < a.rows; n0 += NMS_THREADS) {
+      const int n = n0 + tid;
+      const bool pass = n < a.rows && img[(size_t)n * rowlen + 4] > ct;
+      const unsigned long long m = __ballot(pass);
+      int base = 0;
+      if ((tid & 63) == 0 && m) base = atomicAdd(&n_obj, (int)__popcll(m));
+      base = __shfl(base, 0);
+      if (pass) cand_row[base + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)n;
     }
     __syncthreads();
     {
