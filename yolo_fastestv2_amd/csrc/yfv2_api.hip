@@ -1454,6 +1454,26 @@ int yfv2_forward_u8(yfv2_handle h, const uint8_t* x, int32_t B, float* const out
   return run_plan(h, x, true, B, out6, static_cast<hipStream_t>(stream), nullptr);
 }
 
+static DecodeArgs decode_args(yfv2_handle h, const float* const out6[6], int32_t B) {
+  DecodeArgs a{};
+  for (int sc = 0; sc < 2; ++sc) {
+    a.reg[sc] = out6[sc * 3 + 0];
+    a.obj[sc] = out6[sc * 3 + 1];
+    a.cls[sc] = out6[sc * 3 + 2];
+    a.fh[sc] = h->fh[sc];
+    a.fw[sc] = h->fw[sc];
+    // utils.py:332  stride = cfg["height"] / r.shape[0]  (python float -> fp32 scalar multiply)
+    a.stride[sc] = (float)((double)h->cfg.height / (double)h->fh[sc]);
+  }
+  for (int i = 0; i < 12; ++i) a.anchors[i] = h->cfg.anchors[i];
+  a.B = B;
+  a.classes = h->cfg.classes;
+  a.rows = h->rows;
+  return a;
+}
+// handel_preds + non_max_suppression behind a forward whose logits sit in h->logits: one launch that decodes each image into
+// LDS (default), or decode_kernel<compact> + nms_kernel over candidate rows in HBM (YFV2_POSTFUSE=0, the A/B reference)
+static int post_impl(yfv2_handle h, int32_t B, float conf_thres, double iou_thres, float* dets, int32_t* idx, int32_t* count, void* stream);
 static int decode_impl(yfv2_handle h, const float* const out6[6], int32_t B, float* boxes, float* cand, void* stream);
 static int nms_impl(yfv2_handle h, const float* boxes, int compact, int32_t B, float conf_thres, double iou_thres,
                     const int32_t* classes, int32_t n_classes, float* dets, int32_t* idx, int32_t* count, void* stream);
@@ -1469,22 +1489,9 @@ static int decode_impl(yfv2_handle h, const float* const out6[6], int32_t B, flo
   for (int i = 0; i < 6; ++i)
     if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_decode: null logit tensor");
   DeviceGuard guard(h->device);
-  DecodeArgs a{};
-  for (int sc = 0; sc < 2; ++sc) {
-    a.reg[sc] = out6[sc * 3 + 0];
-    a.obj[sc] = out6[sc * 3 + 1];
-    a.cls[sc] = out6[sc * 3 + 2];
-    a.fh[sc] = h->fh[sc];
-    a.fw[sc] = h->fw[sc];
-    // utils.py:332  stride = cfg["height"] / r.shape[0]  (python float -> fp32 scalar multiply)
-    a.stride[sc] = (float)((double)h->cfg.height / (double)h->fh[sc]);
-  }
-  for (int i = 0; i < 12; ++i) a.anchors[i] = h->cfg.anchors[i];
+  DecodeArgs a = decode_args(h, out6, B);
   a.boxes = boxes;
   a.cand = cand;
-  a.B = B;
-  a.classes = h->cfg.classes;
-  a.rows = h->rows;
   yfv2_launch_decode(a, static_cast<hipStream_t>(stream));
   HIP_TRY(h, hipGetLastError());
   return YFV2_OK;
@@ -1526,10 +1533,30 @@ int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, doub
   for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
   rc = yfv2_forward(h, x, B, out6, stream);
   if (rc) return rc;
-  // compact candidate rows instead of the (B,1815,85) tensor: same arithmetic, 10x less traffic
-  rc = decode_impl(h, out6, B, nullptr, h->cand.p, stream);
-  if (rc) return rc;
-  return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
+  return post_impl(h, B, conf_thres, iou_thres, dets, idx, count, stream);
+}
+
+static int post_impl(yfv2_handle h, int32_t B, float conf_thres, double iou_thres, float* dets, int32_t* idx, int32_t* count, void* stream) {
+  if (!dets || !idx || !count) return fail(h, YFV2_ERR_ARG, "yfv2_detect: null pointer");
+  float* out6[6];
+  for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
+  static const bool fused = [] { const char* e = std::getenv("YFV2_POSTFUSE"); return !(e && e[0] == '0'); }();
+  if (!fused) {
+    // compact candidate rows instead of the (B,1815,85) tensor: same arithmetic, 10x less traffic
+    const int rc = decode_impl(h, out6, B, nullptr, h->cand.p, stream);
+    if (rc) return rc;
+    return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
+  }
+  DeviceGuard guard(h->device);
+  const DecodeArgs d = decode_args(h, out6, B);
+  NmsArgs a{};
+  a.boxes = nullptr; a.compact = 1; a.dets = dets; a.idx = idx; a.count = count;
+  a.classes = nullptr; a.n_classes = 0;
+  a.B = B; a.rows = h->rows; a.nc = h->cfg.classes;
+  a.conf_thres = conf_thres; a.iou_thres = iou_thres;
+  yfv2_launch_decode_nms(d, a, static_cast<hipStream_t>(stream));
+  HIP_TRY(h, hipGetLastError());
+  return YFV2_OK;
 }
 
 int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres, double iou_thres, float* dets, int32_t* idx,
@@ -1540,9 +1567,7 @@ int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres,
   for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
   rc = yfv2_forward_u8(h, x, B, out6, stream);
   if (rc) return rc;
-  rc = decode_impl(h, out6, B, nullptr, h->cand.p, stream);
-  if (rc) return rc;
-  return nms_impl(h, h->cand.p, 1, B, conf_thres, iou_thres, nullptr, 0, dets, idx, count, stream);
+  return post_impl(h, B, conf_thres, iou_thres, dets, idx, count, stream);
 }
 
 // enqueue only: the overflow flag is sticky in the handle until yfv2_batch_statistics_overflow reads it

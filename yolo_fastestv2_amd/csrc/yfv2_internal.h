@@ -329,3 +329,4 @@ size_t yfv2_resize_lds_bytes(int SW, int W);
 void yfv2_launch_resize(const ResizeArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);
+void yfv2_launch_decode_nms(const DecodeArgs& d, const NmsArgs& a, hipStream_t s);   // yfv2_detect: decode + NMS in one launch

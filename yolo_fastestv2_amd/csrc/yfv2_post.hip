@@ -9,6 +9,80 @@
 // fp32 sigmoid as ATen's CPU kernel evaluates it: 1 / (1 + exp(-x)), true division
 __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
 
+// One compact candidate row (cx, cy, w, h | obj, conf, class, 0) of image b, scale sc, grid cell `cell`, anchor `part`
+// (part 3 of a cell's 4-lane group only helps with the softmax).  Called by 4 consecutive lanes per cell with `cc` = the
+// cell clamped into the map, so that the group's shuffles stay convergent; the result is meaningful for ok && part < 3.
+// Arithmetic = handel_preds (utils/utils.py:303-358) followed by the first two steps of non_max_suppression
+// (conf = max_j fl32(cls_j * obj) with the FIRST maximal j, :261,267), SURVEY.md App. B.
+__device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int sc, int cc, int part, f32x4& r0, f32x4& r1) {
+  const int fh = a.fh[sc], fw = a.fw[sc], hw = fh * fw;
+  const int nc = a.classes;
+  constexpr int MAXPER = 24;  // >= ceil(classes / 4), classes <= 93
+  const int per = (nc + 3) >> 2;
+  const int c_lo = part * per, c_hi = min(nc, c_lo + per);
+  const float* cls = a.cls[sc] + (size_t)b * nc * hw + cc;
+  // Three sweeps over the lane's class slice (max, sum, best product) that re-read the logits (L1 hits) instead of
+  // keeping 24 logits and 24 probabilities in registers: this runs inside the 1024-thread NMS workgroup (128 registers).
+  // Every value is computed by the same expression as in decode_kernel<false>, so the results are identical.
+  auto logit = [&](int i) { const int c = c_lo + i; return cls[(size_t)(c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw]; };   // masked slots re-read a valid class
+  float m = -INFINITY;
+#pragma unroll 4
+  for (int i = 0; i < MAXPER; ++i) {
+    const float v = logit(i);
+    if (c_lo + i < c_hi) m = fmaxf(m, v);
+  }
+  m = fmaxf(m, __shfl_xor(m, 1));
+  m = fmaxf(m, __shfl_xor(m, 2));
+  float sum = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < MAXPER; ++i) {
+    const float v = logit(i);
+    if (c_lo + i < c_hi) sum = __fadd_rn(sum, expf(__fsub_rn(v, m)));
+  }
+  sum = __fadd_rn(sum, __shfl_xor(sum, 1));
+  sum = __fadd_rn(sum, __shfl_xor(sum, 2));
+  float obj3[3], best[3];
+  int bj[3];
+#pragma unroll
+  for (int an = 0; an < 3; ++an) {
+    obj3[an] = sigmoid_f32(a.obj[sc][((size_t)b * 3 + an) * hw + cc]);
+    best[an] = -INFINITY;
+    bj[an] = 0x7fffffff;
+  }
+#pragma unroll 4
+  for (int i = 0; i < MAXPER; ++i) {
+    const float v = logit(i);
+    if (c_lo + i < c_hi) {
+      const float ev = __fdiv_rn(expf(__fsub_rn(v, m)), sum);   // the class probability, as decode_kernel<false> stores it
+#pragma unroll
+      for (int an = 0; an < 3; ++an) {
+        const float pj = __fmul_rn(ev, obj3[an]);
+        if (pj > best[an]) { best[an] = pj; bj[an] = c_lo + i; }  // strict: first maximal index of this slice
+      }
+    }
+  }
+#pragma unroll
+  for (int an = 0; an < 3; ++an)
+#pragma unroll
+    for (int msk = 1; msk < 4; msk <<= 1) {
+      const float ob_ = __shfl_xor(best[an], msk);
+      const int oi = __shfl_xor(bj[an], msk);
+      if (ob_ > best[an] || (ob_ == best[an] && oi < bj[an])) { best[an] = ob_; bj[an] = oi; }
+    }
+  const int an = part < 3 ? part : 0;
+  const int y = cc / fw, x = cc - y * fw;
+  const float* reg = a.reg[sc] + ((size_t)b * 12 + an * 4) * hw + cc;
+  const float t0 = reg[0], t1 = reg[(size_t)hw], t2 = reg[(size_t)2 * hw], t3 = reg[(size_t)3 * hw];
+  const float ob = a.obj[sc][((size_t)b * 3 + an) * hw + cc];
+  const float st = a.stride[sc];
+  const float qw = __fmul_rn(sigmoid_f32(t2), 2.0f), qh = __fmul_rn(sigmoid_f32(t3), 2.0f);
+  r0 = (f32x4){__fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t0), 2.0f), 0.5f), (float)x), st),
+               __fmul_rn(__fadd_rn(__fsub_rn(__fmul_rn(sigmoid_f32(t1), 2.0f), 0.5f), (float)y), st),
+               (float)((double)__fmul_rn(qw, qw) * a.anchors[(sc * 3 + an) * 2 + 0]),
+               (float)((double)__fmul_rn(qh, qh) * a.anchors[(sc * 3 + an) * 2 + 1])};
+  r1 = (f32x4){sigmoid_f32(ob), part == 0 ? best[0] : (part == 1 ? best[1] : best[2]), (float)(part == 0 ? bj[0] : (part == 1 ? bj[1] : bj[2])), 0.f};
+}
+
 // ============================================================================
 // decode  (handel_preds)
 // ============================================================================
@@ -90,39 +164,13 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
   const size_t row0 = (size_t)b * a.rows + (sc ? 3 * a.fh[0] * a.fw[0] : 0) + (size_t)cell0 * 3;
 
   if constexpr (COMPACT) {
-    // yfv2_detect path, all in registers (no LDS -> full occupancy): emit only what NMS consumes -
-    // box, obj, conf = max_j fl32(cls_j*obj) with the FIRST maximal j (utils.py:261,267) and the
-    // class - as one 32-byte row; the 85-wide tensor (617 KB/image) is never written.  Every lane
-    // scans its class slice for each of the 3 anchors, a 4-lane xor-shuffle picks the maximum
-    // with the lowest class index among equals (slices ascend with the lane).
-    float best[3];
-    int bj[3];
-#pragma unroll
-    for (int an = 0; an < 3; ++an) {
-      const float obj = sigmoid_f32(a.obj[sc][((size_t)b * 3 + an) * hw + cc]);
-      float bv = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int i = 0; i < MAXPER; ++i)
-        if (c_lo + i < c_hi) {
-          const float pj = __fmul_rn(ev[i], obj);
-          if (pj > bv) { bv = pj; bi = c_lo + i; }  // strict: first maximal index of this slice
-        }
-#pragma unroll
-      for (int msk = 1; msk < 4; msk <<= 1) {
-        const float ob_ = __shfl_xor(bv, msk);
-        const int oi = __shfl_xor(bi, msk);
-        if (ob_ > bv || (ob_ == bv && oi < bi)) { bv = ob_; bi = oi; }
-      }
-      best[an] = bv;
-      bj[an] = bi;
-    }
+    // compact candidate rows (8 floats) instead of the 85-wide tensor: what the two-launch form of yfv2_detect consumes
+    f32x4 r0, r1;
+    yfv2_compact_row(a, b, sc, cc, part, r0, r1);
     if (ok && part < 3) {
-      float o[5];
-      box_of(part, o);
       float* d = a.cand + (row0 + (size_t)lc * 3 + part) * 8;
-      *reinterpret_cast<f32x4*>(d) = (f32x4){o[0], o[1], o[2], o[3]};
-      *reinterpret_cast<f32x4*>(d + 4) = (f32x4){o[4], best[part], (float)bj[part], 0.f};
+      *reinterpret_cast<f32x4*>(d) = r0;
+      *reinterpret_cast<f32x4*>(d + 4) = r1;
     }
   } else {
     float* srow = stage + (size_t)lc * 3 * rowlen;
@@ -183,8 +231,13 @@ constexpr int NMS_NQ = NMS_THREADS / 64;  // thread groups per 64-candidate chun
 constexpr int NMS_CAP = 2048;      // >= rows (1815); power of two for the bitonic network
 constexpr int NMS_MAX_DET = 300;   // utils/utils.py:243 (== YFV2_MAX_DET)
 
-template <bool COMPACT>
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
+// SRC 0: the (B, rows, 5 + classes) decoded tensor (yfv2_nms); 1: compact candidate rows in global memory (decode_kernel<true>);
+// 2: the logits themselves - the workgroup decodes its image into compact rows in LDS first (yfv2_detect: one launch for
+// handel_preds + non_max_suppression, the candidate rows never exist in HBM)
+template <int SRC>
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a, DecodeArgs dec) {
+  constexpr bool COMPACT = SRC >= 1;
+  extern __shared__ __attribute__((aligned(16))) float crow[];   // SRC == 2: [rows][8]
   __shared__ unsigned long long key[NMS_CAP], key2[NMS_CAP];   // key2: second exchange buffer of the sort
   __shared__ float bx1[NMS_CAP], by1[NMS_CAP], bx2[NMS_CAP], by2[NMS_CAP], area[NMS_CAP];
   __shared__ unsigned char supp[NMS_CAP];
@@ -195,8 +248,27 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
 
   const int tid = threadIdx.x, b = blockIdx.x;
   const int rowlen = COMPACT ? 8 : 5 + a.nc;  // COMPACT rows: cx,cy,w,h,obj,conf,cls,0 (decode_kernel<true>)
-  const float* img = a.boxes + (size_t)b * a.rows * rowlen;
+  const float* img = SRC == 2 ? crow : a.boxes + (size_t)b * a.rows * rowlen;
   const float ct = a.conf_thres;
+  if constexpr (SRC == 2) {
+    // decode this image: 4 lanes per grid cell (yfv2_compact_row), 256 cells per pass over the workgroup
+    for (int sc = 0; sc < 2; ++sc) {
+      const int hw = dec.fh[sc] * dec.fw[sc];
+      const int row_base = sc ? 3 * dec.fh[0] * dec.fw[0] : 0;
+      for (int c0 = 0; c0 < hw; c0 += NMS_THREADS / 4) {
+        const int cell = c0 + (tid >> 2), part = tid & 3;
+        const bool ok = cell < hw;
+        f32x4 r0, r1;
+        yfv2_compact_row(dec, b, sc, ok ? cell : hw - 1, part, r0, r1);
+        if (ok && part < 3) {
+          float* d = crow + (size_t)(row_base + cell * 3 + part) * 8;
+          *reinterpret_cast<f32x4*>(d) = r0;
+          *reinterpret_cast<f32x4*>(d + 4) = r1;
+        }
+      }
+    }
+    __syncthreads();
+  }
   unsigned short* cand_row = reinterpret_cast<unsigned short*>(bx1);  // step 1 only; bx1 is written in step 3
   if (tid == 0) { n_cand = 0; n_keep = 0; n_obj = 0; }
   __syncthreads();
@@ -339,9 +411,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
   // iou(i, j) > thr;  (c) wave 0 walks the chunk in order with scalar bit operations -
   // 3 barriers per 64 candidates instead of one per kept box.  Stops at max_det kept
   // (the reference truncates the full greedy result to its first 300: same rows).
+  // (boxes of different classes sit 4096 apart: their x intervals never meet.  Then w = 0, inter = 0 or NaN and the IoU is
+  // not above any threshold >= 0 - decided after four LDS reads instead of ten and a division)
+  const bool thr_nonneg = a.iou_thres >= 0.0;
   auto overlaps = [&](int i, int j) -> bool {
-    const float xx1 = fmaxf(bx1[i], bx1[j]), yy1 = fmaxf(by1[i], by1[j]);
-    const float xx2 = fminf(bx2[i], bx2[j]), yy2 = fminf(by2[i], by2[j]);
+    const float xx1 = fmaxf(bx1[i], bx1[j]), xx2 = fminf(bx2[i], bx2[j]);
+    if (thr_nonneg && !(xx2 > xx1)) return false;
+    const float yy1 = fmaxf(by1[i], by1[j]), yy2 = fminf(by2[i], by2[j]);
     const float w = fmaxf(0.0f, __fsub_rn(xx2, xx1)), h = fmaxf(0.0f, __fsub_rn(yy2, yy1));
     const float inter = __fmul_rn(w, h);
     const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area[i], area[j]), inter));  // i = kept box
@@ -406,10 +482,25 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a) {
 }
 
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s) {
+  const DecodeArgs none{};
   if (a.compact)
-    hipLaunchKernelGGL(nms_kernel<true>, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
+    hipLaunchKernelGGL(nms_kernel<1>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
   else
-    hipLaunchKernelGGL(nms_kernel<false>, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
+    hipLaunchKernelGGL(nms_kernel<0>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+}
+
+// handel_preds + non_max_suppression of yfv2_detect as ONE launch: a.boxes is unused, the rows are decoded into LDS
+void yfv2_launch_decode_nms(const DecodeArgs& d, const NmsArgs& a, hipStream_t s) {
+  // 85 KB of static LDS (sort keys, box arrays, masks) + up to 64 KB of candidate rows: the dynamic part's cap is what
+  // is left of the CU's 160 KB, not 160 KB (yfv2_allow_full_lds would be refused)
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+  if (!(done.load() & (1ull << dev))) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CAP * 8 * (int)sizeof(float));
+    done.fetch_or(1ull << dev);
+  }
+  hipLaunchKernelGGL(nms_kernel<2>, dim3(a.B), dim3(NMS_THREADS), (size_t)a.rows * 8 * sizeof(float), s, a, d);
 }
 
 // ============================================================================
