@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_DWPW = 9, STEP_S1X2 = 10, STEP_S1CHAIN = 11 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_DWPW = 9, STEP_S1X2 = 10, STEP_S1CHAIN = 11, STEP_S1POOL = 12 };
 
 struct Step {
   int kind = 0;
@@ -76,6 +76,8 @@ struct yfv2_ctx {
   bool stem_pp = false;     // the stem writes pair planes [12][H/4][W/4][2] (consumed by s2px_kernel)
   int s2_label[48] = {0};   // logical channel stored in slot 2*pair + element
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
+  bool bf6 = true;          // pointwise convs on the bf16 matrix cores where a kernel has that form (YFV2_BF6=0 at create time: fp32 MFMA)
+  bool postfuse = true;     // yfv2_detect: decode + NMS as one launch (YFV2_POSTFUSE=0 at create time: two launches)
   bool c2_permuted = false; // stage 3's output (C2) is stored in the chain kernel's order:
   int c2_label[96] = {0};   //   physical channel position k holds logical channel c2_label[k]
   Buf logits[6];
@@ -878,6 +880,52 @@ struct PlanBuilder {
     h->plan.push_back(s);
   }
 
+  // ---- a chain of stride-1 blocks with the whole activation resident in LDS (block_s1pool_kernel, yfv2_block.hip): natural
+  // channel order, so the only host work is cutting every block's filters into the three 32-channel passes the kernel runs:
+  // per pass W1 rows 32 t .. +31 (fragment-major [2][6][64][4]) | W2 columns 32 t .. +31 ([6][2][64][4]) | depthwise taps
+  // [9][32] | sc1 sh1 scd shd [32] | sc2 sh2 [96]
+  void s1pool_block(const std::vector<std::string>& names, int c, int H, int W, const Buf& x, const Buf& y) {
+    const int c2 = c / 2, NB = (int)names.size();
+    std::vector<float> im;
+    for (int k = 0; k < NB && ok; ++k) {
+      Folded f1, fd, f2;
+      ok &= wp.pw(names[k] + ".branch_main.0", names[k] + ".branch_main.1", c2, c2, &f1);
+      ok &= wp.dw(names[k] + ".branch_main.3", names[k] + ".branch_main.4", c2, 3, &fd);
+      ok &= wp.pw(names[k] + ".branch_main.5", names[k] + ".branch_main.6", c2, c2, &f2);
+      if (!ok) break;
+      const float* w1 = &wp.blob[f1.w]; const float* w2 = &wp.blob[f2.w]; const float* wd = &wp.blob[fd.w];
+      for (int t = 0; t < 3; ++t) {
+        const size_t start = im.size();
+        for (int mt = 0; mt < 2; ++mt)
+          for (int s = 0; s < 6; ++s)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 4; ++j) im.push_back(w1[(size_t)(32 * t + 16 * mt + (l & 15)) * c2 + 16 * s + 4 * (l >> 4) + j]);
+        for (int mt = 0; mt < 6; ++mt)
+          for (int s = 0; s < 2; ++s)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 4; ++j) im.push_back(w2[(size_t)(16 * mt + (l & 15)) * c2 + 32 * t + 16 * s + 4 * (l >> 4) + j]);
+        for (int tap = 0; tap < 9; ++tap)
+          for (int ch = 0; ch < 32; ++ch) im.push_back(wd[(size_t)tap * c2 + 32 * t + ch]);
+        for (const size_t* v : {&f1.scale, &f1.shift, &fd.scale, &fd.shift})
+          for (int ch = 0; ch < 32; ++ch) im.push_back(wp.blob[*v + 32 * t + ch]);
+        for (int ch = 0; ch < c2; ++ch) im.push_back(wp.blob[f2.scale + ch]);
+        for (int ch = 0; ch < c2; ++ch) im.push_back(wp.blob[f2.shift + ch]);
+        if ((int)(im.size() - start) != yfv2_s1pool_image_floats()) ok = false;
+      }
+    }
+    Step s;
+    s.kind = STEP_S1POOL;
+    s.c2 = c2;
+    s.s1.in = x.p; s.s1.out = y.p;
+    s.s1.H = H; s.s1.W = W; s.s1.R = H; s.s1.nblk = NB;
+    s.img_off = wp.put(im);
+    s.name = names.front() + " .. " + names.back().substr(names.back().rfind('.') + 1) + " chain of " + std::to_string(NB) +
+             " fused s1 blocks in one launch (whole activation resident in LDS)";
+    s.flops = NB * 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
+    s.bytes = NB * 4.0 * H * W * (2.0 * c);
+    h->plan.push_back(s);
+  }
+
   void block_s1(const std::string& p, int c, int H, int W, const Buf& x, const Buf& y) {
     Folded f;
     const int c2 = c / 2;
@@ -1021,6 +1069,12 @@ struct PlanBuilder {
           s1chain_block(names, cout, hh, ww, *x, *y, h->c2_label);     // blocks 1..7 of the stage as one launch
           h->c2_permuted = ok;
           i = repeats[si] - 1;
+        } else if (const char* envf4 = std::getenv("YFV2_FUSED"); !(envf4 && envf4[0] == '0') && i == 1 && si == 2 &&
+                   yfv2_s1pool_supported(cout / 2, hh, ww)) {
+          std::vector<std::string> names;
+          for (int q = 1; q < repeats[si]; ++q) names.push_back("backbone.stage" + std::to_string(si + 2) + "." + std::to_string(q));
+          s1pool_block(names, cout, hh, ww, *x, *y);                     // stage 4's blocks 1..3 as one launch
+          i = repeats[si] - 1;
         } else if (const char* envf2 = std::getenv("YFV2_FUSED"); !(envf2 && envf2[0] == '0') && i + 1 < repeats[si] &&
                    yfv2_s1x2_supported(cout / 2, hh, ww) && yfv2_block_s1_rows(cout / 2, hh, ww) == hh) {
           const std::string pnext = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i + 1);
@@ -1087,6 +1141,7 @@ std::string step_kernel(const Step& st) {
     case STEP_DWPW: return "dwpw_s2_kernel";
     case STEP_S1X2: return "block_s1x2_kernel";
     case STEP_S1CHAIN: return "block_s1chain_kernel";
+    case STEP_S1POOL: return "block_s1pool_kernel";
   }
   return "?";
 }
@@ -1123,6 +1178,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       PwArgs a = st.pw;
       a.P = B * st.px_per_img;
       a.img = params + st.img_off;
+      a.bf6 = h->bf6 ? 1 : 0;
       if (st.mode == PW_HEAD) {
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
@@ -1133,6 +1189,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       BlockS2Args a = st.s2;
       a.B = B;
       a.img = params + st.img_off;
+      a.bf6 = h->bf6 ? 1 : 0;
       if (!yfv2_launch_block_s2(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused stride-2 kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_TOWER) {
@@ -1142,6 +1199,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.has_head = st.has_head ? 1 : 0;
       a.nchw0 = nullptr; a.nchw1 = nullptr;
       a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
+      a.bf6 = h->bf6 ? 1 : 0;
       if (st.has_head) {
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
@@ -1155,6 +1213,13 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
       if (!yfv2_launch_block_s1x2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no two-block kernel for step '" + st.name + "'");
+    } else if (st.kind == STEP_S1POOL) {
+      BlockS1Args a = st.s1;
+      a.B = B;
+      a.img = params + st.img_off;
+      a.trace = nullptr;
+      if (!yfv2_launch_block_s1pool(a, s))
+        return fail(h, YFV2_ERR_CONFIG, "no pool-chain kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S1CHAIN) {
       BlockS1Args a = st.s1;
       a.B = B;
@@ -1292,6 +1357,8 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     yfv2_destroy(h);
     return rc;
   }
+  if (const char* e = std::getenv("YFV2_BF6")) h->bf6 = !(e[0] == '0');
+  if (const char* e = std::getenv("YFV2_POSTFUSE")) h->postfuse = !(e[0] == '0');
   if (const char* tr = std::getenv("YFV2_TRACE"))
     if (tr[0] == '1') { if (const char* ts = std::getenv("YFV2_TRACE_STEP")) h->trace_step = std::atoi(ts); (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
   *out = h;
@@ -1540,8 +1607,7 @@ static int post_impl(yfv2_handle h, int32_t B, float conf_thres, double iou_thre
   if (!dets || !idx || !count) return fail(h, YFV2_ERR_ARG, "yfv2_detect: null pointer");
   float* out6[6];
   for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
-  static const bool fused = [] { const char* e = std::getenv("YFV2_POSTFUSE"); return !(e && e[0] == '0'); }();
-  if (!fused) {
+  if (!h->postfuse) {
     // compact candidate rows instead of the (B,1815,85) tensor: same arithmetic, 10x less traffic
     const int rc = decode_impl(h, out6, B, nullptr, h->cand.p, stream);
     if (rc) return rc;

@@ -1230,6 +1230,217 @@ static void launch_s1w(const BlockS1Args& a, hipStream_t s) {
   hipLaunchKernelGGL((block_s1w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
 }
 
+// ============================================================================
+// A chain of stride-1 blocks with the WHOLE activation resident in LDS (C2 = 96, maps up to 128 pixels): stage 4's blocks 1..3
+// ============================================================================
+// Reference: N consecutive ShuffleV2Block(stride 1) at 192 channels (shufflenetv2.py:19-32,48-51,57-63).  An 11x11x192
+// image is 93 KB: it fits one CU's LDS whole, in the reference's own channel order, so the chain needs no channel
+// bookkeeping at all: per block
+//   pw1 reads the ODD channels of the pool (two 16-byte reads per lane and chunk, odd elements kept), in three passes of
+//   32 output channels each (the filters do not fit next to the pool: every pass brings its own 27 KB image - 32 rows of
+//   W1, 32 columns of W2, their taps and BN vectors - prefetched into registers during the pass before);
+//   a pass's pw1 output (+BN+ReLU) goes to a small zero-bordered tile T[13][13][32], the depthwise 3x3 (+BN) is formed in
+//   registers from it as the MFMA B fragment and multiplied into the pw2 accumulators (K split over the passes);
+//   after the third pass the accumulators (+BN+ReLU) are the block's 96 fresh channels; the pool is then rewritten in place
+//   to cat(even channels, fresh) = the next block's input (evens gathered through registers between two barriers).
+// One wave = one 16-pixel tile (8 waves, 121 pixels).  Per image: one coalesced read and one coalesced write of the
+// activation instead of three of each, one launch instead of three.
+constexpr int P96_C2 = 96, P96_C = 192, P96_KC = 6, P96_TH = 3, P96_TC = 32;     // thirds of 32 channels = 2 M tiles = 2 chunks
+constexpr int P96_CPP = P96_C + 4;                                               // floats per pool pixel
+constexpr int P96_TP = P96_TC + 4;                                               // floats per T pixel
+constexpr int P96_W1_FL = 2 * P96_KC * 256, P96_W2_FL = P96_KC * 2 * 256;        // fragment-major, per third
+constexpr int P96_IMG_FL = P96_W1_FL + P96_W2_FL + 9 * P96_TC + 4 * P96_TC + 2 * P96_C2;   // + taps, sc1 sh1 scd shd, sc2 sh2
+constexpr int P96_MAXPX = 128;
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a) {
+  constexpr int NW = THREADS / 64;
+  constexpr int N4 = P96_IMG_FL / 4, NIT = (N4 + THREADS - 1) / THREADS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* POOL = lds;                                   // [P96_MAXPX][P96_CPP]
+  float* T = POOL + P96_MAXPX * P96_CPP;               // [(H+2)][(W+2)][P96_TP], border zero
+  float* IMG = T + (a.H + 2) * (a.W + 2) * P96_TP;     // one third's image
+  const int H = a.H, W = a.W, HW = H * W, WP = W + 2, NB = a.nblk;
+  const float invW = 1.0f / (float)W;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int px = 16 * wave + p;
+  const bool pv = px < HW;
+  const int pxc = pv ? px : HW - 1;
+  const int py = yfv2_fdiv(pxc, invW), pxx = pxc - py * W;
+  float* tpix = T + ((py + 1) * WP + pxx + 1) * P96_TP;            // this lane's pixel in T
+  const float* twin = T + (py * WP + pxx) * P96_TP;                // top-left of its 3x3 window
+  float* ppix = POOL + pxc * P96_CPP;
+  static_assert(NW * 16 >= P96_MAXPX, "one tile per wave");
+
+  for (int i = tid; i < (H + 2) * WP * P96_TP / 4; i += THREADS) reinterpret_cast<f32x4*>(T)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // ---- the image into the pool (coalesced 16-byte copy), the first third's filters into IMG
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.in + (size_t)b * HW * P96_C);
+      for (int i = tid; i < HW * (P96_C / 4); i += THREADS) {
+        const int ipx = i / (P96_C / 4), q = i - ipx * (P96_C / 4);
+        *reinterpret_cast<f32x4*>(POOL + ipx * P96_CPP + 4 * q) = src[i];
+      }
+      const f32x4* isrc = reinterpret_cast<const f32x4*>(a.img);
+      for (int i = tid; i < N4; i += THREADS) reinterpret_cast<f32x4*>(IMG)[i] = isrc[i];
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int blk = 0; blk < NB; ++blk) {
+      f32x4 acc2[P96_KC];
+#pragma unroll
+      for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int th = 0; th < P96_TH; ++th) {
+        const int t = blk * P96_TH + th;
+        const bool more = t + 1 < NB * P96_TH;
+        const float* W1t = IMG;
+        const float* W2t = IMG + P96_W1_FL;
+        const float* TAPS = W2t + P96_W2_FL;           // [9][32]
+        const float* CSV = TAPS + 9 * P96_TC;          // sc1 sh1 scd shd [32] | sc2 sh2 [96]
+        // the next third's image travels through registers while this one computes
+        f32x4 nimg[NIT];
+        {
+          const f32x4* isrc = reinterpret_cast<const f32x4*>(a.img + (size_t)(t + 1) * P96_IMG_FL);
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; nimg[k] = (more && i < N4) ? isrc[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+        // ---- pw1 (+BN+ReLU): output channels 32 th .. +31 of the branch, K = the 96 odd channels of the pool
+        {
+          f32x4 acc1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int s2 = 0; s2 < P96_KC; ++s2) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(ppix + 32 * s2 + 8 * g);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(ppix + 32 * s2 + 8 * g + 4);
+            const f32x4 bf = {q0[1], q0[3], q1[1], q1[3]};               // branch inputs 16 s2 + 4 g .. +3 = odd pool channels
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(W1t + ((0 * P96_KC + s2) * 64 + lane) * 4);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(W1t + ((1 * P96_KC + s2) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bf[j], acc1[0], 0, 0, 0);
+              acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bf[j], acc1[1], 0, 0, 0);
+            }
+          }
+          if (pv) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(CSV + 0 * P96_TC + 16 * mt + 4 * g);
+              const f32x4 sh = *reinterpret_cast<const f32x4*>(CSV + 1 * P96_TC + 16 * mt + 4 * g);
+              f32x4 y;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) { const float u = __builtin_fmaf(acc1[mt][c], sc[c], sh[c]); y[c] = u > 0.f ? u : 0.f; }
+              *reinterpret_cast<f32x4*>(tpix + 16 * mt + 4 * g) = y;
+            }
+          }
+        }
+        __syncthreads();   // the depthwise windows reach into the neighbours' pixels
+        // ---- dw3x3 (+BN) in registers -> pw2 partial sums over this third's 32 input channels
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const int cb = 16 * c2 + 4 * g;
+          f32x4 win[9], wl[9], af[P96_KC];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            win[k] = *reinterpret_cast<const f32x4*>(twin + ((k / 3) * WP + (k % 3)) * P96_TP + cb);
+            wl[k] = *reinterpret_cast<const f32x4*>(TAPS + k * P96_TC + cb);
+          }
+          const f32x4 dsc = *reinterpret_cast<const f32x4*>(CSV + 2 * P96_TC + cb);
+          const f32x4 dsh = *reinterpret_cast<const f32x4*>(CSV + 3 * P96_TC + cb);
+#pragma unroll
+          for (int mt = 0; mt < P96_KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2t + ((mt * 2 + c2) * 64 + lane) * 4);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
+#pragma unroll
+          for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], dsc[c], dsh[c]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], acc2[mt], 0, 0, 0);
+        }
+        if (th == P96_TH - 1) {                         // pw2's BN + ReLU (the vectors leave with this image)
+#pragma unroll
+          for (int mt = 0; mt < P96_KC; ++mt) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(CSV + 4 * P96_TC + 16 * mt + 4 * g);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(CSV + 4 * P96_TC + P96_C2 + 16 * mt + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float u = __builtin_fmaf(acc2[mt][c], sc[c], sh[c]); acc2[mt][c] = u > 0.f ? u : 0.f; }
+          }
+        }
+        __syncthreads();   // T and IMG are free
+        if (more) {
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) reinterpret_cast<f32x4*>(IMG)[i] = nimg[k]; }
+        }
+        if (th < P96_TH - 1) __syncthreads();            // (after the last third the barriers of the pool rewrite follow)
+      }
+      // ---- pool <- cat(even channels, fresh): evens gathered through registers between two barriers
+      {
+        constexpr int NQ = P96_C2 / 4;                  // 24 output quads of pass-through channels per pixel
+        constexpr int NEV = (P96_MAXPX * NQ + THREADS - 1) / THREADS;
+        f32x4 ev[NEV];
+#pragma unroll
+        for (int k = 0; k < NEV; ++k) {
+          const int i = tid + k * THREADS;
+          const int ipx = i / NQ, q = i - ipx * NQ;
+          ev[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (ipx < HW) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(POOL + ipx * P96_CPP + 8 * q);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(POOL + ipx * P96_CPP + 8 * q + 4);
+            ev[k] = (f32x4){q0[0], q0[2], q1[0], q1[2]};
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NEV; ++k) {
+          const int i = tid + k * THREADS;
+          const int ipx = i / NQ, q = i - ipx * NQ;
+          if (ipx < HW) *reinterpret_cast<f32x4*>(POOL + ipx * P96_CPP + 4 * q) = ev[k];
+        }
+        if (pv) {
+#pragma unroll
+          for (int mt = 0; mt < P96_KC; ++mt) *reinterpret_cast<f32x4*>(ppix + P96_C2 + 16 * mt + 4 * g) = acc2[mt];
+        }
+        __syncthreads();
+      }
+    }
+    // ---- the pool out (coalesced), then the barrier that frees it for the next image
+    {
+      f32x4* dst = reinterpret_cast<f32x4*>(a.out + (size_t)b * HW * P96_C);
+      for (int i = tid; i < HW * (P96_C / 4); i += THREADS) {
+        const int ipx = i / (P96_C / 4), q = i - ipx * (P96_C / 4);
+        dst[i] = *reinterpret_cast<const f32x4*>(POOL + ipx * P96_CPP + 4 * q);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static long s1pool_lds_floats(int H, int W) { return (long)P96_MAXPX * P96_CPP + (long)(H + 2) * (W + 2) * P96_TP + P96_IMG_FL; }
+int yfv2_s1pool_image_floats() { return P96_IMG_FL; }
+
+bool yfv2_s1pool_supported(int c2, int H, int W) {
+  if (c2 != P96_C2 || H * W > P96_MAXPX || H * W < 1) return false;
+  if (s1pool_lds_floats(H, W) * 4 > 160 * 1024) return false;
+  const char* env = std::getenv("YFV2_S4CHAIN");
+  return !(env && env[0] == '0');
+}
+
+bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s) {
+  if (!yfv2_s1pool_supported(P96_C2, a.H, a.W) || a.nblk < 1) return false;
+  const size_t lds = sizeof(float) * (size_t)s1pool_lds_floats(a.H, a.W);
+  const int blocks = a.B < 256 ? a.B : 256;
+  static std::atomic<unsigned long long> lds_ok0{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1pool_kernel<512>), lds_ok0);
+  hipLaunchKernelGGL((block_s1pool_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  return true;
+}
+
 // LDS budget decides the row tile: the whole image when it fits (no halo recompute).
 int yfv2_block_s1_rows(int c2, int H, int W) {
   const int kc = (c2 + 15) / 16;
@@ -1620,7 +1831,7 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, false>), lds_ok0);
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true>), lds_ok1);
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true, true>), lds_ok2);
-  if (a.pp_in && yfv2_use_bf6()) hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true, true>), dim3(blocks), dim3(512), lds, s, a);   // pw1 on the bf16 matrix cores
+  if (a.pp_in && a.bf6) hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true, true>), dim3(blocks), dim3(512), lds, s, a);   // pw1 on the bf16 matrix cores
   else if (a.pp_in) hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true>), dim3(blocks), dim3(512), lds, s, a);
   else hipLaunchKernelGGL((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
 }
@@ -1902,7 +2113,7 @@ static void launch_tower2(const TowerArgs& a, hipStream_t s) {
                                       (size_t)16 * tw2_plane_slots(a.H, a.W));
   int blocks = a.B < 256 ? a.B : 256;
   static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
-  if (yfv2_use_bf6()) {
+  if (a.bf6) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF, true>), lds_ok1);
     hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF, true>), dim3(blocks), dim3(THREADS), lds, s, a);
     return;

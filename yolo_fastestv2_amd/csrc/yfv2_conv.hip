@@ -272,12 +272,6 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   }
 }
 
-// YFV2_BF6=0 selects the fp32 MFMA (v_mfma_f32_16x16x4_f32) in every kernel that has the bf16x6 form (A/B switch)
-bool yfv2_use_bf6() {
-  static const bool on = [] { const char* e = std::getenv("YFV2_BF6"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
 static void pw_launch(const PwArgs& a, hipStream_t s) {
   const size_t lds = (size_t)MT * 16 * K * sizeof(float);   // K/16 fragments of 256 floats + (K%16 == 8) 128 per M tile
@@ -292,7 +286,7 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   // bf16x6 for the instantiations the default plans use (the streamed large-K forms and the small biased heads); the fully
   // unrolled 6-tile forms of the layer-by-layer fallback would spill with the split operands and stay on the fp32 MFMA
   constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
-  if constexpr (kBf6) if (yfv2_use_bf6()) {
+  if constexpr (kBf6) if (a.bf6) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), lds_ok1);
     hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), dim3(blocks), dim3(THREADS), lds, s, a);
     return;

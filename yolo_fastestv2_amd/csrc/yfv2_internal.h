@@ -127,6 +127,7 @@ struct PwArgs {
   float* nchw0;        // PW_HEAD: co <  split -> nchw0[b][co][hw]
   float* nchw1;        // PW_HEAD: co >= split -> nchw1[b][co-split][hw]
   int split;
+  int bf6;             // run the MFMAs as bf16x6 where the instantiation has that form (handle flag, YFV2_BF6=0 at create time clears it)
 };
 
 // ---- depthwise kxk conv + BN (+ReLU), NHWC, float4 over channels
@@ -182,6 +183,11 @@ bool yfv2_s1x2_supported(int c2, int H, int W);
 bool yfv2_s1chain_supported(int c2, int H, int W);
 int yfv2_s1chain_image_floats();                                    // floats per block image (incl. the two int tables)
 bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s);
+// chain of stride-1 blocks with the whole 192-channel activation resident in LDS (block_s1pool_kernel, stage 4 at 11x11):
+// natural channel order, no bookkeeping; img = per block three images of yfv2_s1pool_image_floats() floats (one per third)
+bool yfv2_s1pool_supported(int c2, int H, int W);
+int yfv2_s1pool_image_floats();
+bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s);
 bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s);   // a.img = first block's LDS image | second block's
 
 // ---- fused ShuffleV2 stride-2 block (yfv2_block.hip)
@@ -196,6 +202,7 @@ struct BlockS2Args {
   int pp_in;
   unsigned pp_mask;
   long long pp_bufstride;
+  int bf6;           // pw1 as bf16x6 (pair-plane input form)
 };
 
 // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
@@ -243,6 +250,7 @@ struct TowerArgs {
   float* nchw0; float* nchw1;
   int B, H, W;
   long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (or null)
+  int bf6;           // pointwise + chained output conv as bf16x6
 };
 
 // ---- decode (handel_preds) and NMS
@@ -272,7 +280,6 @@ struct NmsArgs {
   double iou_thres;
 };
 
-bool yfv2_use_bf6();   // YFV2_BF6=0: fp32 MFMA everywhere (A/B switch), default: bf16x6 where implemented
 // launchers (defined next to the kernels)
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
 // K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
