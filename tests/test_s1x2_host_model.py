@@ -123,6 +123,7 @@ def test_two_block_step_host_packing_and_index_algebra(monkeypatch):
 
 def test_fused_depthwise_pointwise_step_host_packing(monkeypatch):
     monkeypatch.setenv("YFV2_S1CHAIN", "0")   # plain NHWC input to the 96 -> 192 block (the chain permutes C2, tests/test_s1chain_host_model.py)
+    monkeypatch.setenv("YFV2_S2W", "0")       # the plan with stage4.0 as three launches (the default fuses it: tests/test_s2w_host_model.py)
     """dwpw_s2_kernel's image (pointwise fragments | depthwise taps [9][C] | dw scale, shift | pw scale, shift) for the two
     branch tails of the 96 -> 192 block: a numpy model of dw3x3 s2 + BN -> pw + BN + ReLU reading that image, against the
     oracle's layers."""

@@ -1,0 +1,109 @@
+"""CPU check of the fused 96 -> 192 stride-2 launch (block_s2w_kernel, stage4.0): a numpy model that reads ONLY the image
+the host packed for it (W1 | W2 | Wproj | main taps | proj taps | ten BN vectors - yfv2_debug_plan_image) and the channel
+order the plan reports for the block's input (yfv2_debug_plan_c2_label: the stage-3 chain leaves C2 permuted), against the
+oracle's block.  Pins the packing and the per-input-channel re-ordering; the HIP code itself needs the GPU tests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import yolo_fastestv2_amd as yfv2
+from oracle import yfv2_oracle as oracle
+from yolo_fastestv2_amd import _lib
+from yolo_fastestv2_amd._lib import Config, TensorDesc
+
+CIN, KC = 96, 6
+W_FL = KC * KC * 256
+IMG_FL = 3 * W_FL + 2 * 9 * CIN + 10 * CIN
+
+
+def _plan(w):
+    host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point()}
+    arr = (TensorDesc * len(host))()
+    for i, (k, t) in enumerate(host.items()):
+        arr[i].name, arr[i].data, arr[i].numel = k.encode(), t.data_ptr(), t.numel()
+    cfg = Config()
+    cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = 80, 3, 352, 352, 1, 0
+    L = _lib.lib()
+    ns, nb = C.c_int32(0), C.c_int64(0)
+    assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0
+    name = C.create_string_buffer(256)
+    buf = np.zeros(IMG_FL, np.float32)
+    im = None
+    for st in range(ns.value):
+        n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st, name, 256, buf.ctypes.data_as(C.c_void_p), buf.size)
+        if n > 0 and "stage4.0 fused s2 block" in name.value.decode():
+            assert n == IMG_FL
+            im = buf.copy()
+            break
+    lab = (C.c_int32 * 96)()
+    rc = L.yfv2_debug_plan_c2_label(C.byref(cfg), arr, len(host), lab)
+    return im, rc, np.asarray(list(lab))
+
+
+def _frag_matrix(fr):
+    """fragment-major [mt][s][lane][4] -> matrix: row 16 mt + (l & 15), column 16 s + 4 (l >> 4) + j"""
+    m = np.zeros((CIN, CIN), np.float32)
+    fr = fr.reshape(KC, KC, 64, 4)
+    for mt in range(KC):
+        for s in range(KC):
+            for l in range(64):
+                m[16 * mt + (l & 15), 16 * s + 4 * (l >> 4):16 * s + 4 * (l >> 4) + 4] = fr[mt, s, l]
+    return m
+
+
+def _dw_s2(x, taps):
+    """3x3 stride-2 pad-1 depthwise on (H, W, C) with taps [9][C]"""
+    H, W, _ = x.shape
+    pad = np.zeros((H + 2, W + 2, x.shape[2]), np.float32)
+    pad[1:-1, 1:-1] = x
+    d = np.zeros((H // 2, W // 2, x.shape[2]), np.float32)
+    for k in range(9):
+        d += pad[k // 3:k // 3 + H:2, k % 3:k % 3 + W:2] * taps[k]
+    return d
+
+
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_fused_96_channel_stride2_block_host_packing(monkeypatch, chain):
+    monkeypatch.setenv("YFV2_S1CHAIN", chain)   # "1": the input arrives in the chain's channel order; "0": plain NHWC
+    w = yfv2.random_state_dict(11)
+    im, rc, lab = _plan(w)
+    if im is None:
+        pytest.skip("this build's plan has no fused 96-channel stride-2 launch")
+    assert rc == (1 if chain == "1" else 0)     # 1 = the plan permutes C2 (the chain), 0 = natural order; lab is filled either way
+    assert sorted(lab.tolist()) == list(range(96)) and np.array_equal(lab, np.arange(96)) == (chain == "0")
+    torch.manual_seed(3)
+    x = torch.randn(1, CIN, 22, 22)
+    ref = oracle._shuffle_block(w, "backbone.stage4.0", x, 2)[0].permute(1, 2, 0).numpy()
+    xin = x[0].permute(1, 2, 0).numpy()[..., lab]          # position k of the NHWC input holds logical channel lab[k]
+
+    w1, w2, wj = (_frag_matrix(im[i * W_FL:(i + 1) * W_FL]) for i in range(3))
+    o = 3 * W_FL
+    wd = im[o:o + 9 * CIN].reshape(9, CIN); o += 9 * CIN
+    we = im[o:o + 9 * CIN].reshape(9, CIN); o += 9 * CIN
+    cs = im[o:].reshape(10, CIN)                           # sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
+    proj = _dw_s2(xin, we) * cs[6] + cs[7]
+    proj = np.maximum(proj @ wj.T * cs[8] + cs[9], 0.0)
+    t1 = np.maximum(xin @ w1.T * cs[0] + cs[1], 0.0)
+    main = _dw_s2(t1, wd) * cs[2] + cs[3]
+    main = np.maximum(main @ w2.T * cs[4] + cs[5], 0.0)
+    got = np.concatenate([proj, main], -1)
+    err = np.abs(got - ref).max()
+    assert err <= 1e-4 * max(1.0, np.abs(ref).max()), "fused s2 block model vs oracle: max abs err %g" % err
+
+
+def test_band_rows_fit_the_static_bounds():
+    """the kernel's static bounds for the sizes the configuration check admits (input H, W multiples of 32 up to 352):
+    a dry run must plan every one of them (the launcher's LDS request and the staging registers are sized from R)."""
+    w = yfv2.random_state_dict(11)
+    host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point()}
+    arr = (TensorDesc * len(host))()
+    for i, (k, t) in enumerate(host.items()):
+        arr[i].name, arr[i].data, arr[i].numel = k.encode(), t.data_ptr(), t.numel()
+    L = _lib.lib()
+    for H, W in ((352, 352), (320, 320), (288, 384), (64, 96), (32, 32), (352, 32)):
+        cfg = Config()
+        cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = 80, 3, H, W, 1, 0
+        ns, nb = C.c_int32(0), C.c_int64(0)
+        assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0

@@ -485,7 +485,7 @@ struct PlanBuilder {
     Folded f;
     const int oh = H / 2, ow = W / 2, co = 2 * cin;
     const char* env = std::getenv("YFV2_FUSED");
-    const int rfused = (cin == 24 || cin == 48) ? yfv2_block_s2_rows(cin, H, W) : 0;
+    const int rfused = (cin == 24 || cin == 48 || (cin == 96 && !pp_label)) ? yfv2_block_s2_rows(cin, H, W) : 0;   // 96: block_s2w_kernel
     if (!(env && env[0] == '0') && rfused > 0) {
       Folded f1, fd, f2, fpd, fpp;
       ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fpd);
@@ -505,6 +505,10 @@ struct PlanBuilder {
         s.s2.pp_in = 1;
         s.s2.pp_bufstride = pp_bufstride;
         for (int q = 0; q < cin / 2; ++q) if (pp_buf[q]) s.s2.pp_mask |= 1u << q;
+      } else if (in_label && ok) {
+        f1 = wp.permuted_pw_inputs(f1, cin, cin, in_label);
+        fpd = wp.permuted_dw_channels(fpd, cin, 9, in_label);
+        fpp = wp.permuted_pw_inputs(fpp, cin, cin, in_label);
       }
       s.img_off = wp.image_s2(f1, fd, f2, fpd, fpp, cin);
       s.name = p + " fused s2 block: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) | cat";
@@ -1135,7 +1139,7 @@ std::string step_kernel(const Step& st) {
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_S1: return st.c2 == 48 && st.s1.R == st.s1.H ? "block_s1w_kernel" : "block_s1_kernel<" + std::to_string(st.c2) + ",";
     case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4>" : "1, 1>");
-    case STEP_S2: return "block_s2_kernel<" + std::to_string(st.c2) + ",";
+    case STEP_S2: return st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",";
     case STEP_S1PX: return "s1px_kernel";
     case STEP_S2PX: return "s2px_proj_kernel + s2px_main_kernel";
     case STEP_DWPW: return "dwpw_s2_kernel";

@@ -1805,7 +1805,7 @@ static size_t s2_lds_floats(int R, int W) {
   return (size_t)3 * Cfg::W_FL + 2 * Cfg::DW_FL + (size_t)Cfg::NCS * Cfg::KC * 16 + (size_t)(2 * R + 1) * (W + 1) * Cfg::CP + 16;
 }
 
-int yfv2_block_s2_rows(int cin, int H, int W) {
+static int yfv2_block_s2_rows_small(int cin, int H, int W) {
   const int OH = H / 2;
   int best = 0;
   for (int r = 1; r <= OH; ++r) {
@@ -1836,9 +1836,356 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
   else hipLaunchKernelGGL((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
 }
 
+// ============================================================================
+// fused stride-2 block at 96 channels (stage4.0): filters streamed through one LDS slot
+// ============================================================================
+// Same block as block_s2_kernel (proj on the raw tile, pw1 in place, main on pw1's output), re-cut for 96 channels:
+//  * three 96x96 filters (110 KB) do not fit LDS next to a tile: W1 stays resident and ONE 36.8 KB slot holds Wproj
+//    while the proj pointwise runs and W2 while the main pointwise runs.  The slot's next content is fetched into
+//    registers (five 16-byte loads per thread - L2 hits, every workgroup reads the same two filters) two phases ahead
+//    and stored after the barrier that retires the slot's readers;
+//  * a row band has only two or three 16-pixel output tiles, so the depthwise is NOT done in MFMA-fragment form by the
+//    wave that consumes it (three waves per pixel tile would each repeat it: LDS-bound): thread = (output pixel, channel
+//    quad) over the whole band, results to a small tile D, and the pointwise then runs as (pixel tile, pair of
+//    output-channel tiles) units with B fragments from D;
+//  * pw1 takes whole 16-pixel tiles, the tile's six B fragments in registers before its first write (in place without a
+//    barrier); it shares its phase with the proj pointwise, dealt to the waves from opposite ends.
+// Four phases / four barriers per band:
+//    P1  slot <- Wproj (from registers) | depthwise(proj): T1 raw -> D          | registers <- W2
+//    P2  proj pointwise: D x slot -> out[.., 0:96] | pw1 in place on T1         | registers <- next band's rows
+//    P3  slot <- W2                     | depthwise(main): T1 -> D              | registers <- Wproj
+//    P4  T1 <- next band's rows         | main pointwise: D x slot -> out[.., 96:192]
+// The input leaves HBM once and pw1's output never does: 279 KB per image instead of 836 KB for the three launches (proj
+// tail, pw1, main tail) this replaces.
+struct S2WCfg {
+  static constexpr int CIN = 96, KC = 6, CP = 100, KS = 96;
+  static constexpr int W_FL = KC * KC * 256;
+  static constexpr int DW_FL = 9 * KS;
+  static constexpr int NCS = 10;
+  static constexpr int CONST_FL = 2 * DW_FL + NCS * KS;   // WD | WE | CS
+  static constexpr int MAXP = 8;                          // staged 16-byte quads per thread (512 threads)
+  static constexpr int MPER = 2;                          // output-channel tiles per pointwise unit
+};
+
+template <int THREADS, bool BF6>
+__global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
+  using Cfg = S2WCfg;
+  constexpr int CIN = Cfg::CIN, KC = Cfg::KC, CP = Cfg::CP, KS = Cfg::KS;
+  constexpr int NW = THREADS / 64;
+  constexpr int CO = 2 * CIN;
+  constexpr int MPER = Cfg::MPER, MG = KC / MPER;
+  constexpr int QPP = CIN / 4;
+  constexpr int MAXP = Cfg::MAXP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* W1 = lds;
+  float* SL = W1 + Cfg::W_FL;       // the slot: Wproj / W2
+  float* WD = SL + Cfg::W_FL;       // main depthwise taps [9][KS]
+  float* WE = WD + Cfg::DW_FL;      // proj depthwise taps [9][KS]
+  float* CS = WE + Cfg::DW_FL;      // [10][KS]
+  float* T1 = CS + Cfg::NCS * KS;
+  const int H = a.H, W = a.W, R = a.R, OH = H >> 1, OW = W >> 1;
+  const float invW = 1.0f / (float)W, invOW = 1.0f / (float)OW;
+  const int WP = W + 1;
+  const int t1_fl = (2 * R + 1) * WP * CP + 16;
+  float* D = T1 + t1_fl;            // depthwise output of the band [R*OW][CP]
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int tiles_per_img = (OH + R - 1) / R;
+  const int n_items = a.B * tiles_per_img;
+
+  // global image (PlanBuilder::image_s2): W1 | W2 | Wproj | WD | WE | CS
+  const f32x4* gW2 = reinterpret_cast<const f32x4*>(a.img + Cfg::W_FL);
+  const f32x4* gWJ = reinterpret_cast<const f32x4*>(a.img + 2 * Cfg::W_FL);
+  constexpr int WQ4 = Cfg::W_FL / 4;                       // 2304 quads
+  constexpr int NWQ = (WQ4 + THREADS - 1) / THREADS;       // 5
+  f32x4 wq[NWQ];
+  auto slot_issue = [&](const f32x4* src) {
+#pragma unroll
+    for (int k = 0; k < NWQ; ++k) { const int i = tid + k * THREADS; wq[k] = i < WQ4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  };
+  auto slot_commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NWQ; ++k) { const int i = tid + k * THREADS; if (i < WQ4) reinterpret_cast<f32x4*>(SL)[i] = wq[k]; }
+  };
+
+  f32x4 st[MAXP];
+  auto stage_issue = [&](int item_, bool active) {  // always (re)defines every staged register
+    const int item = active ? item_ : 0;
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R, rows = min(R, OH - y0);
+    const int nq = active ? (2 * rows + 1) * W * QPP : 0;
+    const size_t in_px = (size_t)b * H * W;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      const int pix = i / QPP, q = i - pix * QPP;
+      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
+      const int gy = 2 * y0 - 1 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < nq && gy >= 0 && gy < H) v = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)gy * W + x) * CIN + 4 * q);
+      st[j] = v;
+    }
+  };
+  auto stage_commit = [&](int item) {   // rows above the image arrive as zeros; column 0 of T1 (input col -1) is never written
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R, rows = min(R, OH - y0);
+    const int nq = (2 * rows + 1) * W * QPP;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = tid + j * THREADS;
+      if (i >= nq) continue;
+      const int pix = i / QPP, q = i - pix * QPP;
+      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
+      *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = st[j];
+    }
+  };
+  stage_issue(blockIdx.x, (int)blockIdx.x < n_items);
+
+  // prologue: W1 -> W1, Wproj -> slot, taps + BN constants behind them; every load issued before the first store
+  {
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(a.img);
+    constexpr int C4 = Cfg::CONST_FL / 4;                  // 672 quads
+    constexpr int NC = (C4 + THREADS - 1) / THREADS;       // 2
+    f32x4 t1[NWQ], t2[NWQ], t3[NC];
+#pragma unroll
+    for (int k = 0; k < NWQ; ++k) {
+      const int i = tid + k * THREADS;
+      t1[k] = i < WQ4 ? g4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      t2[k] = i < WQ4 ? gWJ[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { const int i = tid + k * THREADS; t3[k] = i < C4 ? g4[3 * WQ4 + i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NWQ; ++k) {
+      const int i = tid + k * THREADS;
+      if (i < WQ4) { reinterpret_cast<f32x4*>(W1)[i] = t1[k]; reinterpret_cast<f32x4*>(SL)[i] = t2[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { const int i = tid + k * THREADS; if (i < C4) reinterpret_cast<f32x4*>(WD)[i] = t3[k]; }
+  }
+  for (int i = tid; i < t1_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // column 0 stays zero
+  __syncthreads();
+  if ((int)blockIdx.x < n_items) stage_commit(blockIdx.x);
+  __syncthreads();
+
+  // ---- depthwise 3x3 s2 (+BN) of the band: thread = (output pixel, channel quad), T1 -> D
+  auto depthwise = [&](const float* taps, const float* dsc_p, const float* dsh_p, int npxB) {
+    for (int i = tid; i < npxB * QPP; i += THREADS) {
+      const int q = i / QPP, cq = i - q * QPP;
+      const int r = yfv2_fdiv(q, invOW), x = q - r * OW;
+      const float* tp = T1 + ((2 * r) * WP + 2 * x) * CP + 4 * cq;   // window rows 2r..2r+2, T1 cols 2x..2x+2
+      f32x4 win[9], wk[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        win[k] = *reinterpret_cast<const f32x4*>(tp + ((k / 3) * WP + (k % 3)) * CP);
+        wk[k] = *reinterpret_cast<const f32x4*>(taps + k * KS + 4 * cq);
+      }
+      const f32x4 dsc = *reinterpret_cast<const f32x4*>(dsc_p + 4 * cq);
+      const f32x4 dsh = *reinterpret_cast<const f32x4*>(dsh_p + 4 * cq);
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wk[k][c], d[c]);
+      f32x4 y;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[c] = __builtin_fmaf(d[c], dsc[c], dsh[c]);
+      *reinterpret_cast<f32x4*>(D + q * CP + 4 * cq) = y;
+    }
+  };
+  // ---- pointwise (+BN+ReLU) on D with the slot's filter; unit = (16 output pixels, MPER output-channel tiles)
+  auto pointwise = [&](const float* psc_p, const float* psh_p, float* out_base, int y0, int npxB) {
+    const int ntB = (npxB + 15) >> 4;
+    for (int u = wave; u < ntB * MG; u += NW) {
+      const int t = u / MG, mg = u - t * MG;
+      const int q = 16 * t + p;
+      const bool pv = q < npxB;
+      const int qc = pv ? q : npxB - 1;
+      f32x4 bf[KC];
+#pragma unroll
+      for (int s = 0; s < KC; ++s) bf[s] = *reinterpret_cast<const f32x4*>(D + qc * CP + 16 * s + 4 * g);
+      f32x4 acc[MPER];
+#pragma unroll
+      for (int m = 0; m < MPER; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KC; ++s) {
+        f32x4 af[MPER];
+#pragma unroll
+        for (int m = 0; m < MPER; ++m) af[m] = *reinterpret_cast<const f32x4*>(SL + (((MPER * mg + m) * KC + s) * 64 + lane) * 4);
+        if constexpr (BF6) {
+          const Bf3B b3 = yfv2_split_b(bf[s]);
+          Bf3A a3[MPER];
+#pragma unroll
+          for (int m = 0; m < MPER; ++m) a3[m] = yfv2_split_a(af[m]);
+#pragma unroll
+          for (int m = 0; m < MPER; ++m) acc[m] = yfv2_mfma6_step<0>(a3[m], b3, acc[m]);
+#pragma unroll
+          for (int m = 0; m < MPER; ++m) acc[m] = yfv2_mfma6_step<1>(a3[m], b3, acc[m]);
+#pragma unroll
+          for (int m = 0; m < MPER; ++m) acc[m] = yfv2_mfma6_step<2>(a3[m], b3, acc[m]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MPER; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s][j], acc[m], 0, 0, 0);
+        }
+      }
+      const int r = yfv2_fdiv(qc, invOW), x = qc - r * OW;
+      float* dst = out_base + ((size_t)(y0 + r) * OW + x) * CO;
+#pragma unroll
+      for (int m = 0; m < MPER; ++m) {
+        const int cb = 16 * (MPER * mg + m) + 4 * g;
+        if (pv) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(psc_p + cb);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(psh_p + cb);
+          f32x4 y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float v = __builtin_fmaf(acc[m][k], sc[k], sh[k]);
+            y[k] = v > 0.f ? v : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(dst + cb) = y;
+        }
+      }
+    }
+  };
+
+  bool slot_pending = false;   // registers hold the next Wproj (every band but the workgroup's first: the prologue loaded it)
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
+    const int y0 = ti * R;                 // first output row
+    const int rows = min(R, OH - y0);
+    const int iy0 = 2 * y0 - 1;            // first input row of T1
+    const int npxA = (2 * rows + 1) * W;
+    const int npxB = rows * OW;
+    float* out_img = a.out + (size_t)b * OH * OW * CO;
+
+    // ================= P1
+    if (slot_pending) slot_commit();
+    slot_issue(gW2);
+    depthwise(WE, CS + 6 * KS, CS + 7 * KS, npxB);
+    __syncthreads();
+
+    // ================= P2: proj pointwise (waves 0, 1, ..) and pw1 in place (tiles dealt from the last wave down)
+    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);
+    pointwise(CS + 8 * KS, CS + 9 * KS, out_img, y0, npxB);
+    {
+      auto tile_off = [&](int t) {
+        const int q = 16 * t + p;
+        const int qc = q < npxA ? q : npxA - 1;
+        const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
+        return (r * WP + x + 1) * CP;
+      };
+      for (int t = NW - 1 - wave; t * 16 < npxA; t += NW) {
+        const int o = tile_off(t);
+        f32x4 bf[KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) bf[s] = *reinterpret_cast<const f32x4*>(T1 + o + 16 * s + 4 * g);
+        const int q = 16 * t + p;
+        const bool valid = q < npxA;
+        const int r = yfv2_fdiv(valid ? q : 0, invW);
+        const int gy = iy0 + r;
+        const bool inimg = valid && gy >= 0 && gy < H;
+        f32x4 accA[KC];
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          f32x4 aw[KC];
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) aw[mt] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
+          if constexpr (BF6) {
+            const Bf3B b3 = yfv2_split_b(bf[s]);
+#pragma unroll
+            for (int mt = 0; mt < KC; ++mt) {
+              const Bf3A a3 = yfv2_split_a(aw[mt]);
+              accA[mt] = yfv2_mfma6_step<0>(a3, b3, accA[mt]);
+              accA[mt] = yfv2_mfma6_step<1>(a3, b3, accA[mt]);
+              accA[mt] = yfv2_mfma6_step<2>(a3, b3, accA[mt]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][j], bf[s][j], accA[mt], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one chunk's six A fragments at a time (a free schedule hoists all 36: spills)
+        }
+        float* dst = T1 + o;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) {
+          const int cb = 16 * mt + 4 * g;
+          if (valid) {
+            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(CS + 0 * KS + cb);
+            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(CS + 1 * KS + cb);
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float v = __builtin_fmaf(accA[mt][c], sc1[c], sh1[c]);
+              y[c] = (inimg && v > 0.f) ? v : 0.f;  // input row -1 is the depthwise zero padding
+            }
+            *reinterpret_cast<f32x4*>(dst + cb) = y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= P3
+    slot_commit();                         // Wproj's readers are done: the slot becomes W2
+    slot_issue(gWJ);
+    slot_pending = true;
+    depthwise(WD, CS + 2 * KS, CS + 3 * KS, npxB);
+    __syncthreads();
+
+    // ================= P4
+    if (item + (int)gridDim.x < n_items) stage_commit(item + gridDim.x);
+    pointwise(CS + 4 * KS, CS + 5 * KS, out_img + CIN, y0, npxB);
+    __syncthreads();
+  }
+}
+
+static size_t s2w_lds_floats(int R, int W) {
+  return (size_t)2 * S2WCfg::W_FL + S2WCfg::CONST_FL + (size_t)(2 * R + 1) * (W + 1) * S2WCfg::CP + 16 + (size_t)R * (W / 2) * S2WCfg::CP;
+}
+
+// rows per work item of the 96-channel kernel: the largest band that fits LDS and the staging registers and keeps pw1
+// at one tile per wave (<= 128 pixels) when any band does; 0 = not supported
+static int s2w_rows(int H, int W) {
+  const char* env = std::getenv("YFV2_S2W");
+  if (env && env[0] == '0') return 0;
+  if ((H & 1) || (W & 1)) return 0;
+  const int OH = H / 2;
+  int best = 0, best128 = 0;
+  for (int r = 1; r <= OH; ++r) {
+    if (s2w_lds_floats(r, W) * 4 > 158 * 1024) break;
+    if ((long)(2 * r + 1) * W * (S2WCfg::CIN / 4) > (long)S2WCfg::MAXP * 512) break;
+    best = r;
+    if ((2 * r + 1) * W <= 128) best128 = r;
+  }
+  return best128 ? best128 : best;
+}
+
+int yfv2_block_s2_rows(int cin, int H, int W) {
+  if (cin == 96) return s2w_rows(H, W);
+  return yfv2_block_s2_rows_small(cin, H, W);
+}
+
+static void launch_s2w(const BlockS2Args& a, hipStream_t s) {
+  const size_t lds = s2w_lds_floats(a.R, a.W) * sizeof(float);
+  const int tiles = (a.H / 2 + a.R - 1) / a.R;
+  int blocks = a.B * tiles;
+  if (blocks > 256) blocks = 256;
+  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2w_kernel<512, false>), lds_ok0);
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2w_kernel<512, true>), lds_ok1);
+  if (a.bf6) hipLaunchKernelGGL((block_s2w_kernel<512, true>), dim3(blocks), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((block_s2w_kernel<512, false>), dim3(blocks), dim3(512), lds, s, a);
+}
+
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
   if (cin == 24) { launch_s2<24>(a, s); return true; }
   if (cin == 48) { launch_s2<48>(a, s); return true; }
+  if (cin == 96 && !a.pp_in) { launch_s2w(a, s); return true; }
   return false;
 }
 
