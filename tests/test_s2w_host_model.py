@@ -1,5 +1,6 @@
 """CPU check of the fused 96 -> 192 stride-2 launch (block_s2w_kernel, stage4.0): a numpy model that reads ONLY the image
-the host packed for it (W1 | W2 | Wproj | main taps | proj taps | ten BN vectors - yfv2_debug_plan_image) and the channel
+the host packed for it (W1 pre-split into bf16 hi/mid/lo operand quads | W2 | Wproj | main taps | proj taps | ten BN vectors
+- yfv2_debug_plan_image) and the channel
 order the plan reports for the block's input (yfv2_debug_plan_c2_label: the stage-3 chain leaves C2 permuted), against the
 oracle's block.  Pins the packing and the per-input-channel re-ordering; the HIP code itself needs the GPU tests."""
 import ctypes as C
@@ -15,7 +16,8 @@ from yolo_fastestv2_amd._lib import Config, TensorDesc
 
 CIN, KC = 96, 6
 W_FL = KC * KC * 256
-IMG_FL = 3 * W_FL + 2 * 9 * CIN + 10 * CIN
+W1P_FL = KC * (KC // 2) * 3 * 256
+IMG_FL = W1P_FL + 2 * W_FL + 2 * 9 * CIN + 10 * CIN
 
 
 def _plan(w):
@@ -53,6 +55,22 @@ def _frag_matrix(fr):
     return m
 
 
+def _presplit_matrix(fr):
+    """[mt][chunk pair][term hi, mid, lo][lane][4 dwords]; dword d = two truncated bf16 (low half first) of columns
+    16 s + 4 (l >> 4) + 2 (d & 1) + {0, 1}, s = 2 sp + (d >> 1).  Returns (hi + mid + lo, hi, mid, lo) as float32 matrices."""
+    u = fr.view(np.uint32).reshape(KC, KC // 2, 3, 64, 4)
+    terms = np.zeros((3, CIN, CIN), np.float32)
+    for mt in range(KC):
+        for sp in range(KC // 2):
+            for l in range(64):
+                for d in range(4):
+                    c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1)
+                    for e in range(2):
+                        bits = ((u[mt, sp, :, l, d] >> (16 * e)) & 0xFFFF).astype(np.uint32) << 16
+                        terms[:, 16 * mt + (l & 15), c + e] = bits.view(np.float32)
+    return (terms[0] + terms[1]) + terms[2], terms
+
+
 def _dw_s2(x, taps):
     """3x3 stride-2 pad-1 depthwise on (H, W, C) with taps [9][C]"""
     H, W, _ = x.shape
@@ -78,8 +96,12 @@ def test_fused_96_channel_stride2_block_host_packing(monkeypatch, chain):
     ref = oracle._shuffle_block(w, "backbone.stage4.0", x, 2)[0].permute(1, 2, 0).numpy()
     xin = x[0].permute(1, 2, 0).numpy()[..., lab]          # position k of the NHWC input holds logical channel lab[k]
 
-    w1, w2, wj = (_frag_matrix(im[i * W_FL:(i + 1) * W_FL]) for i in range(3))
-    o = 3 * W_FL
+    w1, terms = _presplit_matrix(im[:W1P_FL])
+    folded = w["backbone.stage4.0.branch_main.0.weight"].reshape(CIN, CIN).numpy()[:, lab]
+    assert np.array_equal(w1, folded), "hi + mid + lo must reproduce the fp32 filter exactly"
+    assert all(np.array_equal(t.view(np.uint32) & 0xFFFF, np.zeros_like(t, np.uint32)) for t in terms)
+    w2, wj = (_frag_matrix(im[W1P_FL + i * W_FL:W1P_FL + (i + 1) * W_FL]) for i in range(2))
+    o = W1P_FL + 2 * W_FL
     wd = im[o:o + 9 * CIN].reshape(9, CIN); o += 9 * CIN
     we = im[o:o + 9 * CIN].reshape(9, CIN); o += 9 * CIN
     cs = im[o:].reshape(10, CIN)                           # sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp

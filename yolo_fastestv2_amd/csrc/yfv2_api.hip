@@ -289,6 +289,41 @@ struct WeightPacker {
     for (const Folded* f : {&f1, &fd, &f2, &fpd, &fpp}) { push_vec(im, &blob[f->scale], cin, KS); push_vec(im, &blob[f->shift], cin, KS); }
     return put(im);
   }
+  // block_s2w_kernel (96 channels): W1 pre-split for bf16x6 | W2 | Wproj | taps | taps | BN vectors as image_s2.
+  // W1 pre-split: an fp32 weight is the exact sum of three truncated bf16 terms (hi, mid, lo).  Per (tile of 16 output
+  // channels mt, PAIR of 16-channel chunks sp, term) one 16-byte lane quad: {term(w0),term(w1)} {term(w2),term(w3)} of chunk
+  // 2sp, then the same of chunk 2sp+1 - the A operand of one v_mfma_f32_16x16x32_bf16 whose 32 k-slots are the two chunks.
+  static unsigned bf16_trunc_bits(float v) { unsigned u; std::memcpy(&u, &v, 4); return u >> 16; }
+  static float bf16_trunc(float v) { unsigned u; std::memcpy(&u, &v, 4); u &= 0xffff0000u; float r; std::memcpy(&r, &u, 4); return r; }
+  static void push_frag_split3(std::vector<float>& im, const float* w, int M, int K, int MT, int KC) {
+    for (int mt = 0; mt < MT; ++mt)
+      for (int sp = 0; sp < KC / 2; ++sp)
+        for (int term = 0; term < 3; ++term)
+          for (int l = 0; l < 64; ++l)
+            for (int d = 0; d < 4; ++d) {
+              const int s = 2 * sp + (d >> 1);
+              const int r = 16 * mt + (l & 15), c = 16 * s + 4 * (l >> 4) + 2 * (d & 1);
+              unsigned packed = 0;
+              for (int e = 0; e < 2; ++e) {
+                float v = (r < M && c + e < K) ? w[(size_t)r * K + c + e] : 0.f;
+                for (int t = 0; t < term; ++t) v = v - bf16_trunc(v);   // exact in fp32
+                packed |= bf16_trunc_bits(v) << (16 * e);
+              }
+              float f; std::memcpy(&f, &packed, 4);
+              im.push_back(f);
+            }
+  }
+  size_t image_s2w(const Folded& f1, const Folded& fd, const Folded& f2, const Folded& fpd, const Folded& fpp) {
+    const int cin = 96, KC = 6, KS = 96;
+    std::vector<float> im;
+    push_frag_split3(im, &blob[f1.w], cin, cin, KC, KC);
+    push_frag(im, &blob[f2.w], cin, cin, KC, KC);
+    push_frag(im, &blob[fpp.w], cin, cin, KC, KC);
+    push_rows(im, &blob[fd.w], 9, cin, KS);
+    push_rows(im, &blob[fpd.w], 9, cin, KS);
+    for (const Folded* f : {&f1, &fd, &f2, &fpd, &fpp}) { push_vec(im, &blob[f->scale], cin, KS); push_vec(im, &blob[f->shift], cin, KS); }
+    return put(im);
+  }
   // tower kernels: pw [80][84] | output conv [mh16][84] | dw taps [25][80] | scd shd scp shp bias [5][96]
   size_t image_tower(const Folded& fd, const Folded& fp, const Folded* fh, int mh) {
     std::vector<float> im;
@@ -485,7 +520,7 @@ struct PlanBuilder {
     Folded f;
     const int oh = H / 2, ow = W / 2, co = 2 * cin;
     const char* env = std::getenv("YFV2_FUSED");
-    const int rfused = (cin == 24 || cin == 48 || (cin == 96 && !pp_label)) ? yfv2_block_s2_rows(cin, H, W) : 0;   // 96: block_s2w_kernel
+    const int rfused = (cin == 24 || cin == 48 || (cin == 96 && !pp_label && h->bf6)) ? yfv2_block_s2_rows(cin, H, W) : 0;   // 96: block_s2w_kernel (its pw1 is bf16x6 only)
     if (!(env && env[0] == '0') && rfused > 0) {
       Folded f1, fd, f2, fpd, fpp;
       ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fpd);
@@ -510,7 +545,7 @@ struct PlanBuilder {
         fpd = wp.permuted_dw_channels(fpd, cin, 9, in_label);
         fpp = wp.permuted_pw_inputs(fpp, cin, cin, in_label);
       }
-      s.img_off = wp.image_s2(f1, fd, f2, fpd, fpp, cin);
+      s.img_off = cin == 96 ? wp.image_s2w(f1, fd, f2, fpd, fpp) : wp.image_s2(f1, fd, f2, fpd, fpp, cin);
       s.name = p + " fused s2 block: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) | cat";
       s.flops = 2.0 * ((double)H * W * cin * cin + 2.0 * oh * ow * cin * cin + 2.0 * oh * ow * 9 * cin);
       s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * co);

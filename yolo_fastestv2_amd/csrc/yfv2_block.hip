@@ -1849,10 +1849,15 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
 //    quad) over the whole band, results to a small tile D, and the pointwise then runs as (pixel tile, pair of
 //    output-channel tiles) units with B fragments from D;
 //  * pw1 takes whole 16-pixel tiles, the tile's six B fragments in registers before its first write (in place without a
-//    barrier); it shares its phase with the proj pointwise, dealt to the waves from opposite ends.
+//    barrier); it shares its phase with the proj pointwise.  pw1 is 70 % of the block's MFMA work and runs as bf16x6
+//    (yfv2_internal.h) with W1 PRE-SPLIT on the host (WeightPacker::image_s2w): per (output tile, chunk pair, term) one
+//    16-byte operand whose 32 k-slots are the two chunks, so the six products hi.hi hi.mid mid.hi hi.lo lo.hi mid.mid are
+//    six MFMAs per chunk pair with no operand duplication and no VALU work on the filter side (splitting W1's 36
+//    fragments per tile on the fly cost more VALU time than the fp32 MFMAs it replaced: first version, 85 us).  The two
+//    streamed filters stay fp32 (a pre-split slot would not fit) and their pointwise uses the fp32 MFMA.
 // Four phases / four barriers per band:
 //    P1  slot <- Wproj (from registers) | depthwise(proj): T1 raw -> D          | registers <- W2
-//    P2  proj pointwise: D x slot -> out[.., 0:96] | pw1 in place on T1         | registers <- next band's rows
+//    P2  pw1 in place on T1 | proj pointwise: D x slot -> out[.., 0:96]         | registers <- next band's rows
 //    P3  slot <- W2                     | depthwise(main): T1 -> D              | registers <- Wproj
 //    P4  T1 <- next band's rows         | main pointwise: D x slot -> out[.., 96:192]
 // The input leaves HBM once and pw1's output never does: 279 KB per image instead of 836 KB for the three launches (proj
@@ -1860,6 +1865,7 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
 struct S2WCfg {
   static constexpr int CIN = 96, KC = 6, CP = 100, KS = 96;
   static constexpr int W_FL = KC * KC * 256;
+  static constexpr int W1P_FL = KC * (KC / 2) * 3 * 256;  // W1 pre-split: [mt][chunk pair][hi, mid, lo][64 lanes][4 dwords]
   static constexpr int DW_FL = 9 * KS;
   static constexpr int NCS = 10;
   static constexpr int CONST_FL = 2 * DW_FL + NCS * KS;   // WD | WE | CS
@@ -1867,7 +1873,7 @@ struct S2WCfg {
   static constexpr int MPER = 2;                          // output-channel tiles per pointwise unit
 };
 
-template <int THREADS, bool BF6>
+template <int THREADS>
 __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
   using Cfg = S2WCfg;
   constexpr int CIN = Cfg::CIN, KC = Cfg::KC, CP = Cfg::CP, KS = Cfg::KS;
@@ -1877,8 +1883,8 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
   constexpr int QPP = CIN / 4;
   constexpr int MAXP = Cfg::MAXP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* W1 = lds;
-  float* SL = W1 + Cfg::W_FL;       // the slot: Wproj / W2
+  float* W1 = lds;                  // pre-split (bf16 hi/mid/lo operand quads)
+  float* SL = W1 + Cfg::W1P_FL;     // the slot: Wproj / W2 (fp32 fragments)
   float* WD = SL + Cfg::W_FL;       // main depthwise taps [9][KS]
   float* WE = WD + Cfg::DW_FL;      // proj depthwise taps [9][KS]
   float* CS = WE + Cfg::DW_FL;      // [10][KS]
@@ -1892,9 +1898,9 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
   const int tiles_per_img = (OH + R - 1) / R;
   const int n_items = a.B * tiles_per_img;
 
-  // global image (PlanBuilder::image_s2): W1 | W2 | Wproj | WD | WE | CS
-  const f32x4* gW2 = reinterpret_cast<const f32x4*>(a.img + Cfg::W_FL);
-  const f32x4* gWJ = reinterpret_cast<const f32x4*>(a.img + 2 * Cfg::W_FL);
+  // global image (WeightPacker::image_s2w): W1 pre-split | W2 | Wproj | WD | WE | CS
+  const f32x4* gW2 = reinterpret_cast<const f32x4*>(a.img + Cfg::W1P_FL);
+  const f32x4* gWJ = reinterpret_cast<const f32x4*>(a.img + Cfg::W1P_FL + Cfg::W_FL);
   constexpr int WQ4 = Cfg::W_FL / 4;                       // 2304 quads
   constexpr int NWQ = (WQ4 + THREADS - 1) / THREADS;       // 5
   f32x4 wq[NWQ];
@@ -1943,22 +1949,21 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
   // prologue: W1 -> W1, Wproj -> slot, taps + BN constants behind them; every load issued before the first store
   {
     const f32x4* g4 = reinterpret_cast<const f32x4*>(a.img);
+    constexpr int P4 = Cfg::W1P_FL / 4;                    // 3456 quads
+    constexpr int NP = (P4 + THREADS - 1) / THREADS;       // 7
     constexpr int C4 = Cfg::CONST_FL / 4;                  // 672 quads
     constexpr int NC = (C4 + THREADS - 1) / THREADS;       // 2
-    f32x4 t1[NWQ], t2[NWQ], t3[NC];
+    f32x4 t1[NP], t2[NWQ], t3[NC];
 #pragma unroll
-    for (int k = 0; k < NWQ; ++k) {
-      const int i = tid + k * THREADS;
-      t1[k] = i < WQ4 ? g4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      t2[k] = i < WQ4 ? gWJ[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int k = 0; k < NP; ++k) { const int i = tid + k * THREADS; t1[k] = i < P4 ? g4[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { const int i = tid + k * THREADS; t3[k] = i < C4 ? g4[3 * WQ4 + i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int k = 0; k < NWQ; ++k) { const int i = tid + k * THREADS; t2[k] = i < WQ4 ? gWJ[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int k = 0; k < NWQ; ++k) {
-      const int i = tid + k * THREADS;
-      if (i < WQ4) { reinterpret_cast<f32x4*>(W1)[i] = t1[k]; reinterpret_cast<f32x4*>(SL)[i] = t2[k]; }
-    }
+    for (int k = 0; k < NC; ++k) { const int i = tid + k * THREADS; t3[k] = i < C4 ? g4[P4 + 2 * WQ4 + i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { const int i = tid + k * THREADS; if (i < P4) reinterpret_cast<f32x4*>(W1)[i] = t1[k]; }
+#pragma unroll
+    for (int k = 0; k < NWQ; ++k) { const int i = tid + k * THREADS; if (i < WQ4) reinterpret_cast<f32x4*>(SL)[i] = t2[k]; }
 #pragma unroll
     for (int k = 0; k < NC; ++k) { const int i = tid + k * THREADS; if (i < C4) reinterpret_cast<f32x4*>(WD)[i] = t3[k]; }
   }
@@ -1993,9 +1998,14 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
     }
   };
   // ---- pointwise (+BN+ReLU) on D with the slot's filter; unit = (16 output pixels, MPER output-channel tiles)
-  auto pointwise = [&](const float* psc_p, const float* psh_p, float* out_base, int y0, int npxB) {
+  // `shared`: the phase also runs pw1 (tile t on wave t % NW).  SIMD = wave & 3 holds two waves; a pw1 tile costs about 1.5
+  // units.  With the seven tiles + six units of a 5 x 22 band: units 0..3 follow the pw1 tiles of waves 0..3, whose SIMD
+  // partners 4..6 have a tile of their own, and wave 7 (no tile) takes units 4 and 5.
+  auto pointwise = [&](const float* psc_p, const float* psh_p, float* out_base, int y0, int npxB, bool shared) {
     const int ntB = (npxB + 15) >> 4;
-    for (int u = wave; u < ntB * MG; u += NW) {
+    for (int u = 0; u < ntB * MG; ++u) {
+      const int owner = !shared ? u % NW : (u < 4 ? u : NW - 1 - (((u - 4) >> 1) % NW));
+      if (owner != wave) continue;
       const int t = u / MG, mg = u - t * MG;
       const int q = 16 * t + p;
       const bool pv = q < npxB;
@@ -2011,23 +2021,10 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
         f32x4 af[MPER];
 #pragma unroll
         for (int m = 0; m < MPER; ++m) af[m] = *reinterpret_cast<const f32x4*>(SL + (((MPER * mg + m) * KC + s) * 64 + lane) * 4);
-        if constexpr (BF6) {
-          const Bf3B b3 = yfv2_split_b(bf[s]);
-          Bf3A a3[MPER];
 #pragma unroll
-          for (int m = 0; m < MPER; ++m) a3[m] = yfv2_split_a(af[m]);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int m = 0; m < MPER; ++m) acc[m] = yfv2_mfma6_step<0>(a3[m], b3, acc[m]);
-#pragma unroll
-          for (int m = 0; m < MPER; ++m) acc[m] = yfv2_mfma6_step<1>(a3[m], b3, acc[m]);
-#pragma unroll
-          for (int m = 0; m < MPER; ++m) acc[m] = yfv2_mfma6_step<2>(a3[m], b3, acc[m]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int m = 0; m < MPER; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s][j], acc[m], 0, 0, 0);
-        }
+          for (int m = 0; m < MPER; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s][j], acc[m], 0, 0, 0);
       }
       const int r = yfv2_fdiv(qc, invOW), x = qc - r * OW;
       float* dst = out_base + ((size_t)(y0 + r) * OW + x) * CO;
@@ -2065,9 +2062,7 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
     depthwise(WE, CS + 6 * KS, CS + 7 * KS, npxB);
     __syncthreads();
 
-    // ================= P2: proj pointwise (waves 0, 1, ..) and pw1 in place (tiles dealt from the last wave down)
-    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);
-    pointwise(CS + 8 * KS, CS + 9 * KS, out_img, y0, npxB);
+    // ================= P2: pw1 in place, then the proj pointwise
     {
       auto tile_off = [&](int t) {
         const int q = 16 * t + p;
@@ -2075,7 +2070,7 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
         const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
         return (r * WP + x + 1) * CP;
       };
-      for (int t = NW - 1 - wave; t * 16 < npxA; t += NW) {
+      for (int t = wave; t * 16 < npxA; t += NW) {
         const int o = tile_off(t);
         f32x4 bf[KC];
 #pragma unroll
@@ -2089,26 +2084,36 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          f32x4 aw[KC];
+        for (int sp = 0; sp < KC / 2; ++sp) {
+          // B side: split the pair's two chunks into bf16 terms; operand = {chunk 2sp: 4 k-slots, chunk 2sp+1: 4 k-slots}
+          unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
+          yfv2_split3(bf[2 * sp], h0, m0, l0);
+          yfv2_split3(bf[2 * sp + 1], h1, m1, l1);
+          const yfv2_bf16x8 bh = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+          const yfv2_bf16x8 bm = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
+          const yfv2_bf16x8 bl = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+          yfv2_bf16x8 ah[KC], am[KC], al[KC];
 #pragma unroll
-          for (int mt = 0; mt < KC; ++mt) aw[mt] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-          if constexpr (BF6) {
-            const Bf3B b3 = yfv2_split_b(bf[s]);
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt) {
-              const Bf3A a3 = yfv2_split_a(aw[mt]);
-              accA[mt] = yfv2_mfma6_step<0>(a3, b3, accA[mt]);
-              accA[mt] = yfv2_mfma6_step<1>(a3, b3, accA[mt]);
-              accA[mt] = yfv2_mfma6_step<2>(a3, b3, accA[mt]);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][j], bf[s][j], accA[mt], 0, 0, 0);
+          for (int mt = 0; mt < KC; ++mt) {
+            const float* wq3 = W1 + (((mt * (KC / 2) + sp) * 3) * 64 + lane) * 4;
+            ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
+            am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
+            al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
           }
-          __builtin_amdgcn_sched_barrier(0);  // one chunk's six A fragments at a time (a free schedule hoists all 36: spills)
+          // six products, the small ones first; mt innermost: no MFMA waits for the one before it
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, accA[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, accA[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bm, accA[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bh, accA[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bm, accA[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, accA[mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);  // one chunk pair's 18 operand quads at a time
         }
         float* dst = T1 + o;
 #pragma unroll
@@ -2128,6 +2133,8 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
         }
       }
     }
+    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);   // the next band's rows fly until P4 (issued after pw1: registers)
+    pointwise(CS + 8 * KS, CS + 9 * KS, out_img, y0, npxB, true);
     __syncthreads();
 
     // ================= P3
@@ -2139,13 +2146,13 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
 
     // ================= P4
     if (item + (int)gridDim.x < n_items) stage_commit(item + gridDim.x);
-    pointwise(CS + 4 * KS, CS + 5 * KS, out_img + CIN, y0, npxB);
+    pointwise(CS + 4 * KS, CS + 5 * KS, out_img + CIN, y0, npxB, false);
     __syncthreads();
   }
 }
 
 static size_t s2w_lds_floats(int R, int W) {
-  return (size_t)2 * S2WCfg::W_FL + S2WCfg::CONST_FL + (size_t)(2 * R + 1) * (W + 1) * S2WCfg::CP + 16 + (size_t)R * (W / 2) * S2WCfg::CP;
+  return (size_t)S2WCfg::W1P_FL + S2WCfg::W_FL + S2WCfg::CONST_FL + (size_t)(2 * R + 1) * (W + 1) * S2WCfg::CP + 16 + (size_t)R * (W / 2) * S2WCfg::CP;
 }
 
 // rows per work item of the 96-channel kernel: the largest band that fits LDS and the staging registers and keeps pw1
@@ -2175,17 +2182,15 @@ static void launch_s2w(const BlockS2Args& a, hipStream_t s) {
   const int tiles = (a.H / 2 + a.R - 1) / a.R;
   int blocks = a.B * tiles;
   if (blocks > 256) blocks = 256;
-  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2w_kernel<512, false>), lds_ok0);
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2w_kernel<512, true>), lds_ok1);
-  if (a.bf6) hipLaunchKernelGGL((block_s2w_kernel<512, true>), dim3(blocks), dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((block_s2w_kernel<512, false>), dim3(blocks), dim3(512), lds, s, a);
+  static std::atomic<unsigned long long> lds_ok{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2w_kernel<512>), lds_ok);
+  hipLaunchKernelGGL((block_s2w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
   if (cin == 24) { launch_s2<24>(a, s); return true; }
   if (cin == 48) { launch_s2<48>(a, s); return true; }
-  if (cin == 96 && !a.pp_in) { launch_s2w(a, s); return true; }
+  if (cin == 96 && !a.pp_in && a.bf6) { launch_s2w(a, s); return true; }   // planned only with bf16x6 on (image_s2w)
   return false;
 }
 
