@@ -1229,6 +1229,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.B = B;
       a.img = params + st.img_off;
       a.bf6 = h->bf6 ? 1 : 0;
+      a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
       if (!yfv2_launch_block_s2(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused stride-2 kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_TOWER) {

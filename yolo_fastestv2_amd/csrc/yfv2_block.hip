@@ -1849,7 +1849,8 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
 //    quad) over the whole band, results to a small tile D, and the pointwise then runs as (pixel tile, pair of
 //    output-channel tiles) units with B fragments from D;
 //  * pw1 takes whole 16-pixel tiles, the tile's six B fragments in registers before its first write (in place without a
-//    barrier); it shares its phase with the proj pointwise.  pw1 is 70 % of the block's MFMA work and runs as bf16x6
+//    barrier); it shares its phase with the proj pointwise.  (Two tiles per wave on four waves with the proj pointwise on
+//    their SIMD partners was slower: 70 us against 64 - the pw1 waves then bound the phase.)  pw1 is 70 % of the block's MFMA work and runs as bf16x6
 //    (yfv2_internal.h) with W1 PRE-SPLIT on the host (WeightPacker::image_s2w): per (output tile, chunk pair, term) one
 //    16-byte operand whose 32 k-slots are the two chunks, so the six products hi.hi hi.mid mid.hi hi.lo lo.hi mid.mid are
 //    six MFMAs per chunk pair with no operand duplication and no VALU work on the filter side (splitting W1's 36
@@ -1870,7 +1871,7 @@ struct S2WCfg {
   static constexpr int NCS = 10;
   static constexpr int CONST_FL = 2 * DW_FL + NCS * KS;   // WD | WE | CS
   static constexpr int MAXP = 8;                          // staged 16-byte quads per thread (512 threads)
-  static constexpr int MPER = 2;                          // output-channel tiles per pointwise unit
+  static constexpr int MPER = 3;                          // output-channel tiles per pointwise unit
 };
 
 template <int THREADS>
@@ -1904,13 +1905,18 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
   constexpr int WQ4 = Cfg::W_FL / 4;                       // 2304 quads
   constexpr int NWQ = (WQ4 + THREADS - 1) / THREADS;       // 5
   f32x4 wq[NWQ];
+  // (the thread index goes through an opaque register in the staging lambdas: per-quad addresses hoisted out of the band
+  // loop get spilled around pw1, and a scratch reload next to the global loads waits for every load in flight)
+  auto opaque_tid = [&]() { unsigned t = tid; asm volatile("" : "+v"(t)); return t; };
   auto slot_issue = [&](const f32x4* src) {
+    const unsigned t = opaque_tid();
 #pragma unroll
-    for (int k = 0; k < NWQ; ++k) { const int i = tid + k * THREADS; wq[k] = i < WQ4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int k = 0; k < NWQ; ++k) { const unsigned i = t + k * THREADS; wq[k] = i < (unsigned)WQ4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
   };
   auto slot_commit = [&]() {
+    const unsigned t = opaque_tid();
 #pragma unroll
-    for (int k = 0; k < NWQ; ++k) { const int i = tid + k * THREADS; if (i < WQ4) reinterpret_cast<f32x4*>(SL)[i] = wq[k]; }
+    for (int k = 0; k < NWQ; ++k) { const unsigned i = t + k * THREADS; if (i < (unsigned)WQ4) reinterpret_cast<f32x4*>(SL)[i] = wq[k]; }
   };
 
   f32x4 st[MAXP];
@@ -1918,16 +1924,17 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
     const int item = active ? item_ : 0;
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R, rows = min(R, OH - y0);
+    // the band's 2*rows+1 input rows are whole rows: ONE contiguous run of 16-byte quads in NHWC (row -1 of the first band
+    // is the zero padding: its quads are skipped, the pointer below is only dereferenced past them)
     const int nq = active ? (2 * rows + 1) * W * QPP : 0;
-    const size_t in_px = (size_t)b * H * W;
+    const int skip = y0 == 0 ? W * QPP : 0;
+    const float* src = a.in + ((long long)b * H * W + (long long)(2 * y0 - 1) * W) * CIN;
+    const unsigned t = opaque_tid();
 #pragma unroll
     for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
-      const int pix = i / QPP, q = i - pix * QPP;
-      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
-      const int gy = 2 * y0 - 1 + r;
+      const unsigned i = t + j * THREADS;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < nq && gy >= 0 && gy < H) v = *reinterpret_cast<const f32x4*>(a.in + (in_px + (size_t)gy * W + x) * CIN + 4 * q);
+      if (i < (unsigned)nq && i >= (unsigned)skip) v = *reinterpret_cast<const f32x4*>(src + 4u * i);
       st[j] = v;
     }
   };
@@ -1935,9 +1942,10 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R, rows = min(R, OH - y0);
     const int nq = (2 * rows + 1) * W * QPP;
+    const int t = (int)opaque_tid();
 #pragma unroll
     for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
+      const int i = t + j * THREADS;
       if (i >= nq) continue;
       const int pix = i / QPP, q = i - pix * QPP;
       const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
@@ -1945,6 +1953,7 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
     }
   };
   stage_issue(blockIdx.x, (int)blockIdx.x < n_items);
+  YFV2_WSTAMP(0);
 
   // prologue: W1 -> W1, Wproj -> slot, taps + BN constants behind them; every load issued before the first store
   {
@@ -1971,6 +1980,9 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
   __syncthreads();
   if ((int)blockIdx.x < n_items) stage_commit(blockIdx.x);
   __syncthreads();
+  YFV2_WSTAMP(1);
+  int it = 0;   // stamps 2.. of the workgroup's SECOND band (steady state)
+#define S2W_STAMP(k) do { if (it == 1) YFV2_WSTAMP(2 + (k)); } while (0)
 
   // ---- depthwise 3x3 s2 (+BN) of the band: thread = (output pixel, channel quad), T1 -> D
   auto depthwise = [&](const float* taps, const float* dsc_p, const float* dsh_p, int npxB) {
@@ -1997,35 +2009,36 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
       *reinterpret_cast<f32x4*>(D + q * CP + 4 * cq) = y;
     }
   };
-  // ---- pointwise (+BN+ReLU) on D with the slot's filter; unit = (16 output pixels, MPER output-channel tiles)
-  // `shared`: the phase also runs pw1 (tile t on wave t % NW).  SIMD = wave & 3 holds two waves; a pw1 tile costs about 1.5
-  // units.  With the seven tiles + six units of a 5 x 22 band: units 0..3 follow the pw1 tiles of waves 0..3, whose SIMD
-  // partners 4..6 have a tile of their own, and wave 7 (no tile) takes units 4 and 5.
-  auto pointwise = [&](const float* psc_p, const float* psh_p, float* out_base, int y0, int npxB, bool shared) {
+  // ---- pointwise (+BN+ReLU) on D with the slot's filter (fp32 MFMA); unit = (16 output pixels, MPER output-channel tiles).
+  // The unit's 18 filter fragments are requested before the first MFMA.
+  // `after_pw1`: the phase ran pw1 first (tile t on wave t % NW; SIMD = wave & 3 holds waves s and s + 4): the wave pairs
+  // with the fewest tiles take the units - for the seven tiles of a 5 x 22 band wave 7 (no tile) takes units 0 and 1,
+  // waves 0 and 1 units 2 and 3, which leaves every SIMD with three pieces of work but one.
+  auto pointwise = [&](const float* psc_p, const float* psh_p, float* out_base, int y0, int npxB, bool after_pw1) {
     const int ntB = (npxB + 15) >> 4;
     for (int u = 0; u < ntB * MG; ++u) {
-      const int owner = !shared ? u % NW : (u < 4 ? u : NW - 1 - (((u - 4) >> 1) % NW));
+      const int owner = !after_pw1 ? u % NW : (u < 2 ? NW - 1 : (u - 2) % NW);
       if (owner != wave) continue;
       const int t = u / MG, mg = u - t * MG;
       const int q = 16 * t + p;
       const bool pv = q < npxB;
       const int qc = pv ? q : npxB - 1;
-      f32x4 bf[KC];
+      f32x4 bf[KC], af[MPER][KC];
 #pragma unroll
       for (int s = 0; s < KC; ++s) bf[s] = *reinterpret_cast<const f32x4*>(D + qc * CP + 16 * s + 4 * g);
+#pragma unroll
+      for (int s = 0; s < KC; ++s)
+#pragma unroll
+        for (int m = 0; m < MPER; ++m) af[m][s] = *reinterpret_cast<const f32x4*>(SL + (((MPER * mg + m) * KC + s) * 64 + lane) * 4);
       f32x4 acc[MPER];
 #pragma unroll
       for (int m = 0; m < MPER; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        f32x4 af[MPER];
-#pragma unroll
-        for (int m = 0; m < MPER; ++m) af[m] = *reinterpret_cast<const f32x4*>(SL + (((MPER * mg + m) * KC + s) * 64 + lane) * 4);
+      for (int s = 0; s < KC; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int m = 0; m < MPER; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s][j], acc[m], 0, 0, 0);
-      }
+          for (int m = 0; m < MPER; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s][j], bf[s][j], acc[m], 0, 0, 0);
       const int r = yfv2_fdiv(qc, invOW), x = qc - r * OW;
       float* dst = out_base + ((size_t)(y0 + r) * OW + x) * CO;
 #pragma unroll
@@ -2059,10 +2072,13 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
     // ================= P1
     if (slot_pending) slot_commit();
     slot_issue(gW2);
+    S2W_STAMP(0);
     depthwise(WE, CS + 6 * KS, CS + 7 * KS, npxB);
+    S2W_STAMP(1);
     __syncthreads();
+    S2W_STAMP(2);
 
-    // ================= P2: pw1 in place, then the proj pointwise
+    // ================= P2: pw1 in place, one 16-pixel tile per wave and pass (tile t on wave t % NW), then the proj pointwise
     {
       auto tile_off = [&](int t) {
         const int q = 16 * t + p;
@@ -2083,37 +2099,41 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
         f32x4 accA[KC];
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        S2W_STAMP(3);
+        // six stages = (chunk pair sp, half of the output tiles): a stage's nine operand quads are requested one stage ahead
+        // of the 18 MFMAs that use them
+        constexpr int HM = KC / 2;
+        yfv2_bf16x8 aop[2][3][HM];     // [buffer][hi, mid, lo][mt within the half]
+        auto load_stage = [&](int k, yfv2_bf16x8 (&dst)[3][HM]) {
+          const int sp = k >> 1, m0 = (k & 1) * HM;
 #pragma unroll
-        for (int sp = 0; sp < KC / 2; ++sp) {
-          // B side: split the pair's two chunks into bf16 terms; operand = {chunk 2sp: 4 k-slots, chunk 2sp+1: 4 k-slots}
-          unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
-          yfv2_split3(bf[2 * sp], h0, m0, l0);
-          yfv2_split3(bf[2 * sp + 1], h1, m1, l1);
-          const yfv2_bf16x8 bh = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
-          const yfv2_bf16x8 bm = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
-          const yfv2_bf16x8 bl = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
-          yfv2_bf16x8 ah[KC], am[KC], al[KC];
+          for (int m = 0; m < HM; ++m) {
+            const float* wq3 = W1 + ((((m0 + m) * (KC / 2) + sp) * 3) * 64 + lane) * 4;
 #pragma unroll
-          for (int mt = 0; mt < KC; ++mt) {
-            const float* wq3 = W1 + (((mt * (KC / 2) + sp) * 3) * 64 + lane) * 4;
-            ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
-            am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
-            al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
+            for (int term = 0; term < 3; ++term) dst[term][m] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256 * term));
+          }
+        };
+        load_stage(0, aop[0]);
+        yfv2_bf16x8 bh, bm, bl;
+#pragma unroll
+        for (int k = 0; k < 2 * (KC / 2); ++k) {
+          const int sp = k >> 1, m0 = (k & 1) * HM;
+          if (k + 1 < 2 * (KC / 2)) load_stage(k + 1, aop[(k + 1) & 1]);
+          if ((k & 1) == 0) {
+            // B side: split the pair's two chunks into bf16 terms; operand = {chunk 2sp: 4 k-slots, chunk 2sp+1: 4 k-slots}
+            unsigned h0[2], m0_[2], l0[2], h1[2], m1[2], l1[2];
+            yfv2_split3(bf[2 * sp], h0, m0_, l0);
+            yfv2_split3(bf[2 * sp + 1], h1, m1, l1);
+            bh = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+            bm = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0_[0], m0_[1], m1[0], m1[1]});
+            bl = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
           }
           // six products, the small ones first; mt innermost: no MFMA waits for the one before it
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, accA[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, accA[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bm, accA[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bh, accA[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bm, accA[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) accA[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, accA[mt], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);  // one chunk pair's 18 operand quads at a time
+#define S2W_PROD(T_, B_) _Pragma("unroll") for (int m = 0; m < HM; ++m) accA[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop[k & 1][T_][m], B_, accA[m0 + m], 0, 0, 0);
+          S2W_PROD(2, bh) S2W_PROD(0, bl) S2W_PROD(1, bm) S2W_PROD(1, bh) S2W_PROD(0, bm) S2W_PROD(0, bh)
+#undef S2W_PROD
+          __builtin_amdgcn_sched_barrier(0);  // keeps the schedule from hoisting every stage's loads (spills)
+          if (k & 1) S2W_STAMP(4 + sp);
         }
         float* dst = T1 + o;
 #pragma unroll
@@ -2133,22 +2153,34 @@ __global__ __launch_bounds__(THREADS) void block_s2w_kernel(BlockS2Args a) {
         }
       }
     }
+    S2W_STAMP(7);
     stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);   // the next band's rows fly until P4 (issued after pw1: registers)
+    S2W_STAMP(8);
     pointwise(CS + 8 * KS, CS + 9 * KS, out_img, y0, npxB, true);
+    S2W_STAMP(9);
     __syncthreads();
+    S2W_STAMP(10);
 
     // ================= P3
     slot_commit();                         // Wproj's readers are done: the slot becomes W2
     slot_issue(gWJ);
     slot_pending = true;
+    S2W_STAMP(11);
     depthwise(WD, CS + 2 * KS, CS + 3 * KS, npxB);
+    S2W_STAMP(12);
     __syncthreads();
+    S2W_STAMP(13);
 
     // ================= P4
     if (item + (int)gridDim.x < n_items) stage_commit(item + gridDim.x);
+    S2W_STAMP(14);
     pointwise(CS + 4 * KS, CS + 5 * KS, out_img + CIN, y0, npxB, false);
+    S2W_STAMP(15);
     __syncthreads();
+    S2W_STAMP(16);
+    ++it;
   }
+#undef S2W_STAMP
 }
 
 static size_t s2w_lds_floats(int R, int W) {

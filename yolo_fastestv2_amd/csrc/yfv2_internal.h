@@ -203,6 +203,7 @@ struct BlockS2Args {
   unsigned pp_mask;
   long long pp_bufstride;
   int bf6;           // pw1 as bf16x6 (pair-plane input form)
+  long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (block_s2w_kernel; or null)
 };
 
 // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
