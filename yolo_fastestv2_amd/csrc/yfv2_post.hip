@@ -20,13 +20,21 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
   constexpr int MAXPER = 24;  // >= ceil(classes / 4), classes <= 93
   const int per = (nc + 3) >> 2;
   const int c_lo = part * per, c_hi = min(nc, c_lo + per);
-  const float* cls = a.cls[sc] + (size_t)b * nc * hw + cc;
-  // Three sweeps over the lane's class slice (max, sum, best product) that re-read the logits (L1 hits) instead of
-  // keeping 24 logits and 24 probabilities in registers: this runs inside the 1024-thread NMS workgroup (128 registers).
+  const float* cls = a.cls[sc] + (size_t)b * nc * hw;   // wave-uniform base: the per-lane part stays a 32-bit offset (24 addresses live)
+  // The lane's class slice is loaded ONCE, all 24 loads in flight together (masked slots re-read a valid class), and the
+  // three sweeps (max, sum, best product) run on registers; the probabilities are recomputed in the third sweep instead
+  // of being kept (this runs inside the 1024-thread NMS workgroup: 128 registers).  The first fused version re-read the
+  // logits in every sweep in batches of four: 18 dependent round trips per pass instead of one.
   // Every value is computed by the same expression as in decode_kernel<false>, so the results are identical.
-  auto logit = [&](int i) { const int c = c_lo + i; return cls[(size_t)(c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw]; };   // masked slots re-read a valid class
+  float lv[MAXPER];
+#pragma unroll
+  for (int i = 0; i < MAXPER; ++i) {
+    const int c = c_lo + i;
+    lv[i] = cls[(unsigned)((c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw + cc)];
+  }
+  auto logit = [&](int i) { return lv[i]; };
   float m = -INFINITY;
-#pragma unroll 4
+#pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
     const float v = logit(i);
     if (c_lo + i < c_hi) m = fmaxf(m, v);
@@ -34,10 +42,11 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
   m = fmaxf(m, __shfl_xor(m, 1));
   m = fmaxf(m, __shfl_xor(m, 2));
   float sum = 0.f;
-#pragma unroll 4
+#pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
     const float v = logit(i);
     if (c_lo + i < c_hi) sum = __fadd_rn(sum, expf(__fsub_rn(v, m)));
+    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four exps at a time (a free schedule interleaves all 24: spills)
   }
   sum = __fadd_rn(sum, __shfl_xor(sum, 1));
   sum = __fadd_rn(sum, __shfl_xor(sum, 2));
@@ -49,7 +58,7 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
     best[an] = -INFINITY;
     bj[an] = 0x7fffffff;
   }
-#pragma unroll 4
+#pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
     const float v = logit(i);
     if (c_lo + i < c_hi) {
@@ -60,6 +69,7 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
         if (pj > best[an]) { best[an] = pj; bj[an] = c_lo + i; }  // strict: first maximal index of this slice
       }
     }
+    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int an = 0; an < 3; ++an)
@@ -118,12 +128,12 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
   constexpr int MAXPER = 24;  // >= ceil(classes / 4), classes <= 93
   const int per = (nc + 3) >> 2;
   const int c_lo = part * per, c_hi = min(nc, c_lo + per);
-  const float* cls = a.cls[sc] + (size_t)b * nc * hw + cc;
+  const float* cls = a.cls[sc] + (size_t)b * nc * hw;   // wave-uniform base: the per-lane part stays a 32-bit offset (24 addresses live)
   float lv[MAXPER];
 #pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
     const int c = c_lo + i;
-    lv[i] = cls[(size_t)(c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw];   // masked slots re-read a valid class (fewer than 4 classes: quarters 1-3 are empty)
+    lv[i] = cls[(unsigned)((c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw + cc)];   // masked slots re-read a valid class (fewer than 4 classes: quarters 1-3 are empty)
   }
   float m = -INFINITY;
 #pragma unroll
