@@ -50,6 +50,8 @@ struct Step {
   int head0 = -1, head1 = -1; // PW_HEAD: indices into out6
   std::string name;
   double flops = 0, bytes = 0;  // algorithmic, per image
+  int lane = 0;               // 0 = the caller's stream; 1, 2 = the handle's side streams (independent branches of the graph)
+  bool fork_after = false;    // the side streams may start once this launch is done
 };
 
 struct Buf { float* p = nullptr; size_t per_img = 0; };
@@ -78,6 +80,15 @@ struct yfv2_ctx {
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
   bool bf6 = true;          // pointwise convs on the bf16 matrix cores where a kernel has that form (YFV2_BF6=0 at create time: fp32 MFMA)
   bool postfuse = true;     // yfv2_detect: decode + NMS as one launch (YFV2_POSTFUSE=0 at create time: two launches)
+  // The 11x11 towers depend only on the FPN's S3: with YFV2_SIDE=1 at create time they run on two side streams (cls / reg)
+  // next to the 22x22 branch (pw288 -> towers) on the caller's stream, forked and joined with events inside every forward -
+  // the caller still sees one stream.  OFF by default: measured (tools/gpu_ab_side.sh, rocprofv3 timeline in DESIGN.md 4.4)
+  // the launches do overlap, but the 11x11 towers then take 51-59 us instead of 16-24, the 22x22 launches next to them
+  // stretch by 10-20 us, and the fork costs a 9-12 us bubble on the caller's stream: forward 988-995 us against 980-987.
+  bool side = false;
+  hipStream_t side_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  Buf ta_side[2];           // tower intermediates of the side lanes
   bool c2_permuted = false; // stage 3's output (C2) is stored in the chain kernel's order:
   int c2_label[96] = {0};   //   physical channel position k holds logical channel c2_label[k]
   Buf logits[6];
@@ -1015,7 +1026,7 @@ struct PlanBuilder {
     h->plan.push_back(s);
   }
 
-  void tower(const std::string& p, int H, int W, const Buf& s_in, bool is_cls, int scale_idx) {
+  void tower(const std::string& p, int H, int W, const Buf& s_in, bool is_cls, int scale_idx, int lane = 0) {
     Folded f;
     const int px = H * W;
     {
@@ -1027,16 +1038,19 @@ struct PlanBuilder {
         ok &= wp.dw(p + ".5", p + ".6", 72, 5, &fd2);
         ok &= wp.pw(p + ".8", p + ".9", 72, 72, &fp2);
         const int A = h->cfg.anchor_num, nc = h->cfg.classes;
-        tower_half(p + " half a: dw5x5+bn+relu -> pw+bn", H, W, s_in.p, h->ta.p, fd1, fp1, nullptr, 0, 0, -1, -1);
+        float* mid = lane ? h->ta_side[lane - 1].p : h->ta.p;   // a side lane keeps its own intermediate
+        tower_half(p + " half a: dw5x5+bn+relu -> pw+bn", H, W, s_in.p, mid, fd1, fp1, nullptr, 0, 0, -1, -1);
+        h->plan.back().lane = lane;
         if (is_cls) {
           ok &= wp.heads({{"output_obj_layers", A}, {"output_cls_layers", nc}}, 72, &fh);
-          tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_obj+output_cls (bias, NCHW)", H, W, h->ta.p, nullptr, fd2,
+          tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_obj+output_cls (bias, NCHW)", H, W, mid, nullptr, fd2,
                      fp2, &fh, A + nc, A, scale_idx * 3 + 1, scale_idx * 3 + 2);
         } else {
           ok &= wp.heads({{"output_reg_layers", 4 * A}}, 72, &fh);
-          tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_reg (bias, NCHW)", H, W, h->ta.p, nullptr, fd2, fp2, &fh,
+          tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_reg (bias, NCHW)", H, W, mid, nullptr, fd2, fp2, &fh,
                      4 * A, 4 * A, scale_idx * 3 + 0, -1);
         }
+        h->plan.back().lane = lane;
         return;
       }
     }
@@ -1143,6 +1157,7 @@ struct PlanBuilder {
     Folded f;
     ok &= wp.pw("fpn.conv1x1_3.0", "fpn.conv1x1_3.1", 72, 192, &f);
     add_pw("fpn.conv1x1_3 pw192->72+bn+relu", 192, PW_PLAIN, 72, h3 * w3, c3->p, 192, 0, h->f3.p, 72, 0, true, f);
+    h->plan.back().fork_after = true;   // S3 is all the 11x11 towers need
     ok &= wp.pw("fpn.conv1x1_2.0", "fpn.conv1x1_2.1", 72, 288, &f);
     if (h->c2_permuted && ok) {   // columns 192.. read C2 in the chain kernel's channel order
       int lab[288];
@@ -1159,8 +1174,8 @@ struct PlanBuilder {
     }
     h->dbg[4] = h->f2.p; h->dbg_per_img[4] = h->f2.per_img; h->dbg_c[4] = 72;
     h->dbg[5] = h->f3.p; h->dbg_per_img[5] = h->f3.per_img; h->dbg_c[5] = 72;
-    tower("fpn.cls_head_3.block", h3, w3, h->f3, true, 1);
-    tower("fpn.reg_head_3.block", h3, w3, h->f3, false, 1);
+    tower("fpn.cls_head_3.block", h3, w3, h->f3, true, 1, 1);
+    tower("fpn.reg_head_3.block", h3, w3, h->f3, false, 1, 2);
     tower("fpn.cls_head_2.block", h2, w2, h->f2, true, 0);
     tower("fpn.reg_head_2.block", h2, w2, h->f2, false, 0);
   }
@@ -1202,10 +1217,14 @@ size_t logit_elems(const yfv2_ctx* h, int i) {
   return (size_t)c * h->fh[sc] * h->fw[sc];
 }
 
-int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6], hipStream_t s, hipEvent_t* ev /*nullable: 2 per step*/) {
+int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6], hipStream_t main_stream, hipEvent_t* ev /*nullable: 2 per step*/) {
   const float* params = h->d_params;
+  // lanes: independent branches on the handle's side streams (not when the launches are timed one by one)
+  const bool lanes = h->side && !ev;
+  bool forked = false;
   for (size_t i = 0; i < h->plan.size(); ++i) {
     Step& st = h->plan[i];
+    const hipStream_t s = (lanes && forked && st.lane > 0) ? h->side_stream[st.lane - 1] : main_stream;
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i], s));
     if (st.kind == STEP_STEM) {
       StemArgs a = st.stem;
@@ -1299,7 +1318,17 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
         return fail(h, YFV2_ERR_CONFIG, "no depthwise kernel for step '" + st.name + "'");
     }
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i + 1], s));
+    if (lanes && st.fork_after && !forked) {
+      HIP_TRY(h, hipEventRecord(h->ev_fork, main_stream));
+      for (int k = 0; k < 2; ++k) HIP_TRY(h, hipStreamWaitEvent(h->side_stream[k], h->ev_fork, 0));
+      forked = true;
+    }
   }
+  if (forked)
+    for (int k = 0; k < 2; ++k) {   // join: whatever the caller enqueues next sees every logit
+      HIP_TRY(h, hipEventRecord(h->ev_join[k], h->side_stream[k]));
+      HIP_TRY(h, hipStreamWaitEvent(main_stream, h->ev_join[k], 0));
+    }
   HIP_TRY(h, hipGetLastError());
   return YFV2_OK;
 }
@@ -1351,6 +1380,7 @@ int setup_ctx(yfv2_ctx* h, const yfv2_config* cfg, int rows, Alloc alloc) {
   A(&h->f2, (H / 16) * (W / 16) * 72);
   A(&h->f3, (H / 32) * (W / 32) * 72);
   A(&h->ta, (H / 16) * (W / 16) * 72);
+  for (int k = 0; k < 2; ++k) A(&h->ta_side[k], (H / 32) * (W / 32) * 72);
   A(&h->tb, (H / 16) * (W / 16) * 72);
   for (int i = 0; i < 6; ++i) A(&h->logits[i], logit_elems(h, i));
   A(&h->cand, (size_t)rows * 8);
@@ -1399,6 +1429,14 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   }
   if (const char* e = std::getenv("YFV2_BF6")) h->bf6 = !(e[0] == '0');
   if (const char* e = std::getenv("YFV2_POSTFUSE")) h->postfuse = !(e[0] == '0');
+  if (const char* e = std::getenv("YFV2_SIDE")) h->side = (e[0] == '1');
+  if (h->side) {
+    bool okk = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+    for (int k = 0; k < 2 && okk; ++k)
+      okk = hipStreamCreateWithFlags(&h->side_stream[k], hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+    if (!okk) { (void)hipGetLastError(); h->side = false; }   // no side streams: the plan's lanes all map to the caller's stream
+  }
   if (const char* tr = std::getenv("YFV2_TRACE"))
     if (tr[0] == '1') { if (const char* ts = std::getenv("YFV2_TRACE_STEP")) h->trace_step = std::atoi(ts); (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
   *out = h;
@@ -1499,6 +1537,12 @@ void yfv2_destroy(yfv2_handle h) {
   free_buf(&h->s2pp);
   free_buf(&h->t1); free_buf(&h->t2); free_buf(&h->t3);
   free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->ta); free_buf(&h->tb);
+  for (int k = 0; k < 2; ++k) {
+    free_buf(&h->ta_side[k]);
+    if (h->side_stream[k]) (void)hipStreamDestroy(h->side_stream[k]);
+    if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
   free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);
