@@ -16,6 +16,9 @@
  *     hipStream_t passed as void*; NULL = the default stream).  No hidden
  *     device synchronisation, except in yfv2_profile_forward and
  *     yfv2_debug_activation, which are measurement/debug helpers and say so.
+ *     (Opt-in, YFV2_SIDE=1 in the environment of yfv2_create: the coarse-level towers run on two streams the handle
+ *     owns, forked from and joined back into the caller's stream with events inside the call - the caller still
+ *     orders against ONE stream.  Off by default: measured no gain)
  *   - all pointers named x / out6 / boxes / dets / idx / count are DEVICE
  *     pointers; weights passed to yfv2_load_weights are HOST pointers.
  *   - one handle per device, not thread-safe, and ONE STREAM AT A TIME: the handle's workspace (activations, logits
