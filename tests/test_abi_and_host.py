@@ -150,6 +150,64 @@ def test_gather_detections_world_size_2_gloo(tmp_path):
         assert p.returncode == 0 and "rank %d ok" % r in o, o
 
 
+def test_packed_and_async_gather_world_size_2_gloo(tmp_path):
+    """The bench's N>1 step on CPU: buffers from packed_det_buffers (what Engine.new_det_buffers returns) travel as ONE
+    collective into a reusable flat receive buffer; async_op=True returns a handle whose wait() yields the same tensors;
+    two buffer sets in flight, as bench.py keeps them."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from yolo_fastestv2_amd import gather_detections, shard_range
+        from yolo_fastestv2_amd import sharded
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        B = 3                                                            # per rank
+        calls = []
+        real = dist.all_gather_into_tensor
+        def counting(*a, **k):
+            calls.append(1); return real(*a, **k)
+        dist.all_gather_into_tensor = counting
+        g = torch.Generator().manual_seed(0)
+        sets, recv, works, want = [], [], [], []
+        for step in range(4):
+            dets_all = torch.rand(world * B, 300, 6, generator=g); idx_all = torch.randint(0, 1815, (world * B, 300), generator=g, dtype=torch.int32)
+            cnt_all = torch.randint(0, 300, (world * B,), generator=g, dtype=torch.int32)
+            if step < 2:
+                sets.append(sharded.packed_det_buffers(B, "cpu")); recv.append(torch.empty(world * B * 2101)); works.append(None)
+            j = step %% 2
+            if works[j] is not None:
+                d, i, c = works[j].wait()
+                assert torch.equal(d, want[j][0]) and torch.equal(i, want[j][1]) and torch.equal(c, want[j][2]), (rank, step)
+            lo, hi = rank * B, (rank + 1) * B
+            sets[j][0].copy_(dets_all[lo:hi]); sets[j][1].copy_(idx_all[lo:hi]); sets[j][2].copy_(cnt_all[lo:hi])
+            works[j] = gather_detections(*sets[j], async_op=True, out=recv[j])
+            if step < 2: want.append(None)
+            want[j] = (dets_all, idx_all, cnt_all)
+        for j in range(2):
+            assert works[j].wait(unpack=False) is None
+            for r, (d, i, c) in enumerate(sharded.rank_views(recv[j], world, B)):          # zero-copy per-rank views
+                assert d.data_ptr() >= recv[j].data_ptr() and torch.equal(d, want[j][0][r * B:(r + 1) * B])
+                assert torch.equal(i, want[j][1][r * B:(r + 1) * B]) and torch.equal(c, want[j][2][r * B:(r + 1) * B])
+            d, i, c = works[j].wait()
+            assert torch.equal(d, want[j][0]) and torch.equal(i, want[j][1]) and torch.equal(c, want[j][2]), (rank, "tail", j)
+        assert len(calls) == 4, calls                                    # one collective per step
+        d, i, c = gather_detections(*sets[0])                            # synchronous form, own receive buffer
+        assert torch.equal(d, want[0][0]) and torch.equal(i, want[0][1]) and torch.equal(c, want[0][2])
+        assert len(calls) == 5
+        d, i, c = gather_detections(sets[0][0].clone(), sets[0][1].clone(), sets[0][2].clone())   # not packed: three collectives
+        assert torch.equal(d, want[0][0]) and len(calls) == 8
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in o, o
+
+
 def test_detect_sharded_world_size_2_gloo_reassembles_the_single_rank_result(tmp_path):
     """SURVEY.md 8(e) end to end on CPU: the batch is split with shard_range, every rank runs `detect` on ITS images only
     (a stand-in engine whose detections are a deterministic function of each image, so a wrong split, order or padding

@@ -156,9 +156,10 @@ class Engine:
         return out
 
     def new_det_buffers(self, B):
-        return (torch.empty((B, MAX_DET, 6), device=self.device, dtype=torch.float32),
-                torch.empty((B, MAX_DET), device=self.device, dtype=torch.int32),
-                torch.empty((B,), device=self.device, dtype=torch.int32))
+        """(dets, idx, cnt) for `detect` / `nms`: three views of one flat buffer, so that the sharded path's all-gather
+        moves a rank's result in one collective (sharded.gather_detections)."""
+        from .sharded import packed_det_buffers
+        return packed_det_buffers(B, self.device)
 
     def nms(self, boxes, conf_thres, iou_thres, classes=None, out=None):
         boxes = boxes.contiguous()
