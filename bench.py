@@ -141,7 +141,7 @@ def main():
         j = nstep[0] % len(sets)
         nstep[0] += 1
         if works[j] is not None:
-            works[j].wait(unpack=False)   # the gathered result stays packed in recv[j] (sharded.rank_views reads it in place)
+            works[j].wait_host()          # issued two steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
             works[j] = None
         d, i, c = eng.detect(x, a.conf, a.iou, out=sets[j])
         if use_dist:

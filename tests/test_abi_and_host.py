@@ -177,6 +177,7 @@ def test_packed_and_async_gather_world_size_2_gloo(tmp_path):
                 sets.append(sharded.packed_det_buffers(B, "cpu")); recv.append(torch.empty(world * B * 2101)); works.append(None)
             j = step %% 2
             if works[j] is not None:
+                if step == 2: works[j].wait_host()                       # host-side completion, then the ordinary wait
                 d, i, c = works[j].wait()
                 assert torch.equal(d, want[j][0]) and torch.equal(i, want[j][1]) and torch.equal(c, want[j][2]), (rank, step)
             lo, hi = rank * B, (rank + 1) * B
