@@ -129,3 +129,54 @@ def test_band_rows_fit_the_static_bounds():
         cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = 80, 3, H, W, 1, 0
         ns, nb = C.c_int32(0), C.c_int64(0)
         assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0
+
+
+def _presplit_general(fr, MT, K):
+    """[mt][chunk pair][term][lane][4 dwords] -> (16 MT, K) float32 = hi + mid + lo"""
+    KP = K // 32
+    u = fr.view(np.uint32).reshape(MT, KP, 3, 64, 4)
+    terms = np.zeros((3, 16 * MT, K), np.float32)
+    for mt in range(MT):
+        for sp in range(KP):
+            for l in range(64):
+                for d in range(4):
+                    c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1)
+                    for e in range(2):
+                        bits = ((u[mt, sp, :, l, d] >> (16 * e)) & 0xFFFF).astype(np.uint32) << 16
+                        terms[:, 16 * mt + (l & 15), c + e] = bits.view(np.float32)
+    return (terms[0] + terms[1]) + terms[2]
+
+
+@pytest.mark.parametrize("name,K,key", [("fpn.conv1x1_3 pw192", 192, "fpn.conv1x1_3.0.weight"), ("fpn.conv1x1_2 up2x", 288, "fpn.conv1x1_2.0.weight")])
+def test_streamed_pointwise_filters_are_packed_presplit(name, K, key):
+    """pw_kernel<K = 192 / 288, PRE>: the FPN reduces' filters arrive pre-split (bf16 hi / mid / lo operand quads per chunk
+    pair); hi + mid + lo must reproduce the fp32 filter exactly, the C2 columns of conv1x1_2 in the chain's channel order."""
+    w = yfv2.random_state_dict(12)
+    host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point()}
+    arr = (TensorDesc * len(host))()
+    for i, (k, t) in enumerate(host.items()):
+        arr[i].name, arr[i].data, arr[i].numel = k.encode(), t.data_ptr(), t.numel()
+    cfg = Config()
+    cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = 80, 3, 352, 352, 1, 0
+    L = _lib.lib()
+    ns, nb = C.c_int32(0), C.c_int64(0)
+    assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0
+    MT = 5
+    fl = MT * (K // 32) * 3 * 256 + 2 * 16 * MT
+    buf = np.zeros(fl, np.float32)
+    nm = C.create_string_buffer(256)
+    im = None
+    for st in range(ns.value):
+        n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st, nm, 256, buf.ctypes.data_as(C.c_void_p), buf.size)
+        if n > 0 and name in nm.value.decode():
+            assert n == fl, (n, fl)
+            im = buf.copy()
+            break
+    assert im is not None
+    got = _presplit_general(im[:fl - 2 * 16 * MT], MT, K)[:72]
+    ref = w[key].reshape(72, K).numpy()
+    if K == 288:
+        lab = (C.c_int32 * 96)()
+        assert L.yfv2_debug_plan_c2_label(C.byref(cfg), arr, len(host), lab) == 1
+        ref = np.concatenate([ref[:, :192], ref[:, 192:][:, np.asarray(list(lab))]], 1)   # cat(up(C3), C2): C2 columns permuted
+    assert np.array_equal(got, ref)

@@ -251,10 +251,11 @@ struct WeightPacker {
     return off;
   }
   // pw_kernel: filter fragments [MT][K/16][64 lanes][4] (+ an 8-channel tail [MT][64 lanes][2]), scale[MT*16], shift[MT*16]
-  size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */) {
+  size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */, bool presplit = false) {
     const int rows = MT * 16, K16 = K / 16;
     std::vector<float> im;
-    push_frag(im, &blob[f.w], M, K, MT, K16);
+    if (presplit) push_frag_split3(im, &blob[f.w], M, K, MT, K16);   // pw_kernel<.., PRE>: bf16 hi/mid/lo operand quads per chunk pair
+    else push_frag(im, &blob[f.w], M, K, MT, K16);
     if (K % 16)
       for (int mt = 0; mt < MT; ++mt)
         for (int l = 0; l < 64; ++l)
@@ -496,7 +497,8 @@ struct PlanBuilder {
     s.pw.H = 0; s.pw.W = 0; s.pw.HW = px;
     s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0;
     s.px_per_img = px;
-    s.img_off = wp.image_pw(f, M, K, yfv2_pw_tiles(K, mode, M));
+    s.pw.presplit = (h->bf6 && yfv2_pw_presplit_supported(K, mode, M)) ? 1 : 0;
+    s.img_off = wp.image_pw(f, M, K, yfv2_pw_tiles(K, mode, M), s.pw.presplit != 0);
     s.name = name;
     s.flops = 2.0 * px * K * M;
     s.bytes = 4.0 * px * (K + M);

@@ -38,16 +38,21 @@
 //               [0,192) gathered from C3 at (y/2, x/2), [192,288) from C2
 //   PW_HEAD     the three biased output convs (detector.py:17-19,25-31): stores
 //               NCHW logits into two destination tensors split at `split`
-template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false, bool BF6 = false>
+// PRE (streamed bf16x6 forms): the filter arrives pre-split on the host (WeightPacker::push_frag_split3) - per (output
+// tile, PAIR of chunks, term hi / mid / lo) one 16-byte operand whose 32 k-slots are the two chunks.  The six products are six
+// MFMAs per chunk pair with no VALU work on the filter side; splitting the MT filter fragments of every chunk on the fly
+// (each used for only NT = 2 pixel tiles) cost more VALU cycles than the MFMAs they fed.
+template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false, bool BF6 = false, bool PRE = false>
 __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   constexpr int K16 = K / 16;
   constexpr int KT = K % 16;
   static_assert(KT == 0 || KT == 8, "K must be 16*n or 16*n+8");
+  static_assert(!PRE || (STREAM && BF6 && K % 32 == 0), "PRE: streamed bf16x6 form, whole chunk pairs");
   // filter in LDS fragment-major (host-packed, WeightPacker::image_pw): frag (mt, s), lane l holds
   // W[16mt + (l&15)][16s + 4(l>>4) .. +3] - the 64 lanes of a fragment read touch 64 consecutive 16-byte slots, no bank
   // conflicts whatever 16-lane groups the hardware forms (a row-padded [M][K+4] image collides 5-7 slots per group);
   // an 8-channel tail is MT fragments of 8 bytes per lane behind them
-  constexpr int FRAG_FL = MT * K16 * 256;
+  constexpr int FRAG_FL = PRE ? MT * (K16 / 2) * 3 * 256 : MT * K16 * 256;
   constexpr int FILT_FL = FRAG_FL + (KT ? MT * 128 : 0);
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x;
@@ -102,6 +107,51 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
         }
       }
       constexpr int SPLIT = MODE == PW_FPN ? 12 : K16;
+      if constexpr (PRE) {
+        constexpr int KP = K16 / 2;
+        static_assert(SPLIT % 2 == 0, "a chunk pair does not straddle the two inputs");
+        f32x4 bcur[NT][2], bnxt[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) bcur[nt][e] = *reinterpret_cast<const f32x4*>(src0[nt] + 16 * e);
+#pragma unroll 1
+        for (int sp = 0; sp < KP; ++sp) {
+          if (sp + 1 < KP) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) bnxt[nt][e] = *reinterpret_cast<const f32x4*>((2 * sp + 2 < SPLIT ? src0[nt] : src1[nt]) + 16 * (2 * sp + 2 + e));
+          }
+          yfv2_bf16x8 ah[MT], am[MT], al[MT], bh[NT], bm[NT], bl[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float* wq3 = wl + (((mt * KP + sp) * 3) * 64 + lane) * 4;
+            ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
+            am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
+            al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
+            yfv2_split3(bcur[nt][0], h0, m0, l0);
+            yfv2_split3(bcur[nt][1], h1, m1, l1);
+            bh[nt] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+            bm[nt] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
+            bl[nt] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+          }
+          // six products, the small ones first; MT * NT independent accumulators: no MFMA waits for the one before it
+#define PW_PROD(A_, B_)                                                \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[mt], B_[nt], acc[mt][nt], 0, 0, 0);
+          PW_PROD(al, bh) PW_PROD(ah, bl) PW_PROD(am, bm) PW_PROD(am, bh) PW_PROD(ah, bm) PW_PROD(ah, bh)
+#undef PW_PROD
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) bcur[nt][e] = bnxt[nt][e];
+        }
+      } else {
       f32x4 bcur[NT], bnxt[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bcur[nt] = *reinterpret_cast<const f32x4*>(src0[nt]);
@@ -137,6 +187,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
+      }
       }
     } else {
     // ---- B fragments: all K channels of this lane's pixel(s), 16 B per load
@@ -286,6 +337,13 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   // bf16x6 for the instantiations the default plans use (the streamed large-K forms and the small biased heads); the fully
   // unrolled 6-tile forms of the layer-by-layer fallback would spill with the split operands and stay on the fp32 MFMA
   constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
+  if constexpr (STREAM && K % 32 == 0 && K >= 192) if (a.bf6 && a.presplit) {
+    static std::atomic<unsigned long long> lds_ok2{0};
+    const size_t lds_pre = lds * 3 / 2;
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), lds_ok2);
+    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds_pre, s, a);
+    return;
+  }
   if constexpr (kBf6) if (a.bf6) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), lds_ok1);
     hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), dim3(blocks), dim3(THREADS), lds, s, a);
@@ -293,6 +351,14 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   }
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
   hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
+}
+
+// does yfv2_launch_pw have a pre-split (PRE) instantiation for this launch?  (the planner then packs the filter pre-split)
+bool yfv2_pw_presplit_supported(int K, int mode, int M) {
+  const char* env = std::getenv("YFV2_PWSPLIT");
+  if (env && env[0] == '0') return false;
+  const int MT = (M + 15) / 16;
+  return MT == 5 && ((mode == PW_PLAIN && K == 192) || (mode == PW_FPN && K == 288));
 }
 
 // M tiles of the instantiation yfv2_launch_pw picks: the host packs the filter image for exactly that many

@@ -128,6 +128,7 @@ struct PwArgs {
   float* nchw1;        // PW_HEAD: co >= split -> nchw1[b][co-split][hw]
   int split;
   int bf6;             // run the MFMAs as bf16x6 where the instantiation has that form (handle flag, YFV2_BF6=0 at create time clears it)
+  int presplit;        // img holds the filter PRE-SPLIT into bf16 hi/mid/lo operand quads per chunk pair (WeightPacker::image_pw, streamed K = 192 / 288 forms; needs bf6)
 };
 
 // ---- depthwise kxk conv + BN (+ReLU), NHWC, float4 over channels
@@ -286,6 +287,7 @@ void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
 // K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
 int yfv2_pw_tiles(int K, int mode, int M);   // M tiles of the kernel instantiation yfv2_launch_pw uses (the host packs for that many)
+bool yfv2_pw_presplit_supported(int K, int mode, int M);   // the launch has a pre-split (bf16 hi/mid/lo operand quads) form
 bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
 int yfv2_block_s1_rows(int c2, int H, int W);
 bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
