@@ -1706,6 +1706,7 @@ static int post_impl(yfv2_handle h, int32_t B, float conf_thres, double iou_thre
   a.classes = nullptr; a.n_classes = 0;
   a.B = B; a.rows = h->rows; a.nc = h->cfg.classes;
   a.conf_thres = conf_thres; a.iou_thres = iou_thres;
+  a.trace = h->trace_step == -2 ? h->d_trace : nullptr;   // YFV2_TRACE=1 YFV2_TRACE_STEP=-2: stamps of the post launch (tools/trace_post.py)
   yfv2_launch_decode_nms(d, a, static_cast<hipStream_t>(stream));
   HIP_TRY(h, hipGetLastError());
   return YFV2_OK;

@@ -280,6 +280,7 @@ struct NmsArgs {
   int B, rows, nc;
   float conf_thres;
   double iou_thres;
+  long long* trace;    // debug: workgroup 0 / thread 0 writes cycle stamps at phase boundaries (or null)
 };
 
 // launchers (defined next to the kernels)
