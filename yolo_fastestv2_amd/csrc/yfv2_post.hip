@@ -22,8 +22,9 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
   const int c_lo = part * per, c_hi = min(nc, c_lo + per);
   const float* cls = a.cls[sc] + (size_t)b * nc * hw;   // wave-uniform base: the per-lane part stays a 32-bit offset (24 addresses live)
   // The lane's class slice is loaded ONCE, all 24 loads in flight together (masked slots re-read a valid class), and the
-  // three sweeps (max, sum, best product) run on registers; the probabilities are recomputed in the third sweep instead
-  // of being kept (this runs inside the 1024-thread NMS workgroup: 128 registers).  The first fused version re-read the
+  // three sweeps (max, sum, best product) run on registers; the second sweep leaves exp(v - max) in the logit's register,
+  // the third divides it (this runs inside the 1024-thread NMS workgroup: 128 registers, and it is VALU-bound there -
+  // four waves per SIMD - not bandwidth-bound: 24 fewer expf per lane and pass).  The first fused version re-read the
   // logits in every sweep in batches of four: 18 dependent round trips per pass instead of one.
   // Every value is computed by the same expression as in decode_kernel<false>, so the results are identical.
   float lv[MAXPER];
@@ -44,8 +45,9 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
-    const float v = logit(i);
-    if (c_lo + i < c_hi) sum = __fadd_rn(sum, expf(__fsub_rn(v, m)));
+    const float e = expf(__fsub_rn(logit(i), m));
+    lv[i] = e;                                              // the logit is dead from here on: its register keeps the exponential
+    if (c_lo + i < c_hi) sum = __fadd_rn(sum, e);
     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four exps at a time (a free schedule interleaves all 24: spills)
   }
   sum = __fadd_rn(sum, __shfl_xor(sum, 1));
@@ -60,9 +62,8 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
   }
 #pragma unroll
   for (int i = 0; i < MAXPER; ++i) {
-    const float v = logit(i);
     if (c_lo + i < c_hi) {
-      const float ev = __fdiv_rn(expf(__fsub_rn(v, m)), sum);   // the class probability, as decode_kernel<false> stores it
+      const float ev = __fdiv_rn(lv[i], sum);   // the class probability, as decode_kernel<false> stores it
 #pragma unroll
       for (int an = 0; an < 3; ++an) {
         const float pj = __fmul_rn(ev, obj3[an]);
