@@ -14,8 +14,9 @@ from yolo_fastestv2_amd import _lib
 from yolo_fastestv2_amd._lib import Config, TensorDesc
 
 C2, NB = 96, 3
-W1_FL, W2_FL = 2 * 6 * 256, 6 * 2 * 256
-IMG_FL = W1_FL + W2_FL + 9 * 32 + 4 * 32 + 2 * C2
+REST_FL = 9 * 32 + 4 * 32 + 2 * C2
+# fp32 fragments (YFV2_S4BF6=0) / pre-split bf16 hi-mid-lo operand quads per chunk pair (default): [mt][pair][term][64][4]
+SIZES = {False: (2 * 6 * 256, 6 * 2 * 256), True: (2 * 3 * 3 * 256, 6 * 1 * 3 * 256)}
 
 
 def _plan_image(w):
@@ -29,13 +30,28 @@ def _plan_image(w):
     ns, nb = C.c_int32(0), C.c_int64(0)
     assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0
     name = C.create_string_buffer(256)
-    buf = np.zeros(NB * 3 * IMG_FL, np.float32)
+    buf = np.zeros(NB * 3 * (sum(SIZES[True]) + REST_FL), np.float32)
     for st in range(ns.value):
         n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st, name, 256, buf.ctypes.data_as(C.c_void_p), buf.size)
         if n > 0 and "whole activation resident in LDS" in name.value.decode():
-            assert n >= buf.size
-            return buf.copy()
+            return buf[:n].copy()          # (n = what fitted of the blob from the image's start on, not the image's length)
     return None
+
+
+def _presplit(fr, mt_n, kp):
+    """[mt][chunk pair][hi, mid, lo][lane][4 dwords] -> (16 mt_n, 32 kp) = hi + mid + lo; dword d = two truncated bf16 (low
+    half first) of columns 16 (2 sp + (d >> 1)) + 4 (l >> 4) + 2 (d & 1) + {0, 1}"""
+    u = fr.view(np.uint32).reshape(mt_n, kp, 3, 64, 4)
+    terms = np.zeros((3, 16 * mt_n, 32 * kp), np.float32)
+    for mt in range(mt_n):
+        for sp in range(kp):
+            for l in range(64):
+                for d in range(4):
+                    c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1)
+                    for e in range(2):
+                        bits = ((u[mt, sp, :, l, d] >> (16 * e)) & 0xFFFF).astype(np.uint32) << 16
+                        terms[:, 16 * mt + (l & 15), c + e] = bits.view(np.float32)
+    return (terms[0] + terms[1]) + terms[2]
 
 
 def _frags(fr, mt_n, s_n):
@@ -49,11 +65,17 @@ def _frags(fr, mt_n, s_n):
     return m
 
 
-def test_pool_chain_host_packing():
+@pytest.mark.parametrize("form", ["presplit", "fp32"])
+def test_pool_chain_host_packing(monkeypatch, form):
+    if form == "fp32":
+        monkeypatch.setenv("YFV2_S4BF6", "0")
     w = yfv2.random_state_dict(9)
     im = _plan_image(w)
     if im is None:
         pytest.skip("this build's plan has no stage-4 chain launch")
+    pre = form == "presplit"            # the default plan packs pre-split; YFV2_S4BF6=0 the fp32 fragments
+    W1_FL, W2_FL = SIZES[pre]
+    IMG_FL = W1_FL + W2_FL + REST_FL
     torch.manual_seed(2)
     x = torch.randn(1, 192, 11, 11)
     ref = x
@@ -66,8 +88,12 @@ def test_pool_chain_host_packing():
         acc2 = np.zeros((H, W, C2), np.float32)
         for th in range(3):
             t = im[(blk * 3 + th) * IMG_FL:(blk * 3 + th + 1) * IMG_FL]
-            w1t = _frags(t[:W1_FL], 2, 6)                        # (32, 96): rows 32 th .. +31
-            w2t = _frags(t[W1_FL:W1_FL + W2_FL], 6, 2)           # (96, 32): columns 32 th .. +31
+            w1t = _presplit(t[:W1_FL], 2, 3) if pre else _frags(t[:W1_FL], 2, 6)                        # (32, 96): rows 32 th .. +31
+            w2t = _presplit(t[W1_FL:W1_FL + W2_FL], 6, 1) if pre else _frags(t[W1_FL:W1_FL + W2_FL], 6, 2)  # (96, 32): columns 32 th .. +31
+            if pre:   # hi + mid + lo is the fp32 filter, exactly
+                p4 = "backbone.stage4.%d.branch_main." % (blk + 1)
+                assert np.array_equal(w1t, w[p4 + "0.weight"].reshape(C2, C2).numpy()[32 * th:32 * th + 32])
+                assert np.array_equal(w2t, w[p4 + "5.weight"].reshape(C2, C2).numpy()[:, 32 * th:32 * th + 32])
             o = W1_FL + W2_FL
             taps = t[o:o + 288].reshape(9, 32)
             sc1, sh1, scd, shd = t[o + 288:o + 416].reshape(4, 32)

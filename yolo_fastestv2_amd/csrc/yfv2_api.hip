@@ -307,6 +307,25 @@ struct WeightPacker {
   // 2sp, then the same of chunk 2sp+1 - the A operand of one v_mfma_f32_16x16x32_bf16 whose 32 k-slots are the two chunks.
   static unsigned bf16_trunc_bits(float v) { unsigned u; std::memcpy(&u, &v, 4); return u >> 16; }
   static float bf16_trunc(float v) { unsigned u; std::memcpy(&u, &v, 4); u &= 0xffff0000u; float r; std::memcpy(&r, &u, 4); return r; }
+  // the same layout from an element accessor (sub-matrices): MT output tiles x KP chunk pairs, el(row, column)
+  template <class Fn>
+  static void push_split3_fn(std::vector<float>& im, int MT, int KP, Fn el) {
+    for (int mt = 0; mt < MT; ++mt)
+      for (int sp = 0; sp < KP; ++sp)
+        for (int term = 0; term < 3; ++term)
+          for (int l = 0; l < 64; ++l)
+            for (int d = 0; d < 4; ++d) {
+              const int r = 16 * mt + (l & 15), c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1);
+              unsigned packed = 0;
+              for (int e = 0; e < 2; ++e) {
+                float v = el(r, c + e);
+                for (int t = 0; t < term; ++t) v = v - bf16_trunc(v);   // exact in fp32
+                packed |= bf16_trunc_bits(v) << (16 * e);
+              }
+              float f; std::memcpy(&f, &packed, 4);
+              im.push_back(f);
+            }
+  }
   static void push_frag_split3(std::vector<float>& im, const float* w, int M, int K, int MT, int KC) {
     for (int mt = 0; mt < MT; ++mt)
       for (int sp = 0; sp < KC / 2; ++sp)
@@ -938,6 +957,7 @@ struct PlanBuilder {
   // [9][32] | sc1 sh1 scd shd [32] | sc2 sh2 [96]
   void s1pool_block(const std::vector<std::string>& names, int c, int H, int W, const Buf& x, const Buf& y) {
     const int c2 = c / 2, NB = (int)names.size();
+    const bool pre = h->bf6 && yfv2_s1pool_presplit();
     std::vector<float> im;
     for (int k = 0; k < NB && ok; ++k) {
       Folded f1, fd, f2;
@@ -948,6 +968,10 @@ struct PlanBuilder {
       const float* w1 = &wp.blob[f1.w]; const float* w2 = &wp.blob[f2.w]; const float* wd = &wp.blob[fd.w];
       for (int t = 0; t < 3; ++t) {
         const size_t start = im.size();
+        if (pre) {   // bf16 hi / mid / lo operand quads per chunk pair (block_s1pool_kernel<.., PRE>)
+          WeightPacker::push_split3_fn(im, 2, 3, [&](int r, int cc) { return w1[(size_t)(32 * t + r) * c2 + cc]; });    // W1 rows 32 t .. +31, K = 96
+          WeightPacker::push_split3_fn(im, 6, 1, [&](int r, int cc) { return w2[(size_t)r * c2 + 32 * t + cc]; });      // W2 columns 32 t .. +31
+        } else {
         for (int mt = 0; mt < 2; ++mt)
           for (int s = 0; s < 6; ++s)
             for (int l = 0; l < 64; ++l)
@@ -956,13 +980,14 @@ struct PlanBuilder {
           for (int s = 0; s < 2; ++s)
             for (int l = 0; l < 64; ++l)
               for (int j = 0; j < 4; ++j) im.push_back(w2[(size_t)(16 * mt + (l & 15)) * c2 + 32 * t + 16 * s + 4 * (l >> 4) + j]);
+        }
         for (int tap = 0; tap < 9; ++tap)
           for (int ch = 0; ch < 32; ++ch) im.push_back(wd[(size_t)tap * c2 + 32 * t + ch]);
         for (const size_t* v : {&f1.scale, &f1.shift, &fd.scale, &fd.shift})
           for (int ch = 0; ch < 32; ++ch) im.push_back(wp.blob[*v + 32 * t + ch]);
         for (int ch = 0; ch < c2; ++ch) im.push_back(wp.blob[f2.scale + ch]);
         for (int ch = 0; ch < c2; ++ch) im.push_back(wp.blob[f2.shift + ch]);
-        if ((int)(im.size() - start) != yfv2_s1pool_image_floats()) ok = false;
+        if ((int)(im.size() - start) != yfv2_s1pool_image_floats(pre)) ok = false;
       }
     }
     Step s;
@@ -970,6 +995,8 @@ struct PlanBuilder {
     s.c2 = c2;
     s.s1.in = x.p; s.s1.out = y.p;
     s.s1.H = H; s.s1.W = W; s.s1.R = H; s.s1.nblk = NB;
+    s.s1.presplit = pre ? 1 : 0;
+    s.s1.presplit = pre ? 1 : 0;
     s.img_off = wp.put(im);
     s.name = names.front() + " .. " + names.back().substr(names.back().rfind('.') + 1) + " chain of " + std::to_string(NB) +
              " fused s1 blocks in one launch (whole activation resident in LDS)";

@@ -1250,15 +1250,25 @@ constexpr int P96_CPP = P96_C + 4;                                              
 constexpr int P96_TP = P96_TC + 4;                                               // floats per T pixel
 constexpr int P96_W1_FL = 2 * P96_KC * 256, P96_W2_FL = P96_KC * 2 * 256;        // fragment-major, per third
 constexpr int P96_IMG_FL = P96_W1_FL + P96_W2_FL + 9 * P96_TC + 4 * P96_TC + 2 * P96_C2;   // + taps, sc1 sh1 scd shd, sc2 sh2
+// PRE: W1 / W2 pre-split into bf16 hi / mid / lo operand quads per chunk pair (WeightPacker, as block_s2w_kernel's W1):
+// [mt][pair][term][64][4] - W1 of a third = 2 tiles x 3 pairs, W2 = 6 tiles x 1 pair; 1.5x the fp32 fragments
+constexpr int P96_W1P_FL = 2 * (P96_KC / 2) * 3 * 256, P96_W2P_FL = P96_KC * 1 * 3 * 256;
+constexpr int P96_IMGP_FL = P96_W1P_FL + P96_W2P_FL + 9 * P96_TC + 4 * P96_TC + 2 * P96_C2;
 constexpr int P96_MAXPX = 128;
 
-template <int THREADS>
+// PRE (bf16x6 on pre-split filters): the kernel is bound by its fp32 MFMAs (6912 per image: 55 k SIMD-cycles of the launch's
+// 115 k) - the six-product form needs 2.67x fewer matrix-core cycles, and with the filters split on the host the only VALU
+// work added is the split of the B operands: pw1's once per BLOCK (the pool's odd channels do not change during its three
+// passes: nine operand quads stay in registers), pw2's depthwise result once per pass.
+template <int THREADS, bool PRE>
 __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a) {
   constexpr int NW = THREADS / 64;
-  constexpr int N4 = P96_IMG_FL / 4, NIT = (N4 + THREADS - 1) / THREADS;
+  constexpr int IMG_FL = PRE ? P96_IMGP_FL : P96_IMG_FL;
+  constexpr int W1_FL = PRE ? P96_W1P_FL : P96_W1_FL, W2_FL = PRE ? P96_W2P_FL : P96_W2_FL;
+  constexpr int N4 = IMG_FL / 4, NIT = (N4 + THREADS - 1) / THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* POOL = lds;                                   // [P96_MAXPX][P96_CPP]
-  float* T = POOL + P96_MAXPX * P96_CPP;               // [(H+2)][(W+2)][P96_TP], border zero
+  float* POOL = lds;                                   // [H * W][P96_CPP]
+  float* T = POOL + a.H * a.W * P96_CPP;               // [(H+2)][(W+2)][P96_TP], border zero
   float* IMG = T + (a.H + 2) * (a.W + 2) * P96_TP;     // one third's image
   const int H = a.H, W = a.W, HW = H * W, WP = W + 2, NB = a.nblk;
   const float invW = 1.0f / (float)W;
@@ -1292,24 +1302,58 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
       f32x4 acc2[P96_KC];
 #pragma unroll
       for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // PRE: pw1's B operands for the whole block - the 96 odd pool channels of this lane's pixel, per chunk pair
+      yfv2_bf16x8 b1h[PRE ? P96_KC / 2 : 1], b1m[PRE ? P96_KC / 2 : 1], b1l[PRE ? P96_KC / 2 : 1];
+      if constexpr (PRE) {
+#pragma unroll
+        for (int sp = 0; sp < P96_KC / 2; ++sp) {
+          unsigned hh[2][2], mm[2][2], ll[2][2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int s2 = 2 * sp + e;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(ppix + 32 * s2 + 8 * g);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(ppix + 32 * s2 + 8 * g + 4);
+            yfv2_split3((f32x4){q0[1], q0[3], q1[1], q1[3]}, hh[e], mm[e], ll[e]);
+          }
+          b1h[sp] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){hh[0][0], hh[0][1], hh[1][0], hh[1][1]});
+          b1m[sp] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){mm[0][0], mm[0][1], mm[1][0], mm[1][1]});
+          b1l[sp] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){ll[0][0], ll[0][1], ll[1][0], ll[1][1]});
+        }
+      }
 #pragma unroll 1
       for (int th = 0; th < P96_TH; ++th) {
         const int t = blk * P96_TH + th;
         const bool more = t + 1 < NB * P96_TH;
         const float* W1t = IMG;
-        const float* W2t = IMG + P96_W1_FL;
-        const float* TAPS = W2t + P96_W2_FL;           // [9][32]
+        const float* W2t = IMG + W1_FL;
+        const float* TAPS = W2t + W2_FL;               // [9][32]
         const float* CSV = TAPS + 9 * P96_TC;          // sc1 sh1 scd shd [32] | sc2 sh2 [96]
         // the next third's image travels through registers while this one computes
         f32x4 nimg[NIT];
         {
-          const f32x4* isrc = reinterpret_cast<const f32x4*>(a.img + (size_t)(t + 1) * P96_IMG_FL);
+          const f32x4* isrc = reinterpret_cast<const f32x4*>(a.img + (size_t)(t + 1) * IMG_FL);
 #pragma unroll
           for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; nimg[k] = (more && i < N4) ? isrc[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
         }
         // ---- pw1 (+BN+ReLU): output channels 32 th .. +31 of the branch, K = the 96 odd channels of the pool
         {
           f32x4 acc1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          if constexpr (PRE) {
+#pragma unroll
+            for (int sp = 0; sp < P96_KC / 2; ++sp) {
+              yfv2_bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                const float* wq3 = W1t + (((mt * (P96_KC / 2) + sp) * 3) * 64 + lane) * 4;
+                ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
+                am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
+                al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
+              }
+#define P96_PROD(A_, B_) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[mt], B_, acc1[mt], 0, 0, 0);
+              P96_PROD(al, b1h[sp]) P96_PROD(ah, b1l[sp]) P96_PROD(am, b1m[sp]) P96_PROD(am, b1h[sp]) P96_PROD(ah, b1m[sp]) P96_PROD(ah, b1h[sp])
+#undef P96_PROD
+            }
+          } else {
 #pragma unroll
           for (int s2 = 0; s2 < P96_KC; ++s2) {
             const f32x4 q0 = *reinterpret_cast<const f32x4*>(ppix + 32 * s2 + 8 * g);
@@ -1322,6 +1366,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
               acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bf[j], acc1[0], 0, 0, 0);
               acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bf[j], acc1[1], 0, 0, 0);
             }
+          }
           }
           if (pv) {
 #pragma unroll
@@ -1337,6 +1382,45 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
         }
         __syncthreads();   // the depthwise windows reach into the neighbours' pixels
         // ---- dw3x3 (+BN) in registers -> pw2 partial sums over this third's 32 input channels
+        if constexpr (PRE) {
+          f32x4 bfr2[2];
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int cb = 16 * c2 + 4 * g;
+            f32x4 win[9], wl[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+              win[k] = *reinterpret_cast<const f32x4*>(twin + ((k / 3) * WP + (k % 3)) * P96_TP + cb);
+              wl[k] = *reinterpret_cast<const f32x4*>(TAPS + k * P96_TC + cb);
+            }
+            const f32x4 dsc = *reinterpret_cast<const f32x4*>(CSV + 2 * P96_TC + cb);
+            const f32x4 dsh = *reinterpret_cast<const f32x4*>(CSV + 3 * P96_TC + cb);
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bfr2[c2][c] = __builtin_fmaf(d[c], dsc[c], dsh[c]);
+          }
+          unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
+          yfv2_split3(bfr2[0], h0, m0, l0);
+          yfv2_split3(bfr2[1], h1, m1, l1);
+          const yfv2_bf16x8 bh = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+          const yfv2_bf16x8 bm = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
+          const yfv2_bf16x8 bl = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+          yfv2_bf16x8 ah[P96_KC], am[P96_KC], al[P96_KC];
+#pragma unroll
+          for (int mt = 0; mt < P96_KC; ++mt) {
+            const float* wq3 = W2t + ((mt * 3) * 64 + lane) * 4;
+            ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
+            am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
+            al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
+          }
+#define P96_PROD(A_, B_) _Pragma("unroll") for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[mt], B_, acc2[mt], 0, 0, 0);
+          P96_PROD(al, bh) P96_PROD(ah, bl) P96_PROD(am, bm) P96_PROD(am, bh) P96_PROD(ah, bm) P96_PROD(ah, bh)
+#undef P96_PROD
+        } else {
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
           const int cb = 16 * c2 + 4 * g;
@@ -1363,6 +1447,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
 #pragma unroll
             for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], acc2[mt], 0, 0, 0);
         }
+        }
         if (th == P96_TH - 1) {                         // pw2's BN + ReLU (the vectors leave with this image)
 #pragma unroll
           for (int mt = 0; mt < P96_KC; ++mt) {
@@ -1382,7 +1467,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
       // ---- pool <- cat(even channels, fresh): evens gathered through registers between two barriers
       {
         constexpr int NQ = P96_C2 / 4;                  // 24 output quads of pass-through channels per pixel
-        constexpr int NEV = (P96_MAXPX * NQ + THREADS - 1) / THREADS;
+        constexpr int NEV = (P96_MAXPX * NQ + THREADS - 1) / THREADS;   // (registers for up to 128 pixels; the pool itself holds H * W)
         f32x4 ev[NEV];
 #pragma unroll
         for (int k = 0; k < NEV; ++k) {
@@ -1421,23 +1506,32 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
   }
 }
 
-static long s1pool_lds_floats(int H, int W) { return (long)P96_MAXPX * P96_CPP + (long)(H + 2) * (W + 2) * P96_TP + P96_IMG_FL; }
-int yfv2_s1pool_image_floats() { return P96_IMG_FL; }
+static long s1pool_lds_floats(int H, int W, bool pre) { return (long)H * W * P96_CPP + (long)(H + 2) * (W + 2) * P96_TP + (pre ? P96_IMGP_FL : P96_IMG_FL); }
+int yfv2_s1pool_image_floats(bool presplit) { return presplit ? P96_IMGP_FL : P96_IMG_FL; }
+bool yfv2_s1pool_presplit() {
+  const char* env = std::getenv("YFV2_S4BF6");
+  return !(env && env[0] == '0');
+}
 
 bool yfv2_s1pool_supported(int c2, int H, int W) {
   if (c2 != P96_C2 || H * W > P96_MAXPX || H * W < 1) return false;
-  if (s1pool_lds_floats(H, W) * 4 > 160 * 1024) return false;
+  if (s1pool_lds_floats(H, W, true) * 4 > 160 * 1024) return false;
   const char* env = std::getenv("YFV2_S4CHAIN");
   return !(env && env[0] == '0');
 }
 
 bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s) {
   if (!yfv2_s1pool_supported(P96_C2, a.H, a.W) || a.nblk < 1) return false;
-  const size_t lds = sizeof(float) * (size_t)s1pool_lds_floats(a.H, a.W);
+  const size_t lds = sizeof(float) * (size_t)s1pool_lds_floats(a.H, a.W, a.presplit != 0);
   const int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1pool_kernel<512>), lds_ok0);
-  hipLaunchKernelGGL((block_s1pool_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
+  if (a.presplit) {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1pool_kernel<512, true>), lds_ok1);
+    hipLaunchKernelGGL((block_s1pool_kernel<512, true>), dim3(blocks), dim3(512), lds, s, a);
+  } else {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1pool_kernel<512, false>), lds_ok0);
+    hipLaunchKernelGGL((block_s1pool_kernel<512, false>), dim3(blocks), dim3(512), lds, s, a);
+  }
   return true;
 }
 

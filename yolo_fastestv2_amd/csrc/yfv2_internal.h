@@ -165,6 +165,7 @@ struct BlockS1Args {
   int B, H, W;
   int R;             // rows per work item (H % R == 0)
   int nblk;          // block_s1chain_kernel: blocks in the chain (img = their images back to back)
+  int presplit;      // block_s1pool_kernel: the images hold W1 / W2 pre-split for bf16x6 (yfv2_s1pool_image_floats(true) floats each)
 };
 
 // two consecutive stride-1 blocks in one launch (block_s1x2_kernel, C2 = 48): logical branch-input channel held at
@@ -187,7 +188,8 @@ bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s);
 // chain of stride-1 blocks with the whole 192-channel activation resident in LDS (block_s1pool_kernel, stage 4 at 11x11):
 // natural channel order, no bookkeeping; img = per block three images of yfv2_s1pool_image_floats() floats (one per third)
 bool yfv2_s1pool_supported(int c2, int H, int W);
-int yfv2_s1pool_image_floats();
+int yfv2_s1pool_image_floats(bool presplit);
+bool yfv2_s1pool_presplit();   // plan the pre-split (bf16x6) form (YFV2_S4BF6=0: fp32 MFMA form)
 bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s);
 bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s);   // a.img = first block's LDS image | second block's
 
