@@ -423,9 +423,9 @@ def test_other_input_size_320(yfv2, dev):
 
 @pytest.mark.parametrize("env", [{"YFV2_S2PX": "0"}, {"YFV2_FUSED": "0"}, {"YFV2_S1CHAIN": "0"}, {"YFV2_S1CHAIN": "0", "YFV2_S1X2": "0"},
                                  {"YFV2_S1CHAIN": "0", "YFV2_S1X2": "0", "YFV2_S1W": "0", "YFV2_DWPW": "0", "YFV2_S4CHAIN": "0"},
-                                 {"YFV2_S4CHAIN": "0"}, {"YFV2_S2W": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_SIDE": "1"}, {"YFV2_PWSPLIT": "0"}, {"YFV2_S4BF6": "0"}],
+                                 {"YFV2_S4CHAIN": "0"}, {"YFV2_S2W": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_SIDE": "1"}, {"YFV2_PWSPLIT": "0"}, {"YFV2_S4BF6": "0"}, {"YFV2_S1CHAIN_BF6": "0"}],
                          ids=["stage2-on-LDS-kernels", "layer-by-layer", "stage3-as-pairs", "stage3-single-blocks", "round-1-kernels",
-                              "stage4-single-blocks", "stage4.0-as-three-launches", "fp32-mfma-everywhere", "two-launch-post", "side-streams-for-the-11x11-towers", "fpn-filters-split-on-the-fly", "stage4-chain-on-the-fp32-mfma"])
+                              "stage4-single-blocks", "stage4.0-as-three-launches", "fp32-mfma-everywhere", "two-launch-post", "side-streams-for-the-11x11-towers", "fpn-filters-split-on-the-fly", "stage4-chain-on-the-fp32-mfma", "stage3-chain-on-the-fp32-mfma"])
 def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     """The fallback launch plans (stage 2 on the LDS kernels / everything layer by layer / stage 3 as pairs of blocks or as
     single blocks instead of the seven-block chain / the round-1 kernel set) are what runs for shapes the newer kernels do

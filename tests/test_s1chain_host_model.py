@@ -18,6 +18,41 @@ from yolo_fastestv2_amd._lib import Config, TensorDesc
 KC, C2, NB = 3, 48, 7
 W_FL, DW_FL, CST_FL, TBL_FL = KC * KC * 256, 9 * KC * 16, 6 * KC * 16, 64
 IMG_FL = 2 * W_FL + DW_FL + CST_FL + TBL_FL
+BF6 = False          # which image form the helpers below decode; set by _set_form()
+
+
+def _set_form(bf6):
+    """fp32 fragments [3][3][64][4] (block_s1chain_kernel, YFV2_S1CHAIN_BF6=0) or the pre-split form of the default
+    block_s1chain6_kernel: per filter [mt (3)][six 16-byte operands][64][4]"""
+    global W_FL, IMG_FL, BF6
+    BF6 = bf6
+    W_FL = 3 * 6 * 256 if bf6 else KC * KC * 256
+    IMG_FL = 2 * W_FL + DW_FL + CST_FL + TBL_FL
+
+
+def _bf(u):
+    return (u.astype(np.uint32) << 16).view(np.float32)
+
+
+def _decode6(fr):
+    """[mt][hi, mid, lo quads of the chunk pair | {hi,hi} {mid,mid} {hi,lo} of chunk 2][lane][4 dwords] -> (48, 48) float32;
+    every dword = two truncated bf16 (low half first).  Checks the duplicated halves of the single-chunk operands."""
+    u = fr.view(np.uint32).reshape(3, 6, 64, 4)
+    m = np.zeros((3, C2, C2), np.float32)                 # hi, mid, lo
+    for mt in range(3):
+        for l in range(64):
+            r, g = 16 * mt + (l & 15), l >> 4
+            for term in range(3):
+                for d in range(4):
+                    c = 16 * (d >> 1) + 4 * g + 2 * (d & 1)
+                    m[term, r, c], m[term, r, c + 1] = _bf(u[mt, term, l, d] & 0xFFFF), _bf(u[mt, term, l, d] >> 16)
+            hh, mm, hl = u[mt, 3, l], u[mt, 4, l], u[mt, 5, l]
+            assert hh[0] == hh[2] and hh[1] == hh[3] and mm[0] == mm[2] and mm[1] == mm[3] and hl[0] == hh[0] and hl[1] == hh[1]
+            for term, q in ((0, hh[:2]), (1, mm[:2]), (2, hl[2:])):
+                for d in range(2):
+                    c = 32 + 4 * g + 2 * d
+                    m[term, r, c], m[term, r, c + 1] = _bf(q[d] & 0xFFFF), _bf(q[d] >> 16)
+    return (m[0] + m[1]) + m[2]
 
 
 def _descs(w):
@@ -61,7 +96,8 @@ def _frag_matrix(fr):
 
 def _branch(tile_phys, im):
     """tile_phys: (H, W, 48) branch input in PHYSICAL tile order -> (H, W, 3 mt, 4 g, 4 e) accumulators after pw2 + BN + ReLU"""
-    w1, w2 = _frag_matrix(im[:W_FL]), _frag_matrix(im[W_FL:2 * W_FL])
+    dec = _decode6 if BF6 else _frag_matrix
+    w1, w2 = dec(im[:W_FL]), dec(im[W_FL:2 * W_FL])
     wd = im[2 * W_FL:2 * W_FL + DW_FL].reshape(9, C2)
     cs = im[2 * W_FL + DW_FL:2 * W_FL + DW_FL + CST_FL].reshape(6, C2)
     H, W, _ = tile_phys.shape
@@ -161,7 +197,11 @@ def _kernel_model(x, images):
     return z
 
 
-def test_chain_host_packing_and_channel_bookkeeping():
+@pytest.mark.parametrize("form", ["bf16x6-presplit", "fp32"])
+def test_chain_host_packing_and_channel_bookkeeping(monkeypatch, form):
+    if form == "fp32":
+        monkeypatch.setenv("YFV2_S1CHAIN_BF6", "0")
+    _set_form(form != "fp32")
     w = yfv2.random_state_dict(5)
     im, rc, lab = _plan(w)
     if im is None:

@@ -284,6 +284,42 @@ struct WeightPacker {
     push_rows(im, &blob[fd.w], 9, c2, KS);
     for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], c2, KS); push_vec(im, &blob[f->shift], c2, KS); }
   }
+  // block_s1chain6_kernel: a 48x48 filter as [mt (3)][six 16-byte operands][64 lanes][4 dwords]: hi / mid / lo quads of the
+  // chunk PAIR (chunks 0, 1: the 32 k-slots of one bf16 MFMA), then {hi,hi} {mid,mid} {hi,lo} of the single chunk 2 (the
+  // register form of yfv2_split_a); every dword = two truncated bf16, low half first
+  static void push_chain6_filter(std::vector<float>& im, const float* w /* [48][48] */) {
+    auto terms = [&](int r, int c, unsigned (&t3)[3]) {   // packed (value c, value c + 1) of row r: hi, mid, lo
+      for (int t = 0; t < 3; ++t) t3[t] = 0;
+      for (int e = 0; e < 2; ++e) {
+        float v = w[(size_t)r * 48 + c + e];
+        for (int t = 0; t < 3; ++t) { t3[t] |= bf16_trunc_bits(v) << (16 * e); v = v - bf16_trunc(v); }
+      }
+    };
+    auto put_u = [&](unsigned u) { float f; std::memcpy(&f, &u, 4); im.push_back(f); };
+    for (int mt = 0; mt < 3; ++mt) {
+      for (int term = 0; term < 3; ++term)               // the pair: dwords 0, 1 = chunk 0, dwords 2, 3 = chunk 1
+        for (int l = 0; l < 64; ++l)
+          for (int d = 0; d < 4; ++d) {
+            unsigned t3[3];
+            terms(16 * mt + (l & 15), 16 * (d >> 1) + 4 * (l >> 4) + 2 * (d & 1), t3);
+            put_u(t3[term]);
+          }
+      for (int q = 0; q < 3; ++q)                        // the single chunk: {hi,hi} {mid,mid} {hi,lo}
+        for (int l = 0; l < 64; ++l) {
+          unsigned a3[3], b3[3];
+          terms(16 * mt + (l & 15), 32 + 4 * (l >> 4), a3);
+          terms(16 * mt + (l & 15), 32 + 4 * (l >> 4) + 2, b3);
+          const int lo_t = q == 0 ? 0 : (q == 1 ? 1 : 0), hi_t = q == 0 ? 0 : (q == 1 ? 1 : 2);
+          put_u(a3[lo_t]); put_u(b3[lo_t]); put_u(a3[hi_t]); put_u(b3[hi_t]);
+        }
+    }
+  }
+  void append_s1_bf6(std::vector<float>& im, const Folded& f1, const Folded& fd, const Folded& f2) {
+    push_chain6_filter(im, &blob[f1.w]);
+    push_chain6_filter(im, &blob[f2.w]);
+    push_rows(im, &blob[fd.w], 9, 48, 48);
+    for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], 48, 48); push_vec(im, &blob[f->shift], 48, 48); }
+  }
   size_t image_s1(const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
     std::vector<float> im;
     append_s1(im, f1, fd, f2, c2);
@@ -773,6 +809,7 @@ struct PlanBuilder {
   struct ChainLoc { int kind = 0, blk = 0, mt = 0, g = 0, e = 0, off = 0; };   // kind 0: X[off] (loaded up front), 1: accumulator of block blk, 2: parked at Z[off]
   void s1chain_block(const std::vector<std::string>& names, int c, int H, int W, const Buf& x, const Buf& y, int* z_label) {
     const int c2 = c / 2, NB = (int)names.size();
+    const bool bf6 = h->bf6 && yfv2_s1chain_bf6();   // block_s1chain6_kernel: pre-split filters
     std::vector<Folded> f1(NB), fd(NB), f2(NB);
     for (int k = 0; k < NB; ++k) {
       ok &= wp.pw(names[k] + ".branch_main.0", names[k] + ".branch_main.1", c2, c2, &f1[k]);
@@ -913,7 +950,7 @@ struct PlanBuilder {
           nxt[48 + j] = L;
         }
         act.swap(nxt);
-        wp.append_s1(im, f1k, fd[k], f2k, c2);
+        if (bf6) wp.append_s1_bf6(im, f1k, fd[k], f2k); else wp.append_s1(im, f1k, fd[k], f2k, c2);
         for (int t = 0; t < 64; ++t) {                  // int tables as raw bits behind the BN vectors
           float fbits; const int v = t < 36 ? tables[k][t] : 0;
           std::memcpy(&fbits, &v, sizeof(float));
@@ -933,7 +970,7 @@ struct PlanBuilder {
           if (pos < 0 || z_label[pos] != -1) { ok = false; break; }
           z_label[pos] = o;
         }
-        if ((int)(im.size() / NB) != yfv2_s1chain_image_floats()) ok = false;
+        if ((int)(im.size() / NB) != yfv2_s1chain_image_floats(bf6)) ok = false;
       }
     } else {
       ok = false;
@@ -943,6 +980,7 @@ struct PlanBuilder {
     s.c2 = c2;
     s.s1.in = x.p; s.s1.out = y.p;
     s.s1.H = H; s.s1.W = W; s.s1.R = H; s.s1.nblk = NB;
+    s.s1.presplit = bf6 ? 1 : 0;
     s.img_off = wp.put(im);
     s.name = names.front() + " .. " + names.back().substr(names.back().rfind('.') + 1) + " chain of " + std::to_string(NB) +
              " fused s1 blocks in one launch (activations between them stay on chip)";
@@ -1223,7 +1261,7 @@ std::string step_kernel(const Step& st) {
     case STEP_S2PX: return "s2px_proj_kernel + s2px_main_kernel";
     case STEP_DWPW: return "dwpw_s2_kernel";
     case STEP_S1X2: return "block_s1x2_kernel";
-    case STEP_S1CHAIN: return "block_s1chain_kernel";
+    case STEP_S1CHAIN: return st.s1.presplit ? "block_s1chain6_kernel" : "block_s1chain_kernel";
     case STEP_S1POOL: return "block_s1pool_kernel";
   }
   return "?";

@@ -26,6 +26,7 @@
 // HBM traffic per block: read c*H*W, write c*H*W floats (plus halo re-reads served by
 // L2) instead of 3 reads + 3 writes of activations in the unfused plan.
 #include <cstdlib>
+#include <type_traits>
 
 #include "yfv2_internal.h"
 
@@ -1155,28 +1156,386 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a
   }
 }
 
-static long s1chain_lds_floats(int H, int W) {
-  const long pl = (((long)(H + 2) * (W + 1) + 1 + 15) & ~15L);
-  return 2L * CH_IMG_FL + 12L * pl * 4;
+// ============================================================================
+// The chain on bf16x6 (default): block_s1chain6_kernel
+// ============================================================================
+// Same dataflow, tile layout, exchange and host bookkeeping as block_s1chain_kernel above; what changes is the arithmetic
+// of the two pointwise convs and what that needs around it.  The fp32-MFMA chain was bound by its matrix-core time (2232
+// MFMAs of 32 cycles per block and image: 25 k of a block's 38 k ticks) and, in phase B, by LDS reads (taps re-read per
+// tile).  Here:
+//  * W1 / W2 arrive PRE-SPLIT (WeightPacker::append_s1_bf6): K = 48 = one chunk PAIR + one single chunk.  Per output tile
+//    six 16-byte operands: hi / mid / lo quads of the pair (32 k-slots = chunks 0, 1: six MFMAs, no duplication) and the
+//    {hi,hi} {mid,mid} {hi,lo} quads of chunk 2 (three MFMAs against {hi,mid} {lo,hi} of the activations) - nine
+//    v_mfma_f32_16x16x32_bf16 of 16 cycles per (output tile, pixel tile) instead of twelve fp32 MFMAs of 32, and no VALU
+//    work on the filter side;
+//  * the filter operands are read from LDS per PAIR of pixel tiles (not held in registers: 72 VGPRs), the depthwise taps of
+//    a chunk once per pair of tiles;
+//  * an image is 40 KB (10000 floats) instead of 21.6: ONE image buffer.  The next block's image travels through five
+//    registers per thread during phases A and B and is stored in the exchange phase, after the barrier that retires phase
+//    B's reads; the park table of the current block is read into registers before that barrier.
+// Per block image: W1 pre-split [3][6][64][4] | W2 pre-split | dw taps [9][48] | 6 BN vectors | int tables (as above).
+constexpr int CH6_WP_FL = 3 * 6 * 256;
+constexpr int CH6_IMG_FL = 2 * CH6_WP_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + CH_TBL_FL;
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args a) {
+  constexpr int C2 = 48;
+  using Cfg = S1Cfg<C2>;
+  constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2, NT = 4;
+  constexpr int NW = THREADS / 64;
+  constexpr int N4 = CH6_IMG_FL / 4, NIT = (N4 + THREADS - 1) / THREADS;   // float4 per image, per thread (5)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* IM = lds;                                        // the current block's image
+  float* T1 = lds + CH6_IMG_FL;
+  const float* W1P = IM;
+  const float* W2P = IM + CH6_WP_FL;
+  const float* WD = IM + 2 * CH6_WP_FL;
+  const float* CS = WD + Cfg::DW_FL;
+  const int H = a.H, W = a.W, HW = H * W, NB = a.nblk;
+  const int RP = W + 1;
+  const int PL = ((H + 2) * RP + 1 + 15) & ~15;
+  const float invRP = 1.0f / (float)RP;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int s_first = RP + 1;
+  const int n_slots = (H - 1) * RP + W;                   // <= 16 * NT * NW (launcher)
+  YFV2_WSTAMP(0);
+
+  for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
+
+  int sl[NT], pix[NT];
+  bool valid[NT], real[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int q = 16 * (wave + NW * nt) + p;
+    valid[nt] = q < n_slots;
+    sl[nt] = s_first + (valid[nt] ? q : n_slots - 1);
+    const int r1 = yfv2_fdiv(sl[nt], invRP), xs = sl[nt] - r1 * RP;
+    real[nt] = valid[nt] && xs >= 1;                      // column 0 of a haloed row is the shared zero column
+    pix[nt] = real[nt] ? (r1 - 1) * W + (xs - 1) : 0;
+  }
+  float* Tg = T1 + (size_t)g * PL * 4;                    // plane of quad g; quad 4 s + g is 4 s planes further
+  // (a slot index goes through an opaque register wherever an LDS address is formed from it: addresses hoisted out of the
+  // block loop are what the register allocator spills first, and every scratch reload waits for the image loads in flight)
+  auto opq = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+
+  // B operands of one pixel tile from its three chunk fragments: the pair (chunks 0, 1) as hi / mid / lo quads, chunk 2
+  // as {hi,mid} {lo,hi}
+  struct BOps { yfv2_bf16x8 ph, pm, pl; Bf3B s; };
+  auto make_b = [&](f32x4 c0, f32x4 c1, f32x4 c2v) __attribute__((always_inline)) {
+    unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
+    yfv2_split3(c0, h0, m0, l0);
+    yfv2_split3(c1, h1, m1, l1);
+    BOps b;
+    b.ph = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+    b.pm = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
+    b.pl = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+    b.s = yfv2_split_b(c2v);
+    return b;
+  };
+  // acc[n] += W[mt] x B[n] for two pixel tiles: nine products, the small ones first, the two tiles interleaved (the six
+  // filter operands of ONE output tile in registers at a time: 24 VGPRs)
+  auto mfma9 = [&](const float* WP, int mt, const BOps (&b)[2], f32x4 (&acc)[2]) __attribute__((always_inline)) {
+    const float* wq = WP + ((mt * 6) * 64 + lane) * 4;
+    const yfv2_bf16x8 ah = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq));
+    const yfv2_bf16x8 am = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq + 256));
+    const yfv2_bf16x8 al = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq + 512));
+    Bf3A sa;
+    sa.hh = *reinterpret_cast<const u32x4*>(wq + 768);
+    sa.mm = *reinterpret_cast<const u32x4*>(wq + 1024);
+    sa.hl = *reinterpret_cast<const u32x4*>(wq + 1280);
+#define CH6_EACH(EXPR) _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[n] = EXPR;
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[n].ph, acc[n], 0, 0, 0))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[n].pl, acc[n], 0, 0, 0))
+    CH6_EACH(yfv2_mfma6_step<0>(sa, b[n].s, acc[n]))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[n].pm, acc[n], 0, 0, 0))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[n].ph, acc[n], 0, 0, 0))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[n].pm, acc[n], 0, 0, 0))
+    CH6_EACH(yfv2_mfma6_step<1>(sa, b[n].s, acc[n]))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[n].ph, acc[n], 0, 0, 0))
+    CH6_EACH(yfv2_mfma6_step<2>(sa, b[n].s, acc[n]))
+#undef CH6_EACH
+  };
+
+  auto phase_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      if (16 * (wave + NW * (2 * tp)) >= n_slots) continue;   // wave-uniform: neither tile of the pair exists
+      BOps b[2];
+      const int slo[2] = {opq(sl[2 * tp]), opq(sl[2 * tp + 1])};
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        f32x4 bf[KC];
+#pragma unroll
+        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + slo[n]) * 4);
+        b[n] = make_b(bf[0], bf[1], bf[2]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        mfma9(W1P, mt, b, acc);
+        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
+        const f32x4 sh1 = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int nt = 2 * tp + n;
+          if (valid[nt]) {
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float uu = __builtin_fmaf(acc[n][c], sc1[c], sh1[c]);
+              y[c] = (real[nt] && uu > 0.f) ? uu : 0.f;     // the zero column stays zero (depthwise padding)
+            }
+            // (in place: a tile's three input quads were read above, before its first output quad is stored - and only this
+            // lane reads or writes this slot in phase A)
+            *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + slo[n]) * 4) = y;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // one output tile's operands at a time
+      }
+    }
+  };
+  auto phase_b = [&](f32x4 (&bo)[KC][NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) bo[mt][2 * tp + n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (16 * (wave + NW * (2 * tp)) >= n_slots) continue;   // wave-uniform
+      f32x4 dwv[KC][2];
+      const int slo[2] = {opq(sl[2 * tp]), opq(sl[2 * tp + 1])};
+#pragma unroll
+      for (int s = 0; s < KC; ++s) {
+        const int cb = 16 * s + 4 * g;
+        f32x4 wl[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);   // once per pair of tiles
+        const f32x4 lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+        const f32x4 lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const float* win0 = Tg + (size_t)(slo[n] - RP - 1) * 4;
+          f32x4 win[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dwv[s][n][c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // one chunk's taps and windows at a time
+      }
+      BOps b[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) b[n] = make_b(dwv[0][n], dwv[1][n], dwv[2][n]);
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        mfma9(W2P, mt, b, acc);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float u = __builtin_fmaf(acc[n][k], sc[k], sh[k]);
+            bo[mt][2 * tp + n][k] = u > 0.f ? u : 0.f;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // the three quads of the next block's branch input (planes g, 4 + g, 8 + g) at this lane's slots
+  auto write_tile = [&](int nt, f32x4 q0, f32x4 q1, f32x4 q2) __attribute__((always_inline)) {
+    if (!real[nt]) { q0 = (f32x4){0.f, 0.f, 0.f, 0.f}; q1 = q0; q2 = q0; }   // halo slots stay the zero column
+    const int so = opq(sl[nt]);
+    *reinterpret_cast<f32x4*>(T1 + ((size_t)(0 + g) * PL + so) * 4) = q0;
+    *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 + g) * PL + so) * 4) = q1;
+    *reinterpret_cast<f32x4*>(T1 + ((size_t)(8 + g) * PL + so) * 4) = q2;
+  };
+  auto tbl = [&](int i) __attribute__((always_inline)) {                                 // entry i of this lane group in the CURRENT image: PS[mt] = 0..2, XS[c] = 3..8
+    return reinterpret_cast<const int*>(IM + 2 * CH6_WP_FL + Cfg::DW_FL + Cfg::CST_FL)[i * 4 + g];
+  };
+  // The next block's image travels global -> registers -> LDS in two parts, each held in registers across ONE phase only:
+  // its W1 during this block's phase A (stored after the barrier that retires phase A's filter reads - W1 is dead then),
+  // the rest (W2, taps, BN vectors, tables) during phase B (stored in the exchange phase).
+  constexpr int P1_4 = CH6_WP_FL / 4, P2_4 = (CH6_IMG_FL - CH6_WP_FL) / 4;
+  constexpr int NI1 = (P1_4 + THREADS - 1) / THREADS, NI2 = (P2_4 + THREADS - 1) / THREADS;   // 3, 3
+  auto part_issue = [&](int kb_next, int off4, int n4, auto& regs) __attribute__((always_inline)) {
+    const bool more = kb_next < NB;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img + (size_t)(more ? kb_next : 0) * CH6_IMG_FL) + off4;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(regs) / sizeof(regs[0])); ++k) { const int i = tid + k * THREADS; regs[k] = (more && i < n4) ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  };
+  auto part_commit = [&](int off4, int n4, const auto& regs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(regs) / sizeof(regs[0])); ++k) { const int i = tid + k * THREADS; if (i < n4) reinterpret_cast<f32x4*>(IM)[off4 + i] = regs[k]; }
+  };
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float* ximg = a.in + (size_t)b * HW * C;
+    float* zimg = a.out + (size_t)b * HW * C;
+    // ---- everything this image needs from memory up front is requested at once: the image of block 0, and X
+    float hold2[6][NT];                                   // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
+    {
+      f32x4 xq[NT][6];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          xq[nt][c] = *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g);   // halo slots read pixel 0 and are zeroed below
+      {
+        f32x4 i1[NI1], i2[NI2];
+        part_issue(0, 0, P1_4, i1);
+        part_issue(0, P1_4, P2_4, i2);
+        __builtin_amdgcn_sched_barrier(0);                // all requests are out before the first use
+        part_commit(0, P1_4, i1);
+        part_commit(P1_4, P2_4, i2);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (!real[nt]) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) xq[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (valid[nt]) {
+#pragma unroll
+          for (int j = 0; j < KC; ++j)
+            *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * j + g) * PL + sl[nt]) * 4) = (f32x4){xq[nt][2 * j][1], xq[nt][2 * j][3], xq[nt][2 * j + 1][1], xq[nt][2 * j + 1][3]};
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) hold2[c][nt] = xq[nt][c][2];
+      }
+      YFV2_WSTAMP(12);
+      __syncthreads();                                    // image 0 (with its XS table) is in LDS
+      YFV2_WSTAMP(13);
+      // X[16 c + 4 g] pass at least two blocks: parked into the group of the block that consumes them
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int pos = tbl(3 + c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (real[nt]) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
+      }
+    }
+    YFV2_WSTAMP(1);
+
+    f32x4 bo[KC][NT];
+    float Hd[KC][NT];                                     // element 0 of every accumulator quad: branch input of the block after next
+    // one block; FIRST (compile time): the peeled first block, whose exchange draws on X's held elements (hold2 dies with it)
+    auto run_block = [&](const int kb, auto first_tag) __attribute__((always_inline)) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const bool more = kb + 1 < NB;
+      {
+        f32x4 n1[NI1];
+        part_issue(kb + 1, 0, P1_4, n1);                  // the next block's W1 flies during phase A
+        __builtin_amdgcn_sched_barrier(0);
+        phase_a();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb == 1) YFV2_WSTAMP(6);
+        if (FIRST) YFV2_WSTAMP(2);
+        __syncthreads();                                  // phase A's W1 reads are done: W1 may be replaced
+        if (kb == 1) YFV2_WSTAMP(7);
+        if (FIRST) YFV2_WSTAMP(3);
+        if (more) part_commit(0, P1_4, n1);
+      }
+      const int ps0 = tbl(0), ps1 = tbl(1), ps2 = tbl(2);   // this block's park positions: read before the tables are replaced
+      f32x4 n2[NI2];
+      part_issue(kb + 1, P1_4, P2_4, n2);                 // the rest of the next image flies during phase B
+      float plv[3][NT];
+      if constexpr (!FIRST) {
+        // the three parked inputs of the next block (group kb - 1 of Z: parked two or more blocks ago), used in the exchange
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float* zp = zimg + (size_t)pix[nt] * C + 12 * (kb - 1) + 3 * g;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) plv[i][nt] = zp[i];   // (halo slots: pixel 0's values, zeroed by write_tile; last block: unused)
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      phase_b(bo);
+      if (kb == 1) YFV2_WSTAMP(8);
+      if (FIRST) YFV2_WSTAMP(4);
+      if (more) {
+        __syncthreads();                                  // every window, filter and table read of this block is done
+        part_commit(P1_4, P2_4, n2);                      // the rest of the next block's image
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (valid[nt]) {
+            if constexpr (FIRST)
+              write_tile(nt, (f32x4){hold2[0][nt], hold2[1][nt], hold2[2][nt], hold2[3][nt]},
+                         (f32x4){hold2[4][nt], hold2[5][nt], bo[0][nt][1], bo[0][nt][3]},
+                         (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
+            else
+              write_tile(nt, (f32x4){Hd[0][nt], Hd[1][nt], Hd[2][nt], plv[0][nt]},
+                         (f32x4){plv[1][nt], plv[2][nt], bo[0][nt][1], bo[0][nt][3]},
+                         (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
+            if (real[nt]) {
+              float* zp = zimg + (size_t)pix[nt] * C;
+              zp[ps0] = bo[0][nt][2]; zp[ps1] = bo[1][nt][2]; zp[ps2] = bo[2][nt][2];
+            }
+          }
+#pragma unroll
+          for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
+        }
+        __syncthreads();
+        if (kb == 1) YFV2_WSTAMP(9);
+        if (FIRST) YFV2_WSTAMP(5);
+      }
+    };
+    run_block(0, std::true_type{});
+#pragma unroll 1
+    for (int kb = 1; kb < NB; ++kb) run_block(kb, std::false_type{});
+    YFV2_WSTAMP(10);
+    // ---- the last block's output in accumulator order, the held elements of the block before it behind them
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      if (real[nt]) {
+        float* zp = zimg + (size_t)pix[nt] * C;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zp + 16 * mt + 4 * g) = bo[mt][nt];
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt) zp[C2 + 3 * g + mt] = Hd[mt][nt];
+      }
+    YFV2_WSTAMP(11);
+    __syncthreads();                                      // tile and image buffer are rewritten by the next image
+  }
 }
 
-int yfv2_s1chain_image_floats() { return CH_IMG_FL; }
+static long s1chain_lds_floats(int H, int W, bool bf6) {
+  const long pl = (((long)(H + 2) * (W + 1) + 1 + 15) & ~15L);
+  return (bf6 ? (long)CH6_IMG_FL : 2L * CH_IMG_FL) + 12L * pl * 4;
+}
+
+int yfv2_s1chain_image_floats(bool bf6) { return bf6 ? CH6_IMG_FL : CH_IMG_FL; }
+bool yfv2_s1chain_bf6() {
+  const char* env = std::getenv("YFV2_S1CHAIN_BF6");
+  return !(env && env[0] == '0');
+}
 
 bool yfv2_s1chain_supported(int c2, int H, int W) {
   if (c2 != 48) return false;
   if ((H - 1) * (W + 1) + W > 16 * 4 * 8) return false;   // slots <= 4 tiles x 8 waves
-  if (s1chain_lds_floats(H, W) * 4 > 160 * 1024) return false;
+  if (s1chain_lds_floats(H, W, false) * 4 > 160 * 1024 || s1chain_lds_floats(H, W, true) * 4 > 160 * 1024) return false;
   const char* env = std::getenv("YFV2_S1CHAIN");
   return !(env && env[0] == '0');
 }
 
 bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s) {
   if (!yfv2_s1chain_supported(48, a.H, a.W) || a.nblk < 2) return false;
-  const size_t lds = sizeof(float) * (size_t)s1chain_lds_floats(a.H, a.W);
+  const size_t lds = sizeof(float) * (size_t)s1chain_lds_floats(a.H, a.W, a.presplit != 0);
   const int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain_kernel<512>), lds_ok0);
-  hipLaunchKernelGGL((block_s1chain_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
+  if (a.presplit) {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain6_kernel<512>), lds_ok1);
+    hipLaunchKernelGGL((block_s1chain6_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  } else {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain_kernel<512>), lds_ok0);
+    hipLaunchKernelGGL((block_s1chain_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  }
   return true;
 }
 

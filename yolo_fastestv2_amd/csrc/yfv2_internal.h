@@ -183,7 +183,8 @@ bool yfv2_s1x2_supported(int c2, int H, int W);
 // chain of N stride-1 blocks in one launch (block_s1chain_kernel, C2 = 48); see PlanBuilder::s1chain_block for the
 // channel bookkeeping shared by host and kernel
 bool yfv2_s1chain_supported(int c2, int H, int W);
-int yfv2_s1chain_image_floats();                                    // floats per block image (incl. the two int tables)
+int yfv2_s1chain_image_floats(bool bf6);                            // floats per block image (incl. the two int tables)
+bool yfv2_s1chain_bf6();                                            // plan the bf16x6 form (block_s1chain6_kernel; YFV2_S1CHAIN_BF6=0: the fp32-MFMA chain)
 bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s);
 // chain of stride-1 blocks with the whole 192-channel activation resident in LDS (block_s1pool_kernel, stage 4 at 11x11):
 // natural channel order, no bookkeeping; img = per block three images of yfv2_s1pool_image_floats() floats (one per third)
