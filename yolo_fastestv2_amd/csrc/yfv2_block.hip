@@ -1217,6 +1217,10 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   // (a slot index goes through an opaque register wherever an LDS address is formed from it: addresses hoisted out of the
   // block loop are what the register allocator spills first, and every scratch reload waits for the image loads in flight)
   auto opq = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+  // The workgroup communicates through LDS only (a pixel's parked values are stored and loaded back by lanes of ONE wave, in
+  // program order): its barriers wait for the LDS counter, not for the global stores in flight - __syncthreads() would
+  // also drain vmcnt, i.e. stall every block's exchange phase until its park stores are acknowledged by L2.
+  auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   // B operands of one pixel tile from its three chunk fragments: the pair (chunks 0, 1) as hi / mid / lo quads, chunk 2
   // as {hi,mid} {lo,hi}
@@ -1410,7 +1414,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
         for (int c = 0; c < 6; ++c) hold2[c][nt] = xq[nt][c][2];
       }
       YFV2_WSTAMP(12);
-      __syncthreads();                                    // image 0 (with its XS table) is in LDS
+      lds_barrier();                                    // image 0 (with its XS table) is in LDS
       YFV2_WSTAMP(13);
       // X[16 c + 4 g] pass at least two blocks: parked into the group of the block that consumes them
 #pragma unroll
@@ -1437,7 +1441,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
         __builtin_amdgcn_sched_barrier(0);
         if (kb == 1) YFV2_WSTAMP(6);
         if (FIRST) YFV2_WSTAMP(2);
-        __syncthreads();                                  // phase A's W1 reads are done: W1 may be replaced
+        lds_barrier();                                  // phase A's W1 reads are done: W1 may be replaced
         if (kb == 1) YFV2_WSTAMP(7);
         if (FIRST) YFV2_WSTAMP(3);
         if (more) part_commit(0, P1_4, n1);
@@ -1460,7 +1464,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
       if (kb == 1) YFV2_WSTAMP(8);
       if (FIRST) YFV2_WSTAMP(4);
       if (more) {
-        __syncthreads();                                  // every window, filter and table read of this block is done
+        lds_barrier();                                  // every window, filter and table read of this block is done
         part_commit(P1_4, P2_4, n2);                      // the rest of the next block's image
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1481,7 +1485,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
 #pragma unroll
           for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
         }
-        __syncthreads();
+        lds_barrier();
         if (kb == 1) YFV2_WSTAMP(9);
         if (FIRST) YFV2_WSTAMP(5);
       }
