@@ -277,9 +277,10 @@ def main():
             "metric": "images/sec at 352x352 bs=256 per GPU (forward+decode+NMS)", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 tensors, fp32 accumulation everywhere.  Stem, stage 2, the stage-3 chain, stage-4 stride-1 blocks and the "
-                          "depthwise convs: fp32 MFMA / fp32 VALU.  Pointwise convs of stage3.0 (pw1), stage4.0 (pw1), the FPN reduces and the "
-                          "towers incl. the output convs: 6 bf16 x bf16 partial products of operands split EXACTLY into three bf16 terms, fp32 "
+            "arithmetic": "fp32 tensors, fp32 accumulation everywhere.  Stem, stage 2, the streamed pointwise convs of stage4.0 and every "
+                          "depthwise conv: fp32 MFMA / fp32 VALU.  Pointwise convs of stage3.0 (pw1), the stage-3 chain, stage4.0 (pw1), the "
+                          "stage-4 chain, the FPN reduces and the towers incl. the output convs: 6 bf16 x bf16 partial products of operands split "
+                          "EXACTLY into three bf16 terms (filters pre-split on the host where a kernel has that form), fp32 "
                           "accumulate (bf16x6; error vs float64 equals the fp32 MFMA's: tools/ubench/bf16x6.hip, DESIGN.md 4.2; YFV2_BF6=0 "
                           "switches it off).  Every parity test (logits 1e-4, scores 1e-5, identical NMS survivors) runs on this arithmetic.",
             "config": {"workload": "batch %d/GPU synthetic 352x352x3 fp32 (torch.rand), seeded random-init weights, "
