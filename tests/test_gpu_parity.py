@@ -501,6 +501,26 @@ def test_non_square_input_288x384(yfv2, dev):
         assert err <= LOGIT_ATOL * scale, "%s: max abs err %g (scale %g)" % (k, err, scale)
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (64, 96), (352, 32), (96, 384)])
+def test_small_and_strip_shaped_inputs(yfv2, dev, hw):
+    """The smallest maps the configuration check admits (a 2x2 / 1x1 pair of detection maps at 32x32) and strip-shaped
+    ones: one-row bands, partial pixel tiles and the fallbacks of the kernels whose static bounds these shapes miss
+    (the stage-3 chain needs >= 2 rows of slots, the lane-per-pixel stage 2 a minimum width) against the oracle."""
+    w = yfv2.random_state_dict(7)
+    m = yfv2.Detector(80, 3, True).to(dev)
+    m.load_state_dict(w)
+    m.eval()
+    torch.manual_seed(hw[0] + hw[1])
+    x = torch.rand(3, 3, hw[0], hw[1])
+    ref = oracle.forward(w, x)
+    got = m(x.to(dev))
+    for g, r, k in zip(got, ref, LOGIT_KEYS):
+        assert tuple(g.shape) == tuple(r.shape)
+        scale = max(1.0, float(r.abs().max()))
+        err = float((g.cpu() - r).abs().max())
+        assert err <= LOGIT_ATOL * scale, "%dx%d %s: max abs err %g (scale %g)" % (hw[0], hw[1], k, err, scale)
+
+
 def test_batch_statistics_bit_exact_vs_reference_golden(yfv2, dev, golden_stats):
     """evaluation()'s matching loop (utils.py:194-230) as one kernel launch; flags identical to
     the ones the reference function produced on the same detections / targets (jittered copies, twins with tied
