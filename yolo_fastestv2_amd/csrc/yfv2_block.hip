@@ -2071,6 +2071,9 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   for (int i = tid; i < t1_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // column 0 (input col -1) stays zero
   __syncthreads();
 
+  int it = 0;   // per-wave stamps of the workgroup's first three items (tools/trace_waves.py): 1 + 7 * it + {staged, proj, barrier, pw1 (+ barrier), main, barrier}
+#define S2_STAMP(k) do { if (it < 3) YFV2_WSTAMP(1 + 7 * it + (k)); } while (0)
+  YFV2_WSTAMP(0);
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
     const int y0 = ti * R;                 // first output row
@@ -2085,6 +2088,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     // end of the previous item) land in T1; rows above the image and column -1 are zero
     stage_commit(item);
     __syncthreads();
+    S2_STAMP(0);
 
     // ---- one depthwise(s2, 3x3, +BN) -> pointwise(+BN+ReLU) branch over the tile's output pixels,
     // depthwise taps read from T1: branch 1 = proj on the RAW input (T1 as staged),
@@ -2164,7 +2168,9 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
 
     // ================= proj branch first: its depthwise reads the raw tile
     dw_pw_branch(1);
+    S2_STAMP(1);
     __syncthreads();
+    S2_STAMP(2);
 
     // ================= pw1 (+BN+ReLU) IN PLACE over the staged tile.  A wave takes whole 16-pixel tiles with the
     // filter's KC*KC A fragments held in registers: a tile's output overwrites exactly the pixels its own B fragments
@@ -2246,14 +2252,20 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
 #pragma unroll
         for (int s = 0; s < KC; ++s) bf[s] = bn[s];
       }
+      S2_STAMP(3);
       __syncthreads();  // the main branch's windows reach into the neighbours' tiles
+      S2_STAMP(4);
     }
 
     // ================= main branch: depthwise on pw1's output
     dw_pw_branch(0);
+    S2_STAMP(5);
     stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);  // next item's tile flies across the barrier
     __syncthreads();  // T1 is restaged by the next item
+    S2_STAMP(6);
+    ++it;
   }
+#undef S2_STAMP
 }
 
 template <int CIN>
