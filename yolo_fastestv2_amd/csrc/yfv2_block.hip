@@ -1650,13 +1650,29 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     // ---- the image into the pool (coalesced 16-byte copy), the first third's filters into IMG
     {
+      // every load of a batch is issued before its first store (the plain `dst[i] = src[i]` loop compiles to one global
+      // round trip per 16 bytes and thread: 12 + 5 of them here)
       const f32x4* src = reinterpret_cast<const f32x4*>(a.in + (size_t)b * HW * P96_C);
-      for (int i = tid; i < HW * (P96_C / 4); i += THREADS) {
-        const int ipx = i / (P96_C / 4), q = i - ipx * (P96_C / 4);
-        *reinterpret_cast<f32x4*>(POOL + ipx * P96_CPP + 4 * q) = src[i];
-      }
       const f32x4* isrc = reinterpret_cast<const f32x4*>(a.img);
-      for (int i = tid; i < N4; i += THREADS) reinterpret_cast<f32x4*>(IMG)[i] = isrc[i];
+      constexpr int NPX = (P96_MAXPX * (P96_C / 4) + THREADS - 1) / THREADS;   // 12
+      const int n4 = HW * (P96_C / 4);
+      f32x4 ti[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; ti[k] = i < N4 ? isrc[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int k0 = 0; k0 < NPX; k0 += 6) {
+        f32x4 tp[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const int i = tid + (k0 + k) * THREADS; tp[k] = i < n4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int i = tid + (k0 + k) * THREADS;
+          const int ipx = i / (P96_C / 4), q = i - ipx * (P96_C / 4);
+          if (i < n4) *reinterpret_cast<f32x4*>(POOL + ipx * P96_CPP + 4 * q) = tp[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) reinterpret_cast<f32x4*>(IMG)[i] = ti[k]; }
     }
     __syncthreads();
 
