@@ -14,7 +14,13 @@ __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, _
 // cell clamped into the map, so that the group's shuffles stay convergent; the result is meaningful for ok && part < 3.
 // Arithmetic = handel_preds (utils/utils.py:303-358) followed by the first two steps of non_max_suppression
 // (conf = max_j fl32(cls_j * obj) with the FIRST maximal j, :261,267), SURVEY.md App. B.
-__device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int sc, int cc, int part, f32x4& r0, f32x4& r1) {
+// `skip_ct` (the fused NMS launch): when none of the cell's three anchors has obj > skip_ct - their logits arrive in objl,
+// fetched one pass ahead - the class slice is not read at all: non_max_suppression drops rows with obj <= conf_thres before it
+// looks at a class (utils.py:254), so conf / class of such rows are never used (they are written as 0).  With trained weights
+// that is nearly every cell: the launch's decode phase stops being a 164 MB read.
+template <bool SKIP = false>
+__device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int sc, int cc, int part, f32x4& r0, f32x4& r1,
+                                                 const float (&objl)[3] = {0.f, 0.f, 0.f}, float skip_ct = 0.f) {
   const int fh = a.fh[sc], fw = a.fw[sc], hw = fh * fw;
   const int nc = a.classes;
   constexpr int MAXPER = 24;  // >= ceil(classes / 4), classes <= 93
@@ -27,59 +33,61 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
   // four waves per SIMD - not bandwidth-bound: 24 fewer expf per lane and pass).  The first fused version re-read the
   // logits in every sweep in batches of four: 18 dependent round trips per pass instead of one.
   // Every value is computed by the same expression as in decode_kernel<false>, so the results are identical.
-  float lv[MAXPER];
+  float best[3] = {0.f, 0.f, 0.f};
+  int bj[3] = {0, 0, 0};
+  bool need = true;   // (the four lanes of a cell agree: the shuffles below stay inside a converged group of four)
+  if constexpr (SKIP) need = sigmoid_f32(objl[0]) > skip_ct || sigmoid_f32(objl[1]) > skip_ct || sigmoid_f32(objl[2]) > skip_ct;
+  if (need) {
+    float lv[MAXPER];
 #pragma unroll
-  for (int i = 0; i < MAXPER; ++i) {
-    const int c = c_lo + i;
-    lv[i] = cls[(unsigned)((c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw + cc)];
-  }
-  auto logit = [&](int i) { return lv[i]; };
-  float m = -INFINITY;
+    for (int i = 0; i < MAXPER; ++i) {
+      const int c = c_lo + i;
+      lv[i] = cls[(unsigned)((c < c_hi ? c : (c_lo < nc ? c_lo : 0)) * hw + cc)];
+    }
+    float m = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < MAXPER; ++i) {
-    const float v = logit(i);
-    if (c_lo + i < c_hi) m = fmaxf(m, v);
-  }
-  m = fmaxf(m, __shfl_xor(m, 1));
-  m = fmaxf(m, __shfl_xor(m, 2));
-  float sum = 0.f;
+    for (int i = 0; i < MAXPER; ++i)
+      if (c_lo + i < c_hi) m = fmaxf(m, lv[i]);
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXPER; ++i) {
-    const float e = expf(__fsub_rn(logit(i), m));
-    lv[i] = e;                                              // the logit is dead from here on: its register keeps the exponential
-    if (c_lo + i < c_hi) sum = __fadd_rn(sum, e);
-    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four exps at a time (a free schedule interleaves all 24: spills)
-  }
-  sum = __fadd_rn(sum, __shfl_xor(sum, 1));
-  sum = __fadd_rn(sum, __shfl_xor(sum, 2));
-  float obj3[3], best[3];
-  int bj[3];
+    for (int i = 0; i < MAXPER; ++i) {
+      const float e = expf(__fsub_rn(lv[i], m));
+      lv[i] = e;                                            // the logit is dead from here on: its register keeps the exponential
+      if (c_lo + i < c_hi) sum = __fadd_rn(sum, e);
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four exps at a time (a free schedule interleaves all 24: spills)
+    }
+    sum = __fadd_rn(sum, __shfl_xor(sum, 1));
+    sum = __fadd_rn(sum, __shfl_xor(sum, 2));
+    float obj3[3];
 #pragma unroll
-  for (int an = 0; an < 3; ++an) {
-    obj3[an] = sigmoid_f32(a.obj[sc][((size_t)b * 3 + an) * hw + cc]);
-    best[an] = -INFINITY;
-    bj[an] = 0x7fffffff;
-  }
+    for (int an = 0; an < 3; ++an) {
+      obj3[an] = sigmoid_f32(a.obj[sc][((size_t)b * 3 + an) * hw + cc]);
+      best[an] = -INFINITY;
+      bj[an] = 0x7fffffff;
+    }
 #pragma unroll
-  for (int i = 0; i < MAXPER; ++i) {
-    if (c_lo + i < c_hi) {
-      const float ev = __fdiv_rn(lv[i], sum);   // the class probability, as decode_kernel<false> stores it
+    for (int i = 0; i < MAXPER; ++i) {
+      if (c_lo + i < c_hi) {
+        const float ev = __fdiv_rn(lv[i], sum);   // the class probability, as decode_kernel<false> stores it
 #pragma unroll
-      for (int an = 0; an < 3; ++an) {
-        const float pj = __fmul_rn(ev, obj3[an]);
-        if (pj > best[an]) { best[an] = pj; bj[an] = c_lo + i; }  // strict: first maximal index of this slice
+        for (int an = 0; an < 3; ++an) {
+          const float pj = __fmul_rn(ev, obj3[an]);
+          if (pj > best[an]) { best[an] = pj; bj[an] = c_lo + i; }  // strict: first maximal index of this slice
+        }
       }
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
-    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int an = 0; an < 3; ++an)
+#pragma unroll
+      for (int msk = 1; msk < 4; msk <<= 1) {
+        const float ob_ = __shfl_xor(best[an], msk);
+        const int oi = __shfl_xor(bj[an], msk);
+        if (ob_ > best[an] || (ob_ == best[an] && oi < bj[an])) { best[an] = ob_; bj[an] = oi; }
+      }
   }
-#pragma unroll
-  for (int an = 0; an < 3; ++an)
-#pragma unroll
-    for (int msk = 1; msk < 4; msk <<= 1) {
-      const float ob_ = __shfl_xor(best[an], msk);
-      const int oi = __shfl_xor(bj[an], msk);
-      if (ob_ > best[an] || (ob_ == best[an] && oi < bj[an])) { best[an] = ob_; bj[an] = oi; }
-    }
   const int an = part < 3 ? part : 0;
   const int y = cc / fw, x = cc - y * fw;
   const float* reg = a.reg[sc] + ((size_t)b * 12 + an * 4) * hw + cc;
@@ -266,20 +274,36 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a, DecodeArgs 
   NMS_STAMP(0);
   if constexpr (SRC == 2) {
     // decode this image: 4 lanes per grid cell (yfv2_compact_row), 256 cells per pass over the workgroup
-    for (int sc = 0; sc < 2; ++sc) {
-      const int hw = dec.fh[sc] * dec.fw[sc];
-      const int row_base = sc ? 3 * dec.fh[0] * dec.fw[0] : 0;
-      for (int c0 = 0; c0 < hw; c0 += NMS_THREADS / 4) {
-        const int cell = c0 + (tid >> 2), part = tid & 3;
-        const bool ok = cell < hw;
-        f32x4 r0, r1;
-        yfv2_compact_row(dec, b, sc, ok ? cell : hw - 1, part, r0, r1);
-        if (ok && part < 3) {
-          float* d = crow + (size_t)(row_base + cell * 3 + part) * 8;
-          *reinterpret_cast<f32x4*>(d) = r0;
-          *reinterpret_cast<f32x4*>(d + 4) = r1;
-        }
+    constexpr int CPP = NMS_THREADS / 4;                 // cells per pass
+    const int hw0 = dec.fh[0] * dec.fw[0], hw1 = dec.fh[1] * dec.fw[1];
+    const int np0 = (hw0 + CPP - 1) / CPP, np = np0 + (hw1 + CPP - 1) / CPP;
+    const int part = tid & 3;
+    // the three objectness logits of this lane's cell, one pass ahead of their use (they decide whether the pass reads
+    // its class logits at all)
+    auto obj_of = [&](int ps, float (&o)[3]) {
+      const int sc = ps < np0 ? 0 : 1, hw = sc ? hw1 : hw0;
+      const int cell = (ps - (sc ? np0 : 0)) * CPP + (tid >> 2);
+      const int cc = cell < hw ? cell : hw - 1;
+#pragma unroll
+      for (int an = 0; an < 3; ++an) o[an] = ps < np ? dec.obj[sc][((size_t)b * 3 + an) * hw + cc] : 0.f;
+    };
+    float ocur[3], onxt[3];
+    obj_of(0, ocur);
+    for (int ps = 0; ps < np; ++ps) {
+      obj_of(ps + 1, onxt);
+      const int sc = ps < np0 ? 0 : 1, hw = sc ? hw1 : hw0;
+      const int row_base = sc ? 3 * hw0 : 0;
+      const int cell = (ps - (sc ? np0 : 0)) * CPP + (tid >> 2);
+      const bool ok = cell < hw;
+      f32x4 r0, r1;
+      yfv2_compact_row<true>(dec, b, sc, ok ? cell : hw - 1, part, r0, r1, ocur, ct);
+      if (ok && part < 3) {
+        float* d = crow + (size_t)(row_base + cell * 3 + part) * 8;
+        *reinterpret_cast<f32x4*>(d) = r0;
+        *reinterpret_cast<f32x4*>(d + 4) = r1;
       }
+#pragma unroll
+      for (int an = 0; an < 3; ++an) ocur[an] = onxt[an];
     }
     __syncthreads();
   }
