@@ -326,8 +326,101 @@ def make_loss_golden():
     np.savez_compressed(os.path.join(HERE, "golden_loss.npz"), **out)
 
 
+TRAIN_CASES = ((80, 3, 9, 21, 0.001), (20, 2, 4, 22, 0.0004))   # classes, batch, labels, seed, lr
+TRAIN_KEEP = ("backbone.first_conv.0.weight", "backbone.first_conv.1.weight", "backbone.first_conv.1.bias",
+              "backbone.stage2.0.branch_proj.0.weight", "backbone.stage3.3.branch_main.5.weight", "backbone.stage4.1.branch_main.4.bias",
+              "fpn.conv1x1_2.0.weight", "fpn.cls_head_2.block.5.weight", "fpn.reg_head_3.block.9.weight",
+              "output_reg_layers.weight", "output_obj_layers.bias", "output_cls_layers.weight", "output_cls_layers.bias")
+TRAIN_BN = ("backbone.first_conv.1", "backbone.stage3.0.branch_main.4", "fpn.cls_head_3.block.9")
+
+
+def train_case_inputs(classes, B, T, seed):
+    """seeded weights (the package's generator: same keys / shapes as the reference checkpoint), images and labels"""
+    import yolo_fastestv2_amd as yfv2
+    w = yfv2.random_state_dict(seed, classes=classes)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.random((B, 3, 352, 352), dtype=np.float32)
+    t = np.zeros((T, 6), np.float32)
+    t[:, 0] = rng.integers(0, B, T)
+    t[:, 1] = rng.integers(0, classes, T)
+    t[:, 2:4] = rng.random((T, 2)) * 0.9 + 0.05
+    t[:, 4:6] = rng.random((T, 2)) * 0.5 + 0.03
+    return w, x, t
+
+
+def make_train_golden():
+    """golden_train.npz: ONE iteration of the reference's training loop (train.py:93-112) executed with the reference's own
+    modules on CPU - model.detector.Detector in train() mode, utils.loss.compute_loss (same clamp_ shim as the loss golden),
+    total_loss.backward(), torch.optim.SGD(momentum 0.949, weight_decay 0.0005).step() - on seeded weights, images and
+    labels: the four losses, per-parameter gradient norms and maxima for EVERY parameter, full gradients / updated values of
+    a dozen tensors spread over the net, the train-mode logits of image 0, three BatchNorms' running statistics after the
+    step.  The oracle's train_step must reproduce it (checked here before anything is written; the CPU suite re-checks
+    the oracle against the file).  Groundwork for SURVEY.md 8(f) row 3 (training path): parity targets for the backward
+    kernels that do not exist yet."""
+    import importlib.util
+    det, _ = import_reference()
+    spec = importlib.util.spec_from_file_location("ref_loss", os.path.join(REF, "utils", "loss.py"))
+    L = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(L)
+    orig = torch.Tensor.clamp_
+
+    def clamp_(self, mn=None, mx=None):
+        fix = lambda v: int(v) if (torch.is_tensor(v) and not self.is_floating_point()) else v  # noqa: E731
+        return orig(self, fix(mn), fix(mx))
+    torch.Tensor.clamp_ = clamp_
+    anchors = [float(a) for a in np.load(os.path.join(HERE, "cfg_coco.npz"))["anchors"]]
+    out = {"n": np.asarray(len(TRAIN_CASES)), "cases": np.asarray([c[:4] for c in TRAIN_CASES], np.int64),
+           "lr": np.asarray([c[4] for c in TRAIN_CASES], np.float64)}
+    try:
+        for ci, (classes, B, T, seed, lr) in enumerate(TRAIN_CASES):
+            w, x, t = train_case_inputs(classes, B, T, seed)
+            cfg = {"anchor_num": 3, "classes": classes, "width": 352, "height": 352, "anchors": anchors}
+            model = det.Detector(classes, 3, True)
+            print(model.load_state_dict({k: v.clone() for k, v in w.items()}))
+            model.train()
+            opt = torch.optim.SGD(params=model.parameters(), lr=lr, momentum=0.949, weight_decay=0.0005)
+            preds = model(torch.from_numpy(x))
+            ref = L.compute_loss(preds, torch.from_numpy(t), cfg, torch.device("cpu"))
+            ref[3].backward()
+            grads = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+            opt.step()
+            after = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            mine = oracle.train_step(w, torch.from_numpy(x), torch.from_numpy(t), anchors, classes, lr)
+            # ---- the oracle against the reference, before anything is written
+            for a, b in zip(ref, mine["losses"]):
+                assert abs(float(a) - b) <= 1e-6 * max(1.0, abs(float(a))), ("loss", float(a), b)
+            worst = 0.0
+            for k, g in grads.items():
+                d = float((g - mine["grads"][k]).abs().max()); sc = float(g.abs().max())
+                worst = max(worst, d / max(sc, 1e-12))
+                assert d <= 1e-5 * max(sc, 1e-6), ("grad", k, d, sc)
+            for k, v in after.items():
+                d = float((v.double() - mine["new_w"][k].double()).abs().max())
+                assert d <= 1e-6 * max(1.0, float(v.double().abs().max())), ("after", k, d)
+            print("train case", ci, (classes, B, T), [float(v) for v in ref], "worst relative gradient difference oracle vs reference %.2e" % worst)
+            out["targets%d" % ci] = t
+            out["loss%d" % ci] = np.asarray([float(v) for v in ref], np.float32)
+            names = sorted(grads)
+            out["names%d" % ci] = np.asarray(names)
+            out["gnorm%d" % ci] = np.asarray([float(grads[k].double().norm()) for k in names], np.float64)
+            out["gmax%d" % ci] = np.asarray([float(grads[k].abs().max()) for k in names], np.float32)
+            for k in TRAIN_KEEP:
+                out["grad%d:%s" % (ci, k)] = grads[k].numpy()
+                out["after%d:%s" % (ci, k)] = after[k].numpy()
+            for bnn in TRAIN_BN:
+                for sfx in (".running_mean", ".running_var", ".num_batches_tracked"):
+                    out["after%d:%s" % (ci, bnn + sfx)] = after[bnn + sfx].numpy()
+            for pi, pr in enumerate(preds):
+                out["pred%d_%d" % (ci, pi)] = pr[0].detach().numpy()
+    finally:
+        torch.Tensor.clamp_ = orig
+    np.savez_compressed(os.path.join(HERE, "golden_train.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "loss":
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        make_train_golden()   # only golden_train.npz
+    elif len(sys.argv) > 1 and sys.argv[1] == "loss":
         make_loss_golden()    # only golden_loss.npz
     elif len(sys.argv) > 1 and sys.argv[1] == "ap":
         make_ap_golden()      # only golden_ap.npz (the other files are left as committed)
