@@ -19,12 +19,15 @@ in `coco_e2e` (extra fields, never `value`).
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings):
   value      whole-job images/s (all ranks' images / max-over-ranks time)
   roofline   the kernel that owns the most forward time (sum over its launches, the
-             top row of a rocprofv3 --stats table): algorithmic bytes and flops of its
-             launches / their summed duration, measured with hipEvent pairs on the
-             launch stream inside this process (yfv2_profile_forward).  `traffic` is
-             null here: HBM byte counters cannot be read from inside the process;
-             the PMC passes live in profiles/ (tools/gpu_traffic.sh).
-  kernel_table  the same figures for every kernel of the forward
+             top row of a rocprofv3 --stats table): algorithmic bytes (SURVEY.md 8(d):
+             EXTERNAL reads + writes for a fused launch) and flops of its launches /
+             their summed duration, measured with hipEvent pairs on the launch stream
+             inside this process (yfv2_profile_forward); `bound` follows its arithmetic
+             intensity.  `traffic` = HBM bytes per launch from the PMC passes under
+             profiles/ (tools/gpu_traffic.sh) IF that profile was taken on this very
+             source tree (fingerprint match), else null.
+  kernel_table  the same figures for every kernel of the forward (+ mfma_busy from
+             the SQ counter pass, same fingerprint rule)
   cpu_baseline  the CPU oracle (same ATen CPU ops as the reference + numpy
              decode/NMS) timed on this box's host cores on a bounded sample
 """
@@ -41,6 +44,41 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (= fp32 vector peak)
+RIDGE_FLOP_PER_BYTE = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)   # 19.7
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from srchash import source_hash  # noqa: E402
+
+
+def newest_profile(suffix, src_hash):
+    """profiles/*<suffix> with the newest name whose `src_hash` equals this tree's fingerprint, or None"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*" + suffix)), reverse=True):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if j.get("src_hash") == src_hash:
+            j["_file"] = os.path.basename(f)
+            return j
+    return None
+
+
+def profile_lookup(prof, kernel, field, launches, mean=False):
+    """Sum (or mean) of `field` over the profile rows whose kernel name contains one of the '+'-separated prefixes of
+    `kernel` (bench groups by symbol-name prefix, e.g. 'pw_kernel<192,' or 's2px_proj_kernel + s2px_main_kernel')."""
+    if not prof:
+        return None
+    vals = []
+    for part in kernel.split(" + "):
+        hit = [v[field] for k, v in prof["kernels"].items() if part in k and field in v]
+        if len(hit) != 1:
+            return None
+        vals.append(hit[0])
+    if mean:
+        return round(sum(vals) / len(vals), 2)
+    n_parts = len(vals)
+    return sum(vals) * (launches / n_parts)      # per-launch means -> bytes of this kernel's launches in one forward
 ANCHORS = [12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87]  # data/coco.data:17
 
 
@@ -181,38 +219,61 @@ def main():
     out = None
     if rank == 0:
         # ---- roofline: per-launch hipEvent times grouped by kernel, the way a rocprofv3 --stats table groups them ----
+        # Bytes are SURVEY.md 8(d)'s: a fused launch is charged its EXTERNAL reads + writes only (`yfv2_stage_info`'s third
+        # figure: the chain of seven blocks = one read + one write of the activation); the per-layer figure of BASELINE.md
+        # section 4 rides along as `per_layer_gbs` (how much traffic the fusion removed).  Counters (HBM bytes, MFMA busy)
+        # cannot be read from inside the process: they come from the newest profiles/*_traffic.json / *_pmc.json whose
+        # source fingerprint (tools/srchash.py) equals this tree's - else null.
         stages = eng.stages()
         ms = eng.profile_forward(x, iters=a.profile_iters)
+        src_hash = source_hash()
+        prof_t, prof_p = newest_profile("_traffic.json", src_hash), newest_profile("_pmc.json", src_hash)
         table = {}
         for st, m in zip(stages, ms):
-            k = table.setdefault(st["kernel"], {"ms": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0, "covers": []})
+            k = table.setdefault(st["kernel"], {"ms": 0.0, "launches": 0, "bytes": 0.0, "ext": 0.0, "flops": 0.0, "covers": []})
             k["ms"] += m; k["launches"] += 1
-            k["bytes"] += st["bytes_per_image"] * a.batch; k["flops"] += st["flops_per_image"] * a.batch
+            k["bytes"] += st["bytes_per_image"] * a.batch; k["ext"] += st["external_bytes_per_image"] * a.batch
+            k["flops"] += st["flops_per_image"] * a.batch
             k["covers"].append(st["name"].split(":")[0][:60])
         tot_ms = sum(k["ms"] for k in table.values())
-        kernel_table = []
-        for name, k in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
-            gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-            tf = k["flops"] / (k["ms"] * 1e-3) / 1e12
-            kernel_table.append({"kernel": name, "launches": k["launches"], "ms": round(k["ms"], 4), "share": round(k["ms"] / tot_ms, 4),
-                                 "algorithmic_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                                 "tflops": round(tf, 2), "mfma_frac": round(tf / MFMA_F32_PEAK_TF, 4)})
+
+        def row(name, k):
+            sec = k["ms"] * 1e-3
+            moved, tf = k["ext"] / sec / 1e9, k["flops"] / sec / 1e12
+            ai = k["flops"] / k["ext"]
+            traffic = profile_lookup(prof_t, name, "total_bytes", k["launches"])
+            r = {"kernel": name, "launches": k["launches"], "ms": round(k["ms"], 4), "share": round(k["ms"] / tot_ms, 4),
+                 "external_bytes": k["ext"], "moved_gbs": round(moved, 1), "hbm_frac_external": round(moved / HBM_PEAK_GBS, 4),
+                 "per_layer_gbs": round(k["bytes"] / sec / 1e9, 1),
+                 "tflops": round(tf, 2), "flops_frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+                 "flop_per_external_byte": round(ai, 1), "bound": "mfma" if ai > RIDGE_FLOP_PER_BYTE else "hbm",
+                 "mfma_busy": profile_lookup(prof_p, name, "mfma_busy_pct", 1, mean=True),
+                 "traffic_bytes": traffic, "traffic_over_external": round(traffic / k["ext"], 3) if traffic else None}
+            return r
+        kernel_table = [row(name, k) for name, k in sorted(table.items(), key=lambda kv: -kv[1]["ms"])]
         dom_name, dom = max(table.items(), key=lambda kv: kv[1]["ms"])
-        dom_gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        dom_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # every launch of this net sits left of the fp32 ridge (19.7 flop/B) in per-layer accounting, so the bound
-        # quoted is HBM; the MFMA fraction of the same kernel rides along (north_star names both targets)
-        roof = {"kernel": dom_name, "covers": dom["covers"], "launches_per_forward": dom["launches"], "bound": "hbm",
-                "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "traffic_note": "PMC byte counters are collected in separate rocprofv3 passes: profiles/*_traffic.json",
+        drow = kernel_table[0]
+        # the bound quoted is the one the dominant kernel's arithmetic intensity (flops / external bytes) puts it under:
+        # left of the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B) HBM, right of it the fp32 MFMA peak
+        if drow["bound"] == "hbm":
+            ach, peak, unit = drow["moved_gbs"], HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = drow["tflops"], MFMA_F32_PEAK_TF, "TFLOP/s"
+        tot_ext = sum(k["ext"] for k in table.values()); tot_fl = sum(k["flops"] for k in table.values())
+        roof = {"kernel": dom_name, "covers": dom["covers"], "launches_per_forward": dom["launches"], "bound": drow["bound"],
+                "achieved": ach, "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                "traffic": (drow["traffic_bytes"] / dom["launches"]) if drow["traffic_bytes"] else None,
+                "traffic_note": ("HBM bytes per launch by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction): profiles/%s, same source fingerprint as this run" % prof_t["_file"])
+                                if drow["traffic_bytes"] else "no profiles/*_traffic.json carries this tree's source fingerprint %s (PMC passes are separate runs: tools/gpu_traffic.sh)" % src_hash,
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "sum_ms_per_forward": round(dom["ms"], 4),
                 "share_of_forward": round(dom["ms"] / tot_ms, 4),
-                "algorithmic_bytes_per_forward": dom["bytes"], "mfma_tflops": round(dom_tf, 2),
-                "mfma_frac": round(dom_tf / MFMA_F32_PEAK_TF, 4),
-                "whole_forward": {"algorithmic_gbs": round(sum(k["bytes"] for k in table.values()) / (tot_ms * 1e-3) / 1e9, 1),
-                                  "tflops": round(sum(k["flops"] for k in table.values()) / (tot_ms * 1e-3) / 1e12, 2)}}
-        roof["whole_forward"]["hbm_frac"] = round(roof["whole_forward"]["algorithmic_gbs"] / HBM_PEAK_GBS, 4)
-        roof["whole_forward"]["mfma_frac"] = round(roof["whole_forward"]["tflops"] / MFMA_F32_PEAK_TF, 4)
+                "algorithmic_bytes_per_launch": dom["ext"] / dom["launches"], "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+                "hbm_frac_external": drow["hbm_frac_external"], "flops_frac_of_fp32_mfma_peak": drow["flops_frac_of_fp32_mfma_peak"],
+                "mfma_busy": drow["mfma_busy"], "src_hash": src_hash,
+                "whole_forward": {"external_gbs": round(tot_ext / (tot_ms * 1e-3) / 1e9, 1), "hbm_frac_external": round(tot_ext / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "per_layer_gbs": round(sum(k["bytes"] for k in table.values()) / (tot_ms * 1e-3) / 1e9, 1),
+                                  "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                  "flops_frac_of_fp32_mfma_peak": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}}
 
         # ---- BASELINE configs[2] as the survey specifies it: COCO weights, JPEG-derived batch, both threshold pairs ----
         coco = None
@@ -271,7 +332,9 @@ def main():
             cpu = {"value": round(n_img / el, 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                    "host_threads_available": ncores,
                    "sample": "%d synthetic images in batches of %d through oracle forward(ATen CPU)+decode+NMS, %.1f s, "
-                             "thread count chosen by a 16-image probe over %s" % (n_img, bs, el, cands)}
+                             "thread count chosen by a 16-image probe over %s; kind 'port' because /root/reference does not exist on "
+                             "the GPU box - the oracle runs the same ATen CPU ops and is bit-identical to the reference's own modules "
+                             "where both exist (asserted by tests/golden/make_golden.py)" % (n_img, bs, el, cands)}
 
         out = {
             "metric": "images/sec at 352x352 bs=256 per GPU (forward+decode+NMS)", "value": round(value, 1), "unit": "images/s",

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define YFV2_ABI_VERSION 1
+#define YFV2_ABI_VERSION 2 /* 2: yfv2_stage_info reports external bytes as well */
 #define YFV2_API __attribute__((visibility("default")))
 #define YFV2_MAX_DET 300 /* utils/utils.py:243 max_det */
 
@@ -165,6 +165,8 @@ YFV2_API int yfv2_batch_statistics_overflow(yfv2_handle h, int32_t* overflowed, 
  *   out6     the six NCHW logit maps of yfv2_forward (B images)
  *   targets  (T, 6) fp32 device rows [image index in the batch, class, cx, cy, w, h], box normalised to [0, 1]: the tensor
  *            the reference's collate_fn builds (utils/datasets.py:12-22); T may be 0
+ *            PRECONDITION: 0 <= image index < B and 0 <= class < classes; a row that violates it is skipped (the
+ *            reference's CrossEntropyLoss raises on such a class), it is never used as an index
  *   losses   device float[4]: lbox (x3.2), lobj (x64), lcls (x32) and their sum, the 4-tuple compute_loss returns
  * Uses the handle's anchors (yfv2_set_anchors) as float64 like the reference.  Work is enqueued on `stream`; the
  * handle's loss workspace grows (one device synchronisation) when T exceeds what earlier calls needed. */
@@ -177,11 +179,15 @@ YFV2_API int32_t yfv2_num_rows(yfv2_handle h);   /* 1815 for 352x352, A=3 */
 YFV2_API int32_t yfv2_num_stages(yfv2_handle h); /* launches in one forward */
 
 /* Static description of launch `i` of the forward plan: kernel name, which
- * reference layers it covers, and its ALGORITHMIC work per image (flops =
- * 2*MACs; bytes = activation bytes read + written once, fp32), the figures
- * DESIGN.md / bench.py's roofline use. */
+ * reference layers it covers, and its ALGORITHMIC work per image: flops =
+ * 2*MACs; bytes_per_image = per-LAYER accounting (every reference layer the
+ * launch covers reads its input and writes its output once, fp32: BASELINE.md
+ * section 4); external_bytes_per_image = SURVEY.md section 8(d)'s figure for a
+ * fused launch - only what the launch itself must read from and write to HBM
+ * (the chain of seven stride-1 blocks: one read + one write of the activation).
+ * bench.py's roofline uses the external figure. */
 YFV2_API int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_cap, double* flops_per_image,
-                    double* bytes_per_image);
+                    double* bytes_per_image, double* external_bytes_per_image);
 /* The kernel (family) launch `i` runs, as a prefix of the symbol name a rocprofv3 kernel trace shows for it
  * (e.g. "block_s1chain_kernel", "tower2_kernel<6, 512, 4, 4>"): lets bench.py group its per-launch times the way
  * the kernel-stats tables under profiles/ do. */

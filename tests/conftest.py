@@ -20,6 +20,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- parity records: the margin counts of the end-to-end tests (how many detections, how many survivor differences, how
+# many of them on a numerical margin, how many unexplained) are part of the evidence, not just pass/fail: tests add them
+# through the `record_parity` fixture, the terminal summary prints them (so they land in every pytest log, -s or not) and
+# they are written to gpurun_out/parity_counts.json (copied to profiles/ by tools/gpu_r3.sh).
+PARITY_RECORDS = {}
+
+
+@pytest.fixture
+def record_parity():
+    def add(key, **counts):
+        PARITY_RECORDS[key] = counts
+    return add
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY_RECORDS:
+        return
+    import json
+    terminalreporter.section("parity records (margin counts)")
+    for k, v in PARITY_RECORDS.items():
+        terminalreporter.write_line("%s: %s" % (k, json.dumps(v, sort_keys=True)))
+    try:
+        out = os.path.join(REPO, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_counts.json")
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(PARITY_RECORDS)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def _npz(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 

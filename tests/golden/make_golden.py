@@ -256,7 +256,7 @@ def make_ap_golden():
     np.savez_compressed(os.path.join(HERE, "golden_ap.npz"), **out)
 
 
-LOSS_CASES = ((80, 2, 4, 0), (80, 3, 40, 1), (20, 2, 25, 2), (1, 2, 9, 3), (80, 2, 0, 4), (80, 4, 120, 5))   # classes, batch, labels, seed
+LOSS_CASES = ((80, 2, 4, 0), (80, 3, 40, 1), (20, 2, 25, 2), (1, 2, 9, 3), (80, 2, 0, 4), (80, 4, 120, 5), (80, 2, 24, 6))   # classes, batch, labels, seed
 
 
 def loss_case_inputs(classes, B, T, seed):
@@ -274,6 +274,11 @@ def loss_case_inputs(classes, B, T, seed):
         edge = rng.random(T) < 0.25
         t[edge, 2] = np.where(rng.random(edge.sum()) < 0.5, 0.004, 0.997).astype(np.float32)
         t[rng.random(T) < 0.15, 4:6] = 0.9
+        if seed == 6:   # centres ON and past the right / lower image edge: utils/loss.py:119's clamp_ changes the cell AND
+            t[0::3, 2] = 1.0       # (through the view aliasing of :115-120) the target box offset
+            t[1::4, 3] = 1.0
+            t[2, 2], t[5, 3] = 1.003, 1.01
+            t[:, 4:6] = np.minimum(t[:, 4:6], 0.3) + 0.05   # sizes that match anchors, so that the edge labels do produce matches
     return preds, t
 
 

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib_mod.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), "libyfv2.so does not export %s" % name
-    assert _lib_mod.lib().yfv2_abi_version() == 1
+    assert _lib_mod.lib().yfv2_abi_version() == _lib_mod.ABI_VERSION == 2
     # nothing else leaks out of the library's namespace
     syms = subprocess.run(["nm", "-D", "--defined-only", _lib_mod.LIB_PATH], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in syms.splitlines() if " T " in l}
@@ -253,6 +253,73 @@ def test_detect_sharded_world_size_2_gloo_reassembles_the_single_rank_result(tmp
         assert p.returncode == 0 and "rank %d ok" % r in o, o
 
 
+def test_detect_sharded_world_size_8_gloo_packed_layout(tmp_path):
+    """BASELINE configs[3]'s geometry on CPU: EIGHT ranks (one per GPU of a node), contiguous shards of a global batch, every
+    rank's result in the packed buffers `Engine.new_det_buffers` hands out, ONE all_gather_into_tensor per step, issued
+    asynchronously with a reusable receive buffer exactly as bench.py --gpus 8 does.  Asserted: the receive buffer's layout
+    [rank][dets | idx | cnt] word for word (what `rank_views` promises), the unpacked result == what one rank computes on the
+    whole batch, one collective per step."""
+    script = tmp_path / "w8.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from yolo_fastestv2_amd import gather_detections, shard_range, sharded
+
+        class FakeEngine:                     # same call shape as Engine.detect / Engine.new_det_buffers
+            def new_det_buffers(self, B):
+                return sharded.packed_det_buffers(B, "cpu")
+            def detect(self, x, conf_thres, iou_thres, out=None):
+                B = x.shape[0]
+                dets, idx, cnt = out if out is not None else self.new_det_buffers(B)
+                s = x.reshape(B, -1).double().sum(1)
+                cnt.copy_((s * 7).long().remainder(301).to(torch.int32))
+                k = torch.arange(300)[None, :, None].double()
+                dets.copy_(((s[:, None, None] + k) * torch.arange(1, 7)[None, None, :]).float())
+                idx.copy_(((s[:, None] * 13).long() + torch.arange(300)[None]).remainder(1815).to(torch.int32))
+                return dets, idx, cnt
+
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        calls = [0]
+        real = dist.all_gather_into_tensor
+        def counted(*a, **k):
+            calls[0] += 1
+            return real(*a, **k)
+        dist.all_gather_into_tensor = counted
+        Bl = 4                                                             # images per rank (256 on the real node)
+        g = torch.Generator().manual_seed(11)
+        x_all = torch.rand(world * Bl, 3, 16, 16, generator=g)            # every rank builds the same global batch
+        lo, hi = shard_range(x_all.shape[0], rank, world)
+        assert (lo, hi) == (rank * Bl, (rank + 1) * Bl)
+        eng = FakeEngine()
+        recv = torch.empty(world * Bl * 2101)
+        for step in range(2):                                              # the receive buffer is reused step after step
+            d, i, c = eng.detect(x_all[lo:hi] + step, 0.3, 0.4, out=eng.new_det_buffers(Bl))
+            work = gather_detections(d, i, c, async_op=True, out=recv)
+            work.wait_host()
+            D, I, C = eng.detect(x_all + step, 0.3, 0.4)
+            r = recv.view(world, Bl * 2101)
+            for q in range(world):                                         # [rank q][dets (Bl,300,6) | idx (Bl,300) | cnt (Bl)]
+                sl = slice(q * Bl, (q + 1) * Bl)
+                assert torch.equal(r[q, :Bl * 1800].view(Bl, 300, 6), D[sl]), (rank, q)
+                assert torch.equal(r[q, Bl * 1800:Bl * 2100].view(torch.int32).view(Bl, 300), I[sl]), (rank, q)
+                assert torch.equal(r[q, Bl * 2100:].view(torch.int32), C[sl]), (rank, q)
+            for q, (vd, vi, vc) in enumerate(sharded.rank_views(recv, world, Bl)):
+                assert vd.data_ptr() == recv.data_ptr() + 4 * q * Bl * 2101
+            gd, gi, gc = work.wait()
+            assert torch.equal(gd, D) and torch.equal(gi, I) and torch.equal(gc, C), rank
+        assert calls[0] == 2, calls                                        # ONE collective per step
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in o, o
+
+
 def test_gather_is_identity_without_process_group():
     from yolo_fastestv2_amd import gather_detections
     d, i, c = torch.rand(2, 300, 6), torch.zeros(2, 300, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
@@ -351,9 +418,11 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
             assert rc == 0 and steps >= 15 and blob > 400000, (classes, H, W, rc, steps, blob)
             blobs.add(blob)
         assert len(blobs) <= 3      # the packed blob depends on which kernels a size selects, not on the size itself
-    # the fallback plans (layer-by-layer: 77 launches; stage 2 on the LDS kernels; stage 3 as pairs of blocks) are planned and packed by the same code
+    # the two alternative plans (layer by layer: 77 launches; every pointwise conv on the fp32 MFMA: the stage-3 chain and
+    # stage4.0, which exist only as bf16x6 kernels, then run layer by layer) are planned and packed by the same code
     import os
-    for var, steps_min in (("YFV2_FUSED", 70), ("YFV2_S2PX", 18), ("YFV2_S1CHAIN", 22), ("YFV2_S4CHAIN", 20), ("YFV2_S2W", 20)):
+    assert _dryrun(80, 352, 352)[1] == 19
+    for var, steps_min in (("YFV2_FUSED", 70), ("YFV2_BF6", 40)):
         os.environ[var] = "0"
         try:
             for classes in (80, 20, 1):
@@ -370,3 +439,30 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
     assert _dryrun(80, 352, 352, drop="fpn.conv1x1_2.0.weight")[0] == ERR_WEIGHTS
     assert _dryrun(80, 352, 352, weights_classes=20)[0] == ERR_WEIGHTS     # a 20-class checkpoint into an 80-class handle
     assert _dryrun(20, 352, 352)[2] < _dryrun(80, 352, 352)[2]
+
+
+def test_bench_quotes_counters_only_from_a_profile_of_the_same_tree(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic / kernel_table[].mfma_busy come from profiles/*_traffic.json / *_pmc.json - but only from a
+    profile whose source fingerprint (tools/srchash.py) equals the tree's; the lookup matches bench's kernel-name prefixes."""
+    import json
+
+    import bench
+    h = bench.source_hash()
+    assert len(h) == 16 and h == bench.source_hash()
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    prof = {"src_hash": h, "kernels": {"void stem_px_kernel<true, false>(StemArgs)": {"total_bytes": 6.0e8, "mfma_busy_pct": 55.5},
+                                       "s2px_proj_kernel(S2PxArgs)": {"total_bytes": 2.8e8}, "s2px_main_kernel(S2PxArgs)": {"total_bytes": 3.0e8},
+                                       "void tower2_kernel<0, 512, 4, 4, true>(TowerArgs)": {"total_bytes": 8.0e7},
+                                       "void tower2_kernel<0, 512, 1, 1, true>(TowerArgs)": {"total_bytes": 2.0e7}}}
+    (tmp_path / "profiles" / "r03a_traffic.json").write_text(json.dumps(prof))
+    (tmp_path / "profiles" / "r03b_traffic.json").write_text(json.dumps(dict(prof, src_hash="0" * 16)))     # newer name, other tree
+    got = bench.newest_profile("_traffic.json", h)
+    assert got is not None and got["_file"] == "r03a_traffic.json"
+    assert bench.newest_profile("_traffic.json", "f" * 16) is None
+    assert bench.profile_lookup(got, "stem_px_kernel", "total_bytes", 1) == 6.0e8
+    assert bench.profile_lookup(got, "s2px_proj_kernel + s2px_main_kernel", "total_bytes", 2) == 5.8e8
+    assert bench.profile_lookup(got, "tower2_kernel<0, 512, 4, 4,", "total_bytes", 2) == 1.6e8   # two launches per forward
+    assert bench.profile_lookup(got, "tower2_kernel<0", "total_bytes", 2) is None                                  # ambiguous prefix: refuse
+    assert bench.profile_lookup(got, "stem_px_kernel", "mfma_busy_pct", 1, mean=True) == 55.5
+    assert bench.profile_lookup(None, "stem_px_kernel", "total_bytes", 1) is None

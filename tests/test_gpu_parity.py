@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 import torch
 
+import margin_nms
 from conftest import GOLDEN, unpack_ragged
 from oracle import yfv2_oracle as oracle
 
@@ -361,7 +362,7 @@ def _unexplained(o_dec_img, differing, thr, iou_thr):
 
 
 @pytest.mark.parametrize("conf_thres", [0.3, 0.01], ids=["test.py-0.3", "evaluation-0.01"])
-def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, images_u8, coco_weights, conf_thres):
+def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, images_u8, coco_weights, conf_thres, record_parity):
     """BASELINE config 3: batch 256, COCO weights, forward + decode + NMS at the test.py thresholds (0.3 / 0.4) and at
     evaluation()'s (0.01 / 0.4).  Without COCO val the mAP check is detection-set parity: the GPU survivors must equal the
     CPU oracle's.  A difference is accepted ONLY where `_unexplained` finds the decision on a numerical margin; the count of
@@ -373,11 +374,15 @@ def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, imag
     _, o_dec, (o_rows, o_idx) = oracle.detect(coco_weights, x, cfg["anchors"], cfg["height"], conf_thres, 0.4)
     n_det = sum(len(i) for i in o_idx)
     assert n_det > 500, "the synthetic batch must contain real detections (got %d)" % n_det
-    n_diff, bad = 0, []
+    n_diff, bad, n_uncertain, interval_bad = 0, [], 0, []
     for b in range(256):
         got, ref = set(idx[b].tolist()), set(int(v) for v in o_idx[b])
         n_diff += len(got ^ ref)
         bad += [(b, n) for n in _unexplained(o_dec[b], sorted(got ^ ref), conf_thres, 0.4)]
+        # the cascade-aware interval rule (tests/margin_nms.py): what the device MUST and MAY report for this image
+        m = margin_nms.check(o_dec[b], idx[b].tolist(), conf_thres, 0.4)
+        n_uncertain += m["n_uncertain"]
+        interval_bad += [(b, n) for n in m["missing"] + m["forbidden"]]
         common = sorted(got & ref)
         if common:
             gi = {int(n): k for k, n in enumerate(idx[b].tolist())}
@@ -387,10 +392,62 @@ def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, imag
             assert (np.abs(g[:, :4] - r[:, :4]) <= BOX_RTOL * np.maximum(1, np.abs(r[:, :4]))).all()
             assert np.abs(g[:, 4] - r[:, 4]).max() <= SCORE_ATOL and np.array_equal(g[:, 5], r[:, 5])
     print("conf %.2f: %d oracle detections, %d survivor differences, %d unexplained" % (conf_thres, n_det, n_diff, len(bad)))
+    record_parity("coco_batch256_conf%.2f_iou0.40" % conf_thres, n_det=n_det, n_diff=n_diff, explained=n_diff - len(bad),
+                  unexplained=len(bad), interval_rule_violations=len(interval_bad), rows_on_a_margin=n_uncertain)
     assert not bad, "%d unexplained survivor differences out of %d detections (%d on numerical margins): %s" % (
         len(bad), n_det, n_diff - len(bad), bad[:8])
-    if conf_thres == 0.3:
-        assert n_diff <= 2, "at the test.py thresholds the margins are wide (SURVEY.md App. D): %d differences" % n_diff
+    assert not interval_bad, "%d rows violate the interval rule of tests/margin_nms.py: %s" % (len(interval_bad), interval_bad[:8])
+    # the differences are bounded too, not only explained: 0.3 - the margins are wide; 0.01 - r03a measured
+    # N_DIFF_001 (profiles/r03a_parity_counts.json) out of ~11 k detections, the bound leaves a factor of slack for box-to-box
+    # differences in the last bit of a score
+    assert n_diff <= (2 if conf_thres == 0.3 else N_DIFF_BOUND_001), "%d survivor differences at conf %.2f" % (n_diff, conf_thres)
+
+
+N_DIFF_BOUND_001 = 64
+
+
+def test_fused_post_pinned_in_the_bench_regime(yfv2, dev, record_parity):
+    """the launch inside bench.py's `value` is nms_kernel<2> (decode + NMS fused) on the bench's own
+    workload - seeded random-init weights, torch.rand images generated on the device with seed 1000, conf 0.3 / IoU 0.4,
+    B = 256, where EVERY image reports the maximum of 300 detections.  (1) the fused launch equals the three-call path
+    (yfv2_forward -> yfv2_decode -> yfv2_nms, whose NMS is pinned bit-exact against the reference goldens) bit for bit - rows,
+    indices, counts - on all 256 images; (2) the three-call NMS equals the oracle's NMS on the device's own decoded tensor
+    (bit-exact, 32 images); (3) end to end against the CPU oracle's forward + decode + NMS on 16 images under the interval
+    rule of tests/margin_nms.py (a decision may differ only where it sits on a numerical margin), counts recorded."""
+    import bench
+    sd = yfv2.random_state_dict(0)
+    eng = yfv2.Engine(dev, 352, 352, 80, 3, anchors=bench.ANCHORS, max_batch=256)
+    eng.load_state_dict(sd)
+    g = torch.Generator(device=dev).manual_seed(1000)
+    x = torch.rand(256, 3, 352, 352, device=dev, generator=g)
+    d1, i1, c1 = eng.detect(x, 0.3, 0.4)
+    dec = eng.decode(eng.forward(x))
+    d2, i2, c2 = eng.nms(dec, 0.3, 0.4)
+    assert torch.equal(c1, c2), "fused and three-call counts differ"
+    assert int(c1.min()) == 300 and int(c1.max()) == 300, "the bench workload is the 300-detections worst case (got %d..%d)" % (int(c1.min()), int(c1.max()))
+    assert torch.equal(i1, i2), "fused and three-call survivor indices differ"
+    assert torch.equal(d1.view(torch.int32), d2.view(torch.int32)), "fused and three-call rows differ"
+    dec_h = dec[:32].cpu().numpy()
+    o_rows, o_idx = oracle.non_max_suppression(dec_h, 0.3, 0.4)
+    rows, ids = yfv2.unpack_detections(d1[:32], i1[:32], c1[:32])
+    for b in range(32):
+        assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)), b
+        assert np.array_equal(ids[b].numpy(), o_idx[b]), b
+    n16 = 16
+    _, o_dec, (e_rows, e_idx) = oracle.detect(sd, x[:n16].cpu(), bench.ANCHORS, 352, 0.3, 0.4)
+    _assert_decoded_close(dec_h[:n16], o_dec, "bench regime decode")
+    n_diff = n_uncertain = n_cand = 0
+    violations = []
+    for b in range(n16):
+        got, ref = set(ids[b].tolist()), set(int(v) for v in e_idx[b])
+        n_diff += len(got ^ ref)
+        m = margin_nms.check(o_dec[b], ids[b].tolist(), 0.3, 0.4)
+        n_uncertain += m["n_uncertain"]; n_cand += m["n_candidates"]
+        violations += [(b, n) for n in m["missing"] + m["forbidden"]]
+    record_parity("bench_regime_random_weights_conf0.30_iou0.40", images_fused_vs_three_call=256, images_nms_vs_oracle_bitexact=32,
+                  images_end_to_end_vs_oracle=n16, n_det=sum(len(i) for i in e_idx), candidates=n_cand, n_diff=n_diff,
+                  rows_on_a_margin=n_uncertain, interval_rule_violations=len(violations))
+    assert not violations, "%d rows violate the interval rule: %s" % (len(violations), violations[:8])
 
 
 def test_other_input_size_320(yfv2, dev):
@@ -421,15 +478,12 @@ def test_other_input_size_320(yfv2, dev):
         assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)) and np.array_equal(idx[b].numpy(), o_idx[b])
 
 
-@pytest.mark.parametrize("env", [{"YFV2_S2PX": "0"}, {"YFV2_FUSED": "0"}, {"YFV2_S1CHAIN": "0"}, {"YFV2_S1CHAIN": "0", "YFV2_S1X2": "0"},
-                                 {"YFV2_S1CHAIN": "0", "YFV2_S1X2": "0", "YFV2_S1W": "0", "YFV2_DWPW": "0", "YFV2_S4CHAIN": "0"},
-                                 {"YFV2_S4CHAIN": "0"}, {"YFV2_S2W": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_SIDE": "1"}, {"YFV2_PWSPLIT": "0"}, {"YFV2_S4BF6": "0"}, {"YFV2_S1CHAIN_BF6": "0"}],
-                         ids=["stage2-on-LDS-kernels", "layer-by-layer", "stage3-as-pairs", "stage3-single-blocks", "round-1-kernels",
-                              "stage4-single-blocks", "stage4.0-as-three-launches", "fp32-mfma-everywhere", "two-launch-post", "side-streams-for-the-11x11-towers", "fpn-filters-split-on-the-fly", "stage4-chain-on-the-fp32-mfma", "stage3-chain-on-the-fp32-mfma"])
+@pytest.mark.parametrize("env", [{"YFV2_FUSED": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}],
+                         ids=["layer-by-layer", "fp32-mfma-everywhere", "two-launch-post"])
 def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
-    """The fallback launch plans (stage 2 on the LDS kernels / everything layer by layer / stage 3 as pairs of blocks or as
-    single blocks instead of the seven-block chain / the round-1 kernel set) are what runs for shapes the newer kernels do
-    not cover, and what the A/B switches select: same logits as the oracle."""
+    """The three plan switches that remain: everything layer by layer - also what a shape outside a fused
+    kernel's static bounds gets, block by block; every pointwise conv on the fp32 MFMA; decode and NMS as two launches.
+    Same logits as the oracle; the two-launch post must report exactly what the three separate calls report."""
     x = (torch.from_numpy(images_u8[:3]).float() / 255.0)
     ref = oracle.forward(coco_weights, x)
     sd = {k: torch.as_tensor(np.asarray(v)) for k, v in coco_weights.items()}
@@ -445,12 +499,17 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
             else:
                 os.environ[k] = v
     names = [s["name"] for s in eng.stages()]
-    if "YFV2_S1CHAIN" in env:
-        assert not any("chain of 7" in n for n in names), names
-    elif "YFV2_S4CHAIN" in env:
-        assert not any("resident in LDS" in n for n in names), names
-    elif "YFV2_S2PX" in env or "YFV2_FUSED" in env:
-        assert not any("lane-per-pixel" in n for n in names), names
+    if "YFV2_FUSED" in env:
+        assert len(names) >= 70 and not any("chain of" in n or "lane-per-pixel" in n for n in names), names
+    elif "YFV2_BF6" in env:
+        assert not any("chain of 7" in n for n in names) and any("resident in LDS" in n for n in names), names
+    else:
+        assert len(names) == 19
+        eng.set_anchors([12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87])
+        d1 = eng.detect(x.to(dev), 0.3, 0.4)                               # decode_kernel<compact> + nms_kernel<1>
+        d2 = eng.nms(eng.decode(eng.forward(x.to(dev))), 0.3, 0.4)
+        for a, b in zip(d1, d2):
+            assert torch.equal(a, b)
     got = eng.forward(x.to(dev))
     for g, r, k in zip(got, ref, LOGIT_KEYS):
         err = float((g.cpu() - r).abs().max())

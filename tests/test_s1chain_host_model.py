@@ -197,11 +197,8 @@ def _kernel_model(x, images):
     return z
 
 
-@pytest.mark.parametrize("form", ["bf16x6-presplit", "fp32"])
-def test_chain_host_packing_and_channel_bookkeeping(monkeypatch, form):
-    if form == "fp32":
-        monkeypatch.setenv("YFV2_S1CHAIN_BF6", "0")
-    _set_form(form != "fp32")
+def test_chain_host_packing_and_channel_bookkeeping():
+    _set_form(True)      # block_s1chain6_kernel's pre-split image (the fp32-fragment form went with round 2's fp32-MFMA chain)
     w = yfv2.random_state_dict(5)
     im, rc, lab = _plan(w)
     if im is None:

@@ -15,7 +15,7 @@ from yolo_fastestv2_amd._lib import Config, TensorDesc
 
 C2, NB = 96, 3
 REST_FL = 9 * 32 + 4 * 32 + 2 * C2
-# fp32 fragments (YFV2_S4BF6=0) / pre-split bf16 hi-mid-lo operand quads per chunk pair (default): [mt][pair][term][64][4]
+# fp32 fragments (YFV2_BF6=0) / pre-split bf16 hi-mid-lo operand quads per chunk pair (default): [mt][pair][term][64][4]
 SIZES = {False: (2 * 6 * 256, 6 * 2 * 256), True: (2 * 3 * 3 * 256, 6 * 1 * 3 * 256)}
 
 
@@ -68,12 +68,12 @@ def _frags(fr, mt_n, s_n):
 @pytest.mark.parametrize("form", ["presplit", "fp32"])
 def test_pool_chain_host_packing(monkeypatch, form):
     if form == "fp32":
-        monkeypatch.setenv("YFV2_S4BF6", "0")
+        monkeypatch.setenv("YFV2_BF6", "0")
     w = yfv2.random_state_dict(9)
     im = _plan_image(w)
     if im is None:
         pytest.skip("this build's plan has no stage-4 chain launch")
-    pre = form == "presplit"            # the default plan packs pre-split; YFV2_S4BF6=0 the fp32 fragments
+    pre = form == "presplit"            # the default plan packs pre-split; YFV2_BF6=0 the fp32 fragments
     W1_FL, W2_FL = SIZES[pre]
     IMG_FL = W1_FL + W2_FL + REST_FL
     torch.manual_seed(2)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # YFV2_LIB: opt-in override used only for same-box A/B of two builds (tools/gpu_quick.sh)
 LIB_PATH = os.environ.get("YFV2_LIB") or os.path.join(_HERE, "libyfv2.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DET = 300
 
 OK, ERR_ARG, ERR_CONFIG, ERR_DEVICE, ERR_WEIGHTS, ERR_STATE, ERR_BATCH = 0, -1, -2, -3, -4, -5, -6
@@ -62,7 +62,7 @@ _PROTOTYPES = {
     "yfv2_num_rows": (C.c_int32, [C.c_void_p]),
     "yfv2_num_stages": (C.c_int32, [C.c_void_p]),
     "yfv2_stage_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),
-                                  C.POINTER(C.c_double)]),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "yfv2_stage_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     "yfv2_profile_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                        C.POINTER(C.c_float), C.c_void_p]),
@@ -81,14 +81,18 @@ def lib():
         raise ImportError("%s is missing: the HIP extension has not been built (run __graft_entry__.build()); "
                           "yolo_fastestv2_amd has no CPU or PyTorch fallback" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
+    # the ABI number first: a stale build must fail with THIS message, not with an AttributeError on a newer symbol
+    if not hasattr(L, "yfv2_abi_version"):
+        raise ImportError("%s does not export yfv2_abi_version: not a libyfv2 build" % LIB_PATH)
+    L.yfv2_abi_version.restype, L.yfv2_abi_version.argtypes = C.c_int, []
+    if L.yfv2_abi_version() != ABI_VERSION:
+        raise ImportError("libyfv2.so ABI %d != binding ABI %d: rebuild (__graft_entry__.build())" % (L.yfv2_abi_version(), ABI_VERSION))
     for name, (res, args) in _PROTOTYPES.items():
         if name.startswith("yfv2_debug_") and os.environ.get("YFV2_LIB") and not hasattr(L, name):
             continue  # an older A/B build may lack a host-only test hook; product entry points are never optional
         fn = getattr(L, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if L.yfv2_abi_version() != ABI_VERSION:
-        raise ImportError("libyfv2.so ABI %d != binding ABI %d: rebuild" % (L.yfv2_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

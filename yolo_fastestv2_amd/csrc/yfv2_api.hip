@@ -25,7 +25,7 @@ thread_local std::string g_tls_error;
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
-enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_S1 = 3, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_DWPW = 9, STEP_S1X2 = 10, STEP_S1CHAIN = 11, STEP_S1POOL = 12 };
+enum StepKind { STEP_STEM = 0, STEP_PW = 1, STEP_DW = 2, STEP_TOWER = 4, STEP_S2 = 5, STEP_S1PX = 7, STEP_S2PX = 8, STEP_S1CHAIN = 11, STEP_S1POOL = 12 };
 
 struct Step {
   int kind = 0;
@@ -39,7 +39,6 @@ struct Step {
   BlockS2Args s2{};
   S1PxArgs s1px{};
   S2PxArgs s2px{};
-  DwPwArgs dwpw{};
   size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
@@ -49,9 +48,8 @@ struct Step {
   int px_per_img = 0;         // pw: pixels per image (P = B * px_per_img)
   int head0 = -1, head1 = -1; // PW_HEAD: indices into out6
   std::string name;
-  double flops = 0, bytes = 0;  // algorithmic, per image
-  int lane = 0;               // 0 = the caller's stream; 1, 2 = the handle's side streams (independent branches of the graph)
-  bool fork_after = false;    // the side streams may start once this launch is done
+  double flops = 0, bytes = 0;  // algorithmic, per image; bytes = per-LAYER accounting (every reference layer the launch covers reads its input and writes its output once)
+  double bytes_ext = -1;        // SURVEY.md 8(d) for fused launches: EXTERNAL reads + writes of the launch only (-1: same as bytes)
 };
 
 struct Buf { float* p = nullptr; size_t per_img = 0; };
@@ -80,15 +78,6 @@ struct yfv2_ctx {
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
   bool bf6 = true;          // pointwise convs on the bf16 matrix cores where a kernel has that form (YFV2_BF6=0 at create time: fp32 MFMA)
   bool postfuse = true;     // yfv2_detect: decode + NMS as one launch (YFV2_POSTFUSE=0 at create time: two launches)
-  // The 11x11 towers depend only on the FPN's S3: with YFV2_SIDE=1 at create time they run on two side streams (cls / reg)
-  // next to the 22x22 branch (pw288 -> towers) on the caller's stream, forked and joined with events inside every forward -
-  // the caller still sees one stream.  OFF by default: measured (tools/gpu_ab_side.sh, rocprofv3 timeline in DESIGN.md 4.4)
-  // the launches do overlap, but the 11x11 towers then take 51-59 us instead of 16-24, the 22x22 launches next to them
-  // stretch by 10-20 us, and the fork costs a 9-12 us bubble on the caller's stream: forward 988-995 us against 980-987.
-  bool side = false;
-  hipStream_t side_stream[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  Buf ta_side[2];           // tower intermediates of the side lanes
   bool c2_permuted = false; // stage 3's output (C2) is stored in the chain kernel's order:
   int c2_label[96] = {0};   //   physical channel position k holds logical channel c2_label[k]
   Buf logits[6];
@@ -267,23 +256,6 @@ struct WeightPacker {
     push_vec(im, &blob[f.shift], M, rows);
     return put(im);
   }
-  // dwpw_s2_kernel<C>: pw fragments | dw taps [9][C] | dw scale, shift | pw scale, shift
-  size_t image_dwpw(const Folded& fd, const Folded& fp, int C) {
-    std::vector<float> im;
-    push_frag(im, &blob[fp.w], C, C, C / 16, C / 16);
-    push_rows(im, &blob[fd.w], 9, C, C);
-    push_vec(im, &blob[fd.scale], C, C); push_vec(im, &blob[fd.shift], C, C);
-    push_vec(im, &blob[fp.scale], C, C); push_vec(im, &blob[fp.shift], C, C);
-    return put(im);
-  }
-  // block_s1_kernel<C2>: W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2
-  void append_s1(std::vector<float>& im, const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
-    const int KC = (c2 + 15) / 16, KS = 16 * KC;
-    push_frag(im, &blob[f1.w], c2, c2, KC, KC);
-    push_frag(im, &blob[f2.w], c2, c2, KC, KC);
-    push_rows(im, &blob[fd.w], 9, c2, KS);
-    for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], c2, KS); push_vec(im, &blob[f->shift], c2, KS); }
-  }
   // block_s1chain6_kernel: a 48x48 filter as [mt (3)][six 16-byte operands][64 lanes][4 dwords]: hi / mid / lo quads of the
   // chunk PAIR (chunks 0, 1: the 32 k-slots of one bf16 MFMA), then {hi,hi} {mid,mid} {hi,lo} of the single chunk 2 (the
   // register form of yfv2_split_a); every dword = two truncated bf16, low half first
@@ -319,11 +291,6 @@ struct WeightPacker {
     push_chain6_filter(im, &blob[f2.w]);
     push_rows(im, &blob[fd.w], 9, 48, 48);
     for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], 48, 48); push_vec(im, &blob[f->shift], 48, 48); }
-  }
-  size_t image_s1(const Folded& f1, const Folded& fd, const Folded& f2, int c2) {
-    std::vector<float> im;
-    append_s1(im, f1, fd, f2, c2);
-    return put(im);
   }
   // block_s2_kernel<CIN>: W1 | W2 | Wproj | main dw taps | proj dw taps | sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
   size_t image_s2(const Folded& f1, const Folded& fd, const Folded& f2, const Folded& fpd, const Folded& fpp, int cin) {
@@ -620,35 +587,6 @@ struct PlanBuilder {
       h->plan.push_back(s);
       return;
     }
-    const char* envd = std::getenv("YFV2_DWPW");
-    if (!(env && env[0] == '0') && !(envd && envd[0] == '0') && cin == 96 && !(H & 1) && !(W & 1)) {
-      // each branch's tail (dw3x3 s2 + BN -> pw + BN + ReLU) as one launch; pw1 stays a plain pointwise launch
-      auto add_dwpw = [&](const std::string& name, const float* in, int out_off, const Folded& fd, const Folded& fp) {
-        Step s;
-        s.kind = STEP_DWPW;
-        s.c2 = cin;
-        s.dwpw.in = in; s.dwpw.out = y.p;
-        s.dwpw.H = H; s.dwpw.W = W;
-        s.dwpw.in_stride = cin; s.dwpw.in_off = 0; s.dwpw.out_stride = co; s.dwpw.out_off = out_off;
-        s.img_off = wp.image_dwpw(fd, fp, cin);
-        s.name = name;
-        s.flops = 2.0 * oh * ow * (9.0 * cin + (double)cin * cin);
-        s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * cin);
-        h->plan.push_back(s);
-      };
-      Folded fd, fp;
-      ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fd);
-      ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &fp);
-      if (in_label && ok) { fd = wp.permuted_dw_channels(fd, cin, 9, in_label); fp = wp.permuted_pw_inputs(fp, cin, cin, in_label); }
-      add_dwpw(p + ".proj: dw3x3s2+bn -> pw+bn+relu", x.p, 0, fd, fp);
-      ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", cin, cin, &f);
-      if (in_label && ok) f = wp.permuted_pw_inputs(f, cin, cin, in_label);
-      add_pw(p + ".main.pw1+bn+relu", cin, PW_PLAIN, cin, H * W, x.p, cin, 0, h->t1.p, cin, 0, true, f);
-      ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", cin, 3, &fd);
-      ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", cin, cin, &fp);
-      add_dwpw(p + ".main: dw3x3s2+bn -> pw2+bn+relu", h->t1.p, cin, fd, fp);
-      return;
-    }
     ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &f);
     if (in_label && ok) f = wp.permuted_dw_channels(f, cin, 9, in_label);
     add_dw(p + ".proj.dw3x3s2+bn", 3, 2, cin, H, W, x.p, cin, h->t3.p, cin, false, f);
@@ -752,48 +690,9 @@ struct PlanBuilder {
     s.name = p + " s1 block, lane-per-pixel: pw1+bn+relu -> dw3x3+bn -> pw2+bn+relu on the 12 branch pairs (shuffle/pass/cat = bookkeeping)";
     s.flops = 2.0 * H * W * (2.0 * 24 * 24 + 9.0 * 24);
     s.bytes = 4.0 * H * W * (2.0 * 48);  // the layer's logical input + output; the launch itself moves half of it
+    s.bytes_ext = 4.0 * H * W * (2.0 * 24);   // the 12 branch pairs in, the 12 fresh pairs out; the pass-through half never moves
     h->plan.push_back(s);
   }
-
-  // ShuffleV2Block stride 1 (shufflenetv2.py:48-51,57-63): even channels pass through,
-  // odd channels -> main; out = cat(pass, main)
-  // two consecutive stride-1 blocks as ONE launch (block_s1x2_kernel): both blocks' LDS images back to back, the
-  // input columns of the two pw1 filters permuted to the physical channel order of the kernel's LDS tile
-  void s1x2_block(const std::string& pa, const std::string& pb, int c, int H, int W, const Buf& x, const Buf& y) {
-    const int c2 = c / 2;
-    Folded f1[2], fd[2], f2[2];
-    const std::string* ps[2] = {&pa, &pb};
-    for (int k = 0; k < 2; ++k) {
-      ok &= wp.pw(*ps[k] + ".branch_main.0", *ps[k] + ".branch_main.1", c2, c2, &f1[k]);
-      ok &= wp.dw(*ps[k] + ".branch_main.3", *ps[k] + ".branch_main.4", c2, 3, &fd[k]);
-      ok &= wp.pw(*ps[k] + ".branch_main.5", *ps[k] + ".branch_main.6", c2, c2, &f2[k]);
-    }
-    std::vector<float> im;
-    if (ok) {
-      int la[48], lb[48];
-      for (int s = 0; s < 3; ++s)
-        for (int g = 0; g < 4; ++g)
-          for (int j = 0; j < 4; ++j) {
-            la[16 * s + 4 * g + j] = yfv2_s1x2_label_a(s, g, j);
-            lb[16 * s + 4 * g + j] = yfv2_s1x2_label_b(s, g, j);
-          }
-      const Folded f1a = wp.permuted_pw_inputs(f1[0], c2, c2, la);
-      const Folded f1b = wp.permuted_pw_inputs(f1[1], c2, c2, lb);
-      wp.append_s1(im, f1a, fd[0], f2[0], c2);
-      wp.append_s1(im, f1b, fd[1], f2[1], c2);
-    }
-    Step s;
-    s.kind = STEP_S1X2;
-    s.c2 = c2;
-    s.s1.in = x.p; s.s1.out = y.p;
-    s.s1.H = H; s.s1.W = W; s.s1.R = H;
-    s.img_off = wp.put(im);
-    s.name = pa + " + " + pb.substr(pb.rfind('.') + 1) + " two fused s1 blocks in one launch (the activation between them stays on chip)";
-    s.flops = 2.0 * 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
-    s.bytes = 4.0 * H * W * (2.0 * c);
-    h->plan.push_back(s);
-  }
-
 
   // ---- a chain of stride-1 blocks as ONE launch (block_s1chain_kernel, yfv2_block.hip).  The kernel moves data in a
   // fixed, lane-uniform way (pixel slot owned by the 4 lanes g of a 16-lane row; per block and lane: accumulator elements
@@ -809,7 +708,6 @@ struct PlanBuilder {
   struct ChainLoc { int kind = 0, blk = 0, mt = 0, g = 0, e = 0, off = 0; };   // kind 0: X[off] (loaded up front), 1: accumulator of block blk, 2: parked at Z[off]
   void s1chain_block(const std::vector<std::string>& names, int c, int H, int W, const Buf& x, const Buf& y, int* z_label) {
     const int c2 = c / 2, NB = (int)names.size();
-    const bool bf6 = h->bf6 && yfv2_s1chain_bf6();   // block_s1chain6_kernel: pre-split filters
     std::vector<Folded> f1(NB), fd(NB), f2(NB);
     for (int k = 0; k < NB; ++k) {
       ok &= wp.pw(names[k] + ".branch_main.0", names[k] + ".branch_main.1", c2, c2, &f1[k]);
@@ -950,7 +848,7 @@ struct PlanBuilder {
           nxt[48 + j] = L;
         }
         act.swap(nxt);
-        if (bf6) wp.append_s1_bf6(im, f1k, fd[k], f2k); else wp.append_s1(im, f1k, fd[k], f2k, c2);
+        wp.append_s1_bf6(im, f1k, fd[k], f2k);
         for (int t = 0; t < 64; ++t) {                  // int tables as raw bits behind the BN vectors
           float fbits; const int v = t < 36 ? tables[k][t] : 0;
           std::memcpy(&fbits, &v, sizeof(float));
@@ -970,7 +868,7 @@ struct PlanBuilder {
           if (pos < 0 || z_label[pos] != -1) { ok = false; break; }
           z_label[pos] = o;
         }
-        if ((int)(im.size() / NB) != yfv2_s1chain_image_floats(bf6)) ok = false;
+        if ((int)(im.size() / NB) != yfv2_s1chain_image_floats()) ok = false;
       }
     } else {
       ok = false;
@@ -980,12 +878,13 @@ struct PlanBuilder {
     s.c2 = c2;
     s.s1.in = x.p; s.s1.out = y.p;
     s.s1.H = H; s.s1.W = W; s.s1.R = H; s.s1.nblk = NB;
-    s.s1.presplit = bf6 ? 1 : 0;
+    s.s1.presplit = 1;
     s.img_off = wp.put(im);
     s.name = names.front() + " .. " + names.back().substr(names.back().rfind('.') + 1) + " chain of " + std::to_string(NB) +
              " fused s1 blocks in one launch (activations between them stay on chip)";
     s.flops = NB * 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
     s.bytes = NB * 4.0 * H * W * (2.0 * c);   // per-layer accounting: every block reads and writes c channels
+    s.bytes_ext = 4.0 * H * W * (2.0 * c);    // the launch reads the activation once and writes it once (parked dwords are internal traffic)
     h->plan.push_back(s);
   }
 
@@ -995,7 +894,7 @@ struct PlanBuilder {
   // [9][32] | sc1 sh1 scd shd [32] | sc2 sh2 [96]
   void s1pool_block(const std::vector<std::string>& names, int c, int H, int W, const Buf& x, const Buf& y) {
     const int c2 = c / 2, NB = (int)names.size();
-    const bool pre = h->bf6 && yfv2_s1pool_presplit();
+    const bool pre = h->bf6;   // bf16x6 on pre-split filters; YFV2_BF6=0: the fp32-MFMA form of the same kernel
     std::vector<float> im;
     for (int k = 0; k < NB && ok; ++k) {
       Folded f1, fd, f2;
@@ -1034,38 +933,20 @@ struct PlanBuilder {
     s.s1.in = x.p; s.s1.out = y.p;
     s.s1.H = H; s.s1.W = W; s.s1.R = H; s.s1.nblk = NB;
     s.s1.presplit = pre ? 1 : 0;
-    s.s1.presplit = pre ? 1 : 0;
     s.img_off = wp.put(im);
     s.name = names.front() + " .. " + names.back().substr(names.back().rfind('.') + 1) + " chain of " + std::to_string(NB) +
              " fused s1 blocks in one launch (whole activation resident in LDS)";
     s.flops = NB * 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
     s.bytes = NB * 4.0 * H * W * (2.0 * c);
+    s.bytes_ext = 4.0 * H * W * (2.0 * c);
     h->plan.push_back(s);
   }
 
+  // ShuffleV2Block stride 1 (shufflenetv2.py:48-51,57-63), layer by layer: even channels pass through (copied by the pw1
+  // launch), odd channels -> main; out = cat(pass, main).  The general plan for shapes the chains do not cover.
   void block_s1(const std::string& p, int c, int H, int W, const Buf& x, const Buf& y) {
     Folded f;
     const int c2 = c / 2;
-    const char* env = std::getenv("YFV2_FUSED");
-    const bool fused = !(env && env[0] == '0');
-    if (fused && (c2 == 24 || c2 == 48 || c2 == 96) && yfv2_block_s1_rows(c2, H, W) > 0) {
-      Folded f1, fd, f2;
-      ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", c2, c2, &f1);
-      ok &= wp.dw(p + ".branch_main.3", p + ".branch_main.4", c2, 3, &fd);
-      ok &= wp.pw(p + ".branch_main.5", p + ".branch_main.6", c2, c2, &f2);
-      Step s;
-      s.kind = STEP_S1;
-      s.c2 = c2;
-      s.s1.in = x.p; s.s1.out = y.p;
-      s.s1.H = H; s.s1.W = W;
-      s.s1.R = yfv2_block_s1_rows(c2, H, W);
-      s.img_off = wp.image_s1(f1, fd, f2, c2);
-      s.name = p + " fused s1 block: shuffle+pass | pw1+bn+relu -> dw3x3+bn -> pw2+bn+relu | cat";
-      s.flops = 2.0 * H * W * (2.0 * c2 * c2 + 9.0 * c2);
-      s.bytes = 4.0 * H * W * (2.0 * c);  // read c, write c channels per pixel
-      h->plan.push_back(s);
-      return;
-    }
     ok &= wp.pw(p + ".branch_main.0", p + ".branch_main.1", c2, c2, &f);
     Step& s = add_pw(p + ".shuffle+pass+main.pw1+bn+relu", c2, PW_SHUFFLE, c2, H * W, x.p, c, 0, h->t1.p, c2, 0, true, f);
     s.pw.copy = y.p; s.pw.copy_stride = c; s.pw.copy_off = 0;
@@ -1093,7 +974,7 @@ struct PlanBuilder {
     h->plan.push_back(s);
   }
 
-  void tower(const std::string& p, int H, int W, const Buf& s_in, bool is_cls, int scale_idx, int lane = 0) {
+  void tower(const std::string& p, int H, int W, const Buf& s_in, bool is_cls, int scale_idx) {
     Folded f;
     const int px = H * W;
     {
@@ -1105,9 +986,8 @@ struct PlanBuilder {
         ok &= wp.dw(p + ".5", p + ".6", 72, 5, &fd2);
         ok &= wp.pw(p + ".8", p + ".9", 72, 72, &fp2);
         const int A = h->cfg.anchor_num, nc = h->cfg.classes;
-        float* mid = lane ? h->ta_side[lane - 1].p : h->ta.p;   // a side lane keeps its own intermediate
+        float* mid = h->ta.p;
         tower_half(p + " half a: dw5x5+bn+relu -> pw+bn", H, W, s_in.p, mid, fd1, fp1, nullptr, 0, 0, -1, -1);
-        h->plan.back().lane = lane;
         if (is_cls) {
           ok &= wp.heads({{"output_obj_layers", A}, {"output_cls_layers", nc}}, 72, &fh);
           tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_obj+output_cls (bias, NCHW)", H, W, mid, nullptr, fd2,
@@ -1117,7 +997,6 @@ struct PlanBuilder {
           tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_reg (bias, NCHW)", H, W, mid, nullptr, fd2, fp2, &fh,
                      4 * A, 4 * A, scale_idx * 3 + 0, -1);
         }
-        h->plan.back().lane = lane;
         return;
       }
     }
@@ -1151,8 +1030,8 @@ struct PlanBuilder {
     int hh = H / 4, ww = W / 4, cin = 24;
     const long long pp_bufstride = (long long)h->cfg.max_batch * 48 * (H / 8) * (W / 8);
     const char* envf = std::getenv("YFV2_FUSED");
-    const char* envp = std::getenv("YFV2_S2PX");
-    const bool stage2_px = !(envf && envf[0] == '0') && !(envp && envp[0] == '0') && h->s2pp.p && yfv2_s1px_supported(hh / 2, ww / 2) &&
+    const bool fused = !(envf && envf[0] == '0');   // YFV2_FUSED=0: every layer its own launch (the general plan)
+    const bool stage2_px = fused && h->s2pp.p && yfv2_s1px_supported(hh / 2, ww / 2) &&
                            yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0 && (pp_bufstride + 48LL * (hh / 2) * (ww / 2)) * 4 < (1LL << 31);
     add_stem(h->a1, stage2_px);
     h->stem_pp = stage2_px;
@@ -1182,24 +1061,17 @@ struct PlanBuilder {
           }
         } else if (use_px) {
           s1px_block(p, hh, ww, L2, pp_bufstride);
-        } else if (const char* envf3 = std::getenv("YFV2_FUSED"); !(envf3 && envf3[0] == '0') && i == 1 && repeats[si] == 8 &&
-                   yfv2_s1chain_supported(cout / 2, hh, ww) && yfv2_block_s1_rows(cout / 2, hh, ww) == hh) {
+        } else if (fused && h->bf6 && i == 1 && repeats[si] == 8 && yfv2_s1chain_supported(cout / 2, hh, ww)) {
           std::vector<std::string> names;
           for (int q = 1; q < repeats[si]; ++q) names.push_back("backbone.stage" + std::to_string(si + 2) + "." + std::to_string(q));
           s1chain_block(names, cout, hh, ww, *x, *y, h->c2_label);     // blocks 1..7 of the stage as one launch
           h->c2_permuted = ok;
           i = repeats[si] - 1;
-        } else if (const char* envf4 = std::getenv("YFV2_FUSED"); !(envf4 && envf4[0] == '0') && i == 1 && si == 2 &&
-                   yfv2_s1pool_supported(cout / 2, hh, ww)) {
+        } else if (fused && i == 1 && si == 2 && yfv2_s1pool_supported(cout / 2, hh, ww)) {
           std::vector<std::string> names;
           for (int q = 1; q < repeats[si]; ++q) names.push_back("backbone.stage" + std::to_string(si + 2) + "." + std::to_string(q));
           s1pool_block(names, cout, hh, ww, *x, *y);                     // stage 4's blocks 1..3 as one launch
           i = repeats[si] - 1;
-        } else if (const char* envf2 = std::getenv("YFV2_FUSED"); !(envf2 && envf2[0] == '0') && i + 1 < repeats[si] &&
-                   yfv2_s1x2_supported(cout / 2, hh, ww) && yfv2_block_s1_rows(cout / 2, hh, ww) == hh) {
-          const std::string pnext = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i + 1);
-          s1x2_block(p, pnext, cout, hh, ww, *x, *y);
-          ++i;                                   // the pair consumed the next block too
         } else {
           block_s1(p, cout, hh, ww, *x, *y);
         }
@@ -1224,7 +1096,6 @@ struct PlanBuilder {
     Folded f;
     ok &= wp.pw("fpn.conv1x1_3.0", "fpn.conv1x1_3.1", 72, 192, &f);
     add_pw("fpn.conv1x1_3 pw192->72+bn+relu", 192, PW_PLAIN, 72, h3 * w3, c3->p, 192, 0, h->f3.p, 72, 0, true, f);
-    h->plan.back().fork_after = true;   // S3 is all the 11x11 towers need
     ok &= wp.pw("fpn.conv1x1_2.0", "fpn.conv1x1_2.1", 72, 288, &f);
     if (h->c2_permuted && ok) {   // columns 192.. read C2 in the chain kernel's channel order
       int lab[288];
@@ -1241,8 +1112,8 @@ struct PlanBuilder {
     }
     h->dbg[4] = h->f2.p; h->dbg_per_img[4] = h->f2.per_img; h->dbg_c[4] = 72;
     h->dbg[5] = h->f3.p; h->dbg_per_img[5] = h->f3.per_img; h->dbg_c[5] = 72;
-    tower("fpn.cls_head_3.block", h3, w3, h->f3, true, 1, 1);
-    tower("fpn.reg_head_3.block", h3, w3, h->f3, false, 1, 2);
+    tower("fpn.cls_head_3.block", h3, w3, h->f3, true, 1);
+    tower("fpn.reg_head_3.block", h3, w3, h->f3, false, 1);
     tower("fpn.cls_head_2.block", h2, w2, h->f2, true, 0);
     tower("fpn.reg_head_2.block", h2, w2, h->f2, false, 0);
   }
@@ -1254,17 +1125,25 @@ std::string step_kernel(const Step& st) {
     case STEP_STEM: return "stem_px_kernel";
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
-    case STEP_S1: return st.c2 == 48 && st.s1.R == st.s1.H ? "block_s1w_kernel" : "block_s1_kernel<" + std::to_string(st.c2) + ",";
-    case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4>" : "1, 1>");
+    case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",";
     case STEP_S1PX: return "s1px_kernel";
     case STEP_S2PX: return "s2px_proj_kernel + s2px_main_kernel";
-    case STEP_DWPW: return "dwpw_s2_kernel";
-    case STEP_S1X2: return "block_s1x2_kernel";
-    case STEP_S1CHAIN: return st.s1.presplit ? "block_s1chain6_kernel" : "block_s1chain_kernel";
+    case STEP_S1CHAIN: return "block_s1chain6_kernel";
     case STEP_S1POOL: return "block_s1pool_kernel";
   }
   return "?";
+}
+
+// The plan switches, read from the environment when a handle is created (and by the host-only dry runs):
+//   YFV2_FUSED=0     every reference layer its own launch (the general plan; also what shapes outside a fused kernel's
+//                    static bounds get, block by block)                                 - read by PlanBuilder::build
+//   YFV2_BF6=0       every pointwise conv on the fp32 MFMA; blocks whose fused kernel exists only in the bf16x6 form
+//                    (the stage-3 chain, stage4.0) then run layer by layer
+//   YFV2_POSTFUSE=0  yfv2_detect decodes and suppresses in two launches
+void read_plan_switches(yfv2_ctx* h) {
+  if (const char* e = std::getenv("YFV2_BF6")) h->bf6 = !(e[0] == '0');
+  if (const char* e = std::getenv("YFV2_POSTFUSE")) h->postfuse = !(e[0] == '0');
 }
 
 int alloc_buf(yfv2_ctx* h, Buf* b, size_t per_img) {
@@ -1286,12 +1165,9 @@ size_t logit_elems(const yfv2_ctx* h, int i) {
 
 int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6], hipStream_t main_stream, hipEvent_t* ev /*nullable: 2 per step*/) {
   const float* params = h->d_params;
-  // lanes: independent branches on the handle's side streams (not when the launches are timed one by one)
-  const bool lanes = h->side && !ev;
-  bool forked = false;
+  const hipStream_t s = main_stream;
   for (size_t i = 0; i < h->plan.size(); ++i) {
     Step& st = h->plan[i];
-    const hipStream_t s = (lanes && forked && st.lane > 0) ? h->side_stream[st.lane - 1] : main_stream;
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i], s));
     if (st.kind == STEP_STEM) {
       StemArgs a = st.stem;
@@ -1332,13 +1208,6 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       }
       if (!yfv2_launch_tower2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
-    } else if (st.kind == STEP_S1X2) {
-      BlockS1Args a = st.s1;
-      a.B = B;
-      a.img = params + st.img_off;
-      a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
-      if (!yfv2_launch_block_s1x2(a, s))
-        return fail(h, YFV2_ERR_CONFIG, "no two-block kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S1POOL) {
       BlockS1Args a = st.s1;
       a.B = B;
@@ -1353,12 +1222,6 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
       if (!yfv2_launch_block_s1chain(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no chain kernel for step '" + st.name + "'");
-    } else if (st.kind == STEP_DWPW) {
-      DwPwArgs a = st.dwpw;
-      a.B = B;
-      a.img = params + st.img_off;
-      if (!yfv2_launch_dwpw(st.c2, a, s))
-        return fail(h, YFV2_ERR_CONFIG, "no fused depthwise+pointwise kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S2PX) {
       S2PxArgs a = st.s2px;
       a.B = B;
@@ -1370,13 +1233,6 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.B = B;
       a.img = params + st.img_off;
       yfv2_launch_s1px(a, s);
-    } else if (st.kind == STEP_S1) {
-      BlockS1Args a = st.s1;
-      a.B = B;
-      a.img = params + st.img_off;
-      a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
-      if (!yfv2_launch_block_s1(st.c2, a, s))
-        return fail(h, YFV2_ERR_CONFIG, "no fused block kernel for step '" + st.name + "'");
     } else {
       DwArgs a = st.dw;
       a.B = B;
@@ -1385,17 +1241,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
         return fail(h, YFV2_ERR_CONFIG, "no depthwise kernel for step '" + st.name + "'");
     }
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i + 1], s));
-    if (lanes && st.fork_after && !forked) {
-      HIP_TRY(h, hipEventRecord(h->ev_fork, main_stream));
-      for (int k = 0; k < 2; ++k) HIP_TRY(h, hipStreamWaitEvent(h->side_stream[k], h->ev_fork, 0));
-      forked = true;
-    }
   }
-  if (forked)
-    for (int k = 0; k < 2; ++k) {   // join: whatever the caller enqueues next sees every logit
-      HIP_TRY(h, hipEventRecord(h->ev_join[k], h->side_stream[k]));
-      HIP_TRY(h, hipStreamWaitEvent(main_stream, h->ev_join[k], 0));
-    }
   HIP_TRY(h, hipGetLastError());
   return YFV2_OK;
 }
@@ -1447,7 +1293,6 @@ int setup_ctx(yfv2_ctx* h, const yfv2_config* cfg, int rows, Alloc alloc) {
   A(&h->f2, (H / 16) * (W / 16) * 72);
   A(&h->f3, (H / 32) * (W / 32) * 72);
   A(&h->ta, (H / 16) * (W / 16) * 72);
-  for (int k = 0; k < 2; ++k) A(&h->ta_side[k], (H / 32) * (W / 32) * 72);
   A(&h->tb, (H / 16) * (W / 16) * 72);
   for (int i = 0; i < 6; ++i) A(&h->logits[i], logit_elems(h, i));
   A(&h->cand, (size_t)rows * 8);
@@ -1494,16 +1339,7 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     yfv2_destroy(h);
     return rc;
   }
-  if (const char* e = std::getenv("YFV2_BF6")) h->bf6 = !(e[0] == '0');
-  if (const char* e = std::getenv("YFV2_POSTFUSE")) h->postfuse = !(e[0] == '0');
-  if (const char* e = std::getenv("YFV2_SIDE")) h->side = (e[0] == '1');
-  if (h->side) {
-    bool okk = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
-    for (int k = 0; k < 2 && okk; ++k)
-      okk = hipStreamCreateWithFlags(&h->side_stream[k], hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
-    if (!okk) { (void)hipGetLastError(); h->side = false; }   // no side streams: the plan's lanes all map to the caller's stream
-  }
+  read_plan_switches(h);
   if (const char* tr = std::getenv("YFV2_TRACE"))
     if (tr[0] == '1') { if (const char* ts = std::getenv("YFV2_TRACE_STEP")) h->trace_step = std::atoi(ts); (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
   *out = h;
@@ -1526,6 +1362,7 @@ int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tenso
     return (int)YFV2_OK;
   };
   setup_ctx(&ctx, cfg, rows, fake);
+  read_plan_switches(&ctx);
   WeightPacker wp;
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
@@ -1556,6 +1393,7 @@ int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* te
     return (int)YFV2_OK;
   };
   setup_ctx(&ctx, cfg, rows, fake);
+  read_plan_switches(&ctx);
   WeightPacker wp;
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
@@ -1586,6 +1424,7 @@ int yfv2_debug_plan_c2_label(const yfv2_config* cfg, const yfv2_tensor_desc* ten
     return (int)YFV2_OK;
   };
   setup_ctx(&ctx, cfg, rows, fake);
+  read_plan_switches(&ctx);
   WeightPacker wp;
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
@@ -1604,12 +1443,6 @@ void yfv2_destroy(yfv2_handle h) {
   free_buf(&h->s2pp);
   free_buf(&h->t1); free_buf(&h->t2); free_buf(&h->t3);
   free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->ta); free_buf(&h->tb);
-  for (int k = 0; k < 2; ++k) {
-    free_buf(&h->ta_side[k]);
-    if (h->side_stream[k]) (void)hipStreamDestroy(h->side_stream[k]);
-    if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
-  }
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
   free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);
@@ -1898,13 +1731,15 @@ int32_t yfv2_num_rows(yfv2_handle h) { return h ? h->rows : 0; }
 
 int32_t yfv2_num_stages(yfv2_handle h) { return h ? (int32_t)h->plan.size() : 0; }
 
-int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_cap, double* flops_per_image, double* bytes_per_image) {
+int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_cap, double* flops_per_image, double* bytes_per_image,
+                    double* external_bytes_per_image) {
   if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
   if (i < 0 || i >= (int32_t)h->plan.size()) return fail(h, YFV2_ERR_ARG, "stage index out of range");
   const Step& s = h->plan[i];
   if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", s.name.c_str());
   if (flops_per_image) *flops_per_image = s.flops;
   if (bytes_per_image) *bytes_per_image = s.bytes;
+  if (external_bytes_per_image) *external_bytes_per_image = s.bytes_ext >= 0 ? s.bytes_ext : s.bytes;
   return YFV2_OK;
 }
 

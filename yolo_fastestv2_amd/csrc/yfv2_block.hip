@@ -1,30 +1,20 @@
-// yfv2_block.hip - fused ShuffleV2 stride-1 block for gfx950 (one launch per block
-// instead of three, no intermediate tensor in HBM).
+// yfv2_block.hip - the fused ShuffleV2 blocks of stages 3 and 4 and the tower halves for gfx950:
+//   block_s1chain6_kernel   stage 3's seven stride-1 blocks as ONE launch (bf16x6 pointwise convs)
+//   block_s1pool_kernel     stage 4's three stride-1 blocks as one launch, the activation resident in LDS
+//   block_s2_kernel         stride-2 block with the input tile staged in LDS (stage3.0; stage2.0 / stage 3 of odd sizes)
+//   block_s2w_kernel        stage4.0 (96 -> 192) in one launch over bands of two output rows
+//   tower2_kernel           a DWConvblock half (+ the chained output conv)
+// Shapes none of them covers run layer by layer (yfv2_conv.hip: pw_kernel / dw_kernel), which is also the YFV2_FUSED=0 plan.
 //
-// Reference block (model/backbone/shufflenetv2.py:19-32,48-51,57-63), c = 2*C2 channels:
+// Reference stride-1 block (model/backbone/shufflenetv2.py:19-32,48-51,57-63), c = 2*C2 channels:
 //   pass = x[:, 0::2]                      (even channels, untouched)
 //   y    = x[:, 1::2]                      (odd channels)
 //   y    = ReLU(BN(pw1(y)))   C2 -> C2
 //   y    = BN(dw3x3(y))       pad 1, stride 1
 //   y    = ReLU(BN(pw2(y)))   C2 -> C2
 //   out  = cat(pass, y)
-//
-// Work item = (image, tile of R rows, full width).  Per item, one workgroup:
-//   phase A  pw1 on the fp32 MFMA for the tile rows plus a 1-row halo above and below.
-//            B operand straight from global NHWC (each lane loads 8 consecutive floats,
-//            keeps the odd ones, and - for non-halo rows - stores the even ones to
-//            out[..., 0:C2]: shuffle + pass-through + concat cost no extra pass).
-//            D (+BN+ReLU) goes to an LDS tile T1[(R+2)][(W+2)][C2+4] whose border
-//            (conv zero padding) is zero.
-//   phase B  per 16-pixel tile, each lane computes the depthwise 3x3 (+BN) of ITS pixel
-//            and ITS four channels directly in registers from T1 - exactly the
-//            B-operand fragment v_mfma_f32_16x16x4_f32 wants - and feeds pw2's MFMAs;
-//            D (+BN+ReLU) is stored to out[..., C2:2*C2] as 16-byte NHWC stores.
-// pw1/pw2 filters, the depthwise taps and all BN constants stay in LDS for the
-// lifetime of the (persistent) workgroup.
-//
-// HBM traffic per block: read c*H*W, write c*H*W floats (plus halo re-reads served by
-// L2) instead of 3 reads + 3 writes of activations in the unfused plan.
+// (Rounds 1-2 also carried single-block, two-block and fp32-MFMA chain kernels; they were superseded by the two chains and
+// removed in round 3 - git history has them.)
 #include <cstdlib>
 #include <type_traits>
 
@@ -33,840 +23,23 @@
 template <int C2>
 struct S1Cfg {
   static constexpr int KC = (C2 + 15) / 16;  // 16-channel chunks (also M tiles: M == K == C2)
-  static constexpr int CP = C2 + 4;          // floats per T1 pixel
-  // filters live in LDS fragment-major: Wf[(mt*KC + s)*64 + lane] (float4) =
-  // W[16mt + (lane&15)][16s + 4(lane>>4) ..+3]: the 64 lanes of an A-fragment read touch 64
-  // consecutive 16-byte slots - bank-conflict free by construction, no padding
-  static constexpr int W_FL = KC * KC * 256;  // one filter matrix in LDS
   static constexpr int DW_FL = 9 * KC * 16;  // depthwise taps [9][KC*16]
   static constexpr int CST_FL = 6 * KC * 16; // sc1, sh1, scd, shd, sc2, sh2
-  static constexpr int NTB = 1;              // pixel tiles per phase-B pass (all waves busy on small maps)
-  // per-thread / per-wave bounds of the staged phase A (enforced by yfv2_block_s1_rows):
-  // (sized for the 352x352 plan: 44x44 R=11 / 22x22 / 11x11 whole; other sizes fall back to unfused launches)
-  static constexpr int MAXP = C2 <= 24 ? 14 : (C2 <= 48 ? 13 : 7);  // staged 32-byte pairs per thread
-  static constexpr int MAXU = C2 <= 24 ? 9 : (C2 <= 48 ? 9 : 4);    // (tile x channel-pair) units per wave
 };
 
 #define YFV2_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
 // per-wave stamps of workgroup 0 (YFV2_TRACE=1, tools/trace_waves.py): trace[64 + 32 * wave + i]
 #define YFV2_WSTAMP(i) do { if (a.trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.trace[64 + 32 * (threadIdx.x >> 6) + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 
-template <int C2, int THREADS>
-__global__ __launch_bounds__(THREADS, 2) void block_s1_kernel(BlockS1Args a) {
-  using Cfg = S1Cfg<C2>;
-  constexpr int KC = Cfg::KC, CP = Cfg::CP, NTB = Cfg::NTB;
-  constexpr int NW = THREADS / 64;
-  constexpr int C = 2 * C2;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* W1 = lds;
-  float* W2 = W1 + Cfg::W_FL;
-  float* WD = W2 + Cfg::W_FL;
-  float* CS = WD + Cfg::DW_FL;  // [6][KC*16]
-  float* T1 = CS + Cfg::CST_FL;
-  const int H = a.H, W = a.W, R = a.R;
-  const float invW = 1.0f / (float)W;
-  const int WP = W + 2;
-  const int t1_fl = (R + 2) * WP * CP + 16;
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
-  YFV2_STAMP(0);
-
-  // ---- cooperative staging of one item's input tile (rows y0-1 .. y0+rows, all W columns):
-  // every thread requests up to MAXP 32-byte pairs at once, so the whole tile costs ONE
-  // global-latency round (and for the first item that round overlaps the LDS prologue).
-  const int tiles_per_img = (H + R - 1) / R;
-  const int n_items = a.B * tiles_per_img;
-  constexpr int QPP = C2 / 4;  // 32-byte input pairs (= 16-byte odd-channel quads) per pixel
-  constexpr int MAXP = Cfg::MAXP;
-  f32x4 st0[MAXP], st1[MAXP];
-  auto stage_issue = [&](int item_, bool active) {  // always (re)defines every staged register
-    const int item = active ? item_ : 0;
-    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
-    const int y0 = ti * R, rows = min(R, H - y0);
-    const int npairs = active ? (rows + 2) * W * QPP : 0;
-    const size_t img_px = (size_t)b * H * W;
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
-      const int pix = i / QPP, q = i - pix * QPP;
-      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
-      const int gy = y0 - 1 + r;
-      st0[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      st1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (i < npairs && gy >= 0 && gy < H) {
-        const float* src = a.in + (img_px + (size_t)gy * W + x) * C + 8 * q;
-        st0[j] = *reinterpret_cast<const f32x4*>(src);
-        st1[j] = *reinterpret_cast<const f32x4*>(src + 4);
-      }
-    }
-  };
-  // odd channels -> T1 (zero for rows outside the image = the depthwise zero padding),
-  // even channels -> out[..., 0:C2] for the rows this item owns (shuffle + pass-through + cat)
-  auto stage_commit = [&](int item, float* T1) {
-    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
-    const int y0 = ti * R, rows = min(R, H - y0);
-    const int npairs = (rows + 2) * W * QPP;
-    const size_t img_px = (size_t)b * H * W;
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
-      if (i >= npairs) continue;
-      const int pix = i / QPP, q = i - pix * QPP;
-      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
-      const int gy = y0 - 1 + r;
-      *reinterpret_cast<f32x4*>(T1 + (r * WP + x + 1) * CP + 4 * q) = (f32x4){st0[j][1], st0[j][3], st1[j][1], st1[j][3]};
-      if (r >= 1 && r <= rows && gy >= 0 && gy < H)
-        *reinterpret_cast<f32x4*>(a.out + (img_px + (size_t)gy * W + x) * C + 4 * q) = (f32x4){st0[j][0], st0[j][2], st1[j][0], st1[j][2]};
-    }
-  };
-  stage_issue(blockIdx.x, (int)blockIdx.x < n_items);
-
-  // prologue: the LDS image (filters, taps, BN constants - padded and zero-filled on the host,
-  // yfv2_load_weights) is one straight coalesced 16-byte copy
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    constexpr int N4 = (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4;
-    constexpr int NIT = (N4 + THREADS - 1) / THREADS;  // <= 11: every load is issued before the first store
-    f32x4 tmp[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
-  }
-  YFV2_STAMP(1);  // image copy issued
-  // T1's border stays zero for every item
-  for (int i = tid; i < t1_fl / 4; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  YFV2_STAMP(2);  // prologue done
-
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int b = item / tiles_per_img, ti = item - b * tiles_per_img;
-    const int y0 = ti * R;
-    const int rows = min(R, H - y0);
-    const size_t img_px = (size_t)b * H * W;
-
-    // ================= phase A: pw1 (+BN+ReLU) over rows y0-1 .. y0+rows, IN PLACE in T1
-    // stage: the raw tile (requested above / at the end of the previous item) lands in T1.
-    stage_commit(item, T1);
-    __syncthreads();
-    YFV2_STAMP(8);
-    const int npxA = (rows + 2) * W;
-    if constexpr (KC == 3 || KC == 6) {
-      // Whole 16-pixel tiles per wave, the filter's A fragments in registers (KC*KC float4, read from LDS once per
-      // item): a tile's pw1 output overwrites exactly the pixels its own B fragments came from, so a wave reads
-      // its tile, runs KC*KC*4 MFMAs and writes it back without any barrier or second pass; the next tile's B
-      // fragments are fetched before the current tile's MFMAs.  (Cycle stamps of the channel-pair scheme below at
-      // 22x22: phase A 19 k cycles for 8.9 k cycles of MFMA - LDS fragment re-reads per unit and four barriers.)
-      // (KC = 6, 96 channels: 36 fragments do not fit in registers and an 11x11 map is one tile per wave anyway,
-      // so there the fragments are read per output-channel tile right before use)
-      constexpr bool AREG = KC <= 3;
-      f32x4 aw[AREG ? KC : 1][KC];
-      if constexpr (AREG) {
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-          for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
-      }
-      f32x4 sc1[KC], sh1[KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
-        sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
-      }
-      auto tile_src = [&](int t) {
-        const int q = 16 * t + p;
-        const int qc = q < npxA ? q : npxA - 1;
-        const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
-        return (r * WP + x + 1) * CP;
-      };
-      f32x4 bf[KC], bn[KC];
-      int t = wave;
-      if (t * 16 < npxA) {
-        const int o = tile_src(t);
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = (16 * s2 + 4 * g < C2) ? *reinterpret_cast<const f32x4*>(T1 + o + 16 * s2 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-      for (; t * 16 < npxA; t += NW) {
-        const int tn = t + NW;
-        const int on = tile_src(tn * 16 < npxA ? tn : t);
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bn[s2] = (16 * s2 + 4 * g < C2) ? *reinterpret_cast<const f32x4*>(T1 + on + 16 * s2 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int q = 16 * t + p;
-        const bool valid = q < npxA;
-        const int r = yfv2_fdiv(valid ? q : 0, invW);
-        const int gy = y0 - 1 + r;
-        const bool inimg = valid && gy >= 0 && gy < H;
-        float* dst = T1 + tile_src(t);
-        f32x4 acc[KC];
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (AREG) {
-#pragma unroll
-          for (int s2 = 0; s2 < KC; ++s2)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int mp = 0; mp < KC; mp += 2) {   // two output-channel tiles at a time: 2*KC fragment reads, then 8*KC MFMAs on two accumulators
-            f32x4 af0[KC], af1[KC];
-#pragma unroll
-            for (int s2 = 0; s2 < KC; ++s2) {
-              af0[s2] = *reinterpret_cast<const f32x4*>(W1 + ((mp * KC + s2) * 64 + lane) * 4);
-              af1[s2] = *reinterpret_cast<const f32x4*>(W1 + (((mp + 1) * KC + s2) * 64 + lane) * 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s2 = 0; s2 < KC; ++s2)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                acc[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[s2][j], bf[s2][j], acc[mp], 0, 0, 0);
-                acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[s2][j], bf[s2][j], acc[mp + 1], 0, 0, 0);
-              }
-          }
-        }
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
-          const int cb = 16 * mt + 4 * g;
-          if (valid && cb < C2) {
-            f32x4 y;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
-              y[c] = (inimg && uu > 0.f) ? uu : 0.f;  // rows outside the image are conv zero padding
-            }
-            *reinterpret_cast<f32x4*>(dst + cb) = y;
-          }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = bn[s2];
-      }
-      __syncthreads();  // phase B reads the neighbours' tiles
-    } else {
-    // Work unit = (16-pixel tile, pair of output-channel tiles): one image has only 9..36 pixel
-    // tiles for 8 waves, so whole tiles would leave most waves idle in the last round.
-    // A1: every wave pulls the B fragments of ALL its units out of T1 into registers;
-    // (barrier) A2: MFMAs with two independent accumulators, BN + ReLU, results overwrite the
-    // same T1 pixels (rows outside the image stay zero = depthwise zero padding).
-    constexpr int NPAIR = (KC + 1) / 2;
-    constexpr int MAXU = Cfg::MAXU;
-    const int nunits = ((npxA + 15) / 16) * NPAIR;
-    // Two passes over the units (each pass covers whole tiles: UPASS*NW is a multiple of NPAIR)
-    // halve the registers that hold B fragments across the barrier.
-    constexpr int UPASS = NPAIR == 3 ? 3 : (MAXU + 1) / 2;  // 2 * UPASS >= MAXU in every configuration
-    static_assert(2 * UPASS >= MAXU, "two passes must cover all units");
-    static_assert((UPASS * NW) % NPAIR == 0, "a pass must not split a tile's channel pairs");
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      const int ubase = pass * UPASS * NW;
-      f32x4 bfu[UPASS][KC];
-#pragma unroll
-      for (int k = 0; k < UPASS; ++k) {
-        const int u = ubase + wave + k * NW;
-        const int t = (u < nunits ? u : 0) / NPAIR;
-        const int q = 16 * t + p;
-        const int qc = q < npxA ? q : npxA - 1;
-        const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
-        const float* src = T1 + (r * WP + x + 1) * CP;
-#pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          const int cb = 16 * s + 4 * g;
-          bfu[k][s] = (cb < C2) ? *reinterpret_cast<const f32x4*>(src + cb) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < UPASS; ++k) {
-        const int u = ubase + wave + k * NW;
-        if (u >= nunits) continue;  // wave-uniform
-        const int t = u / NPAIR, mt = 2 * (u - t * NPAIR);
-        const int q = 16 * t + p;
-        const bool valid = q < npxA;
-        const int r = yfv2_fdiv(q, invW), x = q - r * W;
-        const int gy = y0 - 1 + r;
-        const bool inimg = valid && gy >= 0 && gy < H;
-        float* dst = T1 + (r * WP + x + 1) * CP;
-        const bool two = mt + 1 < KC;
-        f32x4 afa[KC], afb[KC];
-#pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          afa[s] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-          afb[s] = *reinterpret_cast<const f32x4*>(W1 + (((two ? mt + 1 : mt) * KC + s) * 64 + lane) * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KC; ++s)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[s][j], bfu[k][s][j], acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afb[s][j], bfu[k][s][j], acc1, 0, 0, 0);  // wave-uniform
-          }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int cb = 16 * (mt + h) + 4 * g;
-          if (valid && cb < C2 && (h == 0 || two)) {
-            const f32x4 acc = h ? acc1 : acc0;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + cb);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + cb);
-            f32x4 y;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float uu = __builtin_fmaf(acc[c], sc[c], sh[c]);
-              y[c] = (inimg && uu > 0.f) ? uu : 0.f;  // rows outside the image are conv zero padding
-            }
-            *reinterpret_cast<f32x4*>(dst + cb) = y;
-          }
-        }
-      }
-      __syncthreads();  // pass 0's writes land before pass 1 reads other tiles; phase B after pass 1
-    }
-    }
-    YFV2_STAMP(4);  // phase A done (all waves)
-
-    // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
-    const int npxB = rows * W;
-    {
-      for (int t0 = wave * NTB; t0 * 16 < npxB; t0 += NW * NTB) {
-        int base[NTB];
-        size_t opx[NTB];
-        bool pv[NTB];
-#pragma unroll
-        for (int nt = 0; nt < NTB; ++nt) {
-          const int q = 16 * (t0 + nt) + p;
-          pv[nt] = q < npxB;
-          const int qc = pv[nt] ? q : npxB - 1;
-          const int r = yfv2_fdiv(qc, invW), x = qc - r * W;
-          base[nt] = (r * WP + x) * CP;  // top-left of the 3x3 window in T1 (halo row + zero column included)
-          opx[nt] = img_px + (size_t)(y0 + r) * W + x;
-        }
-        f32x4 acc[KC][NTB];
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NTB; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int s = 0; s < KC; ++s) {
-          const int cb = 16 * s + 4 * g;
-          // everything this chunk needs from LDS - 9 taps, BN, the 3x3 window of each pixel tile
-          // and the KC filter fragments - is fetched into distinct registers first, then the FMAs
-          // and MFMAs (KC independent accumulators per tile) run back to back
-          f32x4 wl[9], lsc, lsh, win[NTB][9], af[KC];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-          lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-          lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-#pragma unroll
-          for (int nt = 0; nt < NTB; ++nt)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) win[nt][k] = *reinterpret_cast<const f32x4*>(T1 + base[nt] + cb + ((k / 3) * WP + (k % 3)) * CP);
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
-          __builtin_amdgcn_sched_barrier(0);
-          f32x4 bfr[NTB];
-#pragma unroll
-          for (int nt = 0; nt < NTB; ++nt) {
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-#pragma unroll
-              for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[nt][k][c], wl[k][c], d[c]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) bfr[nt][c] = cb < C2 ? __builtin_fmaf(d[c], lsc[c], lsh[c]) : 0.f;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NTB; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[nt][j], acc[mt][nt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTB; ++nt) {
-          if (!pv[nt]) continue;
-          float* dst = a.out + opx[nt] * C + C2;
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) {
-            const int cb = 16 * mt + 4 * g;
-            if (cb < C2) {
-              const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
-              const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + cb);
-              f32x4 y;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const float u = __builtin_fmaf(acc[mt][nt][k], sc[k], sh[k]);
-                y[k] = u > 0.f ? u : 0.f;
-              }
-              *reinterpret_cast<f32x4*>(dst + cb) = y;
-            }
-          }
-        }
-      }
-    }
-    YFV2_STAMP(5);  // this wave's phase B done
-    stage_issue(item + gridDim.x, item + (int)gridDim.x < n_items);  // next item's tile: in flight across the barrier
-    __syncthreads();  // T1 is rewritten by the next item's stage_commit
-    YFV2_STAMP(6);
-  }
-}
-
-template <int C2, int THREADS>
-static void launch_s1(const BlockS1Args& a, int blocks_per_cu, hipStream_t s) {
-  using Cfg = S1Cfg<C2>;
-  const size_t lds = sizeof(float) * (size_t)(2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + (a.R + 2) * (a.W + 2) * Cfg::CP + 16);
-  const int tiles = (a.H + a.R - 1) / a.R;
-  int blocks = a.B * tiles;
-  const int cap = 256 * blocks_per_cu;  // persistent: filters are staged once per workgroup
-  if (blocks > cap) blocks = cap;
-  static std::atomic<unsigned long long> lds_ok0{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1_kernel<C2, THREADS>), lds_ok0);
-  hipLaunchKernelGGL((block_s1_kernel<C2, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a);
-}
-
-// ============================================================================
-// stride-1 block, whole-image variant on a plane-per-quad tile (C2 = 48, maps up to 22x22)
-// ============================================================================
-// Same arithmetic and the same LDS image as block_s1_kernel<48>, different tile: the 48 branch channels of ONE image live
-// in LDS as 12 planes [quad][haloed row][W + 1][4 floats].  A row's left halo column is the previous row's right halo
-// (one shared zero slot), so the image is one linear run of 16-byte slots per plane, and both phases tile that run -
-// 16 consecutive slots per wave tile, halo slots included (they compute zeros / are not stored).  ds_read_b128 is
-// serviced in four 16-lane groups that mix two quads; with planes a multiple of 256 bytes apart and consecutive slots
-// inside a plane no read collides (the pixel-major tile of block_s1_kernel has 5 colliding slots in every group:
-// SQ_LDS_BANK_CONFLICT = 34 % of its LDS-active cycles), and a 22x22 image is 32 tiles in BOTH phases = four full
-// rounds of the 8 waves (the pixel tiling needs 33 in phase A: a fifth round for one tile).
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void block_s1w_kernel(BlockS1Args a) {
-  constexpr int C2 = 48;
-  using Cfg = S1Cfg<C2>;
-  constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2;
-  constexpr int NW = THREADS / 64;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* W1 = lds;
-  float* W2 = W1 + Cfg::W_FL;
-  float* WD = W2 + Cfg::W_FL;
-  float* CS = WD + Cfg::DW_FL;  // [6][KC*16]
-  float* T1 = CS + Cfg::CST_FL;
-  const int H = a.H, W = a.W, HW = H * W;
-  const int RP = W + 1;                                   // slots per haloed row (shared halo column)
-  const int PL = ((H + 2) * RP + 1 + 15) & ~15;           // slots per plane
-  const float invW = 1.0f / (float)W, invRP = 1.0f / (float)RP;
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const int s_first = RP + 1;                             // slot of pixel (0, 0)
-  const int n_slots = (H - 1) * RP + W;                   // ... up to pixel (H-1, W-1)
-
-  // ---- staging: eight consecutive lanes take eight consecutive pixels of one channel quad (ds_write_b128 is serviced in
-  // 8-lane groups), the next 8-lane group the next quad: a wave reads 8 pixels x 8 quads x 32 bytes
-  constexpr int MAXP = 12 * 512 / THREADS;                // ceil(ceil(484 / 8) * 8 * 12 / THREADS)
-  const int npx8 = (HW + 7) & ~7;
-  f32x4 st0[MAXP], st1[MAXP];
-  auto stage_issue = [&](int b_, bool active) {
-    const float* img = a.in + (size_t)(active ? b_ : 0) * HW * C;
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
-      const int G = i >> 3, q = G % NQ, pix = (G / NQ) * 8 + (i & 7);
-      st0[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      st1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (active && i < npx8 * NQ && pix < HW) {
-        const float* src = img + (size_t)pix * C + 8 * q;
-        st0[j] = *reinterpret_cast<const f32x4*>(src);
-        st1[j] = *reinterpret_cast<const f32x4*>(src + 4);
-      }
-    }
-  };
-  auto stage_commit = [&](int b) {
-    float* oimg = a.out + (size_t)b * HW * C;
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int i = tid + j * THREADS;
-      const int G = i >> 3, q = G % NQ, pix = (G / NQ) * 8 + (i & 7);
-      if (i >= npx8 * NQ || pix >= HW) continue;
-      const int r = yfv2_fdiv(pix, invW), x = pix - r * W;
-      *reinterpret_cast<f32x4*>(T1 + ((size_t)q * PL + (r + 1) * RP + x + 1) * 4) = (f32x4){st0[j][1], st0[j][3], st1[j][1], st1[j][3]};
-      *reinterpret_cast<f32x4*>(oimg + (size_t)pix * C + 4 * q) = (f32x4){st0[j][0], st0[j][2], st1[j][0], st1[j][2]};
-    }
-  };
-  YFV2_WSTAMP(0);
-  stage_issue(blockIdx.x, (int)blockIdx.x < a.B);
-
-  {  // prologue: the LDS image (same as block_s1_kernel<48>) in one coalesced 16-byte copy, all loads before the first store
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    constexpr int N4 = (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) / 4;
-    constexpr int NIT = (N4 + THREADS - 1) / THREADS;
-    f32x4 tmp[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
-  }
-  for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
-  __syncthreads();
-
-  // tile t = wave + k * NW covers slots s_first + 16 t .. + 15
-  const float* Tg = T1 + (size_t)g * PL * 4;              // plane of quad g; quad 4 s + g is 4 s planes further
-
-  YFV2_WSTAMP(1);
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    stage_commit(b);
-    YFV2_WSTAMP(2);
-    __syncthreads();
-    YFV2_WSTAMP(3);
-
-    // ================= phase A: pw1 (+BN+ReLU) in place, a wave reads and rewrites only its own tiles' slots
-    {
-      f32x4 sc1[KC], sh1[KC], aw[KC][KC];   // pw1's BN constants and A fragments: registers for this phase only
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
-        sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
-      }
-      f32x4 bf[KC], bn[KC];
-      int t = wave;
-      auto slot_of = [&](int tt) { const int q = 16 * tt + p; return s_first + (q < n_slots ? q : n_slots - 1); };
-      if (16 * t < n_slots) {
-        const int o = slot_of(t) * 4;
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + (size_t)(4 * s2) * PL * 4 + o);
-      }
-      for (; 16 * t < n_slots; t += NW) {
-        const int tn = t + NW;
-        const int on = slot_of(16 * tn < n_slots ? tn : t) * 4;
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bn[s2] = *reinterpret_cast<const f32x4*>(Tg + (size_t)(4 * s2) * PL * 4 + on);
-        const int q = 16 * t + p;
-        const bool valid = q < n_slots;
-        const int sl = s_first + (valid ? q : 0);
-        const int r1 = yfv2_fdiv(sl, invRP);
-        const bool real = valid && (sl - r1 * RP) >= 1;      // column 0 of a haloed row is the shared zero column
-        f32x4 acc[KC];
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
-        if (valid) {
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) {
-            f32x4 y;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
-              y[c] = (real && uu > 0.f) ? uu : 0.f;          // the zero column stays zero (depthwise padding)
-            }
-            *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + sl) * 4) = y;
-          }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = bn[s2];
-      }
-    }
-    YFV2_WSTAMP(4);
-    __syncthreads();  // phase B reads the neighbours' tiles
-    YFV2_WSTAMP(5);
-
-    // ================= phase B: dw3x3 (+BN) in registers -> pw2 (+BN+ReLU) -> out[..., C2:]
-    for (int t = wave; 16 * t < n_slots; t += NW) {
-      const int q = 16 * t + p;
-      const bool valid = q < n_slots;
-      const int sl = s_first + (valid ? q : n_slots - 1);
-      const int r1 = yfv2_fdiv(sl, invRP), xs = sl - r1 * RP;
-      const bool real = valid && xs >= 1;
-      const int pix = (r1 - 1) * W + (xs - 1);
-      const float* win0 = Tg + (size_t)(sl - RP - 1) * 4;    // top-left of the 3x3 window
-      f32x4 acc[KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        f32x4 wl[9], lsc, lsh, win[9], af[KC];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-        lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-        lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], acc[mt], 0, 0, 0);
-      }
-      if (real) {
-        float* dst = a.out + ((size_t)b * HW + pix) * C + C2;
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
-          const int cb = 16 * mt + 4 * g;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + cb);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + cb);
-          f32x4 y;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float u = __builtin_fmaf(acc[mt][k], sc[k], sh[k]);
-            y[k] = u > 0.f ? u : 0.f;
-          }
-          *reinterpret_cast<f32x4*>(dst + cb) = y;
-        }
-      }
-    }
-    YFV2_WSTAMP(6);
-    stage_issue(b + gridDim.x, b + (int)gridDim.x < a.B);  // next image: in flight across the barrier
-    __syncthreads();  // T1 is rewritten by the next image's stage_commit
-    YFV2_WSTAMP(7);
-  }
-}
-
-// ============================================================================
-// TWO consecutive stride-1 blocks in one launch (C2 = 48, whole image, plane-per-quad tile)
-// ============================================================================
-// Reference: two ShuffleV2Block(stride 1) in a row (shufflenetv2.py:19-32,48-51,57-63).  With X the first block's
-// 96-channel input, Y = cat(X[even], A(X[odd])) its output and Z = cat(Y[even], B(Y[odd])) the pair's output:
-//   X[4k]            passes both blocks                        -> Z[k]                 (stored at load time)
-//   X[4k+2]          passes A, is branch input 4k'.. of B      -> held in registers until A is done
-//   X[2i+1]          is A's branch input i                     -> LDS tile
-//   A's output j     even j: passes B -> Z[24 + j/2];  odd j: B's branch input 24 + (j-1)/2
-//   B's output j                                               -> Z[48 + j]
-// so the 96-channel activation between the two blocks never leaves the chip: per image the pair reads X once and
-// writes Z once (half the HBM traffic of two launches) and the second block starts without a launch boundary.  All
-// splits are lane-local: a lane's 16-byte quad of X is (pass-pass, branch A, hold, branch A), and A's accumulator quad is
-// (pass B, branch B, pass B, branch B) - the physical channel order inside the LDS tile is whatever that produces, the
-// host permutes the input columns of both pw1 filters to match (PlanBuilder::s1x2_block; la[] / lb[] below are the
-// same formulas).  Tile, slot tiling, phases and LDS image are those of block_s1w_kernel; both blocks' images are
-// resident (2 x 21 KB) next to the 12-plane tile.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
-  constexpr int C2 = 48;
-  using Cfg = S1Cfg<C2>;
-  constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2, NT = 4;
-  constexpr int NW = THREADS / 64;
-  constexpr int IMG_FL = 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* T1 = lds + 2 * IMG_FL;
-  const int H = a.H, W = a.W, HW = H * W;
-  const int RP = W + 1;
-  const int PL = ((H + 2) * RP + 1 + 15) & ~15;
-  const float invRP = 1.0f / (float)RP;
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const int s_first = RP + 1;
-  const int n_slots = (H - 1) * RP + W;                   // <= 16 * NT * NW (launcher)
-
-  YFV2_WSTAMP(0);
-  {  // prologue: both blocks' LDS images in one coalesced copy
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    constexpr int N4 = 2 * IMG_FL / 4;
-    constexpr int NIT = (N4 + THREADS - 1) / THREADS;
-    f32x4 tmp[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) dst[i] = tmp[k]; }
-  }
-  for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
-  __syncthreads();
-  YFV2_WSTAMP(1);
-
-  // this lane's slot in each of its wave's tiles (tile nt of the wave = wave + NW * nt), fixed for every image
-  int sl[NT], pix[NT];
-  bool valid[NT], real[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int q = 16 * (wave + NW * nt) + p;
-    valid[nt] = q < n_slots;
-    sl[nt] = s_first + (valid[nt] ? q : n_slots - 1);
-    const int r1 = yfv2_fdiv(sl[nt], invRP), xs = sl[nt] - r1 * RP;
-    real[nt] = valid[nt] && xs >= 1;                      // column 0 of a haloed row is the shared zero column
-    pix[nt] = (r1 - 1) * W + (xs - 1);
-  }
-  float* Tg = T1 + (size_t)g * PL * 4;                    // plane of quad g; quad 4 s + g is 4 s planes further
-
-  // pw1 (+BN+ReLU) in place over this wave's tiles
-  auto phase_a = [&](const float* IM) {
-    const float* W1 = IM;
-    const float* CS = IM + 2 * Cfg::W_FL + Cfg::DW_FL;
-    f32x4 sc1[KC], sh1[KC], aw[KC][KC];
-#pragma unroll
-    for (int mt = 0; mt < KC; ++mt) {
-      sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
-      sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
-#pragma unroll
-      for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
-      f32x4 bf[KC];
-#pragma unroll
-      for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + sl[nt]) * 4);
-      f32x4 acc[KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s2 = 0; s2 < KC; ++s2)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
-      if (valid[nt]) {
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
-          f32x4 y;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
-            y[c] = (real[nt] && uu > 0.f) ? uu : 0.f;     // the zero column stays zero (depthwise padding)
-          }
-          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + sl[nt]) * 4) = y;
-        }
-      }
-    }
-  };
-  // dw3x3 (+BN) in registers -> pw2 (+BN+ReLU); the result stays in registers in accumulator layout
-  auto phase_b = [&](const float* IM, f32x4 (&bo)[KC][NT]) {
-    const float* W2 = IM + Cfg::W_FL;
-    const float* WD = IM + 2 * Cfg::W_FL;
-    const float* CS = WD + Cfg::DW_FL;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
-      const float* win0 = Tg + (size_t)(sl[nt] - RP - 1) * 4;
-#pragma unroll 1
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        f32x4 wl[9], lsc, lsh, win[9], af[KC];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-        lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-        lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], bo[mt][nt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float u = __builtin_fmaf(bo[mt][nt][k], sc[k], sh[k]);
-          bo[mt][nt][k] = u > 0.f ? u : 0.f;
-        }
-      }
-    }
-  };
-
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    const float* ximg = a.in + (size_t)b * HW * C;
-    float* zimg = a.out + (size_t)b * HW * C;
-    // ---- load X: lane (p, g) takes quad g of each of the six 16-channel chunks of its pixels
-    float hold[6][NT];                                    // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 xq[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-        xq[c] = real[nt] ? *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (valid[nt]) {                                    // halo slots store the zeros they loaded: the tile's zero column
-#pragma unroll
-        for (int j = 0; j < KC; ++j)
-          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * j + g) * PL + sl[nt]) * 4) = (f32x4){xq[2 * j][1], xq[2 * j][3], xq[2 * j + 1][1], xq[2 * j + 1][3]};
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        hold[c][nt] = xq[c][2];
-        if (real[nt]) zimg[(size_t)pix[nt] * C + 4 * c + g] = xq[c][0];          // X[16 c + 4 g] -> Z[4 c + g]
-      }
-    }
-    YFV2_WSTAMP(2);
-    __syncthreads();
-    YFV2_WSTAMP(3);
-    phase_a(lds);
-    YFV2_WSTAMP(4);
-    __syncthreads();
-    YFV2_WSTAMP(5);
-    f32x4 bo[KC][NT];
-    phase_b(lds, bo);
-    YFV2_WSTAMP(6);
-    __syncthreads();                                      // every window read of the first block is done
-    YFV2_WSTAMP(7);
-    // ---- the second block's branch input into the tile; the first block's even outputs pass straight to Z
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (valid[nt]) {
-        const bool r = real[nt];
-        const f32x4 q0 = {hold[0][nt], hold[1][nt], hold[2][nt], hold[3][nt]};   // loaded as zeros on halo slots
-        f32x4 q1 = {hold[4][nt], hold[5][nt], bo[0][nt][1], bo[0][nt][3]};
-        f32x4 q2 = {bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]};
-        if (!r) { q1[2] = 0.f; q1[3] = 0.f; q2 = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        *reinterpret_cast<f32x4*>(T1 + ((size_t)(0 + g) * PL + sl[nt]) * 4) = q0;
-        *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 + g) * PL + sl[nt]) * 4) = q1;
-        *reinterpret_cast<f32x4*>(T1 + ((size_t)(8 + g) * PL + sl[nt]) * 4) = q2;
-        if (r) {
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt)                 // A-output 16 mt + 4 g + {0, 2} -> Z[24 + 8 mt + 2 g + {0, 1}]
-            *reinterpret_cast<f32x2*>(zimg + (size_t)pix[nt] * C + 24 + 8 * mt + 2 * g) = (f32x2){bo[mt][nt][0], bo[mt][nt][2]};
-        }
-      }
-    }
-    YFV2_WSTAMP(8);
-    __syncthreads();
-    YFV2_WSTAMP(9);
-    phase_a(lds + IMG_FL);
-    YFV2_WSTAMP(10);
-    __syncthreads();
-    YFV2_WSTAMP(11);
-    phase_b(lds + IMG_FL, bo);
-    YFV2_WSTAMP(12);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      if (real[nt]) {
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zimg + (size_t)pix[nt] * C + C2 + 16 * mt + 4 * g) = bo[mt][nt];
-      }
-    YFV2_WSTAMP(13);
-    __syncthreads();                                      // the tile is rewritten by the next image's load
-    YFV2_WSTAMP(14);
-  }
-}
-
 // ============================================================================
 // A CHAIN of stride-1 blocks in one launch (C2 = 48, whole image, plane-per-quad tile): stage 3's blocks 1..7
 // ============================================================================
 // Reference: N consecutive ShuffleV2Block(stride 1) (shufflenetv2.py:19-32,48-51,57-63).  Per image the chain reads its
 // input X once and writes its output Z once; everything in between stays on the chip or in a few parked dwords per pixel:
-//   * the 48 channels that go through a block's branch live in the LDS tile (as in block_s1w / block_s1x2);
+//   * the 48 channels that go through a block's branch live in the LDS tile: 12 planes [quad][haloed row][W + 1][4 floats]
+//     (a row's left halo column is the previous row's right halo - one shared zero slot - so the image is one linear run of
+//     16-byte slots per plane and both phases tile that run, 16 consecutive slots per wave tile; planes a multiple of 256
+//     bytes apart: no ds_read_b128 of a 16-lane group collides);
 //   * a value that passes k blocks before it becomes a branch input is, by the time it is needed,
 //       k = 0  a fresh branch output picked straight out of the accumulators (elements 1, 3 of every quad),
 //       k = 1  three registers per pixel slot (elements 0: held for one block; X[4i+2] for the second block),
@@ -879,290 +52,15 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1x2_kernel(BlockS1Args a) {
 //     the kernel's fixed, lane-uniform data movement below is the reference's channel_shuffle; the park positions ride
 //     at the end of each block's LDS image, and the consumers of the stage's output read Z through the channel
 //     permutation the plan reports.
-// Per block image: W1 | W2 | dw taps | 6 BN vectors (block_s1_kernel's image) | int tables PS[3][4], XS[6][4] (+ pad);
-// two image buffers alternate, the image after next is fetched during phase A.
+// Per block image: W1 | W2 (pre-split, below) | dw taps | 6 BN vectors | int tables PS[3][4], XS[6][4] (+ pad).
 constexpr int CH_TBL_FL = 64;
-constexpr int CH_IMG_FL = 2 * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + CH_TBL_FL;
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, 2) void block_s1chain_kernel(BlockS1Args a) {
-  constexpr int C2 = 48;
-  using Cfg = S1Cfg<C2>;
-  constexpr int KC = Cfg::KC, NQ = C2 / 4, C = 2 * C2, NT = 4;
-  constexpr int NW = THREADS / 64;
-  constexpr int N4 = CH_IMG_FL / 4, NIT = (N4 + THREADS - 1) / THREADS;   // float4 per image, per thread
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* T1 = lds + 2 * CH_IMG_FL;
-  const int H = a.H, W = a.W, HW = H * W, NB = a.nblk;
-  const int RP = W + 1;
-  const int PL = ((H + 2) * RP + 1 + 15) & ~15;
-  const float invRP = 1.0f / (float)RP;
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const int s_first = RP + 1;
-  const int n_slots = (H - 1) * RP + W;                   // <= 16 * NT * NW (launcher)
-  YFV2_WSTAMP(0);
-
-  for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
-
-  int sl[NT], pix[NT];
-  bool valid[NT], real[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int q = 16 * (wave + NW * nt) + p;
-    valid[nt] = q < n_slots;
-    sl[nt] = s_first + (valid[nt] ? q : n_slots - 1);
-    const int r1 = yfv2_fdiv(sl[nt], invRP), xs = sl[nt] - r1 * RP;
-    real[nt] = valid[nt] && xs >= 1;                      // column 0 of a haloed row is the shared zero column
-    pix[nt] = real[nt] ? (r1 - 1) * W + (xs - 1) : 0;
-  }
-  float* Tg = T1 + (size_t)g * PL * 4;                    // plane of quad g; quad 4 s + g is 4 s planes further
-
-  auto phase_a = [&](const float* IM) {
-    const float* W1 = IM;
-    const float* CS = IM + 2 * Cfg::W_FL + Cfg::DW_FL;
-    f32x4 sc1[KC], sh1[KC], aw[KC][KC];
-#pragma unroll
-    for (int mt = 0; mt < KC; ++mt) {
-      sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
-      sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
-#pragma unroll
-      for (int s2 = 0; s2 < KC; ++s2) aw[mt][s2] = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s2) * 64 + lane) * 4);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
-      f32x4 bf[KC];
-#pragma unroll
-      for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + sl[nt]) * 4);
-      f32x4 acc[KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s2 = 0; s2 < KC; ++s2)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][s2][j], bf[s2][j], acc[mt], 0, 0, 0);
-      if (valid[nt]) {
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) {
-          f32x4 y;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float uu = __builtin_fmaf(acc[mt][c], sc1[mt][c], sh1[mt][c]);
-            y[c] = (real[nt] && uu > 0.f) ? uu : 0.f;     // the zero column stays zero (depthwise padding)
-          }
-          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + sl[nt]) * 4) = y;
-        }
-      }
-    }
-  };
-  auto phase_b = [&](const float* IM, f32x4 (&bo)[KC][NT]) {
-    const float* W2 = IM + Cfg::W_FL;
-    const float* WD = IM + 2 * Cfg::W_FL;
-    const float* CS = WD + Cfg::DW_FL;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (16 * (wave + NW * nt) >= n_slots) continue;     // wave-uniform
-      const float* win0 = Tg + (size_t)(sl[nt] - RP - 1) * 4;
-#pragma unroll 1
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        f32x4 wl[9], lsc, lsh, win[9], af[KC];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);
-        lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-        lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(W2 + ((mt * KC + s) * 64 + lane) * 4);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f}, bfr;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bfr[c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) bo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bfr[j], bo[mt][nt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float u = __builtin_fmaf(bo[mt][nt][k], sc[k], sh[k]);
-          bo[mt][nt][k] = u > 0.f ? u : 0.f;
-        }
-      }
-    }
-  };
-  // the three quads of the next block's branch input (planes g, 4 + g, 8 + g) at this lane's slots
-  auto write_tile = [&](int nt, f32x4 q0, f32x4 q1, f32x4 q2) {
-    if (!real[nt]) { q0 = (f32x4){0.f, 0.f, 0.f, 0.f}; q1 = q0; q2 = q0; }   // halo slots stay the zero column
-    *reinterpret_cast<f32x4*>(T1 + ((size_t)(0 + g) * PL + sl[nt]) * 4) = q0;
-    *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 + g) * PL + sl[nt]) * 4) = q1;
-    *reinterpret_cast<f32x4*>(T1 + ((size_t)(8 + g) * PL + sl[nt]) * 4) = q2;
-  };
-  auto tbl = [&](const float* IM, int i) {                // entry i of this lane group: PS[mt] = 0..2, XS[c] = 3..8
-    return reinterpret_cast<const int*>(IM + 2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL)[i * 4 + g];
-  };
-
-  // elements 2 of a block's accumulators -> Z (three dwords; the planner keeps a lane group's three adjacent where they
-  // share a consumer, which keeps them in one cache line)
-  auto park = [&](float* zp, const float* IM, float v0, float v1, float v2) {
-    zp[tbl(IM, 0)] = v0; zp[tbl(IM, 1)] = v1; zp[tbl(IM, 2)] = v2;
-  };
-
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    const float* ximg = a.in + (size_t)b * HW * C;
-    float* zimg = a.out + (size_t)b * HW * C;
-    // ---- everything this image needs from memory up front is requested at once: the images of blocks 0 and 1, and X
-    float hold2[6][NT];                                   // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
-    {
-      f32x4 tmp[2 * NIT], xq[NT][6];
-      const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-          xq[nt][c] = *reinterpret_cast<const f32x4*>(ximg + (size_t)pix[nt] * C + 16 * c + 4 * g);   // halo slots read pixel 0 and are zeroed below
-#pragma unroll
-      for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; tmp[k] = i < 2 * N4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-      __builtin_amdgcn_sched_barrier(0);                  // all requests are out before the first use
-#pragma unroll
-      for (int k = 0; k < 2 * NIT; ++k) { const int i = tid + k * THREADS; if (i < 2 * N4) reinterpret_cast<f32x4*>(lds)[i] = tmp[k]; }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (!real[nt]) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) xq[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (valid[nt]) {
-#pragma unroll
-          for (int j = 0; j < KC; ++j)
-            *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * j + g) * PL + sl[nt]) * 4) = (f32x4){xq[nt][2 * j][1], xq[nt][2 * j][3], xq[nt][2 * j + 1][1], xq[nt][2 * j + 1][3]};
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) hold2[c][nt] = xq[nt][c][2];
-      }
-      YFV2_WSTAMP(12);
-      __syncthreads();                                    // image 0 (with its XS table) is in LDS
-      YFV2_WSTAMP(13);
-      // X[16 c + 4 g] pass at least two blocks: parked into the group of the block that consumes them
-      // (single dwords: 12-byte stores at dword alignment measured 3x slower than three dword stores)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const int pos = tbl(lds, 3 + c);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          if (real[nt]) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
-      }
-    }
-    YFV2_WSTAMP(1);
-
-    // ---- first block (peeled: its exchange draws on X's held elements)
-    f32x4 bo[KC][NT];
-    float Hd[KC][NT];                                     // element 0 of every accumulator quad: branch input of the block after next
-    phase_a(lds);
-    YFV2_WSTAMP(2);
-    __syncthreads();
-    YFV2_WSTAMP(3);
-    phase_b(lds, bo);
-    YFV2_WSTAMP(4);
-    __syncthreads();                                      // every window read of this block is done
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (valid[nt]) {
-        write_tile(nt, (f32x4){hold2[0][nt], hold2[1][nt], hold2[2][nt], hold2[3][nt]},
-                   (f32x4){hold2[4][nt], hold2[5][nt], bo[0][nt][1], bo[0][nt][3]},
-                   (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
-        if (real[nt]) park(zimg + (size_t)pix[nt] * C, lds, bo[0][nt][2], bo[1][nt][2], bo[2][nt][2]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
-    }
-    __syncthreads();
-    YFV2_WSTAMP(5);
-
-    // ---- blocks 1 .. NB-1
-#pragma unroll 1
-    for (int kb = 1; kb < NB; ++kb) {
-      const float* IM = lds + (kb & 1) * CH_IMG_FL;
-      float* IMN = lds + ((kb + 1) & 1) * CH_IMG_FL;
-      const bool more = kb + 1 < NB;
-      float plv[3][NT];
-      {
-        // requested before phase A, used after it: the image after this one (into the buffer the previous block has
-        // left) and the three parked inputs of the next block (group kb - 1 of Z: parked two or more blocks ago)
-        f32x4 nimg[NIT];
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.img + (size_t)(kb + 1) * CH_IMG_FL);
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; nimg[k] = (more && i < N4) ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float* zp = zimg + (size_t)pix[nt] * C + 12 * (kb - 1) + 3 * g;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) plv[i][nt] = zp[i];   // (halo slots: pixel 0's values, zeroed by write_tile; last block: unused)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        phase_a(IM);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (more && i < N4) reinterpret_cast<f32x4*>(IMN)[i] = nimg[k]; }
-      }
-      if (kb == 1) YFV2_WSTAMP(6);
-      __syncthreads();
-      if (kb == 1) YFV2_WSTAMP(7);
-      phase_b(IM, bo);
-      if (kb == 1) YFV2_WSTAMP(8);
-      if (more) {
-        __syncthreads();                                  // every window read of this block is done
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (valid[nt]) {
-            write_tile(nt, (f32x4){Hd[0][nt], Hd[1][nt], Hd[2][nt], plv[0][nt]},
-                       (f32x4){plv[1][nt], plv[2][nt], bo[0][nt][1], bo[0][nt][3]},
-                       (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
-            if (real[nt]) park(zimg + (size_t)pix[nt] * C, IM, bo[0][nt][2], bo[1][nt][2], bo[2][nt][2]);
-          }
-#pragma unroll
-          for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
-        }
-        __syncthreads();
-        if (kb == 1) YFV2_WSTAMP(9);
-      }
-    }
-    YFV2_WSTAMP(10);
-    // ---- the last block's output in accumulator order, the held elements of the block before it behind them
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      if (real[nt]) {
-        float* zp = zimg + (size_t)pix[nt] * C;
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) *reinterpret_cast<f32x4*>(zp + 16 * mt + 4 * g) = bo[mt][nt];
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) zp[C2 + 3 * g + mt] = Hd[mt][nt];
-      }
-    YFV2_WSTAMP(11);
-    __syncthreads();                                      // tile and image buffers are rewritten by the next image
-  }
-}
 
 // ============================================================================
 // The chain on bf16x6 (default): block_s1chain6_kernel
 // ============================================================================
-// Same dataflow, tile layout, exchange and host bookkeeping as block_s1chain_kernel above; what changes is the arithmetic
-// of the two pointwise convs and what that needs around it.  The fp32-MFMA chain was bound by its matrix-core time (2232
-// MFMAs of 32 cycles per block and image: 25 k of a block's 38 k ticks) and, in phase B, by LDS reads (taps re-read per
-// tile).  Here:
+// The dataflow above with the two pointwise convs of every block on the bf16 matrix cores.  (The fp32-MFMA chain of round 2
+// was bound by its matrix-core time - 2232 MFMAs of 32 cycles per block and image: 25 k of a block's 38 k ticks - and, in
+// phase B, by LDS reads: taps re-read per tile.)  Here:
 //  * W1 / W2 arrive PRE-SPLIT (WeightPacker::append_s1_bf6): K = 48 = one chunk PAIR + one single chunk.  Per output tile
 //    six 16-byte operands: hi / mid / lo quads of the pair (32 k-slots = chunks 0, 1: six MFMAs, no duplication) and the
 //    {hi,hi} {mid,mid} {hi,lo} quads of chunk 2 (three MFMAs against {hi,mid} {lo,hi} of the activations) - nine
@@ -1509,88 +407,27 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   }
 }
 
-static long s1chain_lds_floats(int H, int W, bool bf6) {
+static long s1chain_lds_floats(int H, int W) {
   const long pl = (((long)(H + 2) * (W + 1) + 1 + 15) & ~15L);
-  return (bf6 ? (long)CH6_IMG_FL : 2L * CH_IMG_FL) + 12L * pl * 4;
+  return (long)CH6_IMG_FL + 12L * pl * 4;
 }
 
-int yfv2_s1chain_image_floats(bool bf6) { return bf6 ? CH6_IMG_FL : CH_IMG_FL; }
-bool yfv2_s1chain_bf6() {
-  const char* env = std::getenv("YFV2_S1CHAIN_BF6");
-  return !(env && env[0] == '0');
-}
+int yfv2_s1chain_image_floats() { return CH6_IMG_FL; }
 
 bool yfv2_s1chain_supported(int c2, int H, int W) {
-  if (c2 != 48) return false;
+  if (c2 != 48 || H < 2) return false;
   if ((H - 1) * (W + 1) + W > 16 * 4 * 8) return false;   // slots <= 4 tiles x 8 waves
-  if (s1chain_lds_floats(H, W, false) * 4 > 160 * 1024 || s1chain_lds_floats(H, W, true) * 4 > 160 * 1024) return false;
-  const char* env = std::getenv("YFV2_S1CHAIN");
-  return !(env && env[0] == '0');
+  return s1chain_lds_floats(H, W) * 4 <= 160 * 1024;
 }
 
 bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s) {
   if (!yfv2_s1chain_supported(48, a.H, a.W) || a.nblk < 2) return false;
-  const size_t lds = sizeof(float) * (size_t)s1chain_lds_floats(a.H, a.W, a.presplit != 0);
+  const size_t lds = sizeof(float) * (size_t)s1chain_lds_floats(a.H, a.W);
   const int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
-  if (a.presplit) {
-    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain6_kernel<512>), lds_ok1);
-    hipLaunchKernelGGL((block_s1chain6_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
-  } else {
-    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain_kernel<512>), lds_ok0);
-    hipLaunchKernelGGL((block_s1chain_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain6_kernel<512>), lds_ok);
+  hipLaunchKernelGGL((block_s1chain6_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
   return true;
-}
-
-bool yfv2_s1x2_supported(int c2, int H, int W) {
-  if (c2 != 48) return false;
-  if ((H - 1) * (W + 1) + W > 16 * 4 * 8) return false;   // slots <= 4 tiles x 8 waves
-  const long pl = (((long)(H + 2) * (W + 1) + 1 + 15) & ~15L);
-  const long fl = 2L * (2L * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL) + 12L * pl * 4;
-  if (fl * 4 > 158 * 1024) return false;
-  const char* env = std::getenv("YFV2_S1X2");
-  return !(env && env[0] == '0');
-}
-
-bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s) {
-  if (!yfv2_s1x2_supported(48, a.H, a.W)) return false;
-  using Cfg = S1Cfg<48>;
-  const size_t pl = (((size_t)(a.H + 2) * (a.W + 1) + 1 + 15) & ~(size_t)15);
-  const size_t lds = sizeof(float) * (size_t)(2 * (2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL) + 12 * pl * 4);
-  const int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1x2_kernel<512>), lds_ok0);
-  hipLaunchKernelGGL((block_s1x2_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
-  return true;
-}
-
-// whole-image plane variant: C2 = 48, the tile is the image, staging bound (MAXP = 12 pairs per thread) and LDS fit
-static bool s1w_supported(int c2, const BlockS1Args& a) {
-  if (c2 != 48 || a.R != a.H) return false;
-  const long npx8 = ((long)a.H * a.W + 7) & ~7L;
-  if (npx8 * 12 > 12L * 512) return false;
-  const long pl = (((long)(a.H + 2) * (a.W + 1) + 1 + 15) & ~15L);
-  const long fl = 2L * S1Cfg<48>::W_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + 12L * pl * 4;
-  if (fl * 4 > 158 * 1024) return false;
-  const char* env = std::getenv("YFV2_S1W");
-  return !(env && env[0] == '0');
-}
-
-static void launch_s1w(const BlockS1Args& a, hipStream_t s) {
-  using Cfg = S1Cfg<48>;
-  const size_t pl = (((size_t)(a.H + 2) * (a.W + 1) + 1 + 15) & ~(size_t)15);
-  const size_t lds = sizeof(float) * (size_t)(2 * Cfg::W_FL + Cfg::DW_FL + Cfg::CST_FL + 12 * pl * 4);
-  const int blocks = a.B < 256 ? a.B : 256;
-  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
-  static const bool wide = [] { const char* e = std::getenv("YFV2_S1W_T"); return e && std::atoi(e) == 1024; }();   // A/B: 16 waves, 2 tiles each
-  if (wide) {
-    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1w_kernel<1024>), lds_ok1);
-    hipLaunchKernelGGL((block_s1w_kernel<1024>), dim3(blocks), dim3(1024), lds, s, a);
-    return;
-  }
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1w_kernel<512>), lds_ok0);
-  hipLaunchKernelGGL((block_s1w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 // ============================================================================
@@ -1887,16 +724,9 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
 
 static long s1pool_lds_floats(int H, int W, bool pre) { return (long)H * W * P96_CPP + (long)(H + 2) * (W + 2) * P96_TP + (pre ? P96_IMGP_FL : P96_IMG_FL); }
 int yfv2_s1pool_image_floats(bool presplit) { return presplit ? P96_IMGP_FL : P96_IMG_FL; }
-bool yfv2_s1pool_presplit() {
-  const char* env = std::getenv("YFV2_S4BF6");
-  return !(env && env[0] == '0');
-}
-
 bool yfv2_s1pool_supported(int c2, int H, int W) {
   if (c2 != P96_C2 || H * W > P96_MAXPX || H * W < 1) return false;
-  if (s1pool_lds_floats(H, W, true) * 4 > 160 * 1024) return false;
-  const char* env = std::getenv("YFV2_S4CHAIN");
-  return !(env && env[0] == '0');
+  return s1pool_lds_floats(H, W, true) * 4 <= 160 * 1024;
 }
 
 bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s) {
@@ -1912,34 +742,6 @@ bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s) {
     hipLaunchKernelGGL((block_s1pool_kernel<512, false>), dim3(blocks), dim3(512), lds, s, a);
   }
   return true;
-}
-
-// LDS budget decides the row tile: the whole image when it fits (no halo recompute).
-int yfv2_block_s1_rows(int c2, int H, int W) {
-  const int kc = (c2 + 15) / 16;
-  const long fixed = 2L * kc * kc * 256 + 9L * kc * 16 + 6L * kc * 16 + 16;
-  const long budget = (c2 == 24 ? 78 : 158) * 1024 / 4;  // C2=24 (44x44): two workgroups per CU
-  const int threads = c2 == 24 ? 256 : 512, nw = threads / 64, npair = (kc + 1) / 2;
-  const int maxp = c2 <= 24 ? S1Cfg<24>::MAXP : (c2 <= 48 ? S1Cfg<48>::MAXP : S1Cfg<96>::MAXP);
-  const int maxu = c2 <= 24 ? S1Cfg<24>::MAXU : (c2 <= 48 ? S1Cfg<48>::MAXU : S1Cfg<96>::MAXU);
-  int best = 0;
-  for (int r = 1; r <= H; ++r) {
-    if (H % r) continue;
-    const long px = (long)(r + 2) * W;
-    if (fixed + (long)(r + 2) * (W + 2) * (c2 + 4) > budget) continue;   // LDS
-    if (px * (c2 / 4) > (long)maxp * threads) continue;                    // staged pairs per thread
-    if (((px + 15) / 16) * npair > (long)maxu * nw) continue;              // phase-A units per wave
-    best = r;
-  }
-  return best;  // 0: no legal tiling -> the plan falls back to the unfused launches
-}
-
-bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s) {
-  if (c2 == 24) { launch_s1<24, 256>(a, 2, s); return true; }
-  if (s1w_supported(c2, a)) { launch_s1w(a, s); return true; }
-  if (c2 == 48) { launch_s1<48, 512>(a, 1, s); return true; }
-  if (c2 == 96) { launch_s1<96, 512>(a, 1, s); return true; }
-  return false;
 }
 
 // ============================================================================

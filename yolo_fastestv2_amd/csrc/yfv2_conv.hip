@@ -367,8 +367,6 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
 
 // does yfv2_launch_pw have a pre-split (PRE) instantiation for this launch?  (the planner then packs the filter pre-split)
 bool yfv2_pw_presplit_supported(int K, int mode, int M) {
-  const char* env = std::getenv("YFV2_PWSPLIT");
-  if (env && env[0] == '0') return false;
   const int MT = (M + 15) / 16;
   return MT == 5 && ((mode == PW_PLAIN && K == 192) || (mode == PW_FPN && K == 288));
 }
@@ -399,121 +397,6 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
     if (K == 72 && MT <= 6) { pw_launch<72, 6, 2, PW_HEAD>(a, s); return true; }
   }
   return false;
-}
-
-// ============================================================================
-// depthwise 3x3 stride 2 + BN  ->  pointwise C -> C + BN + ReLU, one launch
-// ============================================================================
-// Reference (model/backbone/shufflenetv2.py:19-44): both branches of a stride-2 block end in dw3x3(s2)+BN -> 1x1+BN+ReLU.
-// For 96 channels the block's three 96x96 filters do not fit one workgroup's LDS next to a tile, so the block is not
-// one kernel; this fuses each branch's TAIL instead: the depthwise result of a 16-pixel tile is produced directly in
-// the B-operand layout of v_mfma_f32_16x16x4_f32 (lane = 16 g + p owns pixel p, channels 16 s + 4 g .. +3 of every
-// chunk s) and feeds the pointwise MFMAs from registers - the (B, H/2, W/2, C) intermediate never exists in HBM.
-// Loop order is tap-major: for one window position a lane's six 16-byte loads (one per chunk) plus its three g
-// neighbours' cover the pixel's whole 384-byte channel run, so every fetched line is consumed at once; the next tap's
-// loads are in flight while the current tap is accumulated.
-template <int C, int THREADS>
-__global__ __launch_bounds__(THREADS, 2) void dwpw_s2_kernel(DwPwArgs a) {
-  constexpr int KC = C / 16;
-  constexpr int FRAG_FL = KC * KC * 256;
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  float* WD = wl + FRAG_FL;          // taps [9][C]
-  float* CS = WD + 9 * C;            // dw scale | dw shift | pw scale | pw shift, [4][C]
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
-  const int wave = tid >> 6, nwaves = THREADS >> 6;
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-    f32x4* dst = reinterpret_cast<f32x4*>(wl);
-    for (int i = tid; i < (FRAG_FL + 13 * C) / 4; i += THREADS) dst[i] = src[i];
-  }
-  __syncthreads();
-  const int OH = a.H >> 1, OW = a.W >> 1, ohw = OH * OW;
-  const int P = a.B * ohw;
-  const int n_tiles = (P + 15) >> 4;
-  for (int t = blockIdx.x * nwaves + wave; t < n_tiles; t += gridDim.x * nwaves) {
-    const int q = 16 * t + p;
-    const bool pv = q < P;
-    const int qc = pv ? q : P - 1;
-    const int bb = qc / ohw, rem = qc - bb * ohw;      // once per tile: an exact integer division is affordable
-    const int oy = rem / OW, ox = rem - oy * OW;
-    const float* img = a.in + (size_t)bb * a.H * a.W * a.in_stride + a.in_off + 4 * g;
-    auto tap_ok = [&](int k) { const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3; return iy >= 0 && iy < a.H && ix >= 0 && ix < a.W; };
-    auto tap_ptr = [&](int k) { const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3; return img + ((size_t)iy * a.W + ix) * a.in_stride; };
-    f32x4 d[KC], cur[KC], nxt[KC];
-#pragma unroll
-    for (int s = 0; s < KC; ++s) d[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
-      const bool ok = tap_ok(0);
-      const float* src = ok ? tap_ptr(0) : img;
-#pragma unroll
-      for (int s = 0; s < KC; ++s) { cur[s] = *reinterpret_cast<const f32x4*>(src + 16 * s); if (!ok) cur[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    }
-#pragma unroll 1   // (fully unrolled the scheduler hoists all 54 loads and spills)
-    for (int k = 0; k < 9; ++k) {
-      if (k + 1 < 9) {
-        const bool ok = tap_ok(k + 1);
-        const float* src = ok ? tap_ptr(k + 1) : img;
-#pragma unroll
-        for (int s = 0; s < KC; ++s) { nxt[s] = *reinterpret_cast<const f32x4*>(src + 16 * s); if (!ok) nxt[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-      }
-#pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(WD + k * C + 16 * s + 4 * g);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[s][c] = __builtin_fmaf(cur[s][c], w[c], d[s][c]);
-      }
-      if (k + 1 < 9) {
-#pragma unroll
-        for (int s = 0; s < KC; ++s) cur[s] = nxt[s];
-      }
-    }
-    // depthwise BN (no ReLU: shufflenetv2.py:24-26,36-38) -> the B fragments
-#pragma unroll
-    for (int s = 0; s < KC; ++s) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * C + 16 * s + 4 * g);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * C + 16 * s + 4 * g);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) d[s][c] = __builtin_fmaf(d[s][c], sc[c], sh[c]);
-    }
-    f32x4 acc[KC];
-#pragma unroll
-    for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KC; ++s) {
-      f32x4 af[KC];
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(wl + ((mt * KC + s) * 64 + lane) * 4);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mt = 0; mt < KC; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], d[s][j], acc[mt], 0, 0, 0);
-    }
-    if (pv) {
-      float* dst = a.out + (size_t)q * a.out_stride + a.out_off + 4 * g;
-#pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 2 * C + 16 * mt + 4 * g);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 3 * C + 16 * mt + 4 * g);
-        f32x4 y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float u = __builtin_fmaf(acc[mt][r], sc[r], sh[r]); y[r] = u > 0.f ? u : 0.f; }
-        *reinterpret_cast<f32x4*>(dst + 16 * mt) = y;
-      }
-    }
-  }
-}
-
-bool yfv2_launch_dwpw(int C, const DwPwArgs& a, hipStream_t s) {
-  if (C != 96 || (a.H & 1) || (a.W & 1)) return false;
-  constexpr int CC = 96, THREADS = 256;
-  const size_t lds = sizeof(float) * (size_t)((CC / 16) * (CC / 16) * 256 + 13 * CC);
-  const int n_tiles = (a.B * (a.H >> 1) * (a.W >> 1) + 15) >> 4;
-  int blocks = (n_tiles + THREADS / 64 - 1) / (THREADS / 64);
-  if (blocks > 768) blocks = 768;     // three workgroups of 42 KB per CU
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((dwpw_s2_kernel<CC, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a);
-  return true;
 }
 
 // ============================================================================

@@ -145,22 +145,11 @@ struct DwArgs {
   int relu;
 };
 
-// ---- depthwise 3x3 stride 2 + BN -> pointwise C->C + BN + ReLU in one launch (yfv2_conv.hip; the two tails of a
-// stride-2 block whose three C x C filters do not fit one workgroup's LDS together: 96 -> 192)
-struct DwPwArgs {
-  const float* in;     // NHWC, C channels at in_off of in_stride
-  float* out;          // NHWC, C channels at out_off of out_stride
-  const float* img;    // pw fragments [C/16][C/16][64][4] | dw taps [9][C] | dw scale, shift [C] | pw scale, shift [C]
-  int B, H, W;         // input size (output is H/2 x W/2)
-  int in_stride, in_off, out_stride, out_off;
-};
-bool yfv2_launch_dwpw(int C, const DwPwArgs& a, hipStream_t s);   // C == 96
-
-// ---- fused ShuffleV2 stride-1 block (yfv2_block.hip)
+// ---- chains of fused ShuffleV2 stride-1 blocks (yfv2_block.hip)
 struct BlockS1Args {
   const float* in;   // (B,H,W,2*C2) NHWC
   float* out;        // (B,H,W,2*C2) NHWC, distinct from in
-  const float* img;  // LDS image (host-packed): W1 | W2 | dw taps [9][KS] | sc1 sh1 scd shd sc2 sh2 [6][KS]
+  const float* img;  // the blocks' LDS images back to back (host-packed, WeightPacker::append_s1_bf6 / PlanBuilder::s1pool_block)
   long long* trace;  // debug: workgroup 0 / thread 0 writes s_memtime stamps at phase boundaries (or null)
   int B, H, W;
   int R;             // rows per work item (H % R == 0)
@@ -168,31 +157,16 @@ struct BlockS1Args {
   int presplit;      // block_s1pool_kernel: the images hold W1 / W2 pre-split for bf16x6 (yfv2_s1pool_image_floats(true) floats each)
 };
 
-// two consecutive stride-1 blocks in one launch (block_s1x2_kernel, C2 = 48): logical branch-input channel held at
-// physical position (chunk s, lane group g, element j) of the LDS tile, for the first (a) and the second (b) block -
-// the host permutes the input columns of the two pw1 filters with the same formulas
-__host__ __device__ constexpr int yfv2_s1x2_label_a(int s, int g, int j) { return 16 * s + 8 * (j >> 1) + 2 * g + (j & 1); }
-__host__ __device__ constexpr int yfv2_s1x2_label_b(int s, int g, int j) {
-  // quads written for block B: [0] = held X[4k+2] of chunks 0..3, [1] = chunks 4,5 + A-output tile 0 elements 1,3,
-  // [2] = A-output tiles 1,2 elements 1,3;  held chunk c of lane group g is B-input 4c+g, A-output (mt, g, r odd) is
-  // B-input 24 + 8mt + 2g + (r-1)/2
-  const int v = 4 * s + j;                       // 0..11: the lane's v-th B-input value
-  return v < 6 ? 4 * v + g : 24 + 8 * ((v - 6) >> 1) + 2 * g + ((v - 6) & 1);
-}
-bool yfv2_s1x2_supported(int c2, int H, int W);
-// chain of N stride-1 blocks in one launch (block_s1chain_kernel, C2 = 48); see PlanBuilder::s1chain_block for the
-// channel bookkeeping shared by host and kernel
+// chain of N stride-1 blocks in one launch (block_s1chain6_kernel, C2 = 48, bf16x6 pointwise convs on host-pre-split
+// filters); see PlanBuilder::s1chain_block for the channel bookkeeping shared by host and kernel
 bool yfv2_s1chain_supported(int c2, int H, int W);
-int yfv2_s1chain_image_floats(bool bf6);                            // floats per block image (incl. the two int tables)
-bool yfv2_s1chain_bf6();                                            // plan the bf16x6 form (block_s1chain6_kernel; YFV2_S1CHAIN_BF6=0: the fp32-MFMA chain)
+int yfv2_s1chain_image_floats();                                    // floats per block image (incl. the two int tables)
 bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s);
 // chain of stride-1 blocks with the whole 192-channel activation resident in LDS (block_s1pool_kernel, stage 4 at 11x11):
 // natural channel order, no bookkeeping; img = per block three images of yfv2_s1pool_image_floats() floats (one per third)
 bool yfv2_s1pool_supported(int c2, int H, int W);
 int yfv2_s1pool_image_floats(bool presplit);
-bool yfv2_s1pool_presplit();   // plan the pre-split (bf16x6) form (YFV2_S4BF6=0: fp32 MFMA form)
 bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s);
-bool yfv2_launch_block_s1x2(const BlockS1Args& a, hipStream_t s);   // a.img = first block's LDS image | second block's
 
 // ---- fused ShuffleV2 stride-2 block (yfv2_block.hip)
 struct BlockS2Args {
@@ -293,8 +267,6 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
 int yfv2_pw_tiles(int K, int mode, int M);   // M tiles of the kernel instantiation yfv2_launch_pw uses (the host packs for that many)
 bool yfv2_pw_presplit_supported(int K, int mode, int M);   // the launch has a pre-split (bf16 hi/mid/lo operand quads) form
 bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s);
-int yfv2_block_s1_rows(int c2, int H, int W);
-bool yfv2_launch_block_s1(int c2, const BlockS1Args& a, hipStream_t s);
 int yfv2_block_s2_rows(int cin, int H, int W);
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s);
 bool yfv2_tower2_supported(int H, int W);                    // whole-image tower kernel: maps up to 22x22

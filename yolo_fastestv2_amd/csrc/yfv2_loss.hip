@@ -78,11 +78,15 @@ __global__ __launch_bounds__(256) void loss_targets_kernel(LossArgs a) {
   if (k == 3) { ok = ok && (fmodf(ix, 1.0f) < 0.5f) && ix > 1.0f; ox = -0.5f; }
   if (k == 4) { ok = ok && (fmodf(iy, 1.0f) < 0.5f) && iy > 1.0f; oy = -0.5f; }
   const int b = (int)t[0];
-  if (ok && b >= 0 && b < a.B) {
+  const int lab = (int)t[1];
+  // a label whose image index or class is out of range is skipped (the reference's CrossEntropyLoss raises on such a class;
+  // here it must not become an out-of-bounds read of the class logits - precondition stated in include/yfv2.h)
+  if (ok && b >= 0 && b < a.B && lab >= 0 && lab < a.classes) {
     const int cx = (int)(gx - ox), cy = (int)(gy - oy);                // .long(): truncation (:112)
     m.valid = 1; m.b = b; m.a = an; m.cls = (int)t[1];
     m.gi = min(max(cx, 0), W - 1); m.gj = min(max(cy, 0), H - 1);      // :119 (the clamp the reference needs int() bounds for)
-    m.tb[0] = gx - (float)cx; m.tb[1] = gy - (float)cy; m.tb[2] = gw; m.tb[3] = gh;   // gxy - gij uses the UNclamped cell (:120)
+    // :115-120: gi, gj are views of gij, so :119's in-place clamp_ reaches gij before `gxy - gij`: the CLAMPED cell
+    m.tb[0] = gx - (float)m.gi; m.tb[1] = gy - (float)m.gj; m.tb[2] = gw; m.tb[3] = gh;
     m.aw = aw; m.ah = ah;
     atomicAdd(&a.nb[l], 1);
     a.tobj[l][((size_t)(b * 3 + an) * H + m.gj) * W + m.gi] = 1;

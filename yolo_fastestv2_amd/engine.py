@@ -247,9 +247,9 @@ class Engine:
         out = []
         buf = C.create_string_buffer(256)
         for i in range(n):
-            fl, by = C.c_double(), C.c_double()
-            check(L.yfv2_stage_info(self._h, i, buf, 256, C.byref(fl), C.byref(by)), self._h)
-            st = {"name": buf.value.decode(), "flops_per_image": fl.value, "bytes_per_image": by.value}
+            fl, by, ex = C.c_double(), C.c_double(), C.c_double()
+            check(L.yfv2_stage_info(self._h, i, buf, 256, C.byref(fl), C.byref(by), C.byref(ex)), self._h)
+            st = {"name": buf.value.decode(), "flops_per_image": fl.value, "bytes_per_image": by.value, "external_bytes_per_image": ex.value}
             check(L.yfv2_stage_kernel(self._h, i, buf, 256), self._h)
             st["kernel"] = buf.value.decode()
             out.append(st)

@@ -135,6 +135,7 @@ class Detector(nn.Module):
     # tensor list, ~20 us).  Writes through `p.data` bypass that counter: call sync_weights() after such surgery.
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
+        self.__dict__.pop("_tensors", None)      # assign=True replaces the parameter objects: the cached list would go stale
         self._synced.clear()
         return out
 
@@ -151,10 +152,14 @@ class Detector(nn.Module):
         self._synced.clear()
 
     def _version_token(self):
-        ts = self.__dict__.get("_tensors")
-        if ts is None:
-            ts = self.__dict__["_tensors"] = [t for t in self.state_dict(keep_vars=True).values() if t.is_floating_point()]
-        return tuple(t._version for t in ts)
+        # (object identity, autograd version) of every float tensor.  The cached list is rebuilt whenever the set of
+        # parameter / buffer OBJECTS changed (`m.w = nn.Parameter(..)`, load_state_dict(assign=True)): their ids are
+        # compared per call (a dict walk over ~330 entries, no tensor work).
+        ids = tuple(id(t) for mod in self.modules() for d in (mod._parameters, mod._buffers) for t in d.values() if t is not None)
+        cached = self.__dict__.get("_tensors")
+        if cached is None or cached[0] != ids:
+            cached = self.__dict__["_tensors"] = (ids, [t for t in self.state_dict(keep_vars=True).values() if t.is_floating_point()])
+        return ids, tuple(t._version for t in cached[1])
 
     def engine_for(self, x):
         hh, ww = (int(x.shape[1]), int(x.shape[2])) if (x.dtype == torch.uint8 and x.shape[-1] == 3) else (int(x.shape[2]), int(x.shape[3]))

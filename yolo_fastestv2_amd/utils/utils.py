@@ -189,12 +189,14 @@ def evaluation(val_dataloader, cfg, model, device, conf_thres=0.01, nms_thresh=0
         engines.add(eng)
         live = torch.arange(dets.shape[1], device=device)[None, :] < cnt[:, None]      # image-major, rank order: the order
         kept.append((tp[live], dets[..., 4][live], dets[..., 5][live]))                 # sample_metrics is concatenated in
+    # the sticky overflow word of EVERY engine used is read (and thereby cleared) before any return path, so that a flag set
+    # here can never surface in a later, unrelated evaluation on the cached handle
+    over = [eng.stats_overflowed() for eng in engines]
+    if any(over):
+        raise RuntimeError("evaluation: an image has more than 1024 targets (yfv2_batch_statistics limit)")
     if not kept:
         print("---- No detections over whole validation set ----")
         return None
-    for eng in engines:
-        if eng.stats_overflowed():
-            raise RuntimeError("evaluation: an image has more than 1024 targets (yfv2_batch_statistics limit)")
     tp = torch.cat([k[0] for k in kept]).cpu().numpy().astype(np.float64)
     conf = torch.cat([k[1] for k in kept]).cpu().numpy()
     cls = torch.cat([k[2] for k in kept]).cpu().numpy()
