@@ -77,8 +77,7 @@ def profile_lookup(prof, kernel, field, launches, mean=False):
         vals.append(hit[0])
     if mean:
         return round(sum(vals) / len(vals), 2)
-    n_parts = len(vals)
-    return sum(vals) * (launches / n_parts)      # per-launch means -> bytes of this kernel's launches in one forward
+    return sum(vals) * launches      # per-launch means -> bytes per forward (a '+' step launches each of its kernels once)
 ANCHORS = [12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87]  # data/coco.data:17
 
 

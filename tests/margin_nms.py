@@ -14,6 +14,8 @@ interval logic over the oracle's decoded rows, cascades included:
   max_det    (utils.py:287-288) a KEPT candidate must be reported if fewer than 300 KEPT-or-UNCERTAIN precede it, a candidate
              may be reported only if it is KEPT or UNCERTAIN and fewer than 300 KEPT precede it
 
+The three margins default to what the COCO-weights tests grant; a caller whose two executions agree less tightly (random
+weights: larger logits, larger absolute differences) passes the margins it MEASURED (`eps_conf`, `eps_tie`, `eps_iou`).
 `check(...)` returns the rows a device result must contain, the rows it may contain, and the number of UNCERTAIN rows (the
 "margin count" the parity records quote).  Test infrastructure only - nothing in the product imports this.
 """
@@ -28,9 +30,11 @@ MAX_WH = 4096.0
 KEPT, UNCERTAIN, SUPPRESSED = 0, 1, 2
 
 
-def classify(dec_img, conf_thres, iou_thres, classes=None):
+def classify(dec_img, conf_thres, iou_thres, classes=None, eps_conf=None, eps_tie=None, eps_iou=None):
     """dec_img: (rows, 5 + nc) decoded rows of ONE image (the oracle's).  Returns (row ids in visiting order, status per
     visited row, conf per visited row)."""
+    EPS_CONF, EPS_TIE, EPS_IOU = (globals()["EPS_CONF"] if eps_conf is None else eps_conf, globals()["EPS_TIE"] if eps_tie is None else eps_tie,
+                                  globals()["EPS_IOU"] if eps_iou is None else eps_iou)
     d = np.asarray(dec_img, dtype=np.float32)
     obj = d[:, 4]
     pool = np.flatnonzero(obj > conf_thres - EPS_CONF)
@@ -88,10 +92,10 @@ def classify(dec_img, conf_thres, iou_thres, classes=None):
     return pool, status, conf
 
 
-def check(dec_img, got_rows, conf_thres, iou_thres, classes=None):
+def check(dec_img, got_rows, conf_thres, iou_thres, classes=None, **eps):
     """got_rows: the survivor indices a device reported for this image.  Returns a dict with the rows it must / may
     contain violated (`missing`, `forbidden`), and the margin counts."""
-    pool, status, _ = classify(dec_img, conf_thres, iou_thres, classes)
+    pool, status, _ = classify(dec_img, conf_thres, iou_thres, classes, **eps)
     must, may = set(), set()
     n_kept = n_possible = 0
     for r, st in zip(pool.tolist(), status.tolist()):

@@ -461,7 +461,7 @@ def test_bench_quotes_counters_only_from_a_profile_of_the_same_tree(tmp_path, mo
     assert got is not None and got["_file"] == "r03a_traffic.json"
     assert bench.newest_profile("_traffic.json", "f" * 16) is None
     assert bench.profile_lookup(got, "stem_px_kernel", "total_bytes", 1) == 6.0e8
-    assert bench.profile_lookup(got, "s2px_proj_kernel + s2px_main_kernel", "total_bytes", 2) == 5.8e8
+    assert bench.profile_lookup(got, "s2px_proj_kernel + s2px_main_kernel", "total_bytes", 1) == 5.8e8
     assert bench.profile_lookup(got, "tower2_kernel<0, 512, 4, 4,", "total_bytes", 2) == 1.6e8   # two launches per forward
     assert bench.profile_lookup(got, "tower2_kernel<0", "total_bytes", 2) is None                                  # ambiguous prefix: refuse
     assert bench.profile_lookup(got, "stem_px_kernel", "mfma_busy_pct", 1, mean=True) == 55.5

@@ -40,6 +40,7 @@ struct Step {
   S1PxArgs s1px{};
   S2PxArgs s2px{};
   size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
+  size_t img_off3 = 0;        // STEP_STEM: the two-term fp16 filter image of stem_h3_kernel (fp32 input, yfv2_stem16.hip)
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
   // offsets into the param blob, resolved to pointers after the upload
@@ -475,6 +476,50 @@ struct WeightPacker {
     for (int co = 0; co < 24; ++co) im[11 * 64 + co] = blob[f.shift + co];
     return put(im);
   }
+  // stem_h3_kernel (yfv2_stem16.hip): the BN-folded filter times 2^sw as TWO fp16 terms (w = h1 + h2 to 2^-24, round to
+  // nearest) in the A-operand order of v_mfma_f32_16x16x32_f16: [channel tile 2][term 2][lane 64][dword 4], lane = 16 g + r
+  // holds output channel 16 t + r, K slots 8 g .. 8 g + 7, two halves per dword (low half = even slot).  Slot -> tap:
+  //   g < 3 (input channel g): (ky,kx) = (0,1) (0,2) (1,1) (1,2) (0,0) (1,0) (2,0) (2,1);   g = 3: slots 1, 3, 7 = tap (2,2)
+  //   of input channels 0, 1, 2, the rest zero.       Then shift * 2^sw [32 channels, zero beyond 24] and 2^-sw.
+  static float rn_f16(float v) { return (float)(_Float16)v; }
+  static unsigned f16_bits(float v) { const _Float16 h = (_Float16)v; unsigned short u; std::memcpy(&u, &h, 2); return u; }
+  size_t image_stem16(const Folded& f) {
+    const float* w = &blob[f.w];   // [27 taps t = ci*9 + ky*3 + kx][24 co]
+    auto folded = [&](int co, int ci, int ky, int kx) { return w[(ci * 9 + ky * 3 + kx) * 24 + co] * blob[f.scale + co]; };
+    float mx = 0.f;
+    for (int co = 0; co < 24; ++co)
+      for (int t = 0; t < 27; ++t) mx = std::fmax(mx, std::fabs(w[t * 24 + co] * blob[f.scale + co]));
+    int sw = 0;
+    if (mx > 0.f && std::isfinite(mx)) { sw = 14 - (int)std::ceil(std::log2(mx)); if (sw > 24) sw = 24; if (sw < -14) sw = -14; }
+    const float up = std::ldexp(1.0f, sw);
+    static const int TAP[8][2] = {{0, 1}, {0, 2}, {1, 1}, {1, 2}, {0, 0}, {1, 0}, {2, 0}, {2, 1}};
+    auto slot_value = [&](int co, int g, int j) -> float {
+      if (co >= 24) return 0.f;
+      if (g < 3) return folded(co, g, TAP[j][0], TAP[j][1]) * up;
+      if (j == 1) return folded(co, 0, 2, 2) * up;
+      if (j == 3) return folded(co, 1, 2, 2) * up;
+      if (j == 7) return folded(co, 2, 2, 2) * up;
+      return 0.f;
+    };
+    std::vector<float> im;
+    for (int t = 0; t < 2; ++t)
+      for (int term = 0; term < 2; ++term)
+        for (int l = 0; l < 64; ++l)
+          for (int d = 0; d < 4; ++d) {
+            unsigned packed = 0;
+            for (int e = 0; e < 2; ++e) {
+              const float v = slot_value(16 * t + (l & 15), l >> 4, 2 * d + e);
+              const float h1 = rn_f16(v);
+              packed |= f16_bits(term == 0 ? h1 : v - h1) << (16 * e);   // v - h1 is exact in fp32
+            }
+            float fb; std::memcpy(&fb, &packed, 4);
+            im.push_back(fb);
+          }
+    for (int co = 0; co < 32; ++co) im.push_back(co < 24 ? blob[f.shift + co] * up : 0.f);
+    im.push_back(std::ldexp(1.0f, -sw));
+    while (im.size() % 4) im.push_back(0.f);
+    return put(im);
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -497,6 +542,7 @@ struct PlanBuilder {
     s.stem.pp_out = pp_out ? 1 : 0;
     s.img_off = wp.image_stem(f);
     s.img_off2 = wp.image_stem(f, 1.0f / 255.0f);
+    s.img_off3 = wp.image_stem16(f);
     s.name = "stem conv3x3s2+bn+relu+maxpool3x3s2";
     const double ch = h->cfg.height / 2.0, cw = h->cfg.width / 2.0;
     s.flops = 2.0 * ch * cw * 27 * 24;
@@ -1122,7 +1168,7 @@ struct PlanBuilder {
 // kernel (family) a plan step launches, as it appears in a rocprofv3 kernel trace (prefix of the symbol name)
 std::string step_kernel(const Step& st) {
   switch (st.kind) {
-    case STEP_STEM: return "stem_px_kernel";
+    case STEP_STEM: return "stem_h3_kernel";   // fp32 input, default plan (uint8 input / YFV2_BF6=0: stem_px_kernel)
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
@@ -1174,6 +1220,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.x = x; a.B = B; a.u8_in = x_u8 ? 1 : 0;
       a.img = params + st.img_off;
       a.img_u8 = params + st.img_off2;
+      a.img16 = h->bf6 ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: the 4x4x1 fp32-MFMA stem
       yfv2_launch_stem(a, s);
     } else if (st.kind == STEP_PW) {
       PwArgs a = st.pw;

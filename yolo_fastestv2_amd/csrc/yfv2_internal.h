@@ -103,6 +103,8 @@ struct StemArgs {
   int u8_in;           // input is uint8 NHWC; img_u8 = the filter image with 1/255 folded in
   const float* img_u8;
   int pp_out;          // 1: write pair planes [B][12][H/4][W/4][2] (stage 2 in lane-per-pixel form), 0: NHWC
+  const float* img16;  // yfv2_stem16.hip (fp32 input on the f16 matrix cores): filter as two fp16 terms in MFMA A-operand order
+                       // [tile 2][term 2][64 lanes][4 dwords] | shift * 2^sw [32] | 2^-sw (WeightPacker::image_stem16); null: use the 4x4x1 kernel
 };
 
 // ---- pointwise 1x1 conv on the fp32 MFMA, NHWC
@@ -261,7 +263,8 @@ struct NmsArgs {
 };
 
 // launchers (defined next to the kernels)
-void yfv2_launch_stem(const StemArgs& a, hipStream_t s);
+void yfv2_launch_stem(const StemArgs& a, hipStream_t s);      // picks yfv2_stem16.hip's kernel for fp32 input when a.img16 is set
+void yfv2_launch_stem16(const StemArgs& a, hipStream_t s);
 // K in {24,48,72,96,192,288}; mode PW_*; returns false if the (K, mode, M) combination has no kernel
 bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s);
 int yfv2_pw_tiles(int K, int mode, int M);   // M tiles of the kernel instantiation yfv2_launch_pw uses (the host packs for that many)
