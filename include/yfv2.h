@@ -93,7 +93,9 @@ YFV2_API int yfv2_set_anchors(yfv2_handle h, const double anchors[12]);
 /* ---- the hot path ---------------------------------------------------------- */
 
 /* replaces: model/detector.py:21-47 Detector.forward (export_onnx=False).
- * x: (B,3,H,W) fp32 NCHW in [0,1].  out6: six NCHW fp32 logit tensors in the
+ * x: (B,3,H,W) fp32 NCHW in [0,1] (test.py:38; any |x| < 255.9 is computed to fp32 accuracy, beyond that the default
+ * plan's stem - two-term fp16 operands on the matrix cores, yfv2_stem16.hip - overflows; YFV2_BF6=0 at create time and
+ * the uint8 entry point yfv2_forward_u8 have no such bound).  out6: six NCHW fp32 logit tensors in the
  * reference's return order (reg_2, obj_2, cls_2, reg_3, obj_3, cls_3) with
  * shapes (B,4A,H/16,W/16) (B,A,..) (B,classes,..) and the same at H/32. */
 YFV2_API int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream);

@@ -479,8 +479,8 @@ struct WeightPacker {
   // stem_h3_kernel (yfv2_stem16.hip): the BN-folded filter times 2^sw as TWO fp16 terms (w = h1 + h2 to 2^-24, round to
   // nearest) in the A-operand order of v_mfma_f32_16x16x32_f16: [channel tile 2][term 2][lane 64][dword 4], lane = 16 g + r
   // holds output channel 16 t + r, K slots 8 g .. 8 g + 7, two halves per dword (low half = even slot).  Slot -> tap:
-  //   g < 3 (input channel g): (ky,kx) = (0,1) (0,2) (1,1) (1,2) (0,0) (1,0) (2,0) (2,1);   g = 3: slots 1, 3, 7 = tap (2,2)
-  //   of input channels 0, 1, 2, the rest zero.       Then shift * 2^sw [32 channels, zero beyond 24] and 2^-sw.
+  //   g < 3 (input channel g): (ky,kx) = (0,1) (0,2) (1,1) (1,2) (0,0) (1,0) (2,0) (2,1);   g = 3: slots 2, 3, 7 = tap (2,2)
+  //   of input channels 0, 1, 2, the rest zero.       Then shift * 2^(sw+8) [32 channels, zero beyond 24] and 2^-(sw+8).
   static float rn_f16(float v) { return (float)(_Float16)v; }
   static unsigned f16_bits(float v) { const _Float16 h = (_Float16)v; unsigned short u; std::memcpy(&u, &h, 2); return u; }
   size_t image_stem16(const Folded& f) {
@@ -496,7 +496,7 @@ struct WeightPacker {
     auto slot_value = [&](int co, int g, int j) -> float {
       if (co >= 24) return 0.f;
       if (g < 3) return folded(co, g, TAP[j][0], TAP[j][1]) * up;
-      if (j == 1) return folded(co, 0, 2, 2) * up;
+      if (j == 2) return folded(co, 0, 2, 2) * up;
       if (j == 3) return folded(co, 1, 2, 2) * up;
       if (j == 7) return folded(co, 2, 2, 2) * up;
       return 0.f;
@@ -515,8 +515,9 @@ struct WeightPacker {
             float fb; std::memcpy(&fb, &packed, 4);
             im.push_back(fb);
           }
-    for (int co = 0; co < 32; ++co) im.push_back(co < 24 ? blob[f.shift + co] * up : 0.f);
-    im.push_back(std::ldexp(1.0f, -sw));
+    // the kernel scales the image by 2^8 before splitting it (yfv2_stem16.hip): accumulators carry 2^(sw+8)
+    for (int co = 0; co < 32; ++co) im.push_back(co < 24 ? std::ldexp(blob[f.shift + co], sw + 8) : 0.f);
+    im.push_back(std::ldexp(1.0f, -(sw + 8)));
     while (im.size() % 4) im.push_back(0.f);
     return put(im);
   }

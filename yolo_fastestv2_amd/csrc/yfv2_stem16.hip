@@ -13,8 +13,11 @@
 // the error per product is below the one rounding v_mfma_f32_4x4x1_f32 makes, measured in tests/test_stem16_host_model.py
 // (numpy model of this arithmetic vs float64 and vs the fp32 conv).  The filter (BN scale folded) is split on the HOST and
 // pre-scaled by a power of two 2^sw that puts its largest entry near 2^14 (exact; undone with the same power of two after
-// pooling), so that the second terms of small weights stay normal numbers; the image is split in the kernel, unscaled:
-// valid for |x| < 65504, far beyond any pixel scaling (the reference feeds [0, 1], test.py:38).
+// pooling), so that the second terms of small weights stay normal numbers; the image is split in the kernel after an exact
+// scaling by 2^8 (fp16's absolute floor 2^-25 then sits at 2^-33 of a pixel: below one fp32 ulp of every pixel value >=
+// 1/255; unscaled, a dark image's second terms would be subnormal and the result 100x less accurate than the fp32 conv -
+// tests/test_stem16_host_model.py).  Valid for |x| < 255.9: the reference feeds [0, 1] (test.py:38), raw 0..255 pixels fit too;
+// larger magnitudes overflow fp16 (stated in include/yfv2.h; the uint8 entry points and YFV2_BF6=0 have no such bound).
 //
 // GEMM shape.  D[channel][pixel] += W[channel][k] X[k][pixel], 16 x 16 x 32 per instruction: 24 channels = two channel tiles
 // (the second half empty), K = 27 taps in 32 slots, N = 16 pixels.  A wave = ONE strip of 16 lanes' worth of pooled columns
@@ -30,9 +33,18 @@
 //     tile O:  X0.v2 X0.v3 | X1.v2 X1.v3 | X0.v1  X1.v1  | X2.v1  X2.v2        (same taps, columns shifted by two)
 // - the first two register pairs are the packed conversion of a loaded pair as it stands.  That is 8 of a channel's 9
 // taps; the ninth, (2,2), of all three channels lives in lane group 3, which runs the SAME instructions on other data:
-// its X0, X1, X2 are row 2y+1 of channels 0, 1, 2, the last one loaded one column to the right, which puts (2,2) of the
-// three channels into slots 1, 3 and 7 of both tiles; the filter image is zero in its other slots.
-// No LDS, no barriers, nothing carried between conv rows except the pooled maxima.
+// its "X1" is (ch0, ch1) of columns 4px+1 | 4px+3 of row 2y+1 and its "X2" is ch2 of the same columns, which puts tap (2,2)
+// of the three channels into slots 2, 3 and 7 of both tiles; the filter image is zero in its other slots.  Lane group 3
+// loads nothing: those values sit in the registers of lanes (p, 0..2) and come over with six ds_bpermute_b32 per conv row.
+// No LDS storage, no barriers; carried between conv rows: the split row 2y+1 (= the next row's 2y-1) and the pooled maxima.
+//
+// Measured (round 3, same-box A/Bs at B = 256): the 4x4x1 kernel 145-151 us; this arithmetic with one conv
+// row of load lookahead 148 (the compute had moved off the critical path, the kernel was now bound by bytes in flight);
+// two conv rows of lookahead (this form, 140 VGPRs, 3 waves per SIMD) 134; a MEMORY-ONLY build of the same loads and
+// stores (no conversion, no MFMA) 120-128 - reads alone 92, writes alone 38-45: the launch is bound by its HBM access
+// pattern (strips of 240 bytes per row and plane), not by arithmetic; every input value loaded once (lane group 3 by
+// ds_bpermute instead of three extra L2-hit loads, row 2y-1 carried instead of re-read) 118-124.  4 waves per SIMD by
+// register cap spills (258 us); 4, 2 or 11 bands per image instead of 8: 126-131.
 #include "yfv2_internal.h"
 
 typedef _Float16 yfv2_h8 __attribute__((ext_vector_type(8)));
@@ -43,12 +55,14 @@ namespace {
 __device__ __forceinline__ unsigned dpp_row_shr1_u(unsigned v) {   // lane l <- lane l-1 inside its 16-lane row, 0 at p = 0
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
 }
+__device__ __forceinline__ int f2i(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ float i2f(int v) { return __builtin_bit_cast(float, v); }
 __device__ __forceinline__ float dpp_row_shr1_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
 }
 // two fp32 -> (h1, h2) packed pairs; h1 + h2 reproduces each value to 2^-24 (see header)
 __device__ __forceinline__ void split2(float a, float b, unsigned& h1, unsigned& h2) {
-  const f32x2 v = {a, b};
+  const f32x2 v = (f32x2){a, b} * 256.0f;                                        // exact; undone with the filter's 2^-sw
   const yfv2_h2 t1 = __builtin_convertvector(v, yfv2_h2);                       // v_cvt_pk_f16_f32 (RN)
   const f32x2 r = v - __builtin_convertvector(t1, f32x2);                       // exact
   const yfv2_h2 t2 = __builtin_convertvector(r, yfv2_h2);
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
   const int nwg = gridDim.x;
   const int wid = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
   const int b = __builtin_amdgcn_readfirstlane(wid / wpi), wi = __builtin_amdgcn_readfirstlane(wid - b * wpi);
-  const int band = wi % bands, strip = wi / bands;
+  const int strip = wi % strips, band = wi / strips;   // the strips of a band run side by side: their halo columns and partial lines meet in L2
   const int lane = threadIdx.x, p = lane & 15, g = lane >> 4;
   const int px = 15 * strip + p;
   const bool lvalid = px < PW;
@@ -93,14 +107,15 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + (size_t)b * 3 * H * W * 4), 0, 3 * H * W * 4, 0x00020000);
   const int rowb = W * 4;
   constexpr int OOB = (int)0x80000000;
-  // byte offsets of the lane's three loads for conv row y: g < 3: rows 2y-1, 2y, 2y+1 of channel g; g = 3: row 2y+1 of
-  // channels 0, 1, 2, the last one a column to the right
-  const int colb = 4 * px * 4;
-  const int o0 = g < 3 ? (g * H - 1) * rowb + colb : (0 * H + 1) * rowb + colb;
-  const int o1 = g < 3 ? (g * H + 0) * rowb + colb : (1 * H + 1) * rowb + colb;
-  const int o2 = g < 3 ? (g * H + 1) * rowb + colb : (2 * H + 1) * rowb + colb + 4;
+  // Every input value is loaded from memory ONCE: lane groups 0..2 load rows 2y and 2y+1 of their channel per conv row (row
+  // 2y-1 is the previous conv row's 2y+1: its split form is carried), lane group 3 loads nothing - its three taps are
+  // columns 4px+1 / 4px+3 of row 2y+1 of the three channels, which sit in the registers of lanes (p, 0..2): six
+  // ds_bpermute_b32 per conv row.  (Loading them again instead - three more 16-byte loads per lane and row, all L2 hits -
+  // cost 10 us of the launch's 120: measured with a memory-only build of this kernel.)
+  const int chan_off = (lvalid && g < 3) ? g * H * rowb + 4 * px * 4 : OOB;
+  const int src0 = (0 * 16 + p) * 4, src1 = (1 * 16 + p) * 4, src2 = (2 * 16 + p) * 4;   // ds_bpermute byte addresses of lanes (p, 0..2)
 
-  // filter: [tile 2][term 2][64 lanes][4 dwords] fp16 pairs, then shift * 2^sw [32], then 2^-sw
+  // filter: [tile 2][term 2][64 lanes][4 dwords] fp16 pairs, then shift * 2^(sw+8) [32], then 2^-(sw+8)
   yfv2_h8 wa[2][2];
   {
     const u32x4* wimg = reinterpret_cast<const u32x4*>(a.img16);
@@ -113,19 +128,27 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
   const f32x4 sh0 = *reinterpret_cast<const f32x4*>(cst + 4 * g), sh1 = *reinterpret_cast<const f32x4*>(cst + 16 + 4 * g);
   const float unscale = cst[32];
 
-  auto load3 = [&](int y, f32x4 (&raw)[3]) {       // conv row y of this lane
-    const int base = lvalid ? 2 * y * rowb : OOB;
-    // the row above the image (y = 0, lane groups 0..2) is padding: its offset would land in the previous channel plane
-    const int off0 = (y == 0 && g < 3) ? OOB : base + o0;
-    raw[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off0, 0, 0));
-    raw[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lvalid ? base + o1 : OOB, 0, 0));
-    raw[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lvalid ? base + o2 : OOB, 0, 0));
+  auto load_row = [&](int r) -> f32x4 {            // input row r of the lane's channel (zeros for lane group 3 / outside the image)
+    const int off = (chan_off != OOB && r >= 0) ? chan_off + r * rowb : OOB;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
   };
+  auto load2 = [&](int y, f32x4 (&raw)[2]) { raw[0] = load_row(2 * y); raw[1] = load_row(2 * y + 1); };
 
-  // conv row -> horizontally pooled raw values hp[tile][4] = max(O[p-1], E[p], O[p]) (BN shift inside, pre-ReLU, x 2^sw)
-  auto conv_row = [&](const f32x4 (&raw)[3], f32x4 (&hp)[2]) {
-    Row16 x0, x1, x2;
-    split_row(raw[0], x0); split_row(raw[1], x1); split_row(raw[2], x2);
+  // conv row y from the carried row 2y-1 (x0) and the freshly loaded rows 2y, 2y+1 -> horizontally pooled raw values
+  // hp[tile][4] = max(O[p-1], E[p], O[p]) (BN shift inside, pre-ReLU, x 2^(sw+8)); x0 <- the split row 2y+1
+  auto conv_row = [&](Row16& x0, const f32x4 (&raw)[2], f32x4 (&hp)[2]) {
+    f32x4 r1 = raw[0], r2 = raw[1];
+    {   // lane group 3: (ch0, ch1) of columns 4px+1 | 4px+3 into X1's v0 v1 | v2 v3, ch2 into X2's v0 | v2
+      const int a1 = f2i(raw[1][1]), a3 = f2i(raw[1][3]);   // (by-value helper: bit_cast of a vector ELEMENT lvalue reads element 0 with this hipcc)
+      const int e0 = __builtin_amdgcn_ds_bpermute(src0, a1), e1 = __builtin_amdgcn_ds_bpermute(src1, a1), e2 = __builtin_amdgcn_ds_bpermute(src2, a1);
+      const int q0 = __builtin_amdgcn_ds_bpermute(src0, a3), q1 = __builtin_amdgcn_ds_bpermute(src1, a3), q2 = __builtin_amdgcn_ds_bpermute(src2, a3);
+      if (g == 3) {
+        r1 = (f32x4){i2f(e0), i2f(e1), i2f(q0), i2f(q1)};
+        r2 = (f32x4){i2f(e2), 0.f, i2f(q2), 0.f};
+      }
+    }
+    Row16 x1, x2;
+    split_row(r1, x1); split_row(r2, x2);
     yfv2_h8 be[2], bo[2];                           // B operands of tile E / tile O, per term
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -134,6 +157,7 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
       be[k] = __builtin_bit_cast(yfv2_h8, e);
       bo[k] = __builtin_bit_cast(yfv2_h8, o);
     }
+    x0 = x2;
     f32x4 ae[2] = {sh0, sh1}, ao[2] = {sh0, sh1};
     // w1 x2, w2 x1, w1 x1 - smallest terms first; the four accumulators of a product are independent
 #pragma unroll
@@ -149,27 +173,37 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
         hp[t][e] = __builtin_fmaxf(__builtin_fmaxf(dpp_row_shr1_f(ao[t][e]), ae[t][e]), ao[t][e]);
   };
 
-  // carried: hp of the odd conv row above the current pooled row (0 above the image: post-ReLU equivalent of the padding)
+  // carried: hp of the odd conv row above the current pooled row (0 above the image: post-ReLU equivalent of the padding),
+  // and the split form of the input row above the next conv row (zeros above the image = the conv's padding)
   f32x4 up[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  f32x4 bufA[3], bufB[3];
+  Row16 carry;
+  // Two sets of row buffers: while a pooled row is computed from one set, the four loads of the NEXT pooled row fill the
+  // other (bandwidth = bytes in flight / latency: one conv row of lookahead left the kernel at the old kernel's 4.3 TB/s)
+  f32x4 re0[2], ro0[2], re1[2], ro1[2];
   if (py0 > 0) {
-    load3(2 * py0 - 1, bufA);
-    load3(2 * py0, bufB);
-    conv_row(bufA, up);
+    f32x4 hb[2];
+    const f32x4 top = load_row(4 * py0 - 3);       // row above conv row 2 py0 - 1
+    load2(2 * py0 - 1, hb);
+    load2(2 * py0, re0);
+    load2(2 * py0 + 1, ro0);
+    split_row(top, carry);
+    conv_row(carry, hb, up);
   } else {
-    load3(0, bufB);
+    load2(0, re0);
+    load2(1, ro0);
+    split_row((f32x4){0.f, 0.f, 0.f, 0.f}, carry);
   }
   float* __restrict__ ob = PPOUT ? a.out + (size_t)b * 24 * PH * PW + ((size_t)py0 * PW + (st_ok ? px : 0)) * 2
                                  : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
   const int ylast = (H >> 1) - 1;
-#pragma unroll 1
-  for (int t = 0; t < a.R; ++t) {
+  auto step = [&](int t, const f32x4 (&ce)[2], const f32x4 (&co)[2], f32x4 (&ne)[2], f32x4 (&no)[2]) {
     const int y = 2 * (py0 + t);
+    load2(min(y + 2, ylast - 1), ne);              // next pooled row (past the image's end: a re-read that stays in range)
+    load2(min(y + 3, ylast), no);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 h0[2], h1[2];
-    load3(y + 1, bufA);                            // odd conv row of this pooled row: in flight during the even one
-    conv_row(bufB, h0);
-    load3(min(y + 2, ylast), bufB);                // next pooled row's even conv row (past the band: a re-read that stays in range)
-    conv_row(bufA, h1);
+    conv_row(carry, ce, h0);
+    conv_row(carry, co, h1);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       f32x4 o;
@@ -190,7 +224,14 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
       }
     }
     ob += PPOUT ? (size_t)PW * 2 : (size_t)PW * 24;
+  };
+  int t = 0;
+#pragma unroll 1
+  for (; t + 1 < a.R; t += 2) {
+    step(t, re0, ro0, re1, ro1);
+    step(t + 1, re1, ro1, re0, ro0);
   }
+  if (t < a.R) step(t, re0, ro0, re1, ro1);
 }
 
 void yfv2_launch_stem16(const StemArgs& a, hipStream_t s) {
