@@ -40,7 +40,7 @@ struct Step {
   S1PxArgs s1px{};
   S2PxArgs s2px{};
   size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
-  size_t img_off3 = 0;        // STEP_STEM: the two-term fp16 filter image of stem_h3_kernel (fp32 input, yfv2_stem16.hip)
+  size_t img_off3 = 0;        // STEP_STEM / STEP_S2PX: the two-term fp16 image of stem_h3_kernel / s2h_kernel
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
   // offsets into the param blob, resolved to pointers after the upload
@@ -404,6 +404,132 @@ struct WeightPacker {
     push_taps_quad(im, wd, scd);
     return put(im);
   }
+  // ---- s1h_kernel (yfv2_stage2h.hip): the same block with both pointwise convs as two-term fp16 operands in the A-operand
+  // order of v_mfma_f32_16x16x32_f16.  Lane (l, g = lane >> 4) owns channel POSITIONS npos(g, j), j = 0..7: 4g + j for j < 4
+  // (channel tile 0), 16 + 4g + (j - 4) for j >= 4 and g < 2 (tile 1), none otherwise - as K slots of the B operand and as
+  // rows 4g..4g+3 of the D tiles alike.  Position n = pair n / 2, element n & 1 of the 12 branch pairs; order[] as image_s1px.
+  static int s1h_npos(int g, int j) { return j < 4 ? 4 * g + j : (g < 2 ? 16 + 4 * g + (j - 4) : -1); }
+  static int pow2_for(float mx) {   // sw with mx * 2^sw in (2^13, 2^14]
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
+    int sw = 14 - (int)std::ceil(std::log2(mx));
+    return sw > 24 ? 24 : (sw < -14 ? -14 : sw);
+  }
+  // el(row position, K position) -> [tile 2][term 2][64][4 dwords] of fp16 pairs
+  template <class Fn>
+  static void push_h3_filter(std::vector<float>& im, Fn el) {
+    for (int t = 0; t < 2; ++t)
+      for (int term = 0; term < 2; ++term)
+        for (int l = 0; l < 64; ++l)
+          for (int d = 0; d < 4; ++d) {
+            unsigned packed = 0;
+            for (int e = 0; e < 2; ++e) {
+              const int n = s1h_npos(l >> 4, 2 * d + e), r = 16 * t + (l & 15);
+              const float v = (n >= 0 && r < 24) ? el(r, n) : 0.f;
+              const float h1 = rn_f16(v);
+              packed |= f16_bits(term == 0 ? h1 : v - h1) << (16 * e);
+            }
+            float fb; std::memcpy(&fb, &packed, 4);
+            im.push_back(fb);
+          }
+  }
+  size_t image_s1h(const Folded& f1, const Folded& fd, const Folded& f2, const int (&order)[24], const int (&src_off)[12], const int (&dst_off)[12]) {
+    const float* w1 = &blob[f1.w]; const float* w2 = &blob[f2.w]; const float* wd = &blob[fd.w];
+    const float* sc1 = &blob[f1.scale]; const float* sh1 = &blob[f1.shift];
+    const float* scd = &blob[fd.scale]; const float* shd = &blob[fd.shift];
+    const float* sc2 = &blob[f2.scale]; const float* sh2 = &blob[f2.shift];
+    auto e1 = [&](int r, int n) { return w1[(size_t)r * 24 + order[n]] * sc1[r]; };                 // pw1: natural output channel r, input position n
+    auto e2 = [&](int r, int n) { return w2[(size_t)order[r] * 24 + n] * sc2[order[r]]; };          // pw2: output position r, natural input channel n
+    float m1 = 0.f, m2 = 0.f;
+    for (int r = 0; r < 24; ++r)
+      for (int n = 0; n < 24; ++n) { m1 = std::fmax(m1, std::fabs(e1(r, n))); m2 = std::fmax(m2, std::fabs(e2(r, n))); }
+    const int sw1 = pow2_for(m1), sw2 = pow2_for(m2);
+    std::vector<float> im;
+    push_h3_filter(im, [&](int r, int n) { return std::ldexp(e1(r, n), sw1); });
+    push_h3_filter(im, [&](int r, int n) { return std::ldexp(e2(r, n), sw2); });
+    // taps [18][64]: lane (l, g), register q holds tap f = 4q + (l & 3) = cs * 9 + dy * 3 + dx of the lane's channel slot cs;
+    // they see relu(pw1) * 2^(sw1+4) and must hand pw2 its input times 2^4: BN scale * 2^-sw1
+    for (int q = 0; q < 18; ++q)
+      for (int l = 0; l < 64; ++l) {
+        const int f = 4 * q + (l & 3), cs = f / 9, tt = f % 9, n = s1h_npos(l >> 4, cs);
+        im.push_back(n >= 0 ? std::ldexp(wd[(size_t)tt * 24 + n] * scd[n], -sw1) : 0.f);
+      }
+    for (int n = 0; n < 32; ++n) im.push_back(n < 24 ? std::ldexp(sh1[n], sw1 + 4) : 0.f);
+    for (int n = 0; n < 32; ++n) {   // the depthwise BN shift goes through pw2 (linear): bias2 = shift2 + scale2 * (W2 . shiftd)
+      float v = 0.f;
+      if (n < 24) {
+        const int r = order[n];
+        double acc = 0; for (int k = 0; k < 24; ++k) acc += (double)w2[(size_t)r * 24 + k] * shd[k];
+        v = std::ldexp(sh2[r] + sc2[r] * (float)acc, sw2 + 4);
+      }
+      im.push_back(v);
+    }
+    im.push_back(std::ldexp(1.0f, -(sw2 + 4)));
+    while (im.size() < 3272) im.push_back(0.f);
+    for (int which = 0; which < 2; ++which)           // per-lane byte offsets of the lane's four pairs: read from / written to
+      for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < 64; ++l) {
+          const int g = l >> 4, kk = k < 2 ? 2 * g + k : (g < 2 ? 8 + 2 * g + (k - 2) : -1);
+          const int v = kk < 0 ? (int)0x80000000 : (which ? dst_off[kk] : src_off[kk]);
+          float fb; std::memcpy(&fb, &v, 4);
+          im.push_back(fb);
+        }
+    return put(im);
+  }
+  // s2h_kernel (yfv2_stage2h.hip): stage2.0 with both branches in one wave.  Input positions = natural channels (the stem's
+  // pair planes); output position r of a branch = its channel pos[r] (pos[][] of PlanBuilder::s2px_block: 0..15 = the branch's
+  // eight whole pairs, 16..23 = its halves of the eight pairs that mix a proj and a main channel).
+  static void push_quad_taps(std::vector<float>& im, const float* wd, const float* scd, int shift_pow2) {
+    for (int q = 0; q < 18; ++q)
+      for (int l = 0; l < 64; ++l) {
+        const int f = 4 * q + (l & 3), cs = f / 9, tt = f % 9, n = s1h_npos(l >> 4, cs);
+        im.push_back(n >= 0 ? std::ldexp(wd[(size_t)tt * 24 + n] * scd[n], shift_pow2) : 0.f);
+      }
+  }
+  size_t image_s2h(const Folded& f1, const Folded& fd, const Folded& f2, const Folded& fpd, const Folded& fpp, const int (&pos)[2][24],
+                   const int (&st2_off)[2][8], const int (&st1_off)[2][8], int IH, int IW) {
+    const float* w1 = &blob[f1.w]; const float* w2 = &blob[f2.w]; const float* wq = &blob[fpp.w];
+    const float* sc1 = &blob[f1.scale]; const float* sc2 = &blob[f2.scale]; const float* scq = &blob[fpp.scale];
+    auto e1 = [&](int r, int n) { return w1[(size_t)r * 24 + n] * sc1[r]; };
+    auto ep = [&](int r, int n) { return wq[(size_t)pos[0][r] * 24 + n] * scq[pos[0][r]]; };
+    auto e2 = [&](int r, int n) { return w2[(size_t)pos[1][r] * 24 + n] * sc2[pos[1][r]]; };
+    float m1 = 0.f, mp = 0.f, m2 = 0.f;
+    for (int r = 0; r < 24; ++r)
+      for (int n = 0; n < 24; ++n) { m1 = std::fmax(m1, std::fabs(e1(r, n))); mp = std::fmax(mp, std::fabs(ep(r, n))); m2 = std::fmax(m2, std::fabs(e2(r, n))); }
+    const int sw1 = pow2_for(m1), swp = pow2_for(mp), sw2 = pow2_for(m2);
+    std::vector<float> im;
+    push_h3_filter(im, [&](int r, int n) { return std::ldexp(e1(r, n), sw1); });
+    push_h3_filter(im, [&](int r, int n) { return std::ldexp(ep(r, n), swp); });
+    push_h3_filter(im, [&](int r, int n) { return std::ldexp(e2(r, n), sw2); });
+    push_quad_taps(im, &blob[fd.w], &blob[fd.scale], -sw1);     // main: sees relu(pw1) * 2^(sw1+4), hands pw2 its input * 2^4
+    push_quad_taps(im, &blob[fpd.w], &blob[fpd.scale], 0);      // proj: sees the raw input * 2^4
+    for (int n = 0; n < 32; ++n) im.push_back(n < 24 ? std::ldexp(blob[f1.shift + n], sw1 + 4) : 0.f);
+    auto bias = [&](const float* w, const Folded& fp_, const Folded& fdw, int c) {   // shift + scale * (W . depthwise shift)
+      double acc = 0; for (int k = 0; k < 24; ++k) acc += (double)w[(size_t)c * 24 + k] * blob[fdw.shift + k];
+      return blob[fp_.shift + c] + blob[fp_.scale + c] * (float)acc;
+    };
+    for (int n = 0; n < 32; ++n) im.push_back(n < 24 ? std::ldexp(bias(wq, fpp, fpd, pos[0][n]), swp + 4) : 0.f);
+    for (int n = 0; n < 32; ++n) im.push_back(n < 24 ? std::ldexp(bias(w2, f2, fd, pos[1][n]), sw2 + 4) : 0.f);
+    im.push_back(std::ldexp(1.0f, -(swp + 4)));
+    im.push_back(std::ldexp(1.0f, -(sw2 + 4)));
+    while (im.size() < 5480) im.push_back(0.f);
+    auto put_i = [&](int v) { float fb; std::memcpy(&fb, &v, 4); im.push_back(fb); };
+    const int NONE = (int)0x80000000;
+    for (int k = 0; k < 4; ++k)                      // loads: the lane's four input pair planes
+      for (int l = 0; l < 64; ++l) {
+        const int g = l >> 4, kk = k < 2 ? 2 * g + k : (g < 2 ? 8 + 2 * g + (k - 2) : -1);
+        put_i(kk < 0 ? NONE : kk * IH * IW * 8);
+      }
+    for (int k = 0; k < 8; ++k)                      // stores: proj whole pairs (2), main whole pairs (2), mixed pairs (4)
+      for (int l = 0; l < 64; ++l) {
+        const int g = l >> 4;
+        int v = NONE;
+        if (k < 2) v = st2_off[0][2 * g + k];
+        else if (k < 4) v = st2_off[1][2 * g + (k - 2)];
+        else if (g < 2) v = st1_off[0][4 * g + (k - 4)];   // the pair's base: proj sits in element 0, main in element 1
+        put_i(v);
+      }
+    return put(im);
+  }
   // depthwise 3x3 taps of 24 channels, BN scale folded: [54][64], lane&3 = k of register q holds tap 4q+k, flat index c*9 + dy*3 + dx
   static void push_taps_quad(std::vector<float>& im, const float* wd, const float* scd) {
     const size_t base = im.size();
@@ -693,7 +819,12 @@ struct PlanBuilder {
     s.s2px.IH = IH; s.s2px.IW = IW;
     s.s2px.in_stride = 24 * IH * IW; s.s2px.out_stride = 48 * OH * OW;
     s.s2px.in_records = 24 * IH * IW * 4; s.s2px.out_records = 48 * OH * OW * 4;
-    if (ok) { s.img_off = wp.image_s2px_proj(fpd, fpp, pos[0]); s.img_off2 = wp.image_s2px_main(f1, fd, f2, pos[1]); }
+    if (ok) {
+      s.img_off = wp.image_s2px_proj(fpd, fpp, pos[0]); s.img_off2 = wp.image_s2px_main(f1, fd, f2, pos[1]);
+      for (int i = 0; i < 8; ++i)   // s2h_kernel stores a mixed pair whole: proj must sit in element 0, main right behind it
+        if ((s.s2px.st1_off[0][i] & 7) != 0 || s.s2px.st1_off[1][i] != s.s2px.st1_off[0][i] + 4) ok = false;
+      if (ok) s.img_off3 = wp.image_s2h(f1, fd, f2, fpd, fpp, pos, s.s2px.st2_off, s.s2px.st1_off, IH, IW);
+    }
     s.name = p + " s2 block, lane-per-pixel: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) -> pair planes";
     s.flops = 2.0 * ((double)IH * IW * 24 * 24 + 2.0 * OH * OW * 24 * 24 + 2.0 * OH * OW * 9 * 24);
     s.bytes = 4.0 * ((double)IH * IW * 24 + (double)OH * OW * 48);
@@ -733,7 +864,7 @@ struct PlanBuilder {
     s.s1px.H = H; s.s1px.W = W;
     s.s1px.img_stride = 48 * H * W;
     s.s1px.num_records = (int)((bufstride + 48LL * H * W) * 4);
-    if (ok) s.img_off = wp.image_s1px(f1, fd, f2, order);
+    if (ok) { s.img_off = wp.image_s1px(f1, fd, f2, order); s.img_off2 = wp.image_s1h(f1, fd, f2, order, s.s1px.src_off, s.s1px.dst_off); }
     s.name = p + " s1 block, lane-per-pixel: pw1+bn+relu -> dw3x3+bn -> pw2+bn+relu on the 12 branch pairs (shuffle/pass/cat = bookkeeping)";
     s.flops = 2.0 * H * W * (2.0 * 24 * 24 + 9.0 * 24);
     s.bytes = 4.0 * H * W * (2.0 * 48);  // the layer's logical input + output; the launch itself moves half of it
@@ -1174,8 +1305,8 @@ std::string step_kernel(const Step& st) {
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",";
-    case STEP_S1PX: return "s1px_kernel";
-    case STEP_S2PX: return "s2px_proj_kernel + s2px_main_kernel";
+    case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
+    case STEP_S2PX: return "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel)
     case STEP_S1CHAIN: return "block_s1chain6_kernel";
     case STEP_S1POOL: return "block_s1pool_kernel";
   }
@@ -1275,11 +1406,13 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.B = B;
       a.img[0] = params + st.img_off;
       a.img[1] = params + st.img_off2;
+      a.img16 = h->bf6 ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: the two role kernels on the 4x4x1 fp32 MFMA
       yfv2_launch_s2px(a, s);
     } else if (st.kind == STEP_S1PX) {
       S1PxArgs a = st.s1px;
       a.B = B;
       a.img = params + st.img_off;
+      a.img16 = h->bf6 ? params + st.img_off2 : nullptr;   // YFV2_BF6=0: s1px_kernel on the 4x4x1 fp32 MFMA
       yfv2_launch_s1px(a, s);
     } else {
       DwArgs a = st.dw;

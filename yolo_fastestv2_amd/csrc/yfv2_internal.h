@@ -204,6 +204,7 @@ struct S1PxArgs {
   int num_records;     // bytes addressable from an image base (covers its copy in buffer 1)
   int src_off[12];     // byte offsets (from the image base in buffer 0) of the 12 branch pairs: where they are read ...
   int dst_off[12];     // ... and where the block's output for the same pairs is written (the other buffer)
+  const float* img16;  // s1h_kernel's image (yfv2_stage2h.hip, WeightPacker::image_s1h); null: s1px_kernel
 };
 // stride-2 block of stage 2 (24 -> 48 channels) in lane-per-pixel form; two wave roles (proj / main branch)
 struct S2PxArgs {
@@ -216,10 +217,13 @@ struct S2PxArgs {
   int in_records, out_records;     // bytes addressable from an image base
   int st2_off[2][8];   // per role: byte offsets of the 8 pair planes its output positions 0..15 fill (8-byte stores)
   int st1_off[2][8];   // per role: byte offsets (plane + element) of output positions 16..23 (4-byte stores)
+  const float* img16;  // s2h_kernel's image (yfv2_stage2h.hip, WeightPacker::image_s2h: both branches in one wave); null: the two role kernels
 };
-void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // two kernels (proj role, main role)
+void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // a.img16 set: yfv2_launch_s2h (one kernel); else two kernels (proj role, main role)
+void yfv2_launch_s2h(const S2PxArgs& a, hipStream_t s);
 bool yfv2_s1px_supported(int H, int W);
-void yfv2_launch_s1px(const S1PxArgs& a, hipStream_t s);
+void yfv2_launch_s1px(const S1PxArgs& a, hipStream_t s);   // a.img16 set: yfv2_launch_s1h
+void yfv2_launch_s1h(const S1PxArgs& a, hipStream_t s);
 
 // ---- fused DWConvblock half (yfv2_block.hip): dw5x5+BN+ReLU -> pw72+BN [-> output conv]
 struct TowerArgs {

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(64, 1) void s2px_main_kernel(S2PxArgs a) { s2px_dis
 __global__ __launch_bounds__(64, 1) void s2px_proj_kernel(S2PxArgs a) { s2px_dispatch<false>(a); }
 
 void yfv2_launch_s2px(const S2PxArgs& a0, hipStream_t s) {
+  if (a0.img16) { yfv2_launch_s2h(a0, s); return; }   // both branches in one wave, input read once (yfv2_stage2h.hip)
   const int OW = a0.IW / 2, OH = a0.IH / 2;
   for (int role = 0; role < 2; ++role) {
     S2PxArgs a = a0;
@@ -405,6 +406,7 @@ void yfv2_launch_s2px(const S2PxArgs& a0, hipStream_t s) {
 bool yfv2_s1px_supported(int H, int W) { return H >= 8 && W >= 16 && (long)48 * H * W * 4 < (1L << 28); }
 
 void yfv2_launch_s1px(const S1PxArgs& a0, hipStream_t s) {
+  if (a0.img16) { yfv2_launch_s1h(a0, s); return; }   // both pointwise convs on the f16 matrix cores (yfv2_stage2h.hip)
   S1PxArgs a = a0;
   a.nstrips = a.W <= 16 ? 1 : (a.W - 2 + 13) / 14;
   a.nb = 5;   // 3 strips x 5 bands = 15 units = 4 waves per image: 1024 waves at 256 images, 11 steps each (4 bands: 768 waves x 13 steps measured 7 % slower, 6 or 8 bands 15-30 % slower)

@@ -70,7 +70,6 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h1, unsigned&
   h2 = __builtin_bit_cast(unsigned, t2);
 }
 // low halves / high halves / mixed picks of two packed registers
-__device__ __forceinline__ unsigned pack_lo_lo(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // {a.lo, b.lo}
 __device__ __forceinline__ unsigned pack_hi_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // {a.hi, b.hi}
 __device__ __forceinline__ unsigned pack_hi_lo(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }   // {a.hi, b.lo}
 
