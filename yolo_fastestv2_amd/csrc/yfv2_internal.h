@@ -184,7 +184,10 @@ struct BlockS2Args {
   long long pp_bufstride;
   int bf6;           // pw1 as bf16x6 (pair-plane input form)
   long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (block_s2w_kernel; or null)
+  const float* img16;  // s3h_kernel's image (stage3.0 from pair planes in streaming form, yfv2_stage2h.hip; WeightPacker::image_s3h) or null
 };
+bool yfv2_s3h_supported(int H, int W);
+void yfv2_launch_s3h(const BlockS2Args& a, hipStream_t s);
 
 // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
 // slot s = 2*pair + element of the pair-plane layout -> logical channel of the stage's FIRST block output

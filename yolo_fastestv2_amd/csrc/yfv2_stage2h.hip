@@ -402,3 +402,200 @@ void yfv2_launch_s2h(const S2PxArgs& a0, hipStream_t s) {
   a.nb = (OH + a.R - 1) / a.R;
   hipLaunchKernelGGL(s2h_kernel, dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
 }
+
+// ============================================================================
+// stage3.0: the stride-2 block 48 -> 96 (44x44 -> 22x22) in the same streaming form
+// ============================================================================
+// Reads stage 2's pair planes (two buffers, slot bookkeeping folded into the filter columns / tap channels on the host,
+// as for block_s2_kernel<48, .., PPIN>), writes plain NHWC (B, 22, 22, 96) for the stage-3 chain.  Same dataflow as
+// s2h_kernel with 48 channels: a lane holds 12 channel positions q = 4t + e <-> channel 16t + 4g + e (t = 0..2: the three
+// channel tiles; as K slots: chunk q / 8, slot q % 8 - two K chunks, the second half empty), a pointwise conv is 3 tiles x 2
+// chunks x 3 products = 18 MFMAs per pixel tile.  The three 48 x 48 filters are 36 two-term operands per lane - 144
+// registers - so they live in LDS (36 KB, fragment-major: the 64 lanes of an operand read hit 64 consecutive 16-byte slots)
+// and are read once per input row; a workgroup = the four (strip, band) waves of ONE image sharing that image, one wave
+// per SIMD (the two branches' carried rows, column sums and taps are ~320 registers per lane), no barrier after the
+// prologue.  Rounds 1-2: block_s2_kernel<48> (tile staged in LDS, 8 waves per image, barriers per phase) 73-77 us.
+// image (floats): W1 | Wproj | W2, each [tile 3][chunk 2][term 2][64 lanes][4 dwords] = 3072 | taps main [27][64] | taps proj
+// [27][64] | sh1, bias_proj, bias2 (x 2^(sw+4)) [3][48] | 2^-(swp+4), 2^-(sw2+4) | pad | per-lane load byte offsets [6][64]
+constexpr int S3H_WFL = 3072, S3H_TM = 9216, S3H_TP = 9216 + 1728, S3H_CST = 9216 + 3456, S3H_OFFS = S3H_CST + 148;
+
+namespace {
+// 48 -> 48 pointwise conv of 16 pixels, filter operands from LDS
+__device__ __forceinline__ void pw_h3_48(const float* W, int lane, const f32x2 (&in)[6], const f32x4 (&init)[3], f32x4 (&acc)[3]) {
+  u32x4 b1[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, b2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { unsigned h1, h2; split2(in[k], h1, h2); b1[k >> 2][k & 3] = h1; b2[k >> 2][k & 3] = h2; }
+  const u32x4* Wq = reinterpret_cast<const u32x4*>(W) + lane;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = init[t];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const yfv2_h8 x1 = __builtin_bit_cast(yfv2_h8, b1[c]), x2 = __builtin_bit_cast(yfv2_h8, b2[c]);
+    yfv2_h8 wa[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) wa[t][k] = __builtin_bit_cast(yfv2_h8, Wq[((t * 2 + c) * 2 + k) * 64]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], x2, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], x1, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], x1, acc[t], 0, 0, 0);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int IH = a.H, IW = a.W, OH = IH >> 1, OW = IW >> 1;
+  const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+  const int R = a.R, nb = (OH + R - 1) / R;
+  const int units = nstrips * nb, wpi = (units + 3) >> 2;     // workgroups per image
+  const int b = blockIdx.x / wpi, wi = blockIdx.x - b * wpi;
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 15, g = lane >> 4;
+  const int uid = wi * 4 + (tid >> 6);
+  const float* img = a.img16;
+  {   // the three filters -> LDS (straight 16-byte copy, every load issued before the first store)
+    const f32x4* src = reinterpret_cast<const f32x4*>(img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    f32x4 tmp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tmp[k] = src[tid + k * 256];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst[tid + k * 256] = tmp[k];
+  }
+  __syncthreads();
+  if (uid >= units) return;
+  const int strip = uid % nstrips, band = uid / nstrips;
+  const int ox = 15 * strip + l;
+  const bool xok = ox < OW;
+  const bool st_lane = xok && (l > 0 || strip == 0);
+  const int y0 = band * R, y1 = min(OH, y0 + R);
+  constexpr int OOB = (int)0x80000000;
+  const float* W1 = lds; const float* WP = lds + S3H_WFL; const float* W2 = lds + 2 * S3H_WFL;
+
+  // input: stage 2's two pair-plane buffers of this image (a.in = buffer 0; buffer 1 follows at + pp_bufstride floats)
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * 48 * IH * IW), 0,
+                                                                   (int)((a.pp_bufstride + 48LL * IH * IW) * 4), 0x00020000);
+  float tm[27], tp[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) { tm[q] = img[S3H_TM + q * 64 + lane]; tp[q] = img[S3H_TP + q * 64 + lane]; }
+  f32x4 sh1[3], bip[3], bi2[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    sh1[t] = *reinterpret_cast<const f32x4*>(img + S3H_CST + 16 * t + 4 * g);
+    bip[t] = *reinterpret_cast<const f32x4*>(img + S3H_CST + 48 + 16 * t + 4 * g);
+    bi2[t] = *reinterpret_cast<const f32x4*>(img + S3H_CST + 96 + 16 * t + 4 * g);
+  }
+  const float unscale_p = img[S3H_CST + 144], unscale_2 = img[S3H_CST + 145];
+  int loff[6];
+  {
+    const int* po = reinterpret_cast<const int*>(img + S3H_OFFS);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) loff[k] = xok ? po[k * 64 + lane] + 2 * ox * 8 : OOB;
+  }
+  const int irowb = IW * 8;
+  float* __restrict__ outp = a.out + ((size_t)b * OH * OW + (st_lane ? ox : 0)) * 96 + 4 * g;
+
+  auto load_row = [&](int iy, f32x4 (&X)[6]) {
+    const bool rok = iy >= 0 && iy < IH;           // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      X[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rok && loff[k] != OOB) ? loff[k] + iy * irowb : OOB, 0, 0));
+  };
+  auto columns = [&](const f32x4 (&X)[6], float lim, float (&xe)[12], float (&xo)[12], float (&te)[12], float (&to)[12]) {
+    f32x2 ine[6], ino[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const f32x4 v = X[k] * 16.0f;
+      ine[k] = (f32x2){v[0], v[1]}; ino[k] = (f32x2){v[2], v[3]};
+      xe[2 * k] = v[0]; xe[2 * k + 1] = v[1]; xo[2 * k] = v[2]; xo[2 * k + 1] = v[3];
+    }
+    f32x4 ae[3], ao[3];
+    pw_h3_48(W1, lane, ine, sh1, ae);
+    pw_h3_48(W1, lane, ino, sh1, ao);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      te[c] = __builtin_amdgcn_fmed3f(ae[c >> 2][c & 3], 0.f, lim);
+      to[c] = __builtin_amdgcn_fmed3f(ao[c >> 2][c & 3], 0.f, lim);
+    }
+  };
+#define YFV2_TQ(T, c, t) T[((c) * 9 + (t)) >> 2]
+#define YFV2_TK(c, t) (((c) * 9 + (t)) & 3)
+  auto acc_row = [&](auto dyc, const float (&T)[27], const float (&v0)[12], const float (&v1)[12], float (&S)[12], float (&Q)[12]) {
+    constexpr int DY = decltype(dyc)::value;
+    [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
+      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(T, Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(T, Cs, 0), v1[Cs]),
+                         quad_fmac1<YFV2_TK(Cs, 2)>(S[Cs], YFV2_TQ(T, Cs, 2), v1[Cs]))
+                : (void)quad_fmac3<YFV2_TK(Cs, DY * 3 + 1), YFV2_TK(Cs, DY * 3), YFV2_TK(Cs, DY * 3 + 2)>(
+                      S[Cs], Q[Cs], YFV2_TQ(T, Cs, DY * 3 + 1), YFV2_TQ(T, Cs, DY * 3), YFV2_TQ(T, Cs, DY * 3 + 2), v0[Cs], v1[Cs])), ...);
+    }(std::make_integer_sequence<int, 12>{});
+  };
+
+  f32x4 X[6], Y[6];
+  float cxe[12], cxo[12], cte[12], cto[12];
+  {
+    const int iy = 2 * y0 - 1;
+    load_row(iy, X);
+    load_row(iy + 1, Y);
+    columns(X, (xok && iy >= 0) ? __builtin_inff() : 0.f, cxe, cxo, cte, cto);
+    load_row(iy + 2, X);
+  }
+  const float limx = xok ? __builtin_inff() : 0.f;
+  for (int j = 0; j < R; ++j) {
+    const int oy = y0 + j;
+    float Sm[12], Qm[12], Sp[12], Qp[12], xe[12], xo[12], te[12], to[12];
+    acc_row(std::integral_constant<int, 0>{}, tm, cte, cto, Sm, Qm);
+    acc_row(std::integral_constant<int, 0>{}, tp, cxe, cxo, Sp, Qp);
+    columns(Y, limx, xe, xo, te, to);
+    acc_row(std::integral_constant<int, 1>{}, tm, te, to, Sm, Qm);
+    acc_row(std::integral_constant<int, 1>{}, tp, xe, xo, Sp, Qp);
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 2, Y);
+    __builtin_amdgcn_sched_barrier(0);
+    columns(X, limx, cxe, cxo, cte, cto);
+    acc_row(std::integral_constant<int, 2>{}, tm, cte, cto, Sm, Qm);
+    acc_row(std::integral_constant<int, 2>{}, tp, cxe, cxo, Sp, Qp);
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 3, X);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 dm[6], dp[6];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      dpp_src_ready(Qm[c]); dpp_src_ready(Qp[c]);
+      dm[c >> 1][c & 1] = Sm[c] + row_shr1(Qm[c]);
+      dp[c >> 1][c & 1] = Sp[c] + row_shr1(Qp[c]);
+    }
+    f32x4 am[3], ap[3];
+    pw_h3_48(WP, lane, dp, bip, ap);
+    pw_h3_48(W2, lane, dm, bi2, am);
+    if (st_lane && oy < y1) {
+      float* o = outp + (size_t)oy * OW * 96;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        f32x4 vp, vm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vp[e] = __builtin_fmaxf(ap[t][e], 0.f) * unscale_p; vm[e] = __builtin_fmaxf(am[t][e], 0.f) * unscale_2; }
+        *reinterpret_cast<f32x4*>(o + 16 * t) = vp;          // proj: channels 0..47
+        *reinterpret_cast<f32x4*>(o + 48 + 16 * t) = vm;     // main: channels 48..95
+      }
+    }
+  }
+#undef YFV2_TQ
+#undef YFV2_TK
+}
+
+bool yfv2_s3h_supported(int H, int W) { return H >= 4 && W >= 4 && !(H & 1) && !(W & 1) && W / 2 <= 16 * 15; }
+
+void yfv2_launch_s3h(const BlockS2Args& a0, hipStream_t s) {
+  BlockS2Args a = a0;
+  const int OH = a.H / 2, OW = a.W / 2;
+  const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+  int nb = (4 + nstrips - 1) / nstrips;             // about four (strip, band) waves per image: one workgroup
+  if (nb > OH) nb = OH;
+  a.R = (OH + nb - 1) / nb;
+  nb = (OH + a.R - 1) / a.R;
+  const int units = nstrips * nb;
+  hipLaunchKernelGGL(s3h_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), 3 * S3H_WFL * sizeof(float), s, a);
+}
