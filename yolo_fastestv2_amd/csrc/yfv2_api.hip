@@ -590,6 +590,56 @@ struct WeightPacker {
       }
     return put(im);
   }
+  // s4h_kernel (yfv2_stage2h.hip): stage4.0 (96 -> 192).  Lane (l, g) owns positions n96(g, q) = 16 (q / 4) + 4g + q % 4,
+  // q = 0..23; K chunk q / 8, slot q % 8.  Input positions = physical NHWC channel positions of stage 3's output (the Folded
+  // objects passed in already have their input columns / depthwise channels in that order), outputs natural.
+  size_t image_s4h(const Folded& f1, const Folded& fd, const Folded& f2, const Folded& fpd, const Folded& fpp) {
+    const Folded* fs[3] = {&f1, &fpp, &f2};
+    int sw[3];
+    std::vector<float> im;
+    for (int f = 0; f < 3; ++f) {
+      const float* w = &blob[fs[f]->w]; const float* sc = &blob[fs[f]->scale];
+      float mx = 0.f;
+      for (int r = 0; r < 96; ++r)
+        for (int n = 0; n < 96; ++n) mx = std::fmax(mx, std::fabs(w[(size_t)r * 96 + n] * sc[r]));
+      sw[f] = pow2_for(mx);
+      for (int t = 0; t < 6; ++t)
+        for (int c = 0; c < 3; ++c)
+          for (int term = 0; term < 2; ++term)
+            for (int l = 0; l < 64; ++l)
+              for (int d = 0; d < 4; ++d) {
+                unsigned packed = 0;
+                for (int e = 0; e < 2; ++e) {
+                  const int q = 8 * c + 2 * d + e, r = 16 * t + (l & 15);
+                  const float v = std::ldexp(w[(size_t)r * 96 + n48(l >> 4, q)] * sc[r], sw[f]);   // n48's formula is n96's
+                  const float h1 = rn_f16(v);
+                  packed |= f16_bits(term == 0 ? h1 : v - h1) << (16 * e);
+                }
+                float fb; std::memcpy(&fb, &packed, 4);
+                im.push_back(fb);
+              }
+    }
+    auto taps = [&](const Folded& fdw, int shift_pow2) {     // [54][64]: lane (l, g), register q' holds tap f = 4q' + (l & 3) = q * 9 + dy * 3 + dx
+      for (int qq = 0; qq < 54; ++qq)
+        for (int l = 0; l < 64; ++l) {
+          const int f = 4 * qq + (l & 3), q = f / 9, tt = f % 9, n = n48(l >> 4, q);
+          im.push_back(std::ldexp(blob[fdw.w + (size_t)tt * 96 + n] * blob[fdw.scale + n], shift_pow2));
+        }
+    };
+    taps(fd, -sw[0]);
+    taps(fpd, 0);
+    for (int n = 0; n < 96; ++n) im.push_back(std::ldexp(blob[f1.shift + n], sw[0] + 4));
+    auto bias = [&](const Folded& fp_, const Folded& fdw, int c) {
+      double acc = 0; for (int k = 0; k < 96; ++k) acc += (double)blob[fp_.w + (size_t)c * 96 + k] * blob[fdw.shift + k];
+      return blob[fp_.shift + c] + blob[fp_.scale + c] * (float)acc;
+    };
+    for (int n = 0; n < 96; ++n) im.push_back(std::ldexp(bias(fpp, fpd, n), sw[1] + 4));
+    for (int n = 0; n < 96; ++n) im.push_back(std::ldexp(bias(f2, fd, n), sw[2] + 4));
+    im.push_back(std::ldexp(1.0f, -(sw[1] + 4)));
+    im.push_back(std::ldexp(1.0f, -(sw[2] + 4)));
+    im.push_back(0.f); im.push_back(0.f);
+    return put(im);
+  }
   // depthwise 3x3 taps of 24 channels, BN scale folded: [54][64], lane&3 = k of register q holds tap 4q+k, flat index c*9 + dy*3 + dx
   static void push_taps_quad(std::vector<float>& im, const float* wd, const float* scd) {
     const size_t base = im.size();
@@ -816,6 +866,8 @@ struct PlanBuilder {
       s.img_off = cin == 96 ? wp.image_s2w(f1, fd, f2, fpd, fpp) : wp.image_s2(f1, fd, f2, fpd, fpp, cin);
       if (cin == 48 && pp_label && ok && h->bf6 && yfv2_s3h_supported(H, W))   // the streaming form on the f16 matrix cores (yfv2_stage2h.hip)
         s.img_off3 = wp.image_s3h(f1, fd, f2, fpd, fpp, s.s2.pp_mask, pp_bufstride, H, W);
+      if (cin == 96 && !pp_label && ok && h->bf6 && yfv2_s4h_supported(H, W))
+        s.img_off3 = wp.image_s4h(f1, fd, f2, fpd, fpp);
       s.name = p + " fused s2 block: proj(dw3x3s2+bn -> pw+bn+relu) | main(pw1+bn+relu -> dw3x3s2+bn -> pw2+bn+relu) | cat";
       s.flops = 2.0 * ((double)H * W * cin * cin + 2.0 * oh * ow * cin * cin + 2.0 * oh * ow * 9 * cin);
       s.bytes = 4.0 * ((double)H * W * cin + (double)oh * ow * co);
@@ -1366,7 +1418,7 @@ std::string step_kernel(const Step& st) {
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
-    case STEP_S2: return st.img_off3 ? std::string("s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
+    case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
     case STEP_S2PX: return "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel)
     case STEP_S1CHAIN: return "block_s1chain6_kernel";
@@ -1434,7 +1486,8 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.bf6 = h->bf6 ? 1 : 0;
       a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
       a.img16 = (st.img_off3 && h->bf6) ? params + st.img_off3 : nullptr;
-      if (a.img16) yfv2_launch_s3h(a, s);
+      if (a.img16 && st.c2 == 48) yfv2_launch_s3h(a, s);
+      else if (a.img16 && st.c2 == 96) yfv2_launch_s4h(a, s);
       else if (!yfv2_launch_block_s2(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused stride-2 kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_TOWER) {

@@ -188,6 +188,8 @@ struct BlockS2Args {
 };
 bool yfv2_s3h_supported(int H, int W);
 void yfv2_launch_s3h(const BlockS2Args& a, hipStream_t s);
+bool yfv2_s4h_supported(int H, int W);                         // stage4.0 (96 -> 192, NHWC in) in streaming form with two wave roles
+void yfv2_launch_s4h(const BlockS2Args& a, hipStream_t s);
 
 // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
 // slot s = 2*pair + element of the pair-plane layout -> logical channel of the stage's FIRST block output

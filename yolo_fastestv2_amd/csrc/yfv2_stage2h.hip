@@ -23,6 +23,7 @@
 //     stage-2 activations are < 10 with the COCO weights and with random-init ones), all undone exactly: pw1's inside the
 //     taps, pw2's after its ReLU.
 #include "yfv2_internal.h"
+#include <atomic>
 #include <utility>
 
 typedef _Float16 yfv2_h8 __attribute__((ext_vector_type(8)));
@@ -598,4 +599,206 @@ void yfv2_launch_s3h(const BlockS2Args& a0, hipStream_t s) {
   nb = (OH + a.R - 1) / a.R;
   const int units = nstrips * nb;
   hipLaunchKernelGGL(s3h_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), 3 * S3H_WFL * sizeof(float), s, a);
+}
+
+// ============================================================================
+// stage4.0: the stride-2 block 96 -> 192 (22x22 -> 11x11), streaming form with two wave ROLES
+// ============================================================================
+// NHWC in (stage 3's output, in whatever channel order the chain kernel leaves it: folded into the filter columns / tap
+// channels on the host), NHWC out.  96 channels = 24 positions per lane (q = 4t + e <-> channel 16t + 4g + e, t = 0..5; K
+// chunk q / 8, slot q % 8: three full chunks), a pointwise conv = 6 tiles x 3 chunks x 3 products = 54 MFMAs per pixel tile.
+// The carried rows, column sums and taps of BOTH branches would be ~600 registers per lane, so the branches are two wave
+// roles of one workgroup (role = wave & 1; they share the input rows through L1 / L2 and the three filters - 108 KB of
+// two-term fp16 operands - through LDS); a workgroup = 2 bands x 2 roles = the four waves of ONE image, one per SIMD.
+// Rounds 1-2: block_s2w_kernel (bands of two output rows, four barrier-separated phases, Wproj / W2 streamed through one
+// LDS slot) 61-67 us.
+// image (floats): W1 | Wproj | W2, each [tile 6][chunk 3][term 2][64 lanes][4 dwords] = 9216 | taps main [54][64] | taps proj
+// [54][64] | sh1, bias_proj, bias2 (x 2^(sw+4)) [3][96] | 2^-(swp+4), 2^-(sw2+4)
+constexpr int S4H_WFL = 9216, S4H_TM = 27648, S4H_TP = 27648 + 3456, S4H_CST = 27648 + 6912;
+
+namespace {
+// 96 -> 96 pointwise conv of 16 pixels, filter operands from LDS (one 16-byte read per (tile, chunk, term), used at once)
+__device__ __forceinline__ void pw_h3_96(const float* W, int lane, const f32x2 (&in)[12], const f32x4 (&init)[6], f32x4 (&acc)[6]) {
+  const u32x4* Wq = reinterpret_cast<const u32x4*>(W) + lane;
+#pragma unroll
+  for (int t = 0; t < 6; ++t) acc[t] = init[t];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    u32x4 b1, b2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { unsigned h1, h2; split2(in[4 * c + k], h1, h2); b1[k] = h1; b2[k] = h2; }
+    const yfv2_h8 x1 = __builtin_bit_cast(yfv2_h8, b1), x2 = __builtin_bit_cast(yfv2_h8, b2);
+    yfv2_h8 wa[6][2];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) wa[t][k] = __builtin_bit_cast(yfv2_h8, Wq[((t * 3 + c) * 2 + k) * 64]);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], x2, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], x1, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], x1, acc[t], 0, 0, 0);
+  }
+}
+
+template <bool MAIN>
+__device__ __forceinline__ void s4h_body(const BlockS2Args& a, const float* lds, int b, int strip, int band, int R, int lane) {
+  const int IH = a.H, IW = a.W, OH = IH >> 1, OW = IW >> 1;
+  const int l = lane & 15, g = lane >> 4;
+  const int ox = 15 * strip + l;
+  const bool xok = ox < OW;
+  const bool st_lane = xok && (l > 0 || strip == 0);
+  const int y0 = band * R, y1 = min(OH, y0 + R);
+  constexpr int OOB = (int)0x80000000;
+  const float* img = a.img16;
+  const float* W1 = lds; const float* WB = lds + (MAIN ? 2 : 1) * S4H_WFL;   // this role's second filter: W2 (main) / Wproj
+
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * 96 * IH * IW), 0, 96 * IH * IW * 4, 0x00020000);
+  float tq[54];
+#pragma unroll
+  for (int q = 0; q < 54; ++q) tq[q] = img[(MAIN ? S4H_TM : S4H_TP) + q * 64 + lane];
+  f32x4 sh1[6], bib[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    sh1[t] = *reinterpret_cast<const f32x4*>(img + S4H_CST + 16 * t + 4 * g);
+    bib[t] = *reinterpret_cast<const f32x4*>(img + S4H_CST + (MAIN ? 192 : 96) + 16 * t + 4 * g);
+  }
+  const float unscale = img[S4H_CST + 288 + (MAIN ? 1 : 0)];
+  const int lbase = xok ? (2 * ox * 96 + 4 * g) * 4 : OOB;     // byte offset of (column 2ox, channel 4g) inside an input row
+  const int irowb = IW * 96 * 4;
+  float* __restrict__ outp = a.out + ((size_t)b * OH * OW + (st_lane ? ox : 0)) * 192 + (MAIN ? 96 : 0) + 4 * g;
+
+  // one input row: X[t] = channels 16t+4g..+3 of column 2ox, X[6 + t] = the same of column 2ox+1
+  auto load_row = [&](int iy, f32x4 (&X)[12]) {
+    const bool rok = iy >= 0 && iy < IH;           // wave-uniform
+    const int base = (rok && lbase != OOB) ? lbase + iy * irowb : OOB;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      X[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, base, t * 64, 0));          // (an out-of-range voffset stays out of range)
+      X[6 + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, base, 384 + t * 64, 0));
+    }
+  };
+  // this role's depthwise input of one input row, both columns: raw x 2^4 (proj) / relu(pw1) x 2^(sw1+4), 0 outside the image (main)
+  auto columns = [&](const f32x4 (&X)[12], float lim, float (&ve)[24], float (&vo)[24]) {
+    if constexpr (MAIN) {
+      f32x2 in[12];
+      f32x4 acc[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) { const f32x4 v = X[t] * 16.0f; in[2 * t] = (f32x2){v[0], v[1]}; in[2 * t + 1] = (f32x2){v[2], v[3]}; }
+      pw_h3_96(W1, lane, in, sh1, acc);
+#pragma unroll
+      for (int c = 0; c < 24; ++c) ve[c] = __builtin_amdgcn_fmed3f(acc[c >> 2][c & 3], 0.f, lim);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) { const f32x4 v = X[6 + t] * 16.0f; in[2 * t] = (f32x2){v[0], v[1]}; in[2 * t + 1] = (f32x2){v[2], v[3]}; }
+      pw_h3_96(W1, lane, in, sh1, acc);
+#pragma unroll
+      for (int c = 0; c < 24; ++c) vo[c] = __builtin_amdgcn_fmed3f(acc[c >> 2][c & 3], 0.f, lim);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const f32x4 e = X[t] * 16.0f, o = X[6 + t] * 16.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ve[4 * t + k] = e[k]; vo[4 * t + k] = o[k]; }
+      }
+    }
+  };
+#define YFV2_TQ(c, t) tq[((c) * 9 + (t)) >> 2]
+#define YFV2_TK(c, t) (((c) * 9 + (t)) & 3)
+  auto acc_row = [&](auto dyc, const float (&v0)[24], const float (&v1)[24], float (&S)[24], float (&Q)[24]) {
+    constexpr int DY = decltype(dyc)::value;
+    [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
+      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(Cs, 0), v1[Cs]),
+                         quad_fmac1<YFV2_TK(Cs, 2)>(S[Cs], YFV2_TQ(Cs, 2), v1[Cs]))
+                : (void)quad_fmac3<YFV2_TK(Cs, DY * 3 + 1), YFV2_TK(Cs, DY * 3), YFV2_TK(Cs, DY * 3 + 2)>(
+                      S[Cs], Q[Cs], YFV2_TQ(Cs, DY * 3 + 1), YFV2_TQ(Cs, DY * 3), YFV2_TQ(Cs, DY * 3 + 2), v0[Cs], v1[Cs])), ...);
+    }(std::make_integer_sequence<int, 24>{});
+  };
+
+  f32x4 X[12];
+  float ce[24], co[24];                             // the odd input row above the current output row (dy = 0)
+  {
+    const int iy = 2 * y0 - 1;
+    load_row(iy, X);
+    columns(X, (xok && iy >= 0) ? __builtin_inff() : 0.f, ce, co);
+    load_row(iy + 1, X);
+  }
+  const float limx = xok ? __builtin_inff() : 0.f;
+  for (int j = 0; j < R; ++j) {
+    const int oy = y0 + j;
+    float S[24], Q[24], ve[24], vo[24];
+    acc_row(std::integral_constant<int, 0>{}, ce, co, S, Q);
+    columns(X, limx, ve, vo);                       // even input row 2oy: dy = 1
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 1, X);
+    __builtin_amdgcn_sched_barrier(0);
+    acc_row(std::integral_constant<int, 1>{}, ve, vo, S, Q);
+    columns(X, limx, ce, co);                       // odd input row 2oy+1: dy = 2, and the next output row's dy = 0
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 2, X);
+    __builtin_amdgcn_sched_barrier(0);
+    acc_row(std::integral_constant<int, 2>{}, ce, co, S, Q);
+    f32x2 d[12];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) { dpp_src_ready(Q[c]); d[c >> 1][c & 1] = S[c] + row_shr1(Q[c]); }
+    f32x4 acc[6];
+    pw_h3_96(WB, lane, d, bib, acc);
+    if (st_lane && oy < y1) {
+      float* o = outp + (size_t)oy * OW * 192;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(acc[t][e], 0.f) * unscale;
+        *reinterpret_cast<f32x4*>(o + 16 * t) = v;
+      }
+    }
+  }
+#undef YFV2_TQ
+#undef YFV2_TK
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void s4h_kernel(BlockS2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int OH = a.H >> 1, OW = a.W >> 1;
+  const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+  const int R = a.R, nb = (OH + R - 1) / R;
+  const int units = nstrips * nb, wpi = (units + 1) >> 1;     // workgroups per image: two (strip, band) units x two roles each
+  const int b = blockIdx.x / wpi, wi = blockIdx.x - b * wpi;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  {   // the three filters -> LDS in three rounds of nine 16-byte loads per thread
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img16);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+      f32x4 tmp[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) tmp[k] = src[(r * 9 + k) * 256 + tid];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dst[(r * 9 + k) * 256 + tid] = tmp[k];
+    }
+  }
+  __syncthreads();
+  const int uid = wi * 2 + (wave >> 1);
+  if (uid >= units) return;
+  const int strip = uid % nstrips, band = uid / nstrips;
+  if (wave & 1) s4h_body<true>(a, lds, b, strip, band, R, tid & 63);
+  else s4h_body<false>(a, lds, b, strip, band, R, tid & 63);
+}
+
+bool yfv2_s4h_supported(int H, int W) { return H >= 4 && W >= 4 && !(H & 1) && !(W & 1); }
+
+void yfv2_launch_s4h(const BlockS2Args& a0, hipStream_t s) {
+  BlockS2Args a = a0;
+  const int OH = a.H / 2, OW = a.W / 2;
+  const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+  int nb = (2 + nstrips - 1) / nstrips;             // about two (strip, band) units per image: with the two roles one workgroup
+  if (nb > OH) nb = OH;
+  a.R = (OH + nb - 1) / nb;
+  nb = (OH + a.R - 1) / a.R;
+  const int units = nstrips * nb;
+  static std::atomic<unsigned long long> lds_ok{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&s4h_kernel), lds_ok);
+  hipLaunchKernelGGL(s4h_kernel, dim3(a.B * ((units + 1) / 2)), dim3(256), 3 * S4H_WFL * sizeof(float), s, a);
 }
