@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define YFV2_ABI_VERSION 2 /* 2: yfv2_stage_info reports external bytes as well */
+#define YFV2_ABI_VERSION 3 /* 2: yfv2_stage_info reports external bytes as well; 3: yfv2_train_*, yfv2_sgd_step */
 #define YFV2_API __attribute__((visibility("default")))
 #define YFV2_MAX_DET 300 /* utils/utils.py:243 max_det */
 
@@ -175,6 +175,30 @@ YFV2_API int yfv2_batch_statistics_overflow(yfv2_handle h, int32_t* overflowed, 
 YFV2_API int yfv2_loss(yfv2_handle h, const float* const out6[6], int32_t B, const float* targets, int32_t T, float* losses,
                        float* const grad6[6], void* stream);
 
+/* ---- the rest of the training path: one iteration of train.py:96-123 on the device.
+ * Parameters, their gradients and the BatchNorm buffers are the CALLER's device tensors in the reference's own layouts and
+ * under the reference's state_dict names; nothing is copied.  Correctness-first kernels (plain NCHW fp32, float64
+ * reductions), not the throughput path.
+ *
+ * yfv2_train_bind      tensors: every floating-point entry of the state_dict (weights, biases, running_mean / running_var) as
+ *                      DEVICE pointers; grads: one device buffer per trainable parameter (same names).  Pointers must stay
+ *                      valid until the next bind.
+ * yfv2_train_forward   replaces model/detector.py:21-47 Detector.forward in train() mode (train.py:105): every BatchNorm on
+ *                      batch statistics (biased variance), running statistics moved by momentum 0.1 with the unbiased
+ *                      variance (num_batches_tracked is the caller's integer); writes the six NCHW logit maps and records
+ *                      what the backward needs in a workspace that grows with B.
+ * yfv2_train_backward  replaces total_loss.backward() (train.py:110) from the logits down: grad6 = gradient of the loss
+ *                      w.r.t. the six logit maps (yfv2_loss); ADDS the gradient of every parameter to its bound buffer (zero
+ *                      them first; accumulating over `subdivisions` batches as train.py:122 does is then free).
+ * yfv2_sgd_step        replaces optimizer.step() (torch.optim.SGD as train.py:81-85 builds it: momentum, weight_decay,
+ *                      dampening 0, no Nesterov) for ONE parameter tensor of n elements: d = g + wd p; buf = first_step ? d :
+ *                      momentum buf + d; p -= lr buf.  The warm-up of train.py:113-117 only changes `lr`. */
+YFV2_API int yfv2_train_bind(yfv2_handle h, const yfv2_tensor_desc* tensors, int32_t n, const yfv2_tensor_desc* grads, int32_t ng);
+YFV2_API int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream);
+YFV2_API int yfv2_train_backward(yfv2_handle h, const float* const grad6[6], void* stream);
+YFV2_API int yfv2_sgd_step(yfv2_handle h, float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                           float weight_decay, int32_t first_step, void* stream);
+
 /* ---- introspection / measurement (bench.py, tests) ------------------------- */
 
 YFV2_API int32_t yfv2_num_rows(yfv2_handle h);   /* 1815 for 352x352, A=3 */
@@ -205,6 +229,13 @@ YFV2_API int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, floa
  * to host as (B,H,W,C).  which: 0 stem+pool, 1 stage2, 2 stage3 (C2), 3 stage4
  * (C3), 4 S2 (fpn 22x22), 5 S3 (fpn 11x11).  Returns the element count. */
 YFV2_API int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap);
+
+/* Debug/parity helper for the training path: the output of one ReLU'd conv+BatchNorm of the LAST yfv2_train_forward, dense
+ * (B,C,H,W), copied to host.  conv_name is the state_dict prefix of its conv ("backbone.stage2.0.branch_main.0",
+ * "fpn.cls_head_2.block.5", ...).  Its sign pattern is the set of ReLU decisions that execution took - the gradient parity
+ * test replays the float64 oracle on exactly those decisions (tests/test_train_gpu.py).  Returns the element count (with
+ * host_dst NULL or capacity too small: the count needed, nothing copied), -1 on error.  Synchronises the device. */
+YFV2_API int64_t yfv2_debug_train_relu_output(yfv2_handle h, const char* conv_name, float* host_dst, int64_t capacity);
 
 /* Host-only test hook: validates cfg, builds the launch plan and packs the weights exactly as yfv2_create +
  * yfv2_load_weights do, WITHOUT a device (the workspace gets made-up addresses used only for pointer arithmetic);

@@ -409,8 +409,13 @@ def make_train_golden():
             out["names%d" % ci] = np.asarray(names)
             out["gnorm%d" % ci] = np.asarray([float(grads[k].double().norm()) for k in names], np.float64)
             out["gmax%d" % ci] = np.asarray([float(grads[k].abs().max()) for k in names], np.float32)
-            for k in TRAIN_KEEP:
+            # EVERY gradient is stored (round 3): the reference's fp32 gradients are themselves 1e-2 .. 1e-5 (relative) away from
+            # exact arithmetic - batch-statistics BatchNorm on three images is ill-conditioned - so an implementation that
+            # does not run ATen's very kernels can only be held to "as close to a float64 evaluation as the reference is",
+            # tensor by tensor (tests/test_train_gpu.py)
+            for k in names:
                 out["grad%d:%s" % (ci, k)] = grads[k].numpy()
+            for k in TRAIN_KEEP:
                 out["after%d:%s" % (ci, k)] = after[k].numpy()
             for bnn in TRAIN_BN:
                 for sfx in (".running_mean", ".running_var", ".num_batches_tracked"):

@@ -161,13 +161,15 @@ def test_reference_evaluation_py_replayed(tmp_path, cfg, coco_weights, images_u8
 
 
 @pytest.mark.gpu
-def test_summary_stand_in_in_train_mode_raises_a_clear_error():
-    """train.py:70-71 calls summary() on a freshly built model (train mode).  Training is not implemented here: that call
-    must fail with the explicit message, not with a device fault or a silent eval-mode forward."""
+def test_summary_stand_in_in_train_mode_runs():
+    """train.py:70-71 calls summary() on a freshly built model - in TRAIN mode: hooks + a batch-2 forward.  With the training
+    path in place that is a train-mode forward (batch-statistics BatchNorm): it must run and hand back the six logit maps."""
     import yolo_fastestv2_amd as yfv2
     net = yfv2.Detector(80, 3, True).to("cuda")
-    with pytest.raises(NotImplementedError, match="inference path only"):
-        _summary_stand_in(net, (3, 352, 352), torch.device("cuda"))
+    assert net.training
+    fired, out = _summary_stand_in(net, (3, 352, 352), torch.device("cuda"))
+    assert len(out) == 6 and tuple(out[0].shape) == (2, 12, 22, 22) and tuple(out[5].shape) == (2, 80, 11, 11)
+    assert all(torch.isfinite(o).all() for o in out) and out[0].requires_grad
 
 
 @pytest.mark.gpu

@@ -264,8 +264,8 @@ def test_errors_are_loud(yfv2, model, dev):
     with pytest.raises(ValueError):
         model.engine_for(torch.rand(1, 3, 352, 352, device=dev)).forward(torch.rand(1, 3, 320, 352, device=dev))
     model.train()
-    with pytest.raises(NotImplementedError):
-        model(torch.rand(1, 3, 352, 352, device=dev))
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 352, 352, 3, dtype=torch.uint8, device=dev))   # train mode takes train.py:101's fp32 tensor only
     model.eval()
     with pytest.raises(yfv2.Yfv2Error):
         yfv2.Engine(dev, 352, 352, 80, 3, max_batch=1).forward(torch.rand(1, 3, 352, 352, device=dev))  # no weights

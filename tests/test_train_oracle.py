@@ -86,3 +86,33 @@ def test_warmup_schedule():
     assert oracle.warmup_lr(0.001, 250, 100) == 0.001 * (250 / 500) ** 4
     assert oracle.warmup_lr(0.001, 500, 100) == 0.001
     assert oracle.warmup_lr(0.001, 501, 100) == 0.001
+
+
+def test_relu_decision_replay_and_why_it_is_needed():
+    """train_step(relu_decisions=...) - what tests/test_train_gpu.py compares gradients on.  (a) replaying a run on its own
+    decisions reproduces it exactly; (b) the reference's arithmetic itself (fp32) takes a few of the ~1e7 decisions
+    differently from a float64 evaluation, every one of them on a pre-activation within 1e-3 of zero, and (c) that alone moves
+    gradients by far more than fp32 rounding does: on the SAME decisions fp32 and float64 agree an order of magnitude better."""
+    classes, B, T, seed, lr = make_golden.TRAIN_CASES[0]
+    w, x, t = make_golden.train_case_inputs(classes, B, T, seed)
+    anchors = [float(a) for a in np.load(os.path.join(GOLDEN, "cfg_coco.npz"))["anchors"]]
+    xt, tt = torch.from_numpy(x), torch.from_numpy(t)
+    r32 = oracle.train_step(w, xt, tt, anchors, classes, lr)
+    assert len(r32["pre_relu"]) == 46                                     # stem, 35 in the backbone's blocks, 2 + 8 in the FPN
+    dec32 = {k: v > 0 for k, v in r32["pre_relu"].items()}
+    again = oracle.train_step(w, xt, tt, anchors, classes, lr, relu_decisions=dec32)
+    assert all(torch.equal(again["grads"][k], r32["grads"][k]) for k in r32["grads"]) and again["losses"] == r32["losses"]
+    w64 = {k: (v.double() if v.is_floating_point() else v) for k, v in w.items()}
+    free64 = oracle.train_step(w64, xt.double(), tt, anchors, classes, lr)
+    flips, worst = 0, 0.0
+    for k, pre in free64["pre_relu"].items():
+        d = dec32[k] != (pre > 0)
+        flips += int(d.sum())
+        if d.any():
+            worst = max(worst, float(pre[d].abs().max()))
+    assert 0 < flips < 50 and worst < 1e-3, (flips, worst)
+    same64 = oracle.train_step(w64, xt.double(), tt, anchors, classes, lr, relu_decisions=dec32)
+
+    def rel(a, b):
+        return max(float((a["grads"][k].double() - b["grads"][k]).abs().max()) / max(float(b["grads"][k].abs().max()), 1e-12) for k in b["grads"] if float(b["grads"][k].abs().max()) > 1e-3)
+    assert rel(r32, free64) > 10 * rel(r32, same64), (rel(r32, free64), rel(r32, same64))

@@ -18,6 +18,7 @@ from .model.detector import Detector  # noqa: F401
 from .utils.utils import (ap_per_class, compute_ap, evaluation, get_batch_statistics, handel_preds, load_datafile,  # noqa: F401
                           nms_with_indices, non_max_suppression)
 from .utils.loss import compute_loss  # noqa: F401
+from .utils.optim import SGD  # noqa: F401
 from .weights import export_weights, random_state_dict  # noqa: F401
 from .sharded import detect_sharded, gather_decoded, gather_detections, shard_range  # noqa: F401
 

@@ -89,6 +89,7 @@ struct yfv2_ctx {
   // counters and float64 sums; grown on demand (a growth waits for the device)
   void* d_loss_ws = nullptr;
   size_t loss_ws_bytes = 0;
+  void* train = nullptr;         // training state (yfv2_train.hip), created by yfv2_train_bind
   long long* d_trace = nullptr;  // YFV2_TRACE=1: cycle stamps of the last fused s1 launch (debug)
   int trace_step = -1;           // YFV2_TRACE_STEP=i: only launch i of the plan writes stamps (towers: only then)
   // which buffers hold the stage outputs of the last forward (for debug/parity)
@@ -1599,6 +1600,10 @@ int setup_ctx(yfv2_ctx* h, const yfv2_config* cfg, int rows, Alloc alloc) {
 
 }  // namespace
 
+void** yfv2_ctx_train_slot(yfv2_ctx* h) { return h ? &h->train : nullptr; }
+const yfv2_config* yfv2_ctx_config(yfv2_ctx* h) { return &h->cfg; }
+int yfv2_ctx_fail(yfv2_ctx* h, int code, const char* msg) { return fail(h, code, msg ? msg : ""); }
+
 // ===========================================================================
 // extern "C" surface
 // ===========================================================================
@@ -1745,6 +1750,7 @@ void yfv2_destroy(yfv2_handle h) {
   free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);
   if (h->d_loss_ws) (void)hipFree(h->d_loss_ws);
+  if (h->train) { yfv2_train_release(h->train); h->train = nullptr; }
   if (h->d_params) (void)hipFree(h->d_params);
   delete h;
 }

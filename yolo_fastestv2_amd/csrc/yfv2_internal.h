@@ -328,3 +328,11 @@ void yfv2_launch_resize(const ResizeArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);
 void yfv2_launch_decode_nms(const DecodeArgs& d, const NmsArgs& a, hipStream_t s);   // yfv2_detect: decode + NMS in one launch
+
+// ---- training path (yfv2_train.hip): its state hangs off the handle through an opaque slot owned by yfv2_api.hip
+struct yfv2_ctx;
+struct yfv2_config;
+void** yfv2_ctx_train_slot(yfv2_ctx* h);                       // null handle -> null
+const yfv2_config* yfv2_ctx_config(yfv2_ctx* h);
+int yfv2_ctx_fail(yfv2_ctx* h, int code, const char* msg);      // records the message, returns code
+void yfv2_train_release(void* train_state);                    // called by yfv2_destroy

@@ -1,0 +1,581 @@
+// yfv2_train.hip - SURVEY.md 8(f) row 3, the rest of the training path: one iteration of train.py:96-123 on the device.
+//   yfv2_train_forward   Detector.forward in train() mode (model/backbone/shufflenetv2.py:19-63,74-80,102-109, model/fpn.py,
+//                        model/detector.py:21-47 with every nn.BatchNorm2d on BATCH statistics, running statistics moved by
+//                        momentum 0.1 with the unbiased variance)
+//   yfv2_train_backward  what total_loss.backward() (train.py:110) derives for the 225 parameters from the gradient of the
+//                        loss w.r.t. the six logit maps (yfv2_loss)
+//   yfv2_sgd_step        torch.optim.SGD(momentum, weight_decay, dampening 0, no Nesterov) as train.py:81-85 builds it
+// Behaviour only was read from the reference; autograd's derivatives are restated from the layer definitions.
+//
+// This is the correctness-first slice of the row: plain NCHW fp32 kernels, one thread per output element (reductions: one
+// block per channel / filter entry, float64 accumulators), a tape of closures instead of an autograd engine.  It is NOT the
+// throughput path (BASELINE.json's metric is inference); it exists so that the reference's training loop runs end to end
+// on the MI355X through this library and matches tests/golden/golden_train.npz (the reference's own modules on CPU):
+// gradients to 1e-5 of each tensor's largest entry, updated weights to 1e-6.  Parameters, gradients and BatchNorm buffers are
+// the CALLER's device tensors in the reference's own layouts ((co, ci, k, k), (c,)): nothing is copied or re-laid-out.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/yfv2.h"
+#include "yfv2_internal.h"
+
+namespace {
+
+// a (B, C, H, W) window into an NCHW tensor with Ctot channels: channel c of the view = channel coff + c * cstride of the tensor
+struct V {
+  float* p; int Ctot, coff, cstride, C, H, W;
+  __host__ __device__ size_t at(int b, int c, int y, int x) const { return (((size_t)b * Ctot + coff + (size_t)c * cstride) * H + y) * W + x; }
+};
+
+struct ConvP { V in, out; const float* w; const float* bias; int k, stride, pad, dw, B; };
+
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP a) {
+  const int OH = a.out.H, OW = a.out.W;
+  const size_t n = (size_t)a.B * a.out.C * OH * OW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ox = i % OW, oy = (i / OW) % OH, co = (i / ((size_t)OW * OH)) % a.out.C, b = i / ((size_t)OW * OH * a.out.C);
+  float acc = a.bias ? a.bias[co] : 0.f;
+  const int k = a.k;
+  if (a.dw) {
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * a.stride - a.pad + ky;
+      if (iy < 0 || iy >= a.in.H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * a.stride - a.pad + kx;
+        if (ix >= 0 && ix < a.in.W) acc = __builtin_fmaf(a.w[(co * k + ky) * k + kx], a.in.p[a.in.at(b, co, iy, ix)], acc);
+      }
+    }
+  } else {
+    for (int ci = 0; ci < a.in.C; ++ci)
+      for (int ky = 0; ky < k; ++ky) {
+        const int iy = oy * a.stride - a.pad + ky;
+        if (iy < 0 || iy >= a.in.H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          const int ix = ox * a.stride - a.pad + kx;
+          if (ix >= 0 && ix < a.in.W) acc = __builtin_fmaf(a.w[(((size_t)co * a.in.C + ci) * k + ky) * k + kx], a.in.p[a.in.at(b, ci, iy, ix)], acc);
+        }
+      }
+  }
+  a.out.p[a.out.at(b, co, oy, ox)] = acc;
+}
+
+// d in += conv^T(d out): a.in = gradient view of the input (accumulated into), a.out = gradient of the output
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvP a) {
+  const int IH = a.in.H, IW = a.in.W;
+  const size_t n = (size_t)a.B * a.in.C * IH * IW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ix = i % IW, iy = (i / IW) % IH, ci = (i / ((size_t)IW * IH)) % a.in.C, b = i / ((size_t)IW * IH * a.in.C);
+  const int k = a.k;
+  float acc = 0.f;
+  for (int ky = 0; ky < k; ++ky) {
+    const int ny = iy + a.pad - ky;
+    if (ny < 0 || ny % a.stride) continue;
+    const int oy = ny / a.stride;
+    if (oy >= a.out.H) continue;
+    for (int kx = 0; kx < k; ++kx) {
+      const int nx = ix + a.pad - kx;
+      if (nx < 0 || nx % a.stride) continue;
+      const int ox = nx / a.stride;
+      if (ox >= a.out.W) continue;
+      if (a.dw) acc = __builtin_fmaf(a.w[(ci * k + ky) * k + kx], a.out.p[a.out.at(b, ci, oy, ox)], acc);
+      else
+        for (int co = 0; co < a.out.C; ++co) acc = __builtin_fmaf(a.w[(((size_t)co * a.in.C + ci) * k + ky) * k + kx], a.out.p[a.out.at(b, co, oy, ox)], acc);
+    }
+  }
+  a.in.p[a.in.at(b, ci, iy, ix)] += acc;
+}
+
+// dW[co][ci][ky][kx] += sum_{b, oy, ox} dOut * In   (a.in = the input VALUES, a.out = gradient of the output, a.w unused);
+// one block per (co, ci) - (channel, 0) for depthwise -, every filter entry written by exactly one block: no atomics
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvP a, float* dw_out) {
+  __shared__ double red[256];
+  const int co = blockIdx.x, ci = a.dw ? co : (int)blockIdx.y, cig = a.dw ? 0 : ci, cin_g = a.dw ? 1 : a.in.C;
+  const int k = a.k, kk = k * k, OH = a.out.H, OW = a.out.W;
+  double acc[25];
+  for (int t = 0; t < kk; ++t) acc[t] = 0.0;
+  const int n = a.B * OH * OW;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ox = i % OW, oy = (i / OW) % OH, b = i / (OW * OH);
+    const float g = a.out.p[a.out.at(b, co, oy, ox)];
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * a.stride - a.pad + ky;
+      if (iy < 0 || iy >= a.in.H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * a.stride - a.pad + kx;
+        if (ix >= 0 && ix < a.in.W) acc[ky * k + kx] += (double)g * (double)a.in.p[a.in.at(b, ci, iy, ix)];
+      }
+    }
+  }
+  for (int t = 0; t < kk; ++t) {
+    red[threadIdx.x] = acc[t];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) dw_out[((size_t)co * cin_g + cig) * kk + t] += (float)red[0];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_bwd_kernel(V g, int B, float* db) {
+  __shared__ double red[256];
+  const int co = blockIdx.x, n = B * g.H * g.W;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)g.p[g.at(i / (g.H * g.W), co, (i / g.W) % g.H, i % g.W)];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) db[co] += (float)red[0];
+}
+
+// BatchNorm2d, training mode: per-channel batch mean / biased variance of y (B, C, H, W contiguous); saves mean and
+// 1/sqrt(var + eps); running = 0.9 running + 0.1 (mean | unbiased variance)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, int C, int HW, float* mean, float* invstd, float* run_mean, float* run_var) {
+  __shared__ double red[256];
+  __shared__ double s_mean;
+  const int c = blockIdx.x, n = B * HW;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)y[((size_t)(i / HW) * C + c) * HW + i % HW];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) s_mean = red[0] / n;
+  __syncthreads();
+  const double m = s_mean;
+  acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double d = (double)y[((size_t)(i / HW) * C + c) * HW + i % HW] - m; acc += d * d; }
+  __syncthreads();
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const double var = red[0] / n;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + 1e-5));
+    run_mean[c] = (float)(0.9 * (double)run_mean[c] + 0.1 * m);
+    run_var[c] = (float)(0.9 * (double)run_var[c] + 0.1 * (n > 1 ? var * n / (n - 1) : var));
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, V z, int B, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu) {
+  const int HW = z.H * z.W;
+  const size_t n = (size_t)B * z.C * HW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (i / HW) % z.C, b = i / ((size_t)HW * z.C), r = i % HW;
+  float v = (y[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+  if (relu && !(v > 0.f)) v = 0.f;
+  z.p[z.at(b, c, r / z.W, r % z.W)] = v;
+}
+
+// per channel: sum of dz' and of dz' * xhat (dz' = dz where the ReLU let the value through); -> d beta, d gamma, and the two
+// sums for bn_bwd_apply
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* y, V z, V dz, int B, const float* mean, const float* invstd, int relu, float* sums,
+                                                           float* dgamma, float* dbeta) {
+  __shared__ double r0[256], r1[256];
+  const int c = blockIdx.x, HW = z.H * z.W, n = B * HW;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int b = i / HW, r = i % HW;
+    float g = dz.p[dz.at(b, c, r / z.W, r % z.W)];
+    if (relu && !(z.p[z.at(b, c, r / z.W, r % z.W)] > 0.f)) g = 0.f;
+    const float xh = (y[((size_t)b * z.C + c) * HW + r] - mean[c]) * invstd[c];
+    a0 += (double)g; a1 += (double)g * (double)xh;
+  }
+  r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; } __syncthreads(); }
+  if (threadIdx.x == 0) { sums[2 * c] = (float)r0[0]; sums[2 * c + 1] = (float)r1[0]; dbeta[c] += (float)r0[0]; dgamma[c] += (float)r1[0]; }
+}
+
+// dy = gamma * invstd * (dz' - sum(dz') / N - xhat * sum(dz' xhat) / N)   (dy is the conv output's gradient: single consumer, overwritten)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* y, V z, V dz, float* dy, int B, const float* mean, const float* invstd, const float* gamma,
+                                                          int relu, const float* sums) {
+  const int HW = z.H * z.W;
+  const size_t n = (size_t)B * z.C * HW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (i / HW) % z.C, b = i / ((size_t)HW * z.C), r = i % HW;
+  float g = dz.p[dz.at(b, c, r / z.W, r % z.W)];
+  if (relu && !(z.p[z.at(b, c, r / z.W, r % z.W)] > 0.f)) g = 0.f;
+  const float xh = (y[i] - mean[c]) * invstd[c], inv_n = 1.0f / (float)(B * HW);
+  dy[i] = gamma[c] * invstd[c] * (g - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+}
+
+// max_pool2d(3, 2, 1) as ATen's CPU kernel scans it: window rows then columns, a later value replaces the maximum only if it is
+// greater - the FIRST maximum keeps the gradient
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, float* out, int* arg, int B, int C, int H, int W) {
+  const int OH = H / 2, OW = W / 2;
+  const size_t n = (size_t)B * C * OH * OW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ox = i % OW, oy = (i / OW) % OH;
+  const size_t plane = i / ((size_t)OW * OH);
+  const float* xp = x + plane * H * W;
+  float best = -INFINITY; int bi = -1;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      const float v = xp[iy * W + ix];
+      if (v > best || bi < 0) { best = v; bi = iy * W + ix; }
+    }
+  }
+  out[i] = best; arg[i] = bi;
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dout, const int* arg, float* dx, int B, int C, int H, int W) {
+  const int OH = H / 2, OW = W / 2;
+  const size_t n = (size_t)B * C * H * W, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ix = i % W, iy = (i / W) % H;
+  const size_t plane = i / ((size_t)W * H);
+  float acc = 0.f;
+  for (int oy = iy / 2; oy <= (iy + 1) / 2 && oy < OH; ++oy)
+    for (int ox = ix / 2; ox <= (ix + 1) / 2 && ox < OW; ++ox)
+      if (arg[plane * OH * OW + oy * OW + ox] == iy * W + ix) acc += dout[plane * OH * OW + oy * OW + ox];
+  dx[i] += acc;
+}
+
+// dst view (+)= src view, same (C, H, W)
+__global__ __launch_bounds__(256) void view_copy_kernel(V dst, V src, int B, int accumulate) {
+  const size_t n = (size_t)B * dst.C * dst.H * dst.W, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = i % dst.W, y = (i / dst.W) % dst.H, c = (i / ((size_t)dst.W * dst.H)) % dst.C, b = i / ((size_t)dst.W * dst.H * dst.C);
+  const float v = src.p[src.at(b, c, y, x)];
+  if (accumulate) dst.p[dst.at(b, c, y, x)] += v; else dst.p[dst.at(b, c, y, x)] = v;
+}
+// fpn.py:57-58: dst (2H x 2W) = nearest x2 of src; backward: d src += its four children
+__global__ __launch_bounds__(256) void upsample2_kernel(V dst, V src, int B) {
+  const size_t n = (size_t)B * dst.C * dst.H * dst.W, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = i % dst.W, y = (i / dst.W) % dst.H, c = (i / ((size_t)dst.W * dst.H)) % dst.C, b = i / ((size_t)dst.W * dst.H * dst.C);
+  dst.p[dst.at(b, c, y, x)] = src.p[src.at(b, c, y >> 1, x >> 1)];
+}
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(V dsrc, V ddst, int B) {
+  const size_t n = (size_t)B * dsrc.C * dsrc.H * dsrc.W, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = i % dsrc.W, y = (i / dsrc.W) % dsrc.H, c = (i / ((size_t)dsrc.W * dsrc.H)) % dsrc.C, b = i / ((size_t)dsrc.W * dsrc.H * dsrc.C);
+  dsrc.p[dsrc.at(b, c, y, x)] += ddst.p[ddst.at(b, c, 2 * y, 2 * x)] + ddst.p[ddst.at(b, c, 2 * y, 2 * x + 1)] + ddst.p[ddst.at(b, c, 2 * y + 1, 2 * x)] +
+                                 ddst.p[ddst.at(b, c, 2 * y + 1, 2 * x + 1)];
+}
+
+// torch.optim.SGD, one parameter tensor: d = g + wd p; buf = first ? d : momentum buf + d; p -= lr buf
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, int first) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float d = g[i] + wd * p[i];
+  const float bb = first ? d : momentum * buf[i] + d;
+  buf[i] = bb;
+  p[i] = p[i] - lr * bb;
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+struct Tens { size_t off = 0; int C = 0, H = 0, W = 0; };   // offset (floats) into the activation arena; its gradient sits at the same offset of the gradient arena
+
+struct Train {
+  yfv2_config cfg{};
+  int B = 0;
+  float* acts = nullptr; float* grads = nullptr; size_t arena_floats = 0, used = 0;
+  int* pool_arg = nullptr; size_t pool_arg_n = 0;
+  std::map<std::string, float*> param, pgrad;
+  std::vector<std::function<void(hipStream_t)>> tape;
+  std::map<std::string, V> relu_out;   // conv name -> the view its ReLU wrote (yfv2_debug_train_relu_output)
+  std::string err;
+  bool sizing = false;
+  size_t per_image_floats = 0;
+
+  Tens alloc(int C, int H, int W) {
+    Tens t; t.off = used; t.C = C; t.H = H; t.W = W;
+    used += (((size_t)B * C * H * W) + 63) & ~(size_t)63;
+    return t;
+  }
+  V view(const Tens& t, bool grad, int coff = 0, int cstride = 1, int C = -1) const {
+    return V{(grad ? grads : acts) + t.off, t.C, coff, cstride, C < 0 ? t.C : C, t.H, t.W};
+  }
+  float* P(const std::string& n) { auto it = param.find(n); if (it == param.end() || !it->second) { if (err.empty()) err = "yfv2_train: tensor '" + n + "' is not bound"; return nullptr; } return it->second; }
+  float* G(const std::string& n) { auto it = pgrad.find(n); if (it == pgrad.end() || !it->second) { if (err.empty()) err = "yfv2_train: gradient of '" + n + "' is not bound"; return nullptr; } return it->second; }
+
+  // conv (no bias) + BatchNorm (batch statistics) [+ ReLU]: in view -> zout view (a channel slice of some tensor)
+  void conv_bn(const Tens& tin, int in_coff, int in_cstride, int Cin, const Tens& tout, int out_coff, int Cout, const std::string& conv, const std::string& bn,
+               int k, int stride, int pad, bool dw, bool relu, bool need_din, hipStream_t s) {
+    const int OH = (tin.H + 2 * pad - k) / stride + 1, OW = (tin.W + 2 * pad - k) / stride + 1;
+    Tens y = alloc(Cout, OH, OW);
+    Tens st = alloc(1, 1, 4 * Cout);   // mean | invstd | the two backward sums (2 per channel)
+    if (sizing) return;
+    float* w = P(conv + ".weight"); float* gam = P(bn + ".weight"); float* bet = P(bn + ".bias"); float* rm = P(bn + ".running_mean"); float* rv = P(bn + ".running_var");
+    float* gw = G(conv + ".weight"); float* gg = G(bn + ".weight"); float* gb = G(bn + ".bias");
+    if (!w || !gam || !bet || !rm || !rv || !gw || !gg || !gb) return;
+    float* mean = acts + st.off; float* invstd = mean + Cout; float* sums = invstd + Cout;
+    ConvP c{view(tin, false, in_coff, in_cstride, Cin), view(y, false), w, nullptr, k, stride, pad, dw ? 1 : 0, B};
+    hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(Cout), dim3(256), 0, s, acts + y.off, B, Cout, OH * OW, mean, invstd, rm, rv);
+    const V z = view(tout, false, out_coff, 1, Cout), dz = view(tout, true, out_coff, 1, Cout);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, acts + y.off, z, B, mean, invstd, gam, bet, relu ? 1 : 0);
+    if (relu) relu_out[conv] = z;
+    const int Bc = B;
+    tape.push_back([=, this](hipStream_t st2) {
+      float* yv = acts + y.off; float* dy = grads + y.off;
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(Cout), dim3(256), 0, st2, yv, z, dz, Bc, mean, invstd, relu ? 1 : 0, sums, gg, gb);
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)Bc * Cout * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, Bc, mean, invstd, gam, relu ? 1 : 0, sums);
+      ConvP cw{view(tin, false, in_coff, in_cstride, Cin), view(y, true), nullptr, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
+      hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(Cout, dw ? 1 : Cin), dim3(256), 0, st2, cw, gw);
+      if (need_din) {
+        ConvP cd{view(tin, true, in_coff, in_cstride, Cin), view(y, true), w, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
+        hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)Bc * Cin * tin.H * tin.W)), dim3(256), 0, st2, cd);
+      }
+    });
+  }
+
+  // biased 1x1 output conv (detector.py:25-31): tower -> caller's NCHW logit tensor; its gradient arrives from the caller
+  struct HeadUse { Tens tin; std::string name; int Cout; float* out; const float* dout; };
+  std::vector<HeadUse> heads;
+  void head(const Tens& tin, const std::string& name, int Cout, float* out, hipStream_t s) {
+    if (sizing) return;
+    float* w = P(name + ".weight"); float* bi = P(name + ".bias");
+    if (!w || !bi) return;
+    V o{out, Cout, 0, 1, Cout, tin.H, tin.W};
+    ConvP c{view(tin, false), o, w, bi, 1, 1, 0, 0, B};
+    hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * tin.H * tin.W)), dim3(256), 0, s, c);
+    heads.push_back(HeadUse{tin, name, Cout, out, nullptr});
+  }
+};
+
+}  // namespace
+
+// the training state hangs off the handle through an opaque slot (yfv2_api.hip owns the handle)
+static Train* train_of(yfv2_handle h, bool create) {
+  void** slot = yfv2_ctx_train_slot(h);
+  if (!slot) return nullptr;
+  if (!*slot && create) { Train* t = new Train(); t->cfg = *yfv2_ctx_config(h); *slot = t; }
+  return static_cast<Train*>(*slot);
+}
+void yfv2_train_release(void* p) {
+  Train* t = static_cast<Train*>(p);
+  if (!t) return;
+  if (t->acts) (void)hipFree(t->acts);
+  if (t->grads) (void)hipFree(t->grads);
+  if (t->pool_arg) (void)hipFree(t->pool_arg);
+  delete t;
+}
+
+extern "C" {
+
+int yfv2_train_bind(yfv2_handle h, const yfv2_tensor_desc* tensors, int32_t n, const yfv2_tensor_desc* grads, int32_t ng) {
+  if (!h || !tensors || n <= 0 || !grads || ng <= 0) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_train_bind: bad argument");
+  Train* t = train_of(h, true);
+  t->param.clear(); t->pgrad.clear();
+  for (int i = 0; i < n; ++i) if (tensors[i].name) t->param[tensors[i].name] = const_cast<float*>(tensors[i].data);
+  for (int i = 0; i < ng; ++i) if (grads[i].name) t->pgrad[grads[i].name] = const_cast<float*>(grads[i].data);
+  return YFV2_OK;
+}
+
+int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream) {
+  if (!h || !x || !out6 || B < 1) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_train_forward: bad argument");
+  Train* t = train_of(h, false);
+  if (!t || t->param.empty()) return yfv2_ctx_fail(h, YFV2_ERR_STATE, "yfv2_train_forward: yfv2_train_bind has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  (void)hipSetDevice(t->cfg.device);
+  const int H = t->cfg.height, W = t->cfg.width, A = t->cfg.anchor_num, nc = t->cfg.classes;
+  t->B = B; t->err.clear(); t->tape.clear(); t->heads.clear(); t->relu_out.clear();
+
+  auto build = [&](bool sizing) {
+    t->sizing = sizing; t->used = 0;
+    // the input is NOT copied: a view over the caller's tensor (it needs no gradient)
+    Tens stem = t->alloc(24, H / 2, W / 2), pooled = t->alloc(24, H / 4, W / 4);
+    {
+      // stem conv reads the caller's x directly
+      if (!sizing) {
+        Tens y = t->alloc(24, H / 2, W / 2); Tens st = t->alloc(1, 1, 4 * 24);
+        float* w = t->P("backbone.first_conv.0.weight"); float* gam = t->P("backbone.first_conv.1.weight"); float* bet = t->P("backbone.first_conv.1.bias");
+        float* rm = t->P("backbone.first_conv.1.running_mean"); float* rv = t->P("backbone.first_conv.1.running_var");
+        float* gw = t->G("backbone.first_conv.0.weight"); float* gg = t->G("backbone.first_conv.1.weight"); float* gb = t->G("backbone.first_conv.1.bias");
+        if (w && gam && bet && rm && rv && gw && gg && gb) {
+          const int OH = H / 2, OW = W / 2;
+          float* mean = t->acts + st.off; float* invstd = mean + 24; float* sums = invstd + 24;
+          V xin{const_cast<float*>(x), 3, 0, 1, 3, H, W};
+          ConvP c{xin, t->view(y, false), w, nullptr, 3, 2, 1, 0, B};
+          hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, c);
+          hipLaunchKernelGGL(bn_stats_kernel, dim3(24), dim3(256), 0, s, t->acts + y.off, B, 24, OH * OW, mean, invstd, rm, rv);
+          const V z = t->view(stem, false), dz = t->view(stem, true);
+          hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, t->acts + y.off, z, B, mean, invstd, gam, bet, 1);
+          t->relu_out["backbone.first_conv.0"] = z;
+          Train* tt = t;
+          t->tape.push_back([=](hipStream_t st2) {
+            float* yv = tt->acts + y.off; float* dy = tt->grads + y.off;
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(24), dim3(256), 0, st2, yv, z, dz, B, mean, invstd, 1, sums, gg, gb);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, B, mean, invstd, gam, 1, sums);
+            ConvP cw{xin, tt->view(y, true), nullptr, nullptr, 3, 2, 1, 0, B};
+            hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(24, 3), dim3(256), 0, st2, cw, gw);
+          });
+          // maxpool
+          const size_t np = (size_t)B * 24 * (H / 4) * (W / 4);
+          int* arg = t->pool_arg;
+          hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(np)), dim3(256), 0, s, t->acts + stem.off, t->acts + pooled.off, arg, B, 24, H / 2, W / 2);
+          t->tape.push_back([=](hipStream_t st2) {
+            hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for((size_t)B * 24 * (H / 2) * (W / 2))), dim3(256), 0, st2, tt->grads + pooled.off, arg, tt->grads + stem.off, B, 24,
+                               H / 2, W / 2);
+          });
+        }
+      } else {
+        t->alloc(24, H / 2, W / 2); t->alloc(1, 1, 4 * 24);
+      }
+    }
+    Tens cur = pooled;
+    Tens feats[3];
+    const int repeats[3] = {4, 8, 4}, chans[4] = {24, 48, 96, 192};
+    int cin = 24;
+    for (int si = 0; si < 3; ++si) {
+      const int cout = chans[si + 1], mid = cout / 2;
+      for (int i = 0; i < repeats[si]; ++i) {
+        const std::string p = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i);
+        if (i == 0) {   // stride 2: out = cat(proj(x), main(x))
+          const int inp = cin, oh = cur.H / 2, ow = cur.W / 2;
+          Tens out = t->alloc(cout, oh, ow);
+          Tens pd = t->alloc(inp, oh, ow);
+          t->conv_bn(cur, 0, 1, inp, pd, 0, inp, p + ".branch_proj.0", p + ".branch_proj.1", 3, 2, 1, true, false, true, s);
+          t->conv_bn(pd, 0, 1, inp, out, 0, inp, p + ".branch_proj.2", p + ".branch_proj.3", 1, 1, 0, false, true, true, s);
+          Tens m1 = t->alloc(mid, cur.H, cur.W), m2 = t->alloc(mid, oh, ow);
+          t->conv_bn(cur, 0, 1, inp, m1, 0, mid, p + ".branch_main.0", p + ".branch_main.1", 1, 1, 0, false, true, true, s);
+          t->conv_bn(m1, 0, 1, mid, m2, 0, mid, p + ".branch_main.3", p + ".branch_main.4", 3, 2, 1, true, false, true, s);
+          t->conv_bn(m2, 0, 1, mid, out, inp, cout - inp, p + ".branch_main.5", p + ".branch_main.6", 1, 1, 0, false, true, true, s);
+          cur = out;
+        } else {        // stride 1: even channels pass, odd channels -> main; out = cat(pass, main)
+          const int c = cout, c2 = c / 2;
+          Tens out = t->alloc(c, cur.H, cur.W);
+          if (!sizing) {
+            const V dst = t->view(out, false, 0, 1, c2), src = t->view(cur, false, 0, 2, c2);
+            hipLaunchKernelGGL(view_copy_kernel, dim3(blocks_for((size_t)B * c2 * cur.H * cur.W)), dim3(256), 0, s, dst, src, B, 0);
+            const V gdst = t->view(cur, true, 0, 2, c2), gsrc = t->view(out, true, 0, 1, c2);
+            const int hh = cur.H, ww = cur.W;
+            t->tape.push_back([=](hipStream_t st2) { hipLaunchKernelGGL(view_copy_kernel, dim3(blocks_for((size_t)B * c2 * hh * ww)), dim3(256), 0, st2, gdst, gsrc, B, 1); });
+          }
+          Tens m1 = t->alloc(c2, cur.H, cur.W), m2 = t->alloc(c2, cur.H, cur.W);
+          t->conv_bn(cur, 1, 2, c2, m1, 0, c2, p + ".branch_main.0", p + ".branch_main.1", 1, 1, 0, false, true, true, s);
+          t->conv_bn(m1, 0, 1, c2, m2, 0, c2, p + ".branch_main.3", p + ".branch_main.4", 3, 1, 1, true, false, true, s);
+          t->conv_bn(m2, 0, 1, c2, out, c2, c2, p + ".branch_main.5", p + ".branch_main.6", 1, 1, 0, false, true, true, s);
+          cur = out;
+        }
+      }
+      feats[si] = cur;
+      cin = cout;
+    }
+    const Tens c2 = feats[1], c3 = feats[2];
+    Tens s3 = t->alloc(72, c3.H, c3.W);
+    t->conv_bn(c3, 0, 1, 192, s3, 0, 72, "fpn.conv1x1_3.0", "fpn.conv1x1_3.1", 1, 1, 0, false, true, true, s);
+    auto tower = [&](const std::string& p, const Tens& in) {
+      Tens a1 = t->alloc(72, in.H, in.W), a2 = t->alloc(72, in.H, in.W), a3 = t->alloc(72, in.H, in.W), a4 = t->alloc(72, in.H, in.W);
+      t->conv_bn(in, 0, 1, 72, a1, 0, 72, p + ".0", p + ".1", 5, 1, 2, true, true, true, s);
+      t->conv_bn(a1, 0, 1, 72, a2, 0, 72, p + ".3", p + ".4", 1, 1, 0, false, false, true, s);
+      t->conv_bn(a2, 0, 1, 72, a3, 0, 72, p + ".5", p + ".6", 5, 1, 2, true, true, true, s);
+      t->conv_bn(a3, 0, 1, 72, a4, 0, 72, p + ".8", p + ".9", 1, 1, 0, false, false, true, s);
+      return a4;
+    };
+    const Tens cls3 = tower("fpn.cls_head_3.block", s3), reg3 = tower("fpn.reg_head_3.block", s3);
+    Tens p2 = t->alloc(288, c2.H, c2.W);
+    if (!sizing) {
+      const V up = t->view(p2, false, 0, 1, 192), src3 = t->view(c3, false);
+      hipLaunchKernelGGL(upsample2_kernel, dim3(blocks_for((size_t)B * 192 * c2.H * c2.W)), dim3(256), 0, s, up, src3, B);
+      const V dst2 = t->view(p2, false, 192, 1, 96), src2 = t->view(c2, false);
+      hipLaunchKernelGGL(view_copy_kernel, dim3(blocks_for((size_t)B * 96 * c2.H * c2.W)), dim3(256), 0, s, dst2, src2, B, 0);
+      const V gup = t->view(p2, true, 0, 1, 192), g3 = t->view(c3, true), g2 = t->view(c2, true), gp2 = t->view(p2, true, 192, 1, 96);
+      const int h3 = c3.H, w3 = c3.W, h2 = c2.H, w2 = c2.W;
+      t->tape.push_back([=](hipStream_t st2) {
+        hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(blocks_for((size_t)B * 192 * h3 * w3)), dim3(256), 0, st2, g3, gup, B);
+        hipLaunchKernelGGL(view_copy_kernel, dim3(blocks_for((size_t)B * 96 * h2 * w2)), dim3(256), 0, st2, g2, gp2, B, 1);
+      });
+    }
+    Tens s2 = t->alloc(72, c2.H, c2.W);
+    t->conv_bn(p2, 0, 1, 288, s2, 0, 72, "fpn.conv1x1_2.0", "fpn.conv1x1_2.1", 1, 1, 0, false, true, true, s);
+    const Tens cls2 = tower("fpn.cls_head_2.block", s2), reg2 = tower("fpn.reg_head_2.block", s2);
+    t->head(reg2, "output_reg_layers", 4 * A, out6[0], s);
+    t->head(cls2, "output_obj_layers", A, out6[1], s);
+    t->head(cls2, "output_cls_layers", nc, out6[2], s);
+    t->head(reg3, "output_reg_layers", 4 * A, out6[3], s);
+    t->head(cls3, "output_obj_layers", A, out6[4], s);
+    t->head(cls3, "output_cls_layers", nc, out6[5], s);
+  };
+
+  build(true);
+  const size_t need = t->used;
+  if (need > t->arena_floats) {
+    if (hipDeviceSynchronize() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: device error before growing the workspace");
+    if (t->acts) (void)hipFree(t->acts);
+    if (t->grads) (void)hipFree(t->grads);
+    t->acts = t->grads = nullptr; t->arena_floats = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&t->acts), need * sizeof(float)) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&t->grads), need * sizeof(float)) != hipSuccess)
+      return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: out of device memory for the training workspace");
+    t->arena_floats = need;
+  }
+  const size_t npool = (size_t)B * 24 * (H / 4) * (W / 4);
+  if (npool > t->pool_arg_n) {
+    if (t->pool_arg) { (void)hipDeviceSynchronize(); (void)hipFree(t->pool_arg); }
+    if (hipMalloc(reinterpret_cast<void**>(&t->pool_arg), npool * sizeof(int)) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: out of device memory");
+    t->pool_arg_n = npool;
+  }
+  build(false);
+  if (!t->err.empty()) { t->tape.clear(); return yfv2_ctx_fail(h, YFV2_ERR_WEIGHTS, t->err.c_str()); }
+  if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: launch failed");
+  return YFV2_OK;
+}
+
+int yfv2_train_backward(yfv2_handle h, const float* const grad6[6], void* stream) {
+  Train* t = h ? train_of(h, false) : nullptr;
+  if (!t || t->tape.empty() || t->heads.size() != 6) return yfv2_ctx_fail(h, YFV2_ERR_STATE, "yfv2_train_backward: no recorded yfv2_train_forward");
+  if (!grad6) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_train_backward: null pointer");
+  for (int i = 0; i < 6; ++i) if (!grad6[i]) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_train_backward: null gradient tensor");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int B = t->B;
+  if (hipMemsetAsync(t->grads, 0, t->used * sizeof(float), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_backward: memset failed");
+  // the output convs: weights shared by the two scales -> their gradients accumulate (the caller zeroed the parameter gradients)
+  for (int i = 0; i < 6; ++i) {
+    const auto& u = t->heads[i];
+    float* w = t->P(u.name + ".weight"); float* gw = t->G(u.name + ".weight"); float* gb = t->G(u.name + ".bias");
+    if (!w || !gw || !gb) return yfv2_ctx_fail(h, YFV2_ERR_WEIGHTS, t->err.c_str());
+    V go{const_cast<float*>(grad6[i]), u.Cout, 0, 1, u.Cout, u.tin.H, u.tin.W};
+    hipLaunchKernelGGL(bias_bwd_kernel, dim3(u.Cout), dim3(256), 0, s, go, B, gb);
+    ConvP cw{t->view(u.tin, false), go, nullptr, nullptr, 1, 1, 0, 0, B};
+    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(u.Cout, 72), dim3(256), 0, s, cw, gw);
+    ConvP cd{t->view(u.tin, true), go, w, nullptr, 1, 1, 0, 0, B};
+    hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)B * 72 * u.tin.H * u.tin.W)), dim3(256), 0, s, cd);
+  }
+  for (size_t i = t->tape.size(); i-- > 0;) t->tape[i](s);
+  t->tape.clear(); t->heads.clear();
+  if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_backward: launch failed");
+  return YFV2_OK;
+}
+
+int64_t yfv2_debug_train_relu_output(yfv2_handle h, const char* conv_name, float* host_dst, int64_t capacity) {
+  Train* t = h ? train_of(h, false) : nullptr;
+  if (!t || !conv_name) { (void)yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_debug_train_relu_output: bad argument"); return -1; }
+  const auto it = t->relu_out.find(conv_name);
+  if (it == t->relu_out.end()) { (void)yfv2_ctx_fail(h, YFV2_ERR_STATE, "yfv2_debug_train_relu_output: no such ReLU output in the last yfv2_train_forward"); return -1; }
+  const V z = it->second;
+  const int64_t n = (int64_t)t->B * z.C * z.H * z.W;
+  if (!host_dst || capacity < n) return n;
+  float* dense = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess || hipMalloc(reinterpret_cast<void**>(&dense), (size_t)n * sizeof(float)) != hipSuccess) {
+    (void)yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_debug_train_relu_output: device error"); return -1;
+  }
+  const V d{dense, z.C, 0, 1, z.C, z.H, z.W};
+  hipLaunchKernelGGL(view_copy_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, nullptr, d, z, t->B, 0);
+  const hipError_t e = hipMemcpy(host_dst, dense, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(dense);
+  if (e != hipSuccess) { (void)yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_debug_train_relu_output: copy failed"); return -1; }
+  return n;
+}
+
+int yfv2_sgd_step(yfv2_handle h, float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                  int32_t first_step, void* stream) {
+  if (!h || !param || !grad || !momentum_buf || n < 0) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_sgd_step: bad argument");
+  if (n == 0) return YFV2_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, momentum_buf, (long long)n, lr, momentum,
+                     weight_decay, first_step ? 1 : 0);
+  if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_sgd_step: launch failed");
+  return YFV2_OK;
+}
+
+}  // extern "C"

@@ -233,6 +233,55 @@ class Engine:
                                    gptrs, _stream(self.device)), self._h)
         return losses, grads
 
+    # ---- training path: train.py:96-123 on the device -----------------------------------------
+    def train_bind(self, tensors, grads):
+        """tensors: name -> fp32 device tensor for every floating-point state_dict entry (weights, biases, BatchNorm running
+        statistics); grads: name -> fp32 device buffer for every trainable parameter.  The library keeps the POINTERS."""
+        def table(d):
+            arr = (TensorDesc * len(d))()
+            for i, (k, t) in enumerate(d.items()):
+                if t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous():
+                    raise ValueError("train_bind: '%s' must be a contiguous fp32 tensor on %s" % (k, self.device))
+                arr[i].name, arr[i].data, arr[i].numel = k.encode(), t.data_ptr(), t.numel()
+            return arr
+        self._train_keep = (tensors, grads)          # the tensors must outlive the binding
+        ta, ga = table(tensors), table(grads)
+        check(_lib.lib().yfv2_train_bind(self._h, ta, len(tensors), ga, len(grads)), self._h)
+
+    def train_forward(self, x, out=None):
+        """Detector.forward in train() mode (batch-statistics BatchNorm; running statistics updated in the bound buffers)."""
+        x = self._check_x(x)
+        if x.dtype != torch.float32:
+            raise ValueError("train_forward takes the fp32 (B,3,H,W) tensor train.py:101 builds")
+        B = x.shape[0]
+        if out is None:
+            out = [torch.empty(s, device=self.device, dtype=torch.float32) for s in self.logit_shapes(B)]
+        ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in out])
+        check(_lib.lib().yfv2_train_forward(self._h, _ptr(x), B, ptrs, _stream(self.device)), self._h)
+        self._train_seq = getattr(self, "_train_seq", 0) + 1
+        return tuple(out)
+
+    def train_backward(self, grads6):
+        """From the gradient of the loss w.r.t. the six logit maps down to every parameter: ADDS into the bound gradient buffers."""
+        gs = [g.to(self.device, torch.float32).contiguous() for g in grads6]
+        ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in gs])
+        check(_lib.lib().yfv2_train_backward(self._h, ptrs, _stream(self.device)), self._h)
+
+    def debug_train_relu_output(self, conv_name):
+        """flat host tensor (B*C*H*W, NCHW order): what the ReLU after conv `conv_name` wrote in the last train_forward"""
+        L = _lib.lib()
+        n = L.yfv2_debug_train_relu_output(self._h, conv_name.encode(), None, 0)
+        if n < 0:
+            check(-1, self._h)
+        host = torch.empty(n, dtype=torch.float32)
+        if L.yfv2_debug_train_relu_output(self._h, conv_name.encode(), C.c_void_p(host.data_ptr()), n) != n:
+            check(-1, self._h)
+        return host
+
+    def sgd_step(self, param, grad, buf, lr, momentum, weight_decay, first):
+        check(_lib.lib().yfv2_sgd_step(self._h, _ptr(param), _ptr(grad), _ptr(buf), param.numel(), float(lr), float(momentum), float(weight_decay),
+                                       1 if first else 0, _stream(self.device)), self._h)
+
     def stats_overflowed(self):
         """Waits for the stream; True if any batch_statistics(sync=False) call since the last query met an image with
         more than 1024 targets (its flags are then invalid).  Clears the flag."""

@@ -8,7 +8,10 @@ pointer to libyfv2's HIP kernels through the C ABI (include/yfv2.h); this module
 only owns the parameters (so ``.to()``, ``.parameters()``, ``load_state_dict``
 behave like the reference module) and the glue.
 
-Out of scope: training.  ``forward`` in ``.train()`` mode raises.
+Training: in ``.train()`` mode ``forward`` runs the library's train-mode forward (batch-statistics
+BatchNorm, running statistics updated in this module's buffers) as a ``torch.autograd.Function`` whose backward is the
+library's backward pass - ``total_loss.backward()`` (train.py:110) fills ``.grad`` of every parameter, ``yolo_fastestv2_amd.SGD``
+(or any torch optimizer) steps them.  Correctness-first kernels: see yfv2_train.hip.
 """
 import math
 import os
@@ -77,6 +80,43 @@ def state_spec(classes, anchor_num):
                      ("output_cls_layers", classes)):
         yield name + ".weight", (co, OUT_DEPTH, 1, 1), "conv"
         yield name + ".bias", (co,), "bias"
+
+
+class _TrainForward(torch.autograd.Function):
+    """Detector.forward in train() mode: forward = yfv2_train_forward, backward = yfv2_train_backward (train.py:105-110)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng = module.engine_for(x, sync=False)
+        names = module._train_names()
+        state = {k: v for k, v in module.state_dict(keep_vars=True).items() if v.is_floating_point()}
+        for k, v in state.items():
+            if v.device != x.device or v.dtype != torch.float32 or not v.is_contiguous():
+                raise RuntimeError("training needs every parameter / buffer as a contiguous fp32 tensor on %s ('%s' is not): model.to(device).float()" % (x.device, k))
+        flat = torch.zeros(sum(state[k].numel() for k in names), device=x.device, dtype=torch.float32)
+        views, off = {}, 0
+        for k in names:
+            n = state[k].numel()
+            views[k] = flat[off:off + n].view_as(state[k])
+            off += n
+        eng.train_bind({k: v.data for k, v in state.items()}, views)
+        outs = eng.train_forward(x)
+        with torch.no_grad():
+            for mod in module.modules():
+                nb = mod._buffers.get("num_batches_tracked")
+                if nb is not None:
+                    nb += 1
+        ctx.eng, ctx.seq, ctx.flat, ctx.views, ctx.names = eng, eng._train_seq, flat, views, names
+        return outs
+
+    @staticmethod
+    def backward(ctx, *g6):
+        if ctx.eng._train_seq != ctx.seq:
+            raise RuntimeError("Detector (train mode): backward must follow the forward that produced these logits - another "
+                               "train-mode forward ran on this engine in between")
+        ctx.flat.zero_()
+        ctx.eng.train_backward([g if g is not None else torch.zeros(s, device=ctx.flat.device) for g, s in zip(g6, ctx.eng.logit_shapes(g6[0].shape[0]))])
+        return (None, None) + tuple(ctx.views[k].clone() for k in ctx.names)
 
 
 class _Node(nn.Module):
@@ -161,13 +201,18 @@ class Detector(nn.Module):
             cached = self.__dict__["_tensors"] = (ids, [t for t in self.state_dict(keep_vars=True).values() if t.is_floating_point()])
         return ids, tuple(t._version for t in cached[1])
 
-    def engine_for(self, x):
+    def _train_names(self):
+        return [k for k, _ in self.named_parameters()]
+
+    def engine_for(self, x, sync=True):
         hh, ww = (int(x.shape[1]), int(x.shape[2])) if (x.dtype == torch.uint8 and x.shape[-1] == 3) else (int(x.shape[2]), int(x.shape[3]))
         key = (str(x.device), hh, ww)
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(x.device, hh, ww, self.classes, self.anchor_num, max_batch=int(x.shape[0]))
             self._engines[key] = eng
+        if not sync:
+            return eng           # the training path reads the parameters in place
         tok = self._version_token()
         if self._synced.get(key) != tok:
             eng.load_state_dict(self.state_dict())
@@ -176,11 +221,17 @@ class Detector(nn.Module):
 
     # -- forward ---------------------------------------------------------------------------
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("yolo_fastestv2_amd.Detector implements the inference path only; "
-                                      "call .eval() (training is a 'next' row, SURVEY.md 8(f))")
         if x.device.type != "cuda":
             raise RuntimeError("yolo_fastestv2_amd.Detector has no CPU path: move the input to the MI355X (.to('cuda'))")
+        if self.training:
+            if self.export_onnx:
+                raise NotImplementedError("export_onnx=True is an inference layout (detector.py:33-44): call .eval()")
+            if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+                raise ValueError("train mode takes the fp32 (B,3,H,W) tensor train.py:101 builds")
+            params = [p for _, p in self.named_parameters()]
+            out = _TrainForward.apply(self, x.contiguous(), *params)
+            out[0]._yfv2_engine = self.engine_for(x, sync=False)
+            return out
         eng = self.engine_for(x)
         # extension over the reference surface: a uint8 (B,H,W,3) tensor is the image before test.py:34-38's
         # reshape/permute/float()/255 - the stem kernel does that pre-process in its loads
