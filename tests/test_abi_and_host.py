@@ -417,7 +417,7 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
             rc, steps, blob, _ = _dryrun(classes, H, W)
             assert rc == 0 and steps >= 15 and blob > 400000, (classes, H, W, rc, steps, blob)
             blobs.add(blob)
-        assert len(blobs) <= 3      # the packed blob depends on which kernels a size selects, not on the size itself
+        assert len(blobs) <= 4      # the packed blob depends on which kernels a size selects, not on the size itself
     # the two alternative plans (layer by layer: 77 launches; every pointwise conv on the fp32 MFMA: the stage-3 chain and
     # stage4.0, which exist only as bf16x6 kernels, then run layer by layer) are planned and packed by the same code
     import os

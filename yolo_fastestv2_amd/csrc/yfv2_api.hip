@@ -40,7 +40,7 @@ struct Step {
   S1PxArgs s1px{};
   S2PxArgs s2px{};
   size_t img_off2 = 0;        // STEP_S2PX: main-role image (img_off = proj role); STEP_STEM: filter image for uint8 input
-  size_t img_off3 = 0;        // STEP_STEM / STEP_S2PX / STEP_S2 (stage3.0): the two-term fp16 image of stem_h3_kernel / s2h_kernel / s3h_kernel (0: none)
+  size_t img_off3 = 0;        // STEP_TOWER: towerh_kernel's image; STEP_STEM / STEP_S2PX / STEP_S2 (stage3.0): the two-term fp16 image of stem_h3_kernel / s2h_kernel / s3h_kernel (0: none)
   bool has_head = false;
   int c2 = 0;                 // fused s1 block
   // offsets into the param blob, resolved to pointers after the upload
@@ -370,6 +370,48 @@ struct WeightPacker {
     push_vec(im, &blob[fd.scale], 72, 96); push_vec(im, &blob[fd.shift], 72, 96);
     push_vec(im, &blob[fp.scale], 72, 96); push_vec(im, &blob[fp.shift], 72, 96);
     push_vec(im, fh ? &blob[fh->shift] : nullptr, mh, 96);
+    return put(im);
+  }
+  // towerh_kernel (yfv2_towerh.hip): WP [5][5][64][4 dwords of fp16 pairs: term 1, term 1, term 2, term 2] | CS [4][96] |
+  // WH [mh tiles][5][64][4] | TAPS [5][4][27][4] + 16
+  template <class Fn>
+  static void push_a16(std::vector<float>& im, Fn el, int MT) {   // el(row, col) already scaled
+    for (int mt = 0; mt < MT; ++mt)
+      for (int s = 0; s < 5; ++s)
+        for (int l = 0; l < 64; ++l) {
+          unsigned dw[4] = {0, 0, 0, 0};
+          for (int e = 0; e < 4; ++e) {
+            const float v = el(16 * mt + (l & 15), 16 * s + 4 * (l >> 4) + e);
+            const float h1 = rn_f16(v);
+            dw[e >> 1] |= f16_bits(h1) << (16 * (e & 1));
+            dw[2 + (e >> 1)] |= f16_bits(v - h1) << (16 * (e & 1));
+          }
+          for (int d = 0; d < 4; ++d) { float fb; std::memcpy(&fb, &dw[d], 4); im.push_back(fb); }
+        }
+  }
+  size_t image_towerh(const Folded& fd, const Folded& fp, const Folded* fh, int mh) {
+    std::vector<float> im;
+    const float* wpw = &blob[fp.w];
+    float mp = 0.f, mhd = 0.f;
+    for (int i = 0; i < 72 * 72; ++i) mp = std::fmax(mp, std::fabs(wpw[i]));
+    const int sw = pow2_for(mp);
+    push_a16(im, [&](int r, int c) { return (r < 72 && c < 72) ? std::ldexp(wpw[(size_t)r * 72 + c], sw) : 0.f; }, 5);
+    const int mh_tiles = fh ? ((mh + 15) / 16 <= 1 ? 1 : 6) : 0;
+    int swh = 0;
+    if (fh) { for (int i = 0; i < mh * 72; ++i) mhd = std::fmax(mhd, std::fabs(blob[fh->w + i])); swh = pow2_for(mhd); }
+    for (int c = 0; c < 96; ++c) im.push_back(c < 72 ? std::ldexp(blob[fp.scale + c], -(sw + 4)) : 0.f);
+    push_vec(im, &blob[fp.shift], 72, 96);
+    push_vec(im, fh ? &blob[fh->shift] : nullptr, mh, 96);
+    for (int c = 0; c < 96; ++c) im.push_back(c == 0 ? std::ldexp(1.0f, -(swh + 4)) : 0.f);
+    if (fh) push_a16(im, [&](int r, int c) { return (r < mh && c < 72) ? std::ldexp(blob[fh->w + (size_t)r * 72 + c], swh) : 0.f; }, mh_tiles);
+    for (int s = 0; s < 5; ++s)
+      for (int q = 0; q < 4; ++q)
+        for (int t = 0; t < 27; ++t)
+          for (int e = 0; e < 4; ++e) {
+            const int ch = 16 * s + 4 * q + e;
+            im.push_back(ch >= 72 ? 0.f : t < 25 ? blob[fd.w + (size_t)t * 72 + ch] : 16.0f * (t == 25 ? blob[fd.scale + ch] : blob[fd.shift + ch]));   // x 2^4: exact
+          }
+    for (int i = 0; i < 16; ++i) im.push_back(0.f);   // the scalar-cache warm-up reads whole 64-byte lines
     return put(im);
   }
   // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
@@ -1259,6 +1301,7 @@ struct PlanBuilder {
     s.tw.H = H; s.tw.W = W;
     s.tw.mh = mh; s.tw.split = split;
     s.img_off = wp.image_tower(fd, fp, fh, mh);
+    if (yfv2_towerh_supported(H, W)) s.img_off3 = wp.image_towerh(fd, fp, fh, mh);
     s.has_head = fh != nullptr;
     s.head0 = head0; s.head1 = head1;
     s.name = name;
@@ -1418,7 +1461,9 @@ std::string step_kernel(const Step& st) {
     case STEP_STEM: return "stem_h3_kernel";   // fp32 input, default plan (uint8 input / YFV2_BF6=0: stem_px_kernel)
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
-    case STEP_TOWER: return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
+    case STEP_TOWER:
+      if (st.img_off3) return "towerh_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");   // default plan
+      return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
     case STEP_S2PX: return "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel)
@@ -1499,11 +1544,12 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.nchw0 = nullptr; a.nchw1 = nullptr;
       a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
       a.bf6 = h->bf6 ? 1 : 0;
+      a.img16 = (st.img_off3 && h->bf6) ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: tower2_kernel on the fp32 MFMA
       if (st.has_head) {
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
       }
-      if (!yfv2_launch_tower2(a, s))
+      if (!yfv2_launch_towerh(a, s) && !yfv2_launch_tower2(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S1POOL) {
       BlockS1Args a = st.s1;

@@ -241,6 +241,7 @@ struct TowerArgs {
   int B, H, W;
   long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (or null)
   int bf6;           // pointwise + chained output conv as bf16x6
+  const float* img16;  // towerh_kernel's image (yfv2_towerh.hip), or null: tower2_kernel
 };
 
 // ---- decode (handel_preds) and NMS
@@ -283,6 +284,8 @@ int yfv2_block_s2_rows(int cin, int H, int W);
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s);
 bool yfv2_tower2_supported(int H, int W);                    // whole-image tower kernel: maps up to 22x22
 bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s);
+bool yfv2_towerh_supported(int H, int W);
+bool yfv2_launch_towerh(const TowerArgs& a, hipStream_t s);
 // ---- evaluation statistics (get_batch_statistics): which detections are true positives
 struct StatsArgs {
   const float* dets;     // (B, 300, 6) x1,y1,x2,y2,conf,cls rows of yfv2_nms / yfv2_detect

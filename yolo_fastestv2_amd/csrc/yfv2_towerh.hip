@@ -1,0 +1,390 @@
+// yfv2_towerh.hip - the FPN towers (model/fpn.py:12-25 DWConvblock, behaviour only) and the output convs they feed
+// (model/detector.py:25-31), round 3's replacement of tower2_kernel (yfv2_block.hip; kept for YFV2_BF6=0 and for maps
+// this kernel's lane grid does not cover).
+//
+// One launch = one half of a DWConvblock: dw5x5 (pad 2) + BN + ReLU -> pw 72->72 + BN [-> biased output conv, NCHW].
+// One workgroup of eight waves per image, the image's 72 channels walked in five chunks of 16 (four channel quads).
+//
+// What was wrong with tower2_kernel (per-wave stamps): its depthwise read every tap of every output from
+// LDS - lane = (pixel of a 16-pixel MFMA tile, channel quad), 25 window reads + 25/NT filter reads of 16 bytes per output:
+// 125 ds_read_b128 per wave and chunk, the LDS port busy 6.8 k of a 10.4 k-cycle chunk period at 22x22, and its pointwise
+// split both operands into three bf16 terms at run time (six MFMAs per product, ~30 VALU per filter fragment).  Here:
+//   * depthwise phase: a wave = ONE channel quad x half of the image, a lane = a 2x2 patch of pixels (one pixel at
+//     11x11).  The lane reads its 6x6 window once (36 reads for four outputs instead of 100) and the 25 taps + BN constants
+//     of the quad are wave-uniform: scalar loads, SGPR operands of the packed FMAs - no filter traffic on the LDS port at
+//     all (the table is pulled into the scalar cache in the prologue, each tap row requested one window row ahead).  The
+//     staged input slice is kept as [quad][row parity][row / 2][column parity: slots 0.. / 14..][column / 2] with a row
+//     pitch of 27 16-byte slots, so that the 64 lanes of a read hit consecutive slots of ONE parity plane (patch-row
+//     pitch 27 = 11 mod 16: the four 16-lane groups ds_read_b128 is serviced in are conflict-free for 11 patches per row).
+//   * exchange: the BN'd, ReLU'd result is split ONCE into two fp16 terms (x16 first: fp16's absolute floor) and written
+//     as one 16-byte slot {h1 x4, h2 x4} per (pixel, quad) - which is exactly the B operand (K = 4g..4g+3) of
+//     v_mfma_f32_16x16x16_f16 for lane (pixel, g): one ds_read_b128 per pixel tile and chunk in the pointwise phase.
+//   * pointwise phase: fp16x3 (yfv2_stem16.hip / yfv2_stage2h.hip): filters pre-split on the host into two fp16 terms
+//     (scaled by 2^sw, largest entry near 2^14), the three products w1 x2 + w2 x1 + w1 x1 in 1.5 K=32 MFMAs per 16-channel
+//     chunk (cross terms of a chunk in one instruction, main terms of two chunks in another), fp32 accumulators of a
+//     wave's NT pixel tiles x five output-channel tiles live in registers across the chunks.  The scales are undone exactly
+//     inside the BN scale.  Valid for |activation| < 4094 (as every fp16x3 kernel of the plan).
+//   * chained output conv: the BN'd accumulator tile s IS the B fragment of chunk s (D layout = B layout at K = 16); split
+//     in place.  Its result leaves through LDS: one 16-channel tile [16][H*W] at a time in the (now idle) exchange buffer,
+//     which is a contiguous piece of the NCHW logit tensor - written by all threads as 16-byte (H*W % 4 == 0) or dword
+//     runs instead of 64-byte fragments per (lane group, channel): the scattered form cost 33 k of the 84 k cycles of the
+//     22x22 obj+cls launch.
+// Two barriers per chunk (input slice ready / exchange ready); the next chunk's slice is in flight in registers during
+// the pointwise phase, the next image's first slice during the last chunk.
+#include "yfv2_internal.h"
+#include <atomic>
+
+typedef _Float16 yfv2_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 yfv2_h8 __attribute__((ext_vector_type(8)));
+typedef unsigned yfv2_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) const f32x4 yfv2_cf4;   // constant address space: uniform loads become s_load
+
+#define YFV2_WSTAMP(i) do { if (a.trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.trace[64 + 32 * (threadIdx.x >> 6) + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+
+namespace {
+
+// f32x4 -> {h1.lo, h1.hi, h2.lo, h2.hi}: two fp16 terms per element, h1 + h2 = v to 2^-24 relative (v already carries 2^4)
+__device__ __forceinline__ u32x4 split4(f32x4 v) {
+  const yfv2_h4 t1 = __builtin_convertvector(v, yfv2_h4);                       // v_cvt_pk_f16_f32 (RN)
+  const f32x4 r = v - __builtin_convertvector(t1, f32x4);                       // exact
+  const yfv2_h4 t2 = __builtin_convertvector(r, yfv2_h4);
+  const yfv2_u2 a = __builtin_bit_cast(yfv2_u2, t1), b = __builtin_bit_cast(yfv2_u2, t2);
+  return (u32x4){a[0], a[1], b[0], b[1]};
+}
+// One 16-byte entry = {first fp16 term x4, second term x4} of four consecutive K positions.  v_mfma_f32_16x16x32_f16 gives a
+// lane 8 K slots: with the filter entry {w1, w2} as A and the data entry swapped to {x2, x1} as B, ONE instruction adds the
+// two cross products w1 x2 + w2 x1 of a 16-channel chunk; the main products w1 x1 of TWO chunks share another one.
+__device__ __forceinline__ yfv2_h8 pack8(unsigned a0, unsigned a1, unsigned b0, unsigned b1) { return __builtin_bit_cast(yfv2_h8, (u32x4){a0, a1, b0, b1}); }
+__device__ __forceinline__ f32x4 mfma_cross(u32x4 w, u32x4 x, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(w[0], w[1], w[2], w[3]), pack8(x[2], x[3], x[0], x[1]), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_main2(u32x4 wa, u32x4 wb, yfv2_u2 xa, u32x4 xb, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(wa[0], wa[1], wb[0], wb[1]), pack8(xa[0], xa[1], xb[0], xb[1]), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_main1(u32x4 w, u32x4 x, f32x4 acc) {    // the odd chunk out: upper K half of A = 0 (B's is finite)
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(w[0], w[1], 0u, 0u), pack8(x[0], x[1], x[0], x[1]), acc, 0, 0, 0);
+}
+
+}  // namespace
+
+// image (floats), packed by WeightPacker::image_towerh (yfv2_api.hip):
+//   WP   [mt 5][s 5][64 lanes][4 dwords]   pointwise filter x 2^sw: dwords 0,1 = first fp16 term of W[16mt + l%16][16s + 4(l/16) .. +3], 2,3 = second
+//   CS   [4][96]                           pw BN scale x 2^-(sw+4) | pw BN shift | output-conv bias | [0] = 2^-(swh+4)
+//   WH   [m MH][s 5][64][4]                output conv x 2^swh, as WP
+//   ---- the part above is copied to LDS ----
+//   TAPS [s 5][quad 4][27][4]              depthwise taps t = ky*5 + kx of channels 16s + 4q .. +3, then BN scale x 16, BN shift x 16 (zeros past channel 71); 16 floats of padding
+constexpr int TH_KC = 5, TH_C = 72;
+constexpr int TH_CS = TH_KC * TH_KC * 256;
+constexpr int TH_WH = TH_CS + 4 * 96;
+__host__ __device__ constexpr int th_lds_img(int MH) { return TH_WH + MH * TH_KC * 256; }   // = offset of TAPS
+constexpr int TH_Q = 27;   // parity-plane row pitch (16-byte slots)
+
+constexpr int TH_XOFF = 14;   // the odd-column plane of a row starts here (13 of the 27 slots of a row are used by each parity)
+
+template <int PS> struct ThGeom {
+  static constexpr int YH = PS == 2 ? 13 : 16;                // plane rows: (H + 4) / PS rounded up (H <= 22 / H <= 11)
+  static constexpr int SP = (YH * TH_Q + 15) & ~15;           // (quad, row parity) plane size (slots)
+  static constexpr int TIN_SLOTS = 4 * PS * SP;
+};
+
+template <int MH, int PS, int NT>
+__global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
+  constexpr int KC = TH_KC, C = TH_C, WS = PS + 4, NPAR = PS * PS, Q = TH_Q, SP = ThGeom<PS>::SP, XOFF = TH_XOFF;
+  constexpr int XP = 16 * NT * 8;                              // exchange slots per quad
+  constexpr int NPF = NT;                                      // staged 16-byte pieces per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* WP_ = lds;
+  float* CS = lds + TH_CS;
+  float* WH = lds + TH_WH;
+  float* XB = lds + th_lds_img(MH);
+  float* TIN = XB + 4 * XP * 4;
+  const int H = a.H, W = a.W, HW = H * W;
+  const float invW = 1.0f / (float)W;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grid = gridDim.x;
+  YFV2_WSTAMP(0);
+
+  // ---- staging map: piece i of a chunk -> (pixel, quad): eight consecutive lanes = eight consecutive pixels of one quad, the
+  // next three 8-lane groups the other quads of the same pixels (a wave reads whole 64-byte channel runs)
+  int s_src[NPF], s_dst[NPF];                                  // s_dst < 0: no such pixel
+  const int my_c4 = (tid >> 3) & 3;
+#pragma unroll
+  for (int j = 0; j < NPF; ++j) {
+    const int i = tid + j * 512;
+    const int px = (i & 7) + 8 * (i >> 5);
+    const bool ok = px < HW;
+    const int y = ok ? yfv2_fdiv(px, invW) : 0, x = ok ? px - y * W : 0;
+    const int yy = y + 2, xx = x + 2;
+    s_src[j] = ok ? px * C : 0;                                // (a pixel that does not exist loads pixel 0 and stores nothing)
+    s_dst[j] = ok ? (((my_c4 * PS + (yy % PS)) * SP + (yy / PS) * Q + (xx % PS) * XOFF + xx / PS) * 4) : -1;
+  }
+  // straight-line loads (no branch, no select between issue and use: a conditional load makes the compiler wait for it
+  // on the spot).  Channels past 71 (quads 2, 3 of the last chunk) load channel 0 and are zeroed when stored.
+  auto stage_load = [&](int bb, int sl, f32x4 (&pre)[NPF]) {
+    const int ch = 16 * sl + 4 * my_c4;
+    const float* img = a.in + (size_t)bb * HW * C + (ch < C ? ch : 0);
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) pre[j] = *reinterpret_cast<const f32x4*>(img + s_src[j]);
+  };
+  auto stage_store = [&](int sl, const f32x4 (&pre)[NPF]) {
+    const bool live = 16 * sl + 4 * my_c4 < C;
+#pragma unroll
+    for (int j = 0; j < NPF; ++j)
+      if (s_dst[j] >= 0) *reinterpret_cast<f32x4*>(TIN + s_dst[j]) = live ? pre[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  int b = blockIdx.x;
+  f32x4 pre[NPF];
+  stage_load(b < a.B ? b : 0, 0, pre);                         // the first slice flies during the prologue
+  const int qq = wv >> 1, hh = wv & 1;                         // depthwise role: quad qq of the chunk, half hh of the patches
+
+  // ---- prologue: filters + constants -> LDS (one straight 16-byte copy), planes and exchange zeroed (the halo stays zero)
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.img16);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    constexpr int N4 = th_lds_img(MH) / 4, NIT = (N4 + 511) / 512;
+    f32x4 tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
+    // the tap table of this wave's five quads -> scalar cache while those loads fly: one request per 64-byte line, all
+    // issued back to back (as C++ loads the compiler serialises them in groups of eight, a trip to L2 / HBM each)
+    {
+      const float* tq = a.img16 + th_lds_img(MH) + qq * 108;
+#define YFV2_L(o) "s_load_dword s40, %0, " #o "\n\t"
+#define YFV2_B(o) YFV2_L(o + 0) YFV2_L(o + 64) YFV2_L(o + 128) YFV2_L(o + 192) YFV2_L(o + 256) YFV2_L(o + 320) YFV2_L(o + 384)
+      asm volatile(YFV2_B(0) YFV2_B(1728) YFV2_B(3456) YFV2_B(5184) YFV2_B(6912) "s_waitcnt lgkmcnt(0)" ::"s"(tq) : "s40", "memory");
+#undef YFV2_B
+#undef YFV2_L
+    }
+    constexpr int NZ = 4 * XP + ThGeom<PS>::TIN_SLOTS;
+    for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; if (i < N4) dst[i] = tmp[k]; }
+  }
+  __syncthreads();
+  YFV2_WSTAMP(1);
+  if (b < a.B) {
+    stage_store(0, pre);
+    stage_load(b, 1, pre);
+  }
+
+  // ---- depthwise role: lane -> patch (py, pxx)
+  const int PWn = (W + PS - 1) / PS, PHn = (H + PS - 1) / PS;
+  const int pid = 64 * hh + lane;
+  const bool pvalid = pid < PWn * PHn;
+  const int pidc = pvalid ? pid : 0;
+  const int py = yfv2_fdiv(pidc, 1.0f / (float)PWn), pxx = pidc - py * PWn;
+  const float* win = TIN + ((qq * PS) * SP + py * Q + pxx) * 4;             // window (r, c): + ((r % PS) * SP + (r / PS) * Q + (c % PS) * XOFF + c / PS) * 4
+  int xdst[NPAR];                                                           // exchange slot of the patch's pixels (float offset), -1 = outside
+#pragma unroll
+  for (int k = 0; k < NPAR; ++k) {
+    const int y = PS * py + k / PS, x = PS * pxx + k % PS;
+    xdst[k] = (pvalid && y < H && x < W) ? (qq * XP + y * W + x) * 4 : -1;
+  }
+  // ---- pointwise role: NT pixel tiles of 16
+  int opix[NT];
+  bool pv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int q = 16 * (wv * NT + nt) + p;
+    pv[nt] = q < HW;
+    opix[nt] = q;                                                           // < XP always: pixels past HW read the zeroed exchange tail
+  }
+  const yfv2_cf4* taps = (const yfv2_cf4*)(a.img16 + th_lds_img(MH));
+
+  for (; b < a.B; b += grid) {
+    f32x4 acc[KC][NT];
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    yfv2_u2 xprev[NT];                                                     // first terms of the even chunk, for the pair's main-product MFMA
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xprev[nt] = (yfv2_u2){0u, 0u};
+#pragma unroll 1
+    for (int s = 0; s < KC; ++s) {
+      const bool dw_on = 4 * s + qq < C / 4;
+      const yfv2_cf4* tp = taps + (dw_on ? s * 4 + qq : 0) * 27;
+      f32x4 wt[3][5];                                                       // tap rows ky % 3 (wave-uniform: SGPRs)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) wt[0][kx] = tp[kx];                    // requested before the barrier
+      __syncthreads();                                                      // slice s complete in TIN; exchange free
+      YFV2_WSTAMP(2 + 3 * s);
+      if (dw_on) {
+        f32x4 d[PS][PS];
+#pragma unroll
+        for (int k = 0; k < NPAR; ++k) d[k / PS][k % PS] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // two window rows and three tap rows in flight (left alone the scheduler hoists all 36 reads - 144 registers on top
+        // of the 80 accumulators - and all 27 scalar loads - more SGPRs than there are)
+        f32x4 row[2][WS];
+        auto load_row = [&](int r, f32x4 (&dst)[WS]) {
+#pragma unroll
+          for (int c = 0; c < WS; ++c) dst[c] = *reinterpret_cast<const f32x4*>(win + ((r % PS) * SP + (r / PS) * Q + (c % PS) * XOFF + c / PS) * 4);
+        };
+        load_row(0, row[0]);
+#pragma unroll
+        for (int r = 0; r < WS; ++r) {
+          if (r + 1 < WS) load_row(r + 1, row[(r + 1) & 1]);
+          if (r + 1 < 5) {
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) wt[(r + 1) % 3][kx] = tp[(r + 1) * 5 + kx];
+          }
+#pragma unroll
+          for (int dy = 0; dy < PS; ++dy) {
+            const int ky = r - dy;
+            if (ky < 0 || ky >= 5) continue;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+              for (int dx = 0; dx < PS; ++dx) d[dy][dx] = __builtin_elementwise_fma(row[r & 1][dx + kx], wt[ky % 3][kx], d[dy][dx]);
+          }
+          // pins this row's FMAs here (the DAG scheduler otherwise sinks all of them below all the reads)
+          if constexpr (PS == 2) asm volatile("" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) :: "memory");
+          else asm volatile("" : "+v"(d[0][0]) :: "memory");
+        }
+        const f32x4 sc = tp[25], sh = tp[26];
+#pragma unroll
+        for (int k = 0; k < NPAR; ++k) {
+          f32x4 u = __builtin_elementwise_fma(d[k / PS][k % PS], sc, sh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = u[e] > 0.f ? u[e] : 0.f;                    // (the BN constants carry the 2^4)
+          if (xdst[k] >= 0) *reinterpret_cast<u32x4*>(XB + xdst[k]) = split4(u);
+        }
+      }
+      __syncthreads();                                                      // exchange complete; TIN free
+      YFV2_WSTAMP(3 + 3 * s);
+      u32x4 xb[NT];                                                         // (requested before the staging traffic below)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(XB + (g * XP + opix[nt]) * 4);
+      // the next slice -> TIN, the one after into registers (of the next image after the last chunk)
+      if (s + 1 < KC || b + grid < a.B) stage_store(s + 1 < KC ? s + 1 : 0, pre);
+      {
+        int ns = s + 2, nb = b;
+        if (ns >= KC) { ns -= KC; nb += grid; }
+        stage_load(nb < a.B ? nb : b, ns, pre);
+      }
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const u32x4 wf = *reinterpret_cast<const u32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_cross(wf, xb[nt], acc[mt][nt]);
+        if (s & 1) {
+          const u32x4 w0 = *reinterpret_cast<const u32x4*>(WP_ + ((mt * KC + s - 1) * 64 + lane) * 4);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_main2(w0, wf, xprev[nt], xb[nt], acc[mt][nt]);
+        } else if (s == KC - 1) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_main1(wf, xb[nt], acc[mt][nt]);
+        }
+      }
+      if (!(s & 1)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xprev[nt] = (yfv2_u2){xb[nt][0], xb[nt][1]};
+      }
+      YFV2_WSTAMP(4 + 3 * s);
+    }
+    // pointwise BN (no ReLU: fpn.py:16-17,23-24); the scale carries 2^-(sw+4)
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + 16 * mt + 4 * g);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
+    }
+    YFV2_WSTAMP(17);
+    if constexpr (MH == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (!pv[nt]) continue;
+        float* dst = a.out + ((size_t)b * HW + opix[nt]) * C;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt)
+          if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
+      }
+    } else {
+      // chained output conv: tile s of the BN'd accumulators = B fragment of chunk s; split in place
+      u32x4 xs[KC][NT];
+#pragma unroll
+      for (int s = 0; s < KC; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xs[s][nt] = split4(acc[s][nt] * 16.0f);
+      const float us = CS[3 * 96];
+      float* OT = XB;                                                       // [16 channels][H*W] floats (16 * XP >= 16 * H*W)
+      __syncthreads();                                                      // every wave is done reading the exchange buffer
+#pragma unroll 1
+      for (int m = 0; m < MH; ++m) {
+        const int c0 = 16 * m, c1 = c0 + 16 < a.mh ? c0 + 16 : a.mh;
+        if (c0 >= a.mh) break;
+        u32x4 wf[KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) wf[s] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
+        f32x4 hacc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_cross(wf[s], xs[s][nt], hacc[nt]);
+#pragma unroll
+        for (int s = 0; s + 1 < KC; s += 2)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main2(wf[s], wf[s + 1], (yfv2_u2){xs[s][nt][0], xs[s][nt][1]}, xs[s + 1][nt], hacc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main1(wf[KC - 1], xs[KC - 1][nt], hacc[nt]);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 2 * 96 + c0 + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (!pv[nt]) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) OT[(4 * g + r) * HW + opix[nt]] = __builtin_fmaf(hacc[nt][r], us, bias[r]);
+        }
+        __syncthreads();
+        // channels [c0, c1): those below a.split are a run of nchw0, the rest a run of nchw1
+        const int cs = c0 > a.split ? c0 : (c1 < a.split ? c1 : a.split);   // first channel of the tile that belongs to nchw1
+        auto put = [&](float* dst, const float* src, int n) {
+          if ((HW & 3) == 0) {
+            for (int i = 4 * tid; i < n; i += 2048) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+          } else {
+            for (int i = tid; i < n; i += 512) dst[i] = src[i];
+          }
+        };
+        if (cs > c0) put(a.nchw0 + ((size_t)b * a.split + c0) * HW, OT, (cs - c0) * HW);
+        if (c1 > cs) put(a.nchw1 + ((size_t)b * (a.mh - a.split) + (cs - a.split)) * HW, OT + (cs - c0) * HW, (c1 - cs) * HW);
+        __syncthreads();
+      }
+    }
+    YFV2_WSTAMP(18);
+  }
+}
+
+template <int MH, int PS, int NT>
+static void launch_towerh(const TowerArgs& a, hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + 4 * (4 * 16 * NT * 8 + ThGeom<PS>::TIN_SLOTS));
+  static std::atomic<unsigned long long> lds_ok{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerh_kernel<MH, PS, NT>), lds_ok);
+  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT>), dim3(a.B < 256 ? a.B : 256), dim3(512), lds, s, a);
+}
+
+// 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
+bool yfv2_towerh_supported(int H, int W) {
+  if (H < 1 || W < 1) return false;
+  if (H <= 11 && W <= 11) return true;
+  return H <= 22 && W <= 22 && ((H + 1) / 2) * ((W + 1) / 2) <= 128;
+}
+
+bool yfv2_launch_towerh(const TowerArgs& a, hipStream_t s) {
+  if (!a.img16 || !yfv2_towerh_supported(a.H, a.W)) return false;
+  const int mh_tiles = a.has_head ? (a.mh + 15) / 16 : 0;
+  if (mh_tiles > 6) return false;
+  if (a.H <= 11 && a.W <= 11) {
+    if (mh_tiles == 0) launch_towerh<0, 1, 1>(a, s);
+    else if (mh_tiles == 1) launch_towerh<1, 1, 1>(a, s);
+    else launch_towerh<6, 1, 1>(a, s);
+  } else {
+    if (mh_tiles == 0) launch_towerh<0, 2, 4>(a, s);
+    else if (mh_tiles == 1) launch_towerh<1, 2, 4>(a, s);
+    else launch_towerh<6, 2, 4>(a, s);
+  }
+  return true;
+}
