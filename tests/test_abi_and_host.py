@@ -415,13 +415,13 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
         blobs = set()
         for H, W in sizes:
             rc, steps, blob, _ = _dryrun(classes, H, W)
-            assert rc == 0 and steps >= 15 and blob > 400000, (classes, H, W, rc, steps, blob)
+            assert rc == 0 and steps >= 13 and blob > 400000, (classes, H, W, rc, steps, blob)
             blobs.add(blob)
-        assert len(blobs) <= 4      # the packed blob depends on which kernels a size selects, not on the size itself
+        assert len(blobs) <= 6      # the packed blob depends on which kernels a size selects, not on the size itself
     # the two alternative plans (layer by layer: 77 launches; every pointwise conv on the fp32 MFMA: the stage-3 chain and
     # stage4.0, which exist only as bf16x6 kernels, then run layer by layer) are planned and packed by the same code
     import os
-    assert _dryrun(80, 352, 352)[1] == 19
+    assert _dryrun(80, 352, 352)[1] == 16      # eleven backbone + FPN launches, one launch for the four 11x11 tower halves, four at 22x22
     for var, steps_min in (("YFV2_FUSED", 70), ("YFV2_BF6", 40)):
         os.environ[var] = "0"
         try:

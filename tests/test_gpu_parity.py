@@ -531,7 +531,7 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     elif "YFV2_BF6" in env:
         assert not any("chain of 7" in n for n in names) and any("resident in LDS" in n for n in names), names
     else:
-        assert len(names) == 19
+        assert len(names) == 16
         eng.set_anchors([12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87])
         r1, i1 = yfv2.unpack_detections(*eng.detect(x.to(dev), 0.3, 0.4))                 # decode_kernel<compact> + nms_kernel<1>
         r2, i2 = yfv2.unpack_detections(*eng.nms(eng.decode(eng.forward(x.to(dev))), 0.3, 0.4))

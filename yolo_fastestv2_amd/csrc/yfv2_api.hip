@@ -51,6 +51,8 @@ struct Step {
   std::string name;
   double flops = 0, bytes = 0;  // algorithmic, per image; bytes = per-LAYER accounting (every reference layer the launch covers reads its input and writes its output once)
   double bytes_ext = -1;        // SURVEY.md 8(d) for fused launches: EXTERNAL reads + writes of the launch only (-1: same as bytes)
+  std::vector<Step> jobs;       // STEP_TOWER on towerh_kernel: the tower halves this ONE launch runs one after the other (empty: the step is its own job)
+  int tw_tiles = 0;             // STEP_TOWER on towerh_kernel: output-conv tiles the images of the launch are packed for (0, 1 or 6)
 };
 
 struct Buf { float* p = nullptr; size_t per_img = 0; };
@@ -389,21 +391,20 @@ struct WeightPacker {
           for (int d = 0; d < 4; ++d) { float fb; std::memcpy(&fb, &dw[d], 4); im.push_back(fb); }
         }
   }
-  size_t image_towerh(const Folded& fd, const Folded& fp, const Folded* fh, int mh) {
+  size_t image_towerh(const Folded& fd, const Folded& fp, const Folded* fh, int mh, int mh_tiles) {
     std::vector<float> im;
     const float* wpw = &blob[fp.w];
     float mp = 0.f, mhd = 0.f;
     for (int i = 0; i < 72 * 72; ++i) mp = std::fmax(mp, std::fabs(wpw[i]));
     const int sw = pow2_for(mp);
     push_a16(im, [&](int r, int c) { return (r < 72 && c < 72) ? std::ldexp(wpw[(size_t)r * 72 + c], sw) : 0.f; }, 5);
-    const int mh_tiles = fh ? ((mh + 15) / 16 <= 1 ? 1 : 6) : 0;
     int swh = 0;
     if (fh) { for (int i = 0; i < mh * 72; ++i) mhd = std::fmax(mhd, std::fabs(blob[fh->w + i])); swh = pow2_for(mhd); }
     for (int c = 0; c < 96; ++c) im.push_back(c < 72 ? std::ldexp(blob[fp.scale + c], -(sw + 4)) : 0.f);
     push_vec(im, &blob[fp.shift], 72, 96);
     push_vec(im, fh ? &blob[fh->shift] : nullptr, mh, 96);
     for (int c = 0; c < 96; ++c) im.push_back(c == 0 ? std::ldexp(1.0f, -(swh + 4)) : 0.f);
-    if (fh) push_a16(im, [&](int r, int c) { return (r < mh && c < 72) ? std::ldexp(blob[fh->w + (size_t)r * 72 + c], swh) : 0.f; }, mh_tiles);
+    push_a16(im, [&](int r, int c) { return (fh && r < mh && c < 72) ? std::ldexp(blob[fh->w + (size_t)r * 72 + c], swh) : 0.f; }, mh_tiles);   // zero tiles where a job has no (or a narrower) output conv: one LDS layout per launch
     for (int s = 0; s < 5; ++s)
       for (int q = 0; q < 4; ++q)
         for (int t = 0; t < 27; ++t)
@@ -1301,7 +1302,10 @@ struct PlanBuilder {
     s.tw.H = H; s.tw.W = W;
     s.tw.mh = mh; s.tw.split = split;
     s.img_off = wp.image_tower(fd, fp, fh, mh);
-    if (yfv2_towerh_supported(H, W)) s.img_off3 = wp.image_towerh(fd, fp, fh, mh);
+    // one LDS layout per launch: where the four halves of a map size share a launch (merge_tower_launches) every image is
+    // packed for the widest output conv of the level (obj + cls), else for the step's own
+    s.tw_tiles = yfv2_towerh_multi(H, W) ? ((h->cfg.anchor_num + h->cfg.classes + 15) / 16 <= 1 ? 1 : 6) : (fh ? ((mh + 15) / 16 <= 1 ? 1 : 6) : 0);
+    if (yfv2_towerh_supported(H, W)) s.img_off3 = wp.image_towerh(fd, fp, fh, mh, s.tw_tiles);
     s.has_head = fh != nullptr;
     s.head0 = head0; s.head1 = head1;
     s.name = name;
@@ -1359,6 +1363,37 @@ struct PlanBuilder {
       s.head0 = scale_idx * 3 + 0;
       s.head1 = -1;
     }
+  }
+
+  // towerh_kernel's single-pixel form (maps up to 11x11) runs the four tower halves of a map size in ONE launch (each
+  // workgroup: cls a, cls b, reg a, reg b of its image, in the order the separate launches had): runs of four consecutive
+  // such steps become one step.
+  void merge_tower_launches() {
+    { const char* env = std::getenv("YFV2_TOWERMERGE"); if (env && env[0] == '0') return; }   // debugging aid
+    std::vector<Step> out;
+    for (size_t i = 0; i < h->plan.size();) {
+      auto mergeable = [&](const Step& t) { return t.kind == STEP_TOWER && t.img_off3 != 0 && yfv2_towerh_multi(t.tw.H, t.tw.W) && t.tw.H == h->plan[i].tw.H && t.tw.W == h->plan[i].tw.W; };
+      size_t n = 0;
+      while (i + n < h->plan.size() && n < 4 && mergeable(h->plan[i + n])) ++n;
+      if (n == 4) {
+        Step m = h->plan[i];
+        m.jobs.assign(h->plan.begin() + i, h->plan.begin() + i + 4);
+        m.name = "fpn towers " + std::to_string(m.tw.H) + "x" + std::to_string(m.tw.W) + ": cls_head (dw5+bn+relu -> pw+bn, twice) -> output_obj+output_cls | reg_head -> output_reg, four jobs in one launch";
+        m.flops = 0; m.bytes = 0;
+        double ext = 0;
+        for (const Step& j : m.jobs) {
+          m.flops += j.flops; m.bytes += j.bytes;
+          ext += 4.0 * j.tw.H * j.tw.W * (j.has_head ? (double)j.tw.mh : 72.0);   // half a reads the FPN map, half b writes logits; the 72-channel tensor between them is the launch's own scratch
+        }
+        m.bytes_ext = ext;
+        out.push_back(m);
+        i += 4;
+      } else {
+        out.push_back(h->plan[i]);
+        ++i;
+      }
+    }
+    h->plan.swap(out);
   }
 
   void build() {
@@ -1452,6 +1487,7 @@ struct PlanBuilder {
     tower("fpn.reg_head_3.block", h3, w3, h->f3, false, 1);
     tower("fpn.cls_head_2.block", h2, w2, h->f2, true, 0);
     tower("fpn.reg_head_2.block", h2, w2, h->f2, false, 0);
+    merge_tower_launches();
   }
 };
 
@@ -1462,7 +1498,7 @@ std::string step_kernel(const Step& st) {
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
-      if (st.img_off3) return "towerh_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");   // default plan
+      if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4, 1>" : (st.jobs.empty() ? "1, 1, 1>" : "1, 1, 4>"));   // default plan
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
@@ -1537,20 +1573,34 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       else if (!yfv2_launch_block_s2(st.c2, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no fused stride-2 kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_TOWER) {
-      TowerArgs a = st.tw;
-      a.B = B;
-      a.img = params + st.img_off;
-      a.has_head = st.has_head ? 1 : 0;
-      a.nchw0 = nullptr; a.nchw1 = nullptr;
-      a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
-      a.bf6 = h->bf6 ? 1 : 0;
-      a.img16 = (st.img_off3 && h->bf6) ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: tower2_kernel on the fp32 MFMA
-      if (st.has_head) {
-        a.nchw0 = out6[st.head0];
-        a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
+      auto args_of = [&](const Step& t) {
+        TowerArgs a = t.tw;
+        a.B = B;
+        a.img = params + t.img_off;
+        a.has_head = t.has_head ? 1 : 0;
+        a.nchw0 = nullptr; a.nchw1 = nullptr;
+        a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
+        a.bf6 = h->bf6 ? 1 : 0;
+        a.img16 = (t.img_off3 && h->bf6) ? params + t.img_off3 : nullptr;   // YFV2_BF6=0: tower2_kernel on the fp32 MFMA
+        if (t.has_head) {
+          a.nchw0 = out6[t.head0];
+          a.nchw1 = t.head1 >= 0 ? out6[t.head1] : nullptr;
+        }
+        return a;
+      };
+      bool done = false;
+      if (st.img_off3 && h->bf6) {
+        TowerJobs jobs{};
+        if (st.jobs.empty()) { jobs.j[0] = args_of(st); jobs.n = 1; }
+        else { jobs.n = (int)st.jobs.size(); for (int k = 0; k < jobs.n; ++k) jobs.j[k] = args_of(st.jobs[k]); }
+        done = yfv2_launch_towerh(jobs, st.tw_tiles, s);
       }
-      if (!yfv2_launch_towerh(a, s) && !yfv2_launch_tower2(a, s))
-        return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
+      if (!done) {   // tower2_kernel, one launch per half
+        const size_t nj = st.jobs.empty() ? 1 : st.jobs.size();
+        for (size_t k = 0; k < nj; ++k)
+          if (!yfv2_launch_tower2(args_of(st.jobs.empty() ? st : st.jobs[k]), s))
+            return fail(h, YFV2_ERR_CONFIG, "no tower kernel for step '" + st.name + "'");
+      }
     } else if (st.kind == STEP_S1POOL) {
       BlockS1Args a = st.s1;
       a.B = B;

@@ -285,7 +285,9 @@ bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s);
 bool yfv2_tower2_supported(int H, int W);                    // whole-image tower kernel: maps up to 22x22
 bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s);
 bool yfv2_towerh_supported(int H, int W);
-bool yfv2_launch_towerh(const TowerArgs& a, hipStream_t s);
+bool yfv2_towerh_multi(int H, int W);
+struct TowerJobs { TowerArgs j[4]; int n; };   // towerh_kernel: up to four tower halves of one map size, run one after the other by every workgroup
+bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s);
 // ---- evaluation statistics (get_batch_statistics): which detections are true positives
 struct StatsArgs {
   const float* dets;     // (B, 300, 6) x1,y1,x2,y2,conf,cls rows of yfv2_nms / yfv2_detect

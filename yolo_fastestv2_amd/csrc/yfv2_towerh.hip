@@ -24,11 +24,11 @@
 //     chunk (cross terms of a chunk in one instruction, main terms of two chunks in another), fp32 accumulators of a
 //     wave's NT pixel tiles x five output-channel tiles live in registers across the chunks.  The scales are undone exactly
 //     inside the BN scale.  Valid for |activation| < 4094 (as every fp16x3 kernel of the plan).
-//   * chained output conv: the BN'd accumulator tile s IS the B fragment of chunk s (D layout = B layout at K = 16); split
-//     in place.  Its result leaves through LDS: one 16-channel tile [16][H*W] at a time in the (now idle) exchange buffer,
-//     which is a contiguous piece of the NCHW logit tensor - written by all threads as 16-byte (H*W % 4 == 0) or dword
-//     runs instead of 64-byte fragments per (lane group, channel): the scattered form cost 33 k of the 84 k cycles of the
-//     22x22 obj+cls launch.
+//   * chained output conv: the BN'd accumulator tile s IS the data fragment of chunk s (D layout = operand layout at
+//     K = 16); split in place and used as the A operand - the product is computed TRANSPOSED, so that a lane ends up with
+//     four consecutive pixels of one output channel: 16-byte stores straight into the NCHW logit tensors (dword stores
+//     when H*W % 4 != 0).  tower2_kernel's form (lane = pixel, four channels: dword stores, 64 bytes per channel and
+//     lane group) cost 33 k of the 84 k cycles of the 22x22 obj+cls launch.
 // Two barriers per chunk (input slice ready / exchange ready); the next chunk's slice is in flight in registers during
 // the pointwise phase, the next image's first slice during the last chunk.
 #include "yfv2_internal.h"
@@ -87,8 +87,11 @@ template <int PS> struct ThGeom {
   static constexpr int TIN_SLOTS = 4 * PS * SP;
 };
 
-template <int MH, int PS, int NT>
-__global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
+template <int MH, int PS, int NT, int NJ>
+__global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {
+  constexpr bool MULTI = NJ > 1;                               // several jobs per launch (the 11x11 maps); else exactly jobs.j[0]
+  struct { int B, H, W; long long* trace; } a;                 // geometry, batch and trace buffer are the same for every job
+  a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
   constexpr int KC = TH_KC, C = TH_C, WS = PS + 4, NPAR = PS * PS, Q = TH_Q, SP = ThGeom<PS>::SP, XOFF = TH_XOFF;
   constexpr int XP = 16 * NT * 8;                              // exchange slots per quad
   constexpr int NPF = NT;                                      // staged 16-byte pieces per thread and chunk
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
   }
   // straight-line loads (no branch, no select between issue and use: a conditional load makes the compiler wait for it
   // on the spot).  Channels past 71 (quads 2, 3 of the last chunk) load channel 0 and are zeroed when stored.
-  auto stage_load = [&](int bb, int sl, f32x4 (&pre)[NPF]) {
+  auto stage_load = [&](const float* in, int bb, int sl, f32x4 (&pre)[NPF]) {
     const int ch = 16 * sl + 4 * my_c4;
-    const float* img = a.in + (size_t)bb * HW * C + (ch < C ? ch : 0);
+    const float* img = in + (size_t)bb * HW * C + (ch < C ? ch : 0);
 #pragma unroll
     for (int j = 0; j < NPF; ++j) pre[j] = *reinterpret_cast<const f32x4*>(img + s_src[j]);
   };
@@ -134,41 +137,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
       if (s_dst[j] >= 0) *reinterpret_cast<f32x4*>(TIN + s_dst[j]) = live ? pre[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
   };
 
-  int b = blockIdx.x;
-  f32x4 pre[NPF];
-  stage_load(b < a.B ? b : 0, 0, pre);                         // the first slice flies during the prologue
   const int qq = wv >> 1, hh = wv & 1;                         // depthwise role: quad qq of the chunk, half hh of the patches
-
-  // ---- prologue: filters + constants -> LDS (one straight 16-byte copy), planes and exchange zeroed (the halo stays zero)
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img16);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    constexpr int N4 = th_lds_img(MH) / 4, NIT = (N4 + 511) / 512;
-    f32x4 tmp[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
-    // the tap table of this wave's five quads -> scalar cache while those loads fly: one request per 64-byte line, all
-    // issued back to back (as C++ loads the compiler serialises them in groups of eight, a trip to L2 / HBM each)
-    {
-      const float* tq = a.img16 + th_lds_img(MH) + qq * 108;
-#define YFV2_L(o) "s_load_dword s40, %0, " #o "\n\t"
-#define YFV2_B(o) YFV2_L(o + 0) YFV2_L(o + 64) YFV2_L(o + 128) YFV2_L(o + 192) YFV2_L(o + 256) YFV2_L(o + 320) YFV2_L(o + 384)
-      asm volatile(YFV2_B(0) YFV2_B(1728) YFV2_B(3456) YFV2_B(5184) YFV2_B(6912) "s_waitcnt lgkmcnt(0)" ::"s"(tq) : "s40", "memory");
-#undef YFV2_B
-#undef YFV2_L
-    }
-    constexpr int NZ = 4 * XP + ThGeom<PS>::TIN_SLOTS;
-    for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; if (i < N4) dst[i] = tmp[k]; }
-  }
-  __syncthreads();
-  YFV2_WSTAMP(1);
-  if (b < a.B) {
-    stage_store(0, pre);
-    stage_load(b, 1, pre);
-  }
-
   // ---- depthwise role: lane -> patch (py, pxx)
   const int PWn = (W + PS - 1) / PS, PHn = (H + PS - 1) / PS;
   const int pid = 64 * hh + lane;
@@ -191,7 +160,59 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
     pv[nt] = q < HW;
     opix[nt] = q;                                                           // < XP always: pixels past HW read the zeroed exchange tail
   }
-  const yfv2_cf4* taps = (const yfv2_cf4*)(a.img16 + th_lds_img(MH));
+
+  // ---- the jobs of this launch, one after the other (NJ > 1: the 11x11 maps, where four 15 us launches of 25 k busy cycles
+  // each cost more in launch overhead than the jobs' own serialisation; at 22x22 a job is 60-75 k cycles either way and the
+  // wider kernel - every job on the six-tile LDS layout, both epilogues - spills: separate launches there).  A later job
+  // may read what an earlier one wrote for the SAME image (half b reads half a's output): made visible by the barrier
+  // between jobs (workgroup scope: same CU, same L1, stores waited for).
+#pragma unroll 1
+  for (int ji = 0; ji < (MULTI ? jobs.n : 1); ++ji) {
+  // the job's fields straight from the kernel-argument segment (the jobs are the kernel's only argument: offset 0) by
+  // scalar loads at a dynamic offset.  Indexing jobs.j[ji] makes the compiler copy the array to scratch and turns every
+  // pointer below into a per-lane value (vector loads of the taps: 4x the time); selecting among the four jobs' fields keeps
+  // all 4 x 8 of them in SGPRs (spills).
+  const __attribute__((address_space(4))) TowerArgs& ja = ((const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[MULTI ? ji : 0];
+  const yfv2_cf4* taps = (const yfv2_cf4*)(ja.img16 + th_lds_img(MH));
+  int b = blockIdx.x;
+  f32x4 pre[NPF];
+  stage_load(ja.in, b < a.B ? b : 0, 0, pre);                  // the first slice flies during the job's prologue
+
+  // ---- prologue.  Only what the first depthwise phase needs is waited for here: zeroed planes (the halo stays zero),
+  // slice 0, the tap table in the scalar cache.  The filter image (th_lds_img floats: pointwise + output conv + constants)
+  // is requested now but (11x11 kernels) lands in LDS only after that phase, before its closing barrier: its trip from
+  // L2 / HBM is off the critical path of the job's start.
+  constexpr int N4 = th_lds_img(MH) / 4, NIT = (N4 + 511) / 512;
+  f32x4 tmp[NIT];
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(ja.img16);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
+    constexpr int NZ = 4 * XP + ThGeom<PS>::TIN_SLOTS;
+    if (!MULTI || ji == 0)
+      for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the tap table of this wave's five quads -> scalar cache: one request per 64-byte line, all issued back to back (as C++
+    // loads the compiler serialises them in groups of eight, a trip to L2 / HBM each)
+    const float* tq = ja.img16 + th_lds_img(MH) + qq * 108;
+#define YFV2_L(o) "s_load_dword s40, %0, " #o "\n\t"
+#define YFV2_B(o) YFV2_L(o + 0) YFV2_L(o + 64) YFV2_L(o + 128) YFV2_L(o + 192) YFV2_L(o + 256) YFV2_L(o + 320) YFV2_L(o + 384)
+    asm volatile(YFV2_B(0) YFV2_B(1728) YFV2_B(3456) YFV2_B(5184) YFV2_B(6912) "s_waitcnt lgkmcnt(0)" ::"s"(tq) : "s40", "memory");
+#undef YFV2_B
+#undef YFV2_L
+  }
+  constexpr bool DEFER = PS == 1;                              // (the 2x2-patch kernels have no registers to keep the image in flight)
+  bool image_pending = DEFER;
+  if constexpr (!DEFER) {
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; if (i < N4) dst[i] = tmp[k]; }
+  }
+  __syncthreads();                                             // (the zeroing and the slice store below touch the same cells; the previous job is done with LDS)
+  YFV2_WSTAMP(1);
+  if (b < a.B) {
+    stage_store(0, pre);
+    stage_load(ja.in, b, 1, pre);
+  }
 
   for (; b < a.B; b += grid) {
     f32x4 acc[KC][NT];
@@ -252,6 +273,12 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
           if (xdst[k] >= 0) *reinterpret_cast<u32x4*>(XB + xdst[k]) = split4(u);
         }
       }
+      if (DEFER && image_pending) {                                         // first chunk of the job's first image only
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; if (i < N4) dst[i] = tmp[k]; }
+        image_pending = false;
+      }
       __syncthreads();                                                      // exchange complete; TIN free
       YFV2_WSTAMP(3 + 3 * s);
       u32x4 xb[NT];                                                         // (requested before the staging traffic below)
@@ -262,7 +289,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
       {
         int ns = s + 2, nb = b;
         if (ns >= KC) { ns -= KC; nb += grid; }
-        stage_load(nb < a.B ? nb : b, ns, pre);
+        stage_load(ja.in, nb < a.B ? nb : b, ns, pre);
       }
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
@@ -293,11 +320,11 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
     }
     YFV2_WSTAMP(17);
-    if constexpr (MH == 0) {
+    if (MH == 0 || (MULTI && !ja.has_head)) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if (!pv[nt]) continue;
-        float* dst = a.out + ((size_t)b * HW + opix[nt]) * C;
+        float* dst = ja.out + ((size_t)b * HW + opix[nt]) * C;
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt)
           if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
@@ -310,12 +337,13 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) xs[s][nt] = split4(acc[s][nt] * 16.0f);
       const float us = CS[3 * 96];
-      float* OT = XB;                                                       // [16 channels][H*W] floats (16 * XP >= 16 * H*W)
-      __syncthreads();                                                      // every wave is done reading the exchange buffer
+      // TRANSPOSED product: the data entries as A (rows = the tile's 16 pixels), the filter entries as B (columns = 16 output
+      // channels) - both operands have the same lane layout, so this is the same registers with the arguments swapped - and
+      // lane (c = lane & 15, g) ends up with pixels 4g..4g+3 of the tile for ONE channel: a 16-byte run of the NCHW tensor.
+      const bool vec = (HW & 3) == 0;                                       // (alignment of every channel plane)
 #pragma unroll 1
       for (int m = 0; m < MH; ++m) {
-        const int c0 = 16 * m, c1 = c0 + 16 < a.mh ? c0 + 16 : a.mh;
-        if (c0 >= a.mh) break;
+        if (16 * m >= ja.mh) break;
         u32x4 wf[KC];
 #pragma unroll
         for (int s = 0; s < KC; ++s) wf[s] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
@@ -325,45 +353,47 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerArgs a) {
 #pragma unroll
         for (int s = 0; s < KC; ++s)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_cross(wf[s], xs[s][nt], hacc[nt]);
+          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_cross(xs[s][nt], wf[s], hacc[nt]);
 #pragma unroll
         for (int s = 0; s + 1 < KC; s += 2)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main2(wf[s], wf[s + 1], (yfv2_u2){xs[s][nt][0], xs[s][nt][1]}, xs[s + 1][nt], hacc[nt]);
+          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main2(xs[s][nt], xs[s + 1][nt], (yfv2_u2){wf[s][0], wf[s][1]}, wf[s + 1], hacc[nt]);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main1(wf[KC - 1], xs[KC - 1][nt], hacc[nt]);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(CS + 2 * 96 + c0 + 4 * g);
+        for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main1(xs[KC - 1][nt], wf[KC - 1], hacc[nt]);
+        const int co = 16 * m + p;
+        if (co < ja.mh) {
+          const float bias = CS[2 * 96 + co];
+          float* plane = co < ja.split ? ja.nchw0 + ((size_t)b * ja.split + co) * HW : ja.nchw1 + ((size_t)b * (ja.mh - ja.split) + (co - ja.split)) * HW;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (!pv[nt]) continue;
+          for (int nt = 0; nt < NT; ++nt) {
+            const int px0 = 16 * (wv * NT + nt) + 4 * g;
+            f32x4 y;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) OT[(4 * g + r) * HW + opix[nt]] = __builtin_fmaf(hacc[nt][r], us, bias[r]);
-        }
-        __syncthreads();
-        // channels [c0, c1): those below a.split are a run of nchw0, the rest a run of nchw1
-        const int cs = c0 > a.split ? c0 : (c1 < a.split ? c1 : a.split);   // first channel of the tile that belongs to nchw1
-        auto put = [&](float* dst, const float* src, int n) {
-          if ((HW & 3) == 0) {
-            for (int i = 4 * tid; i < n; i += 2048) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
-          } else {
-            for (int i = tid; i < n; i += 512) dst[i] = src[i];
+            for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(hacc[nt][r], us, bias);
+            if (vec) {
+              if (px0 < HW) *reinterpret_cast<f32x4*>(plane + px0) = y;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (px0 + r < HW) plane[px0 + r] = y[r];
+            }
           }
-        };
-        if (cs > c0) put(a.nchw0 + ((size_t)b * a.split + c0) * HW, OT, (cs - c0) * HW);
-        if (c1 > cs) put(a.nchw1 + ((size_t)b * (a.mh - a.split) + (cs - a.split)) * HW, OT + (cs - c0) * HW, (c1 - cs) * HW);
-        __syncthreads();
+        }
       }
     }
     YFV2_WSTAMP(18);
   }
+  if (MULTI && ji + 1 < jobs.n) __syncthreads();   // workgroup-scope release/acquire: this job's global stores are complete (an agent-scope __threadfence() would write back and invalidate L2 on every XCD: measured 4x the launch time)
+  }
 }
 
-template <int MH, int PS, int NT>
-static void launch_towerh(const TowerArgs& a, hipStream_t s) {
+template <int MH, int PS, int NT, int NJ>
+static void launch_towerh(const TowerJobs& jobs, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + 4 * (4 * 16 * NT * 8 + ThGeom<PS>::TIN_SLOTS));
   static std::atomic<unsigned long long> lds_ok{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerh_kernel<MH, PS, NT>), lds_ok);
-  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT>), dim3(a.B < 256 ? a.B : 256), dim3(512), lds, s, a);
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerh_kernel<MH, PS, NT, NJ>), lds_ok);
+  const int B = jobs.j[0].B;
+  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT, NJ>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
 }
 
 // 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
@@ -372,19 +402,29 @@ bool yfv2_towerh_supported(int H, int W) {
   if (H <= 11 && W <= 11) return true;
   return H <= 22 && W <= 22 && ((H + 1) / 2) * ((W + 1) / 2) <= 128;
 }
+// several tower halves in one launch: the single-pixel kernel only (see the kernel)
+bool yfv2_towerh_multi(int H, int W) { return H >= 1 && W >= 1 && H <= 11 && W <= 11; }
 
-bool yfv2_launch_towerh(const TowerArgs& a, hipStream_t s) {
-  if (!a.img16 || !yfv2_towerh_supported(a.H, a.W)) return false;
-  const int mh_tiles = a.has_head ? (a.mh + 15) / 16 : 0;
-  if (mh_tiles > 6) return false;
-  if (a.H <= 11 && a.W <= 11) {
-    if (mh_tiles == 0) launch_towerh<0, 1, 1>(a, s);
-    else if (mh_tiles == 1) launch_towerh<1, 1, 1>(a, s);
-    else launch_towerh<6, 1, 1>(a, s);
+// The kernel is instantiated for 0, 1 or 6 output-conv tiles; every job's image must be packed for `mh_tiles` of them
+// (WeightPacker::image_towerh pads with zero tiles) - the LDS layout depends on it.
+bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
+  if (jobs.n < 1 || jobs.n > 4) return false;
+  const TowerArgs& a = jobs.j[0];
+  for (int i = 0; i < jobs.n; ++i)
+    if (!jobs.j[i].img16 || jobs.j[i].H != a.H || jobs.j[i].W != a.W || jobs.j[i].B != a.B) return false;
+  if (!yfv2_towerh_supported(a.H, a.W) || (mh_tiles != 0 && mh_tiles != 1 && mh_tiles != 6)) return false;
+  if (jobs.n > 1) {
+    if (!yfv2_towerh_multi(a.H, a.W) || mh_tiles == 0) return false;
+    if (mh_tiles == 1) launch_towerh<1, 1, 1, 4>(jobs, s);
+    else launch_towerh<6, 1, 1, 4>(jobs, s);
+  } else if (a.H <= 11 && a.W <= 11) {
+    if (mh_tiles == 0) launch_towerh<0, 1, 1, 1>(jobs, s);
+    else if (mh_tiles == 1) launch_towerh<1, 1, 1, 1>(jobs, s);
+    else launch_towerh<6, 1, 1, 1>(jobs, s);
   } else {
-    if (mh_tiles == 0) launch_towerh<0, 2, 4>(a, s);
-    else if (mh_tiles == 1) launch_towerh<1, 2, 4>(a, s);
-    else launch_towerh<6, 2, 4>(a, s);
+    if (mh_tiles == 0) launch_towerh<0, 2, 4, 1>(jobs, s);
+    else if (mh_tiles == 1) launch_towerh<1, 2, 4, 1>(jobs, s);
+    else launch_towerh<6, 2, 4, 1>(jobs, s);
   }
   return true;
 }
