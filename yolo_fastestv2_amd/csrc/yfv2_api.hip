@@ -247,8 +247,31 @@ struct WeightPacker {
   size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */, bool presplit = false) {
     const int rows = MT * 16, K16 = K / 16;
     std::vector<float> im;
-    if (presplit) push_frag_split3(im, &blob[f.w], M, K, MT, K16);   // pw_kernel<.., PRE>: bf16 hi/mid/lo operand quads per chunk pair
-    else push_frag(im, &blob[f.w], M, K, MT, K16);
+    int sw = 0;
+    if (presplit) {
+      // pw_kernel<.., PRE>: the filter x 2^sw as two fp16 terms, [mt][chunk pair][term][64 lanes][4 dwords]: dwords 0,1 = K
+      // positions 4g..4g+3 of the pair's first chunk, 2,3 = of its second (one A operand of v_mfma_f32_16x16x32_f16)
+      float mx = 0.f;
+      for (int i = 0; i < M * K; ++i) mx = std::fmax(mx, std::fabs(blob[f.w + i]));
+      sw = pow2_for(mx);
+      for (int mt = 0; mt < MT; ++mt)
+        for (int sp = 0; sp < K16 / 2; ++sp)
+          for (int term = 0; term < 2; ++term)
+            for (int l = 0; l < 64; ++l)
+              for (int d = 0; d < 4; ++d) {
+                unsigned packed = 0;
+                for (int e = 0; e < 2; ++e) {
+                  const int r = 16 * mt + (l & 15), c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1) + e;
+                  const float v = (r < M && c < K) ? std::ldexp(blob[f.w + (size_t)r * K + c], sw) : 0.f;
+                  const float h1 = rn_f16(v);
+                  packed |= f16_bits(term == 0 ? h1 : v - h1) << (16 * e);
+                }
+                float fb; std::memcpy(&fb, &packed, 4);
+                im.push_back(fb);
+              }
+    } else {
+      push_frag(im, &blob[f.w], M, K, MT, K16);
+    }
     if (K % 16)
       for (int mt = 0; mt < MT; ++mt)
         for (int l = 0; l < 64; ++l)
@@ -256,7 +279,8 @@ struct WeightPacker {
             const int r = 16 * mt + (l & 15), c = 16 * K16 + 2 * (l >> 4) + j;
             im.push_back((r < M && c < K) ? blob[f.w + (size_t)r * K + c] : 0.f);
           }
-    push_vec(im, &blob[f.scale], M, rows);
+    if (presplit) for (int i = 0; i < rows; ++i) im.push_back(i < M ? std::ldexp(blob[f.scale + i], -(sw + 4)) : 0.f);   // the accumulators carry 2^(sw+4): undone exactly inside the BN scale
+    else push_vec(im, &blob[f.scale], M, rows);
     push_vec(im, &blob[f.shift], M, rows);
     return put(im);
   }

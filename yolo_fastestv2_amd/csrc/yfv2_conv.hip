@@ -16,6 +16,10 @@
 
 #include "yfv2_internal.h"
 
+typedef _Float16 yfv2_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 yfv2_h8 __attribute__((ext_vector_type(8)));
+typedef unsigned yfv2_u2 __attribute__((ext_vector_type(2)));
+
 // ============================================================================
 // pointwise 1x1 conv on the fp32 matrix cores
 // ============================================================================
@@ -38,10 +42,12 @@
 //               [0,192) gathered from C3 at (y/2, x/2), [192,288) from C2
 //   PW_HEAD     the three biased output convs (detector.py:17-19,25-31): stores
 //               NCHW logits into two destination tensors split at `split`
-// PRE (streamed bf16x6 forms): the filter arrives pre-split on the host (WeightPacker::push_frag_split3) - per (output
-// tile, PAIR of chunks, term hi / mid / lo) one 16-byte operand whose 32 k-slots are the two chunks.  The six products are six
-// MFMAs per chunk pair with no VALU work on the filter side; splitting the MT filter fragments of every chunk on the fly
-// (each used for only NT = 2 pixel tiles) cost more VALU cycles than the MFMAs they fed.
+// PRE (the streamed large-K forms: fpn.conv1x1_2 / conv1x1_3): fp16x3 (yfv2_stem16.hip) - the filter arrives from the host
+// as two fp16 terms x 2^sw (WeightPacker::image_pw), per (output tile, PAIR of chunks, term) one 16-byte operand whose 32
+// k-slots are the two chunks; the activations are scaled by 2^4 and split into two fp16 terms per chunk pair; w1 x2 + w2 x1
+// + w1 x1 = three v_mfma_f32_16x16x32_f16 per (output tile, pixel tile, chunk pair), the scales undone exactly inside the BN
+// scale.  (Round 2's form of this path was bf16x6 with a host-split hi / mid / lo filter: six MFMAs per pair - 13.6 of the
+// 36 us of conv1x1_2 were matrix-core time - 135 KB of LDS and a three-term split per activation quad.)  |x| < 4094.
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false, bool BF6 = false, bool PRE = false>
 __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   constexpr int K16 = K / 16;
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   // W[16mt + (l&15)][16s + 4(l>>4) .. +3] - the 64 lanes of a fragment read touch 64 consecutive 16-byte slots, no bank
   // conflicts whatever 16-lane groups the hardware forms (a row-padded [M][K+4] image collides 5-7 slots per group);
   // an 8-channel tail is MT fragments of 8 bytes per lane behind them
-  constexpr int FRAG_FL = PRE ? MT * (K16 / 2) * 3 * 256 : MT * K16 * 256;
+  constexpr int FRAG_FL = MT * K16 * 256;   // (PRE: [mt][chunk pair][2 terms][256] - the same size)
   constexpr int FILT_FL = FRAG_FL + (KT ? MT * 128 : 0);
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x;
@@ -135,28 +141,33 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 #pragma unroll
               for (int e = 0; e < 2; ++e) bnxt[nt][e] = *reinterpret_cast<const f32x4*>((2 * sp + 2 < SPLIT ? src0[nt] : src1[nt]) + 16 * (2 * sp + 2 + e));
           }
-          yfv2_bf16x8 ah[MT], am[MT], al[MT], bh[NT], bm[NT], bl[NT];
+          yfv2_h8 a1[MT], a2[MT], b1[NT], b2[NT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const float* wq3 = wl + (((mt * KP + sp) * 3) * 64 + lane) * 4;
-            ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
-            am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
-            al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
+            const float* wq2 = wl + (((mt * KP + sp) * 2) * 64 + lane) * 4;
+            a1[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2));
+            a2[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2 + 256));
           }
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
-            yfv2_split3(bcur[nt][0], h0, m0, l0);
-            yfv2_split3(bcur[nt][1], h1, m1, l1);
-            bh[nt] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
-            bm[nt] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
-            bl[nt] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+            u32x4 t1, t2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const f32x4 v = bcur[nt][e] * 16.0f;                                        // fp16's absolute floor: 2^-25 -> 2^-29
+              const yfv2_h4 h1 = __builtin_convertvector(v, yfv2_h4);                       // v_cvt_pk_f16_f32 (RN)
+              const yfv2_h4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4), yfv2_h4);   // the difference is exact
+              const yfv2_u2 u1 = __builtin_bit_cast(yfv2_u2, h1), u2 = __builtin_bit_cast(yfv2_u2, h2);
+              t1[2 * e] = u1[0]; t1[2 * e + 1] = u1[1];
+              t2[2 * e] = u2[0]; t2[2 * e + 1] = u2[1];
+            }
+            b1[nt] = __builtin_bit_cast(yfv2_h8, t1);
+            b2[nt] = __builtin_bit_cast(yfv2_h8, t2);
           }
-          // six products, the small ones first; MT * NT independent accumulators: no MFMA waits for the one before it
+          // three products, the small ones first; MT * NT independent accumulators: no MFMA waits for the one before it
 #define PW_PROD(A_, B_)                                                \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                    \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[mt], B_[nt], acc[mt][nt], 0, 0, 0);
-          PW_PROD(al, bh) PW_PROD(ah, bl) PW_PROD(am, bm) PW_PROD(am, bh) PW_PROD(ah, bm) PW_PROD(ah, bh)
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[mt], B_[nt], acc[mt][nt], 0, 0, 0);
+          PW_PROD(a1, b2) PW_PROD(a2, b1) PW_PROD(a1, b1)
 #undef PW_PROD
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
@@ -351,7 +362,7 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
   if constexpr (STREAM && K % 32 == 0 && K >= 192) if (a.bf6 && a.presplit) {
     static std::atomic<unsigned long long> lds_ok2{0};
-    const size_t lds_pre = lds * 3 / 2;
+    const size_t lds_pre = lds;   // two fp16 terms: the size of the fp32 image
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), lds_ok2);
     hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds_pre, s, a);
     return;
