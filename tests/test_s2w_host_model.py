@@ -131,25 +131,26 @@ def test_band_rows_fit_the_static_bounds():
 
 
 def _presplit_general(fr, MT, K):
-    """[mt][chunk pair][term][lane][4 dwords] -> (16 MT, K) float32 = hi + mid + lo"""
+    """[mt][chunk pair][term 2][lane][4 dwords of fp16 pairs] -> (16 MT, K) float64 = first + second fp16 term"""
     KP = K // 32
-    u = fr.view(np.uint32).reshape(MT, KP, 3, 64, 4)
-    terms = np.zeros((3, 16 * MT, K), np.float32)
+    u = fr.view(np.uint32).reshape(MT, KP, 2, 64, 4)
+    terms = np.zeros((2, 16 * MT, K), np.float64)
     for mt in range(MT):
         for sp in range(KP):
             for l in range(64):
                 for d in range(4):
                     c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1)
                     for e in range(2):
-                        bits = ((u[mt, sp, :, l, d] >> (16 * e)) & 0xFFFF).astype(np.uint32) << 16
-                        terms[:, 16 * mt + (l & 15), c + e] = bits.view(np.float32)
-    return (terms[0] + terms[1]) + terms[2]
+                        bits = ((u[mt, sp, :, l, d] >> (16 * e)) & 0xFFFF).astype(np.uint16)
+                        terms[:, 16 * mt + (l & 15), c + e] = bits.view(np.float16).astype(np.float64)
+    return terms[0] + terms[1]
 
 
 @pytest.mark.parametrize("name,K,key", [("fpn.conv1x1_3 pw192", 192, "fpn.conv1x1_3.0.weight"), ("fpn.conv1x1_2 up2x", 288, "fpn.conv1x1_2.0.weight")])
 def test_streamed_pointwise_filters_are_packed_presplit(name, K, key):
-    """pw_kernel<K = 192 / 288, PRE>: the FPN reduces' filters arrive pre-split (bf16 hi / mid / lo operand quads per chunk
-    pair); hi + mid + lo must reproduce the fp32 filter exactly, the C2 columns of conv1x1_2 in the chain's channel order."""
+    """pw_kernel<K = 192 / 288, PRE>: the FPN reduces' filters arrive as two fp16 terms x 2^sw per chunk pair (fp16x3); their
+    sum must reproduce the scaled fp32 filter to 2^-22 of its largest entry (largest entry in (2^13, 2^14]), the BN scale
+    must carry the exact 2^-(sw+4), the C2 columns of conv1x1_2 in the chain's channel order."""
     w = yfv2.random_state_dict(12)
     host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point()}
     arr = (TensorDesc * len(host))()
@@ -161,7 +162,7 @@ def test_streamed_pointwise_filters_are_packed_presplit(name, K, key):
     ns, nb = C.c_int32(0), C.c_int64(0)
     assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0
     MT = 5
-    fl = MT * (K // 32) * 3 * 256 + 2 * 16 * MT
+    fl = MT * (K // 32) * 2 * 256 + 2 * 16 * MT
     buf = np.zeros(fl, np.float32)
     nm = C.create_string_buffer(256)
     im = None
@@ -178,4 +179,9 @@ def test_streamed_pointwise_filters_are_packed_presplit(name, K, key):
         lab = (C.c_int32 * 96)()
         assert L.yfv2_debug_plan_c2_label(C.byref(cfg), arr, len(host), lab) == 1
         ref = np.concatenate([ref[:, :192], ref[:, 192:][:, np.asarray(list(lab))]], 1)   # cat(up(C3), C2): C2 columns permuted
-    assert np.array_equal(got, ref)
+    sw = 14 - int(np.ceil(np.log2(np.abs(ref).max())))
+    assert 2.0 ** 13 < np.abs(got).max() <= 2.0 ** 14
+    assert np.abs(got - ref.astype(np.float64) * 2.0 ** sw).max() <= 2.0 ** 14 * 2.0 ** -22
+    bn = "fpn.conv1x1_3.1" if K == 192 else "fpn.conv1x1_2.1"
+    scale = (w[bn + ".weight"] / torch.sqrt(w[bn + ".running_var"] + 1e-5)).numpy()
+    assert np.allclose(im[fl - 2 * 16 * MT:fl - 16 * MT][:72] * 2.0 ** (sw + 4), scale, rtol=1e-6, atol=0)
