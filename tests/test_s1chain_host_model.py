@@ -26,33 +26,31 @@ def _set_form(bf6):
     block_s1chain6_kernel: per filter [mt (3)][six 16-byte operands][64][4]"""
     global W_FL, IMG_FL, BF6
     BF6 = bf6
-    W_FL = 3 * 6 * 256 if bf6 else KC * KC * 256
+    W_FL = 3 * 3 * 256 if bf6 else KC * KC * 256
     IMG_FL = 2 * W_FL + DW_FL + CST_FL + TBL_FL
 
 
-def _bf(u):
-    return (u.astype(np.uint32) << 16).view(np.float32)
+def _h(u):
+    return u.astype(np.uint16).view(np.float16).astype(np.float64)
 
 
 def _decode6(fr):
-    """[mt][hi, mid, lo quads of the chunk pair | {hi,hi} {mid,mid} {hi,lo} of chunk 2][lane][4 dwords] -> (48, 48) float32;
-    every dword = two truncated bf16 (low half first).  Checks the duplicated halves of the single-chunk operands."""
-    u = fr.view(np.uint32).reshape(3, 6, 64, 4)
-    m = np.zeros((3, C2, C2), np.float32)                 # hi, mid, lo
+    """[mt][{w1, w1} of the chunk pair | {w2, w2} of the pair | {w1, w2} of chunk 2][lane][4 dwords] -> (48, 48) float64 =
+    the filter x 2^sw as the sum of its two fp16 terms; every dword = two fp16 (low half first)."""
+    u = fr.view(np.uint32).reshape(3, 3, 64, 4)
+    m = np.zeros((2, C2, C2))
     for mt in range(3):
         for l in range(64):
             r, g = 16 * mt + (l & 15), l >> 4
-            for term in range(3):
+            for term in range(2):
                 for d in range(4):
                     c = 16 * (d >> 1) + 4 * g + 2 * (d & 1)
-                    m[term, r, c], m[term, r, c + 1] = _bf(u[mt, term, l, d] & 0xFFFF), _bf(u[mt, term, l, d] >> 16)
-            hh, mm, hl = u[mt, 3, l], u[mt, 4, l], u[mt, 5, l]
-            assert hh[0] == hh[2] and hh[1] == hh[3] and mm[0] == mm[2] and mm[1] == mm[3] and hl[0] == hh[0] and hl[1] == hh[1]
-            for term, q in ((0, hh[:2]), (1, mm[:2]), (2, hl[2:])):
-                for d in range(2):
-                    c = 32 + 4 * g + 2 * d
-                    m[term, r, c], m[term, r, c + 1] = _bf(q[d] & 0xFFFF), _bf(q[d] >> 16)
-    return (m[0] + m[1]) + m[2]
+                    m[term, r, c], m[term, r, c + 1] = _h(u[mt, term, l, d] & 0xFFFF), _h(u[mt, term, l, d] >> 16)
+            for d in range(4):
+                c = 32 + 4 * g + 2 * (d & 1)
+                m[d >> 1, r, c], m[d >> 1, r, c + 1] = _h(u[mt, 2, l, d] & 0xFFFF), _h(u[mt, 2, l, d] >> 16)
+    assert 2.0 ** 13 < np.abs(m[0] + m[1]).max() <= 2.0 ** 14
+    return m[0] + m[1]
 
 
 def _descs(w):
@@ -101,14 +99,15 @@ def _branch(tile_phys, im):
     wd = im[2 * W_FL:2 * W_FL + DW_FL].reshape(9, C2)
     cs = im[2 * W_FL + DW_FL:2 * W_FL + DW_FL + CST_FL].reshape(6, C2)
     H, W, _ = tile_phys.shape
-    y = np.maximum(tile_phys @ w1.T * cs[0] + cs[1], 0.0).astype(np.float32)
+    up = 16.0 if BF6 else 1.0                         # fp16x3: activations x 2^4, filters x 2^sw, both undone inside the BN scale
+    y = np.maximum((tile_phys * up) @ w1.T * cs[0] + cs[1], 0.0).astype(np.float32)
     pad = np.zeros((H + 2, W + 2, C2), np.float32)
     pad[1:-1, 1:-1] = y
     d = np.zeros((H, W, C2), np.float32)
     for k in range(9):
         d += pad[k // 3:k // 3 + H, k % 3:k % 3 + W] * wd[k]
     d = d * cs[2] + cs[3]
-    return np.maximum(d @ w2.T * cs[4] + cs[5], 0.0).astype(np.float32).reshape(H, W, 3, 4, 4)
+    return np.maximum((d * up) @ w2.T * cs[4] + cs[5], 0.0).astype(np.float32).reshape(H, W, 3, 4, 4)
 
 
 def _tables(im):

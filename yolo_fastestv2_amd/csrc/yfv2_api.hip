@@ -287,38 +287,41 @@ struct WeightPacker {
   // block_s1chain6_kernel: a 48x48 filter as [mt (3)][six 16-byte operands][64 lanes][4 dwords]: hi / mid / lo quads of the
   // chunk PAIR (chunks 0, 1: the 32 k-slots of one bf16 MFMA), then {hi,hi} {mid,mid} {hi,lo} of the single chunk 2 (the
   // register form of yfv2_split_a); every dword = two truncated bf16, low half first
-  static void push_chain6_filter(std::vector<float>& im, const float* w /* [48][48] */) {
-    auto terms = [&](int r, int c, unsigned (&t3)[3]) {   // packed (value c, value c + 1) of row r: hi, mid, lo
-      for (int t = 0; t < 3; ++t) t3[t] = 0;
+  // block_s1chain6_kernel: a 48x48 filter x 2^sw as two fp16 terms (w1 = RN16, w2 = RN16 of the rest), [mt (3)][three 16-byte
+  // operands][64 lanes][4 dwords]: {w1 chunk 0, w1 chunk 1}, {w2 chunk 0, w2 chunk 1}, {w1 chunk 2, w2 chunk 2}; a lane's two
+  // dwords of a chunk = K positions 4g..4g+3.  Returns sw.
+  static int push_chain6_filter(std::vector<float>& im, const float* w /* [48][48] */) {
+    float mx = 0.f;
+    for (int i = 0; i < 48 * 48; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+    const int sw = pow2_for(mx);
+    auto term = [&](int r, int c, int t) {               // packed (value c, value c + 1) of row r, fp16 term t
+      unsigned u = 0;
       for (int e = 0; e < 2; ++e) {
-        float v = w[(size_t)r * 48 + c + e];
-        for (int t = 0; t < 3; ++t) { t3[t] |= bf16_trunc_bits(v) << (16 * e); v = v - bf16_trunc(v); }
+        const float v = std::ldexp(w[(size_t)r * 48 + c + e], sw), h1 = rn_f16(v);
+        u |= f16_bits(t == 0 ? h1 : v - h1) << (16 * e);
       }
+      return u;
     };
     auto put_u = [&](unsigned u) { float f; std::memcpy(&f, &u, 4); im.push_back(f); };
-    for (int mt = 0; mt < 3; ++mt) {
-      for (int term = 0; term < 3; ++term)               // the pair: dwords 0, 1 = chunk 0, dwords 2, 3 = chunk 1
+    for (int mt = 0; mt < 3; ++mt)
+      for (int op = 0; op < 3; ++op)
         for (int l = 0; l < 64; ++l)
           for (int d = 0; d < 4; ++d) {
-            unsigned t3[3];
-            terms(16 * mt + (l & 15), 16 * (d >> 1) + 4 * (l >> 4) + 2 * (d & 1), t3);
-            put_u(t3[term]);
+            const int r = 16 * mt + (l & 15), kq = 4 * (l >> 4) + 2 * (d & 1);
+            if (op < 2) put_u(term(r, 16 * (d >> 1) + kq, op));   // the pair: dwords 0, 1 = chunk 0, dwords 2, 3 = chunk 1
+            else put_u(term(r, 32 + kq, d >> 1));                 // chunk 2: dwords 0, 1 = first term, 2, 3 = second
           }
-      for (int q = 0; q < 3; ++q)                        // the single chunk: {hi,hi} {mid,mid} {hi,lo}
-        for (int l = 0; l < 64; ++l) {
-          unsigned a3[3], b3[3];
-          terms(16 * mt + (l & 15), 32 + 4 * (l >> 4), a3);
-          terms(16 * mt + (l & 15), 32 + 4 * (l >> 4) + 2, b3);
-          const int lo_t = q == 0 ? 0 : (q == 1 ? 1 : 0), hi_t = q == 0 ? 0 : (q == 1 ? 1 : 2);
-          put_u(a3[lo_t]); put_u(b3[lo_t]); put_u(a3[hi_t]); put_u(b3[hi_t]);
-        }
-    }
+    return sw;
   }
   void append_s1_bf6(std::vector<float>& im, const Folded& f1, const Folded& fd, const Folded& f2) {
-    push_chain6_filter(im, &blob[f1.w]);
-    push_chain6_filter(im, &blob[f2.w]);
+    const int sw1 = push_chain6_filter(im, &blob[f1.w]);
+    const int sw2 = push_chain6_filter(im, &blob[f2.w]);
     push_rows(im, &blob[fd.w], 9, 48, 48);
-    for (const Folded* f : {&f1, &fd, &f2}) { push_vec(im, &blob[f->scale], 48, 48); push_vec(im, &blob[f->shift], 48, 48); }
+    for (const Folded* f : {&f1, &fd, &f2}) {
+      const int un = f == &f1 ? sw1 + 4 : (f == &f2 ? sw2 + 4 : 0);   // the pointwise accumulators carry 2^(sw+4): undone exactly inside the BN scale
+      for (int i = 0; i < 48; ++i) im.push_back(std::ldexp(blob[f->scale + i], -un));
+      push_vec(im, &blob[f->shift], 48, 48);
+    }
   }
   // block_s2_kernel<CIN>: W1 | W2 | Wproj | main dw taps | proj dw taps | sc1 sh1 scd shd sc2 sh2 scpd shpd scpp shpp
   size_t image_s2(const Folded& f1, const Folded& fd, const Folded& f2, const Folded& fpd, const Folded& fpp, int cin) {

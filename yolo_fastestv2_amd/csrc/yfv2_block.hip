@@ -20,6 +20,10 @@
 
 #include "yfv2_internal.h"
 
+typedef _Float16 yfv2_h4c __attribute__((ext_vector_type(4)));
+typedef _Float16 yfv2_h8c __attribute__((ext_vector_type(8)));
+typedef unsigned yfv2_u2c __attribute__((ext_vector_type(2)));
+
 template <int C2>
 struct S1Cfg {
   static constexpr int KC = (C2 + 15) / 16;  // 16-channel chunks (also M tiles: M == K == C2)
@@ -71,8 +75,11 @@ constexpr int CH_TBL_FL = 64;
 //  * an image is 40 KB (10000 floats) instead of 21.6: ONE image buffer.  The next block's image travels through five
 //    registers per thread during phases A and B and is stored in the exchange phase, after the barrier that retires phase
 //    B's reads; the park table of the current block is read into registers before that barrier.
-// Per block image: W1 pre-split [3][6][64][4] | W2 pre-split | dw taps [9][48] | 6 BN vectors | int tables (as above).
-constexpr int CH6_WP_FL = 3 * 6 * 256;
+// Round 3: the same dataflow on fp16x3 (make_b / mfma9 below): five MFMAs instead of nine, a two-term split, half the filter
+// image (the BN scales of the two pointwise convs carry the exact 2^-(sw+4)).
+// Per block image: W1 [3 mt][{w1,w1} pair | {w2,w2} pair | {w1,w2} chunk 2][64][4] x 2^sw1 | W2 likewise | dw taps [9][48] |
+// 6 BN vectors | int tables (as above).
+constexpr int CH6_WP_FL = 3 * 3 * 256;
 constexpr int CH6_IMG_FL = 2 * CH6_WP_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + CH_TBL_FL;
 
 template <int THREADS>
@@ -120,41 +127,42 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   // also drain vmcnt, i.e. stall every block's exchange phase until its park stores are acknowledged by L2.
   auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  // B operands of one pixel tile from its three chunk fragments: the pair (chunks 0, 1) as hi / mid / lo quads, chunk 2
-  // as {hi,mid} {lo,hi}
-  struct BOps { yfv2_bf16x8 ph, pm, pl; Bf3B s; };
+  // fp16x3 (round 3; yfv2_stem16.hip): every operand = two fp16 terms, w1 x2 + w2 x1 + w1 x1 with fp32 accumulation.
+  // B operands of one pixel tile from its three chunk fragments (x 2^4 first): the pair (chunks 0, 1) as {x1, x1} and
+  // {x2, x2}, chunk 2 as {x2, x1} - against the filter's {w1, w1} {w2, w2} of the pair and {w1, w2} of chunk 2 that is five
+  // v_mfma_f32_16x16x32_f16 per (output tile, pixel tile): the pair's two cross products, chunk 2's cross products in ONE
+  // instruction, the pair's main product, chunk 2's main product ({0, w1} against the same {x2, x1}).  Round 2's bf16x6 form
+  // took nine, a three-term split per activation quad and twice the filter image.
+  struct BOps { yfv2_h8c p1, p2, s; };
   auto make_b = [&](f32x4 c0, f32x4 c1, f32x4 c2v) __attribute__((always_inline)) {
-    unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
-    yfv2_split3(c0, h0, m0, l0);
-    yfv2_split3(c1, h1, m1, l1);
+    unsigned h[3][2], l[3][2];
+    const f32x4 cs[3] = {c0 * 16.0f, c1 * 16.0f, c2v * 16.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const yfv2_h4c t1 = __builtin_convertvector(cs[k], yfv2_h4c);                                   // v_cvt_pk_f16_f32 (RN)
+      const yfv2_h4c t2 = __builtin_convertvector(cs[k] - __builtin_convertvector(t1, f32x4), yfv2_h4c);   // the difference is exact
+      const yfv2_u2c a1 = __builtin_bit_cast(yfv2_u2c, t1), a2 = __builtin_bit_cast(yfv2_u2c, t2);
+      h[k][0] = a1[0]; h[k][1] = a1[1]; l[k][0] = a2[0]; l[k][1] = a2[1];
+    }
     BOps b;
-    b.ph = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
-    b.pm = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
-    b.pl = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
-    b.s = yfv2_split_b(c2v);
+    b.p1 = __builtin_bit_cast(yfv2_h8c, (u32x4){h[0][0], h[0][1], h[1][0], h[1][1]});
+    b.p2 = __builtin_bit_cast(yfv2_h8c, (u32x4){l[0][0], l[0][1], l[1][0], l[1][1]});
+    b.s = __builtin_bit_cast(yfv2_h8c, (u32x4){l[2][0], l[2][1], h[2][0], h[2][1]});
     return b;
   };
-  // acc[n] += W[mt] x B[n] for two pixel tiles: nine products, the small ones first, the two tiles interleaved (the six
-  // filter operands of ONE output tile in registers at a time: 24 VGPRs)
+  // acc[n] += W[mt] x B[n] for two pixel tiles: five products, the small ones first, the two tiles interleaved (the three
+  // filter operands of ONE output tile in registers at a time)
   auto mfma9 = [&](const float* WP, int mt, const BOps (&b)[2], f32x4 (&acc)[2]) __attribute__((always_inline)) {
-    const float* wq = WP + ((mt * 6) * 64 + lane) * 4;
-    const yfv2_bf16x8 ah = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq));
-    const yfv2_bf16x8 am = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq + 256));
-    const yfv2_bf16x8 al = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq + 512));
-    Bf3A sa;
-    sa.hh = *reinterpret_cast<const u32x4*>(wq + 768);
-    sa.mm = *reinterpret_cast<const u32x4*>(wq + 1024);
-    sa.hl = *reinterpret_cast<const u32x4*>(wq + 1280);
+    const float* wq = WP + ((mt * 3) * 64 + lane) * 4;
+    const u32x4 q1 = *reinterpret_cast<const u32x4*>(wq), q2 = *reinterpret_cast<const u32x4*>(wq + 256), qs = *reinterpret_cast<const u32x4*>(wq + 512);
+    const yfv2_h8c w1p = __builtin_bit_cast(yfv2_h8c, q1), w2p = __builtin_bit_cast(yfv2_h8c, q2), ws = __builtin_bit_cast(yfv2_h8c, qs);
+    const yfv2_h8c wm = __builtin_bit_cast(yfv2_h8c, (u32x4){0u, 0u, qs[0], qs[1]});
 #define CH6_EACH(EXPR) _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[n] = EXPR;
-    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[n].ph, acc[n], 0, 0, 0))
-    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[n].pl, acc[n], 0, 0, 0))
-    CH6_EACH(yfv2_mfma6_step<0>(sa, b[n].s, acc[n]))
-    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[n].pm, acc[n], 0, 0, 0))
-    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[n].ph, acc[n], 0, 0, 0))
-    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[n].pm, acc[n], 0, 0, 0))
-    CH6_EACH(yfv2_mfma6_step<1>(sa, b[n].s, acc[n]))
-    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[n].ph, acc[n], 0, 0, 0))
-    CH6_EACH(yfv2_mfma6_step<2>(sa, b[n].s, acc[n]))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(w1p, b[n].p2, acc[n], 0, 0, 0))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(w2p, b[n].p1, acc[n], 0, 0, 0))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(ws, b[n].s, acc[n], 0, 0, 0))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(w1p, b[n].p1, acc[n], 0, 0, 0))
+    CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(wm, b[n].s, acc[n], 0, 0, 0))
 #undef CH6_EACH
   };
 
