@@ -230,11 +230,8 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
           for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
           f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(win[k][c], wl[k][c], d[c]);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) dwv[s][n][c] = __builtin_fmaf(d[c], lsc[c], lsh[c]);
+          for (int k = 0; k < 9; ++k) d = __builtin_elementwise_fma(win[k], wl[k], d);   // packed: two v_pk_fma_f32 per tap
+          dwv[s][n] = __builtin_elementwise_fma(d, lsc, lsh);
         }
         __builtin_amdgcn_sched_barrier(0);                  // one chunk's taps and windows at a time
       }
