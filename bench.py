@@ -339,12 +339,13 @@ def main():
             "metric": "images/sec at 352x352 bs=256 per GPU (forward+decode+NMS)", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 tensors, fp32 accumulation everywhere.  Stem, stage 2, the streamed pointwise convs of stage4.0 and every "
-                          "depthwise conv: fp32 MFMA / fp32 VALU.  Pointwise convs of stage3.0 (pw1), the stage-3 chain, stage4.0 (pw1), the "
-                          "stage-4 chain, the FPN reduces and the towers incl. the output convs: 6 bf16 x bf16 partial products of operands split "
-                          "EXACTLY into three bf16 terms (filters pre-split on the host where a kernel has that form), fp32 "
-                          "accumulate (bf16x6; error vs float64 equals the fp32 MFMA's: tools/ubench/bf16x6.hip, DESIGN.md 4.2; YFV2_BF6=0 "
-                          "switches it off).  Every parity test (logits 1e-4, scores 1e-5, identical NMS survivors) runs on this arithmetic.",
+            "arithmetic": "fp32 tensors, fp32 accumulation everywhere.  Depthwise convs, BatchNorm, ReLU, max-pool, decode: fp32 VALU.  Every "
+                          "convolution with a channel contraction - stem (fp32 input), stage 2, stage3.0, the stage-3 chain, stage4.0, the stage-4 chain, "
+                          "the FPN reduces, the towers and the output convs - is fp16x3: both operands split into two fp16 terms whose sum "
+                          "reproduces them to 2^-24 (filters on the host, scaled by a power of two; activations scaled by 2^4 / 2^8), the three products "
+                          "w1 x2 + w2 x1 + w1 x1 (each exact) accumulated in fp32 by v_mfma_f32_16x16x32_f16, the powers of two undone exactly; error vs "
+                          "float64 within 2x of a plain fp32 convolution's (tests/test_stem16_host_model.py), valid for |activation| < 4094 (|pixel| < "
+                          "255.9).  The uint8 stem and the YFV2_BF6=0 plan run the fp32 MFMA.  Every parity test (logits 1e-4, scores 1e-5, identical NMS survivors) runs on this arithmetic.",
             "config": {"workload": "batch %d/GPU synthetic 352x352x3 fp32 (torch.rand), seeded random-init weights, "
                                    "Detector forward + anchor decode + class-aware NMS(conf %.2f, iou %.2f; 300 detections/image = NMS worst case)%s; "
                                    "BASELINE.json configs[1] (forward only) is the subset reported in forward_only_img_s, configs[2] "

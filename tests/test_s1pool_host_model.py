@@ -15,8 +15,8 @@ from yolo_fastestv2_amd._lib import Config, TensorDesc
 
 C2, NB = 96, 3
 REST_FL = 9 * 32 + 4 * 32 + 2 * C2
-# fp32 fragments (YFV2_BF6=0) / pre-split bf16 hi-mid-lo operand quads per chunk pair (default): [mt][pair][term][64][4]
-SIZES = {False: (2 * 6 * 256, 6 * 2 * 256), True: (2 * 3 * 3 * 256, 6 * 1 * 3 * 256)}
+# fp32 fragments (YFV2_BF6=0) / two fp16 terms x 2^sw per chunk pair (default, fp16x3): [mt][pair][term][64][4]
+SIZES = {False: (2 * 6 * 256, 6 * 2 * 256), True: (2 * 3 * 2 * 256, 6 * 1 * 2 * 256)}
 
 
 def _plan_image(w):
@@ -39,19 +39,19 @@ def _plan_image(w):
 
 
 def _presplit(fr, mt_n, kp):
-    """[mt][chunk pair][hi, mid, lo][lane][4 dwords] -> (16 mt_n, 32 kp) = hi + mid + lo; dword d = two truncated bf16 (low
-    half first) of columns 16 (2 sp + (d >> 1)) + 4 (l >> 4) + 2 (d & 1) + {0, 1}"""
-    u = fr.view(np.uint32).reshape(mt_n, kp, 3, 64, 4)
-    terms = np.zeros((3, 16 * mt_n, 32 * kp), np.float32)
+    """[mt][chunk pair][term 2][lane][4 dwords] -> (16 mt_n, 32 kp) float64 = the sum of the two fp16 terms (the filter x 2^sw);
+    dword d = two fp16 (low half first) of columns 16 (2 sp + (d >> 1)) + 4 (l >> 4) + 2 (d & 1) + {0, 1}"""
+    u = fr.view(np.uint32).reshape(mt_n, kp, 2, 64, 4)
+    terms = np.zeros((2, 16 * mt_n, 32 * kp))
     for mt in range(mt_n):
         for sp in range(kp):
             for l in range(64):
                 for d in range(4):
                     c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1)
                     for e in range(2):
-                        bits = ((u[mt, sp, :, l, d] >> (16 * e)) & 0xFFFF).astype(np.uint32) << 16
-                        terms[:, 16 * mt + (l & 15), c + e] = bits.view(np.float32)
-    return (terms[0] + terms[1]) + terms[2]
+                        bits = ((u[mt, sp, :, l, d] >> (16 * e)) & 0xFFFF).astype(np.uint16)
+                        terms[:, 16 * mt + (l & 15), c + e] = bits.view(np.float16).astype(np.float64)
+    return terms[0] + terms[1]
 
 
 def _frags(fr, mt_n, s_n):
@@ -90,21 +90,24 @@ def test_pool_chain_host_packing(monkeypatch, form):
             t = im[(blk * 3 + th) * IMG_FL:(blk * 3 + th + 1) * IMG_FL]
             w1t = _presplit(t[:W1_FL], 2, 3) if pre else _frags(t[:W1_FL], 2, 6)                        # (32, 96): rows 32 th .. +31
             w2t = _presplit(t[W1_FL:W1_FL + W2_FL], 6, 1) if pre else _frags(t[W1_FL:W1_FL + W2_FL], 6, 2)  # (96, 32): columns 32 th .. +31
-            if pre:   # hi + mid + lo is the fp32 filter, exactly
+            up = 16.0 if pre else 1.0   # fp16x3: activations x 2^4, filters x 2^sw, both undone inside the BN scales
+            if pre:   # the two terms reproduce the filter x 2^sw (largest entry in (2^13, 2^14]) to 2^-22 of that
                 p4 = "backbone.stage4.%d.branch_main." % (blk + 1)
-                assert np.array_equal(w1t, w[p4 + "0.weight"].reshape(C2, C2).numpy()[32 * th:32 * th + 32])
-                assert np.array_equal(w2t, w[p4 + "5.weight"].reshape(C2, C2).numpy()[:, 32 * th:32 * th + 32])
+                for got, full, sl in ((w1t, w[p4 + "0.weight"].reshape(C2, C2).numpy(), np.s_[32 * th:32 * th + 32, :]),
+                                      (w2t, w[p4 + "5.weight"].reshape(C2, C2).numpy(), np.s_[:, 32 * th:32 * th + 32])):
+                    sw = 14 - int(np.ceil(np.log2(np.abs(full).max())))
+                    assert np.abs(got - full[sl].astype(np.float64) * 2.0 ** sw).max() <= 2.0 ** 14 * 2.0 ** -22
             o = W1_FL + W2_FL
             taps = t[o:o + 288].reshape(9, 32)
             sc1, sh1, scd, shd = t[o + 288:o + 416].reshape(4, 32)
             sc2, sh2 = t[o + 416:o + 416 + 2 * C2].reshape(2, C2)
-            y = np.maximum(bi @ w1t.T * sc1 + sh1, 0.0).astype(np.float32)
+            y = np.maximum((bi * up) @ w1t.T * sc1 + sh1, 0.0).astype(np.float32)
             pad = np.zeros((H + 2, W + 2, 32), np.float32)
             pad[1:-1, 1:-1] = y
             d = np.zeros((H, W, 32), np.float32)
             for k in range(9):
                 d += pad[k // 3:k // 3 + H, k % 3:k % 3 + W] * taps[k]
-            acc2 += (d * scd + shd) @ w2t.T
+            acc2 += ((d * scd + shd) * up) @ w2t.T
         fresh = np.maximum(acc2 * sc2 + sh2, 0.0).astype(np.float32)
         pool = np.concatenate((pool[..., 0::2], fresh), -1)
     want = ref[0].permute(1, 2, 0).numpy()

@@ -360,6 +360,25 @@ struct WeightPacker {
               im.push_back(f);
             }
   }
+  // fp16x3 form of the same layout: [mt][chunk pair][term 2][64 lanes][4 dwords of fp16 pairs], el(row, column) already
+  // carrying its power of two
+  template <class Fn>
+  static void push_h2_fn(std::vector<float>& im, int MT, int KP, Fn el) {
+    for (int mt = 0; mt < MT; ++mt)
+      for (int sp = 0; sp < KP; ++sp)
+        for (int term = 0; term < 2; ++term)
+          for (int l = 0; l < 64; ++l)
+            for (int d = 0; d < 4; ++d) {
+              const int r = 16 * mt + (l & 15), c = 16 * (2 * sp + (d >> 1)) + 4 * (l >> 4) + 2 * (d & 1);
+              unsigned packed = 0;
+              for (int e = 0; e < 2; ++e) {
+                const float v = el(r, c + e), h1 = rn_f16(v);
+                packed |= f16_bits(term == 0 ? h1 : v - h1) << (16 * e);
+              }
+              float f; std::memcpy(&f, &packed, 4);
+              im.push_back(f);
+            }
+  }
   static void push_frag_split3(std::vector<float>& im, const float* w, int M, int K, int MT, int KC) {
     for (int mt = 0; mt < MT; ++mt)
       for (int sp = 0; sp < KC / 2; ++sp)
@@ -1266,11 +1285,18 @@ struct PlanBuilder {
       ok &= wp.pw(names[k] + ".branch_main.5", names[k] + ".branch_main.6", c2, c2, &f2);
       if (!ok) break;
       const float* w1 = &wp.blob[f1.w]; const float* w2 = &wp.blob[f2.w]; const float* wd = &wp.blob[fd.w];
+      int sw1 = 0, sw2 = 0;   // fp16x3: one power of two per filter; the BN scales below carry the exact 2^-(sw+4)
+      if (pre) {
+        float m1 = 0.f, m2 = 0.f;
+        for (int i = 0; i < c2 * c2; ++i) { m1 = std::fmax(m1, std::fabs(w1[i])); m2 = std::fmax(m2, std::fabs(w2[i])); }
+        sw1 = WeightPacker::pow2_for(m1); sw2 = WeightPacker::pow2_for(m2);
+      }
+      const int un1 = pre ? sw1 + 4 : 0, un2 = pre ? sw2 + 4 : 0;
       for (int t = 0; t < 3; ++t) {
         const size_t start = im.size();
-        if (pre) {   // bf16 hi / mid / lo operand quads per chunk pair (block_s1pool_kernel<.., PRE>)
-          WeightPacker::push_split3_fn(im, 2, 3, [&](int r, int cc) { return w1[(size_t)(32 * t + r) * c2 + cc]; });    // W1 rows 32 t .. +31, K = 96
-          WeightPacker::push_split3_fn(im, 6, 1, [&](int r, int cc) { return w2[(size_t)r * c2 + 32 * t + cc]; });      // W2 columns 32 t .. +31
+        if (pre) {   // two fp16 terms x 2^sw per chunk pair (block_s1pool_kernel<.., PRE>: fp16x3)
+          WeightPacker::push_h2_fn(im, 2, 3, [&](int r, int cc) { return std::ldexp(w1[(size_t)(32 * t + r) * c2 + cc], sw1); });    // W1 rows 32 t .. +31, K = 96
+          WeightPacker::push_h2_fn(im, 6, 1, [&](int r, int cc) { return std::ldexp(w2[(size_t)r * c2 + 32 * t + cc], sw2); });      // W2 columns 32 t .. +31
         } else {
         for (int mt = 0; mt < 2; ++mt)
           for (int s = 0; s < 6; ++s)
@@ -1284,8 +1310,8 @@ struct PlanBuilder {
         for (int tap = 0; tap < 9; ++tap)
           for (int ch = 0; ch < 32; ++ch) im.push_back(wd[(size_t)tap * c2 + 32 * t + ch]);
         for (const size_t* v : {&f1.scale, &f1.shift, &fd.scale, &fd.shift})
-          for (int ch = 0; ch < 32; ++ch) im.push_back(wp.blob[*v + 32 * t + ch]);
-        for (int ch = 0; ch < c2; ++ch) im.push_back(wp.blob[f2.scale + ch]);
+          for (int ch = 0; ch < 32; ++ch) im.push_back(v == &f1.scale ? std::ldexp(wp.blob[*v + 32 * t + ch], -un1) : wp.blob[*v + 32 * t + ch]);
+        for (int ch = 0; ch < c2; ++ch) im.push_back(std::ldexp(wp.blob[f2.scale + ch], -un2));
         for (int ch = 0; ch < c2; ++ch) im.push_back(wp.blob[f2.shift + ch]);
         if ((int)(im.size() - start) != yfv2_s1pool_image_floats(pre)) ok = false;
       }

@@ -457,7 +457,7 @@ constexpr int P96_W1_FL = 2 * P96_KC * 256, P96_W2_FL = P96_KC * 2 * 256;       
 constexpr int P96_IMG_FL = P96_W1_FL + P96_W2_FL + 9 * P96_TC + 4 * P96_TC + 2 * P96_C2;   // + taps, sc1 sh1 scd shd, sc2 sh2
 // PRE: W1 / W2 pre-split into bf16 hi / mid / lo operand quads per chunk pair (WeightPacker, as block_s2w_kernel's W1):
 // [mt][pair][term][64][4] - W1 of a third = 2 tiles x 3 pairs, W2 = 6 tiles x 1 pair; 1.5x the fp32 fragments
-constexpr int P96_W1P_FL = 2 * (P96_KC / 2) * 3 * 256, P96_W2P_FL = P96_KC * 1 * 3 * 256;
+constexpr int P96_W1P_FL = 2 * (P96_KC / 2) * 2 * 256, P96_W2P_FL = P96_KC * 1 * 2 * 256;   // PRE: two fp16 terms per chunk pair (fp16x3)
 constexpr int P96_IMGP_FL = P96_W1P_FL + P96_W2P_FL + 9 * P96_TC + 4 * P96_TC + 2 * P96_C2;
 constexpr int P96_MAXPX = 128;
 
@@ -524,21 +524,32 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
 #pragma unroll
       for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // PRE: pw1's B operands for the whole block - the 96 odd pool channels of this lane's pixel, per chunk pair
-      yfv2_bf16x8 b1h[PRE ? P96_KC / 2 : 1], b1m[PRE ? P96_KC / 2 : 1], b1l[PRE ? P96_KC / 2 : 1];
+      // (fp16x3, round 3: x 2^4, two fp16 terms; round 2's form was bf16x6 - three terms, six products)
+      yfv2_h8c b1a[PRE ? P96_KC / 2 : 1], b1b[PRE ? P96_KC / 2 : 1];
+      auto split_pair = [&](f32x4 c0, f32x4 c1, yfv2_h8c& t1, yfv2_h8c& t2) __attribute__((always_inline)) {
+        u32x4 u1, u2;
+        const f32x4 cs[2] = {c0 * 16.0f, c1 * 16.0f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const yfv2_h4c h1 = __builtin_convertvector(cs[e], yfv2_h4c);
+          const yfv2_h4c h2 = __builtin_convertvector(cs[e] - __builtin_convertvector(h1, f32x4), yfv2_h4c);
+          const yfv2_u2c a1 = __builtin_bit_cast(yfv2_u2c, h1), a2 = __builtin_bit_cast(yfv2_u2c, h2);
+          u1[2 * e] = a1[0]; u1[2 * e + 1] = a1[1]; u2[2 * e] = a2[0]; u2[2 * e + 1] = a2[1];
+        }
+        t1 = __builtin_bit_cast(yfv2_h8c, u1); t2 = __builtin_bit_cast(yfv2_h8c, u2);
+      };
       if constexpr (PRE) {
 #pragma unroll
         for (int sp = 0; sp < P96_KC / 2; ++sp) {
-          unsigned hh[2][2], mm[2][2], ll[2][2];
+          f32x4 c[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int s2 = 2 * sp + e;
             const f32x4 q0 = *reinterpret_cast<const f32x4*>(ppix + 32 * s2 + 8 * g);
             const f32x4 q1 = *reinterpret_cast<const f32x4*>(ppix + 32 * s2 + 8 * g + 4);
-            yfv2_split3((f32x4){q0[1], q0[3], q1[1], q1[3]}, hh[e], mm[e], ll[e]);
+            c[e] = (f32x4){q0[1], q0[3], q1[1], q1[3]};
           }
-          b1h[sp] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){hh[0][0], hh[0][1], hh[1][0], hh[1][1]});
-          b1m[sp] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){mm[0][0], mm[0][1], mm[1][0], mm[1][1]});
-          b1l[sp] = __builtin_bit_cast(yfv2_bf16x8, (u32x4){ll[0][0], ll[0][1], ll[1][0], ll[1][1]});
+          split_pair(c[0], c[1], b1a[sp], b1b[sp]);
         }
       }
 #pragma unroll 1
@@ -562,16 +573,15 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
           if constexpr (PRE) {
 #pragma unroll
             for (int sp = 0; sp < P96_KC / 2; ++sp) {
-              yfv2_bf16x8 ah[2], am[2], al[2];
+              yfv2_h8c a1[2], a2[2];
 #pragma unroll
               for (int mt = 0; mt < 2; ++mt) {
-                const float* wq3 = W1t + (((mt * (P96_KC / 2) + sp) * 3) * 64 + lane) * 4;
-                ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
-                am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
-                al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
+                const float* wq2 = W1t + (((mt * (P96_KC / 2) + sp) * 2) * 64 + lane) * 4;
+                a1[mt] = __builtin_bit_cast(yfv2_h8c, *reinterpret_cast<const u32x4*>(wq2));
+                a2[mt] = __builtin_bit_cast(yfv2_h8c, *reinterpret_cast<const u32x4*>(wq2 + 256));
               }
-#define P96_PROD(A_, B_) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[mt], B_, acc1[mt], 0, 0, 0);
-              P96_PROD(al, b1h[sp]) P96_PROD(ah, b1l[sp]) P96_PROD(am, b1m[sp]) P96_PROD(am, b1h[sp]) P96_PROD(ah, b1m[sp]) P96_PROD(ah, b1h[sp])
+#define P96_PROD(A_, B_) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[mt], B_, acc1[mt], 0, 0, 0);
+              P96_PROD(a1, b1b[sp]) P96_PROD(a2, b1a[sp]) P96_PROD(a1, b1a[sp])
 #undef P96_PROD
             }
           } else {
@@ -624,22 +634,17 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) bfr2[c2][c] = __builtin_fmaf(d[c], dsc[c], dsh[c]);
           }
-          unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
-          yfv2_split3(bfr2[0], h0, m0, l0);
-          yfv2_split3(bfr2[1], h1, m1, l1);
-          const yfv2_bf16x8 bh = __builtin_bit_cast(yfv2_bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
-          const yfv2_bf16x8 bm = __builtin_bit_cast(yfv2_bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
-          const yfv2_bf16x8 bl = __builtin_bit_cast(yfv2_bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
-          yfv2_bf16x8 ah[P96_KC], am[P96_KC], al[P96_KC];
+          yfv2_h8c x1, x2;
+          split_pair(bfr2[0], bfr2[1], x1, x2);
+          yfv2_h8c a1[P96_KC], a2[P96_KC];
 #pragma unroll
           for (int mt = 0; mt < P96_KC; ++mt) {
-            const float* wq3 = W2t + ((mt * 3) * 64 + lane) * 4;
-            ah[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3));
-            am[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 256));
-            al[mt] = __builtin_bit_cast(yfv2_bf16x8, *reinterpret_cast<const u32x4*>(wq3 + 512));
+            const float* wq2 = W2t + ((mt * 2) * 64 + lane) * 4;
+            a1[mt] = __builtin_bit_cast(yfv2_h8c, *reinterpret_cast<const u32x4*>(wq2));
+            a2[mt] = __builtin_bit_cast(yfv2_h8c, *reinterpret_cast<const u32x4*>(wq2 + 256));
           }
-#define P96_PROD(A_, B_) _Pragma("unroll") for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[mt], B_, acc2[mt], 0, 0, 0);
-          P96_PROD(al, bh) P96_PROD(ah, bl) P96_PROD(am, bm) P96_PROD(am, bh) P96_PROD(ah, bm) P96_PROD(ah, bh)
+#define P96_PROD(A_, B_) _Pragma("unroll") for (int mt = 0; mt < P96_KC; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[mt], B_, acc2[mt], 0, 0, 0);
+          P96_PROD(a1, x2) P96_PROD(a2, x1) P96_PROD(a1, x1)
 #undef P96_PROD
         } else {
 #pragma unroll
