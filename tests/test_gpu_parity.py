@@ -118,6 +118,29 @@ def test_forward_random_weights_odd_batches(yfv2, dev):
             assert err <= LOGIT_ATOL * scale, "B=%d %s: max abs err %g (scale %g)" % (B, k, err, scale)
 
 
+def test_forward_more_images_than_compute_units(yfv2, dev):
+    """Batch 300 on a 256-CU device: every one-workgroup-per-image kernel (the chains, stage3.0 / stage4.0, the towers) runs a
+    second image on 44 of its workgroups, with the next image's first slice prefetched across the image boundary.  Images on
+    both sides of that boundary against the oracle, and bit-identical to what the same image gives in a batch of one."""
+    w = yfv2.random_state_dict(4)
+    m = yfv2.Detector(80, 3, True).to(dev)
+    m.load_state_dict(w)
+    m.eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(300, 3, 352, 352, generator=g)
+    got = [t.cpu() for t in m(x.to(dev))]
+    pick = [0, 43, 44, 255, 256, 299]
+    ref = oracle.forward(w, x[pick])
+    for gt, r, k in zip(got, ref, LOGIT_KEYS):
+        scale = max(1.0, float(r.abs().max()))
+        err = float((gt[pick] - r).abs().max())
+        assert err <= LOGIT_ATOL * scale, "%s: max abs err %g (scale %g)" % (k, err, scale)
+    for i in (44, 256, 299):
+        alone = m(x[i:i + 1].to(dev))
+        for gt, a, k in zip(got, alone, LOGIT_KEYS):
+            assert torch.equal(gt[i], a[0].cpu()), "image %d, %s: differs from its batch-of-one result" % (i, k)
+
+
 def test_batch_invariance_and_permutation(model, dev, images_u8):
     """Size-independent property at the bench batch size: every image's logits are
     bit-identical whatever its position in a 256-batch, and equal to its batch-1 result."""
