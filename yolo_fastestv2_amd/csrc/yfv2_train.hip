@@ -92,15 +92,18 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvP a) {
 }
 
 // dW[co][ci][ky][kx] += sum_{b, oy, ox} dOut * In   (a.in = the input VALUES, a.out = gradient of the output, a.w unused);
-// one block per (co, ci) - (channel, 0) for depthwise -, every filter entry written by exactly one block: no atomics
+// one block per (co, ci, segment of the (b, oy, ox) range) - (channel, 0, segment) for depthwise.  With one segment every
+// filter entry is written by exactly one block; with several (layers with few filter entries and a long reduction: the stem,
+// the depthwise convs - one block per entry left 24..192 blocks on 256 CUs) the partial sums meet in a float atomic.
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvP a, float* dw_out) {
   __shared__ double red[256];
   const int co = blockIdx.x, ci = a.dw ? co : (int)blockIdx.y, cig = a.dw ? 0 : ci, cin_g = a.dw ? 1 : a.in.C;
   const int k = a.k, kk = k * k, OH = a.out.H, OW = a.out.W;
   double acc[25];
   for (int t = 0; t < kk; ++t) acc[t] = 0.0;
-  const int n = a.B * OH * OW;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  const int n = a.B * OH * OW, nseg = gridDim.z, len = (n + nseg - 1) / nseg;
+  const int i0 = blockIdx.z * len, i1 = i0 + len < n ? i0 + len : n;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     const int ox = i % OW, oy = (i / OW) % OH, b = i / (OW * OH);
     const float g = a.out.p[a.out.at(b, co, oy, ox)];
     for (int ky = 0; ky < k; ++ky) {
@@ -116,9 +119,19 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvP a, float* dw
     red[threadIdx.x] = acc[t];
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) dw_out[((size_t)co * cin_g + cig) * kk + t] += (float)red[0];
+    if (threadIdx.x == 0) {
+      float* dst = dw_out + ((size_t)co * cin_g + cig) * kk + t;
+      if (nseg == 1) *dst += (float)red[0]; else atomicAdd(dst, (float)red[0]);
+    }
     __syncthreads();
   }
+}
+// segments for a reduction of n elements next to `others` independent blocks: about 2048 blocks in all, at least 2048 elements each
+inline unsigned reduce_segments(size_t n, size_t others) {
+  size_t s = others >= 2048 ? 1 : 2048 / (others ? others : 1);
+  if (s > 64) s = 64;
+  if (s > n / 2048) s = n / 2048;
+  return (unsigned)(s < 1 ? 1 : s);
 }
 
 __global__ __launch_bounds__(256) void bias_bwd_kernel(V g, int B, float* db) {
@@ -134,31 +147,29 @@ __global__ __launch_bounds__(256) void bias_bwd_kernel(V g, int B, float* db) {
 
 // BatchNorm2d, training mode: per-channel batch mean / biased variance of y (B, C, H, W contiguous); saves mean and
 // 1/sqrt(var + eps); running = 0.9 running + 0.1 (mean | unbiased variance)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, int C, int HW, float* mean, float* invstd, float* run_mean, float* run_var) {
-  __shared__ double red[256];
-  __shared__ double s_mean;
-  const int c = blockIdx.x, n = B * HW;
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += (double)y[((size_t)(i / HW) * C + c) * HW + i % HW];
-  red[threadIdx.x] = acc;
+// per channel and segment: sum and sum of squares of y in double, into acc[4 c + 0, 1] (zeroed per forward)
+__global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* y, int B, int C, int HW, double* acc) {
+  __shared__ double r0[256], r1[256];
+  const int c = blockIdx.x, n = B * HW, nseg = gridDim.y, len = (n + nseg - 1) / nseg;
+  const int i0 = blockIdx.y * len, i1 = i0 + len < n ? i0 + len : n;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) { const double v = (double)y[((size_t)(i / HW) * C + c) * HW + i % HW]; a0 += v; a1 += v * v; }
+  r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) s_mean = red[0] / n;
-  __syncthreads();
-  const double m = s_mean;
-  acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) { const double d = (double)y[((size_t)(i / HW) * C + c) * HW + i % HW] - m; acc += d * d; }
-  __syncthreads();
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) {
-    const double var = red[0] / n;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + 1e-5));
-    run_mean[c] = (float)(0.9 * (double)run_mean[c] + 0.1 * m);
-    run_var[c] = (float)(0.9 * (double)run_var[c] + 0.1 * (n > 1 ? var * n / (n - 1) : var));
-  }
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; } __syncthreads(); }
+  if (threadIdx.x == 0) { atomicAdd(&acc[4 * c + 0], r0[0]); atomicAdd(&acc[4 * c + 1], r1[0]); }
+}
+// mean, 1 / sqrt(biased variance + eps) (variance = E[y^2] - mean^2 in double: the inputs are fp32), running statistics
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(int C, int n, const double* acc, float* mean, float* invstd, float* run_mean, float* run_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double m = acc[4 * c] / n;
+  double var = acc[4 * c + 1] / n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + 1e-5));
+  run_mean[c] = (float)(0.9 * (double)run_mean[c] + 0.1 * m);
+  run_var[c] = (float)(0.9 * (double)run_var[c] + 0.1 * (n > 1 ? var * n / (n - 1) : var));
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, V z, int B, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu) {
@@ -173,12 +184,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, V z, int 
 
 // per channel: sum of dz' and of dz' * xhat (dz' = dz where the ReLU let the value through); -> d beta, d gamma, and the two
 // sums for bn_bwd_apply
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* y, V z, V dz, int B, const float* mean, const float* invstd, int relu, float* sums,
-                                                           float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(256) void bn_bwd_part_kernel(const float* y, V z, V dz, int B, const float* mean, const float* invstd, int relu, double* acc) {
   __shared__ double r0[256], r1[256];
-  const int c = blockIdx.x, HW = z.H * z.W, n = B * HW;
+  const int c = blockIdx.x, HW = z.H * z.W, n = B * HW, nseg = gridDim.y, len = (n + nseg - 1) / nseg;
+  const int i0 = blockIdx.y * len, i1 = i0 + len < n ? i0 + len : n;
   double a0 = 0.0, a1 = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     const int b = i / HW, r = i % HW;
     float g = dz.p[dz.at(b, c, r / z.W, r % z.W)];
     if (relu && !(z.p[z.at(b, c, r / z.W, r % z.W)] > 0.f)) g = 0.f;
@@ -188,7 +199,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* y, V z,
   r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; } __syncthreads(); }
-  if (threadIdx.x == 0) { sums[2 * c] = (float)r0[0]; sums[2 * c + 1] = (float)r1[0]; dbeta[c] += (float)r0[0]; dgamma[c] += (float)r1[0]; }
+  if (threadIdx.x == 0) { atomicAdd(&acc[4 * c + 2], r0[0]); atomicAdd(&acc[4 * c + 3], r1[0]); }
+}
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(int C, const double* acc, float* sums, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  sums[2 * c] = (float)acc[4 * c + 2]; sums[2 * c + 1] = (float)acc[4 * c + 3];
+  dbeta[c] += (float)acc[4 * c + 2]; dgamma[c] += (float)acc[4 * c + 3];
 }
 
 // dy = gamma * invstd * (dz' - sum(dz') / N - xhat * sum(dz' xhat) / N)   (dy is the conv output's gradient: single consumer, overwritten)
@@ -281,6 +298,7 @@ struct Train {
   int B = 0;
   float* acts = nullptr; float* grads = nullptr; size_t arena_floats = 0, used = 0;
   int* pool_arg = nullptr; size_t pool_arg_n = 0;
+  double* dscr = nullptr; size_t dscr_n = 0, dscr_used = 0;   // four doubles per BatchNorm channel: sum, sum of squares, the two backward sums (zeroed per forward)
   std::map<std::string, float*> param, pgrad;
   std::vector<std::function<void(hipStream_t)>> tape;
   std::map<std::string, V> relu_out;   // conv name -> the view its ReLU wrote (yfv2_debug_train_relu_output)
@@ -312,17 +330,22 @@ struct Train {
     float* mean = acts + st.off; float* invstd = mean + Cout; float* sums = invstd + Cout;
     ConvP c{view(tin, false, in_coff, in_cstride, Cin), view(y, false), w, nullptr, k, stride, pad, dw ? 1 : 0, B};
     hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, c);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(Cout), dim3(256), 0, s, acts + y.off, B, Cout, OH * OW, mean, invstd, rm, rv);
+    double* ds = dscr + dscr_used; dscr_used += 4 * (size_t)Cout;
+    if (dscr_used > dscr_n) { if (err.empty()) err = "yfv2_train: BatchNorm scratch exhausted"; return; }
+    const unsigned nseg = reduce_segments((size_t)B * OH * OW, Cout);
+    hipLaunchKernelGGL(bn_stats_part_kernel, dim3(Cout, nseg), dim3(256), 0, s, acts + y.off, B, Cout, OH * OW, ds);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, Cout, B * OH * OW, ds, mean, invstd, rm, rv);
     const V z = view(tout, false, out_coff, 1, Cout), dz = view(tout, true, out_coff, 1, Cout);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, acts + y.off, z, B, mean, invstd, gam, bet, relu ? 1 : 0);
     if (relu) relu_out[conv] = z;
     const int Bc = B;
     tape.push_back([=, this](hipStream_t st2) {
       float* yv = acts + y.off; float* dy = grads + y.off;
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(Cout), dim3(256), 0, st2, yv, z, dz, Bc, mean, invstd, relu ? 1 : 0, sums, gg, gb);
+      hipLaunchKernelGGL(bn_bwd_part_kernel, dim3(Cout, nseg), dim3(256), 0, st2, yv, z, dz, Bc, mean, invstd, relu ? 1 : 0, ds);
+      hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, st2, Cout, ds, sums, gg, gb);
       hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)Bc * Cout * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, Bc, mean, invstd, gam, relu ? 1 : 0, sums);
       ConvP cw{view(tin, false, in_coff, in_cstride, Cin), view(y, true), nullptr, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
-      hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(Cout, dw ? 1 : Cin), dim3(256), 0, st2, cw, gw);
+      hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(Cout, dw ? 1 : Cin, reduce_segments((size_t)Bc * OH * OW, (size_t)Cout * (dw ? 1 : Cin))), dim3(256), 0, st2, cw, gw);
       if (need_din) {
         ConvP cd{view(tin, true, in_coff, in_cstride, Cin), view(y, true), w, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
         hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)Bc * Cin * tin.H * tin.W)), dim3(256), 0, st2, cd);
@@ -359,6 +382,7 @@ void yfv2_train_release(void* p) {
   if (t->acts) (void)hipFree(t->acts);
   if (t->grads) (void)hipFree(t->grads);
   if (t->pool_arg) (void)hipFree(t->pool_arg);
+  if (t->dscr) (void)hipFree(t->dscr);
   delete t;
 }
 
@@ -399,17 +423,21 @@ int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const ou
           V xin{const_cast<float*>(x), 3, 0, 1, 3, H, W};
           ConvP c{xin, t->view(y, false), w, nullptr, 3, 2, 1, 0, B};
           hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, c);
-          hipLaunchKernelGGL(bn_stats_kernel, dim3(24), dim3(256), 0, s, t->acts + y.off, B, 24, OH * OW, mean, invstd, rm, rv);
+          double* ds = t->dscr + t->dscr_used; t->dscr_used += 4 * 24;
+          const unsigned nseg = reduce_segments((size_t)B * OH * OW, 24);
+          hipLaunchKernelGGL(bn_stats_part_kernel, dim3(24, nseg), dim3(256), 0, s, t->acts + y.off, B, 24, OH * OW, ds);
+          hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(256), 0, s, 24, B * OH * OW, ds, mean, invstd, rm, rv);
           const V z = t->view(stem, false), dz = t->view(stem, true);
           hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, t->acts + y.off, z, B, mean, invstd, gam, bet, 1);
           t->relu_out["backbone.first_conv.0"] = z;
           Train* tt = t;
           t->tape.push_back([=](hipStream_t st2) {
             float* yv = tt->acts + y.off; float* dy = tt->grads + y.off;
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(24), dim3(256), 0, st2, yv, z, dz, B, mean, invstd, 1, sums, gg, gb);
+            hipLaunchKernelGGL(bn_bwd_part_kernel, dim3(24, nseg), dim3(256), 0, st2, yv, z, dz, B, mean, invstd, 1, ds);
+            hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(256), 0, st2, 24, ds, sums, gg, gb);
             hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, B, mean, invstd, gam, 1, sums);
             ConvP cw{xin, tt->view(y, true), nullptr, nullptr, 3, 2, 1, 0, B};
-            hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(24, 3), dim3(256), 0, st2, cw, gw);
+            hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(24, 3, reduce_segments((size_t)B * OH * OW, 72)), dim3(256), 0, st2, cw, gw);
           });
           // maxpool
           const size_t np = (size_t)B * 24 * (H / 4) * (W / 4);
@@ -516,6 +544,12 @@ int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const ou
     if (hipMalloc(reinterpret_cast<void**>(&t->pool_arg), npool * sizeof(int)) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: out of device memory");
     t->pool_arg_n = npool;
   }
+  if (!t->dscr) {
+    t->dscr_n = 1 << 16;   // 4 doubles x 16 K BatchNorm channels (the network has ~5 K)
+    if (hipMalloc(reinterpret_cast<void**>(&t->dscr), t->dscr_n * sizeof(double)) != hipSuccess) { t->dscr = nullptr; return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: out of device memory"); }
+  }
+  if (hipMemsetAsync(t->dscr, 0, t->dscr_n * sizeof(double), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: memset failed");
+  t->dscr_used = 0;
   build(false);
   if (!t->err.empty()) { t->tape.clear(); return yfv2_ctx_fail(h, YFV2_ERR_WEIGHTS, t->err.c_str()); }
   if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: launch failed");
@@ -538,7 +572,7 @@ int yfv2_train_backward(yfv2_handle h, const float* const grad6[6], void* stream
     V go{const_cast<float*>(grad6[i]), u.Cout, 0, 1, u.Cout, u.tin.H, u.tin.W};
     hipLaunchKernelGGL(bias_bwd_kernel, dim3(u.Cout), dim3(256), 0, s, go, B, gb);
     ConvP cw{t->view(u.tin, false), go, nullptr, nullptr, 1, 1, 0, 0, B};
-    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(u.Cout, 72), dim3(256), 0, s, cw, gw);
+    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(u.Cout, 72, reduce_segments((size_t)B * u.tin.H * u.tin.W, (size_t)u.Cout * 72)), dim3(256), 0, s, cw, gw);
     ConvP cd{t->view(u.tin, true), go, w, nullptr, 1, 1, 0, 0, B};
     hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)B * 72 * u.tin.H * u.tin.W)), dim3(256), 0, s, cd);
   }
