@@ -1551,7 +1551,8 @@ std::string step_kernel(const Step& st) {
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
-      if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4, 1>" : (st.jobs.empty() ? "1, 1, 1>" : "1, 1, 4>"));   // default plan
+      if (st.img_off3 && !st.jobs.empty()) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
+      if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4, 1>" : "1, 1, 1>");   // default plan
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
@@ -1646,6 +1647,10 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
         TowerJobs jobs{};
         if (st.jobs.empty()) { jobs.j[0] = args_of(st); jobs.n = 1; }
         else { jobs.n = (int)st.jobs.size(); for (int k = 0; k < jobs.n; ++k) jobs.j[k] = args_of(st.jobs[k]); }
+        // half a -> half b of a tower inside one launch: the tensor between them stays in the workgroup's LDS - as long as every
+        // workgroup has ONE image (the job loop is outside the image loop)
+        for (int k = 0; k + 1 < jobs.n; ++k)
+          if (B <= 256 && !jobs.j[k].has_head && jobs.j[k].out == jobs.j[k + 1].in) { jobs.j[k].chain |= 2; jobs.j[k + 1].chain |= 1; }
         done = yfv2_launch_towerh(jobs, st.tw_tiles, s);
       }
       if (!done) {   // tower2_kernel, one launch per half

@@ -242,6 +242,7 @@ struct TowerArgs {
   long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (or null)
   int bf6;           // pointwise + chained output conv as bf16x6
   const float* img16;  // towerh_kernel's image (yfv2_towerh.hip), or null: tower2_kernel
+  int chain;           // towers_kernel job list: bit 0 = the input is what the previous job left in LDS, bit 1 = the output stays in LDS for the next job (no global round trip)
 };
 
 // ---- decode (handel_preds) and NMS

@@ -387,6 +387,225 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {
   }
 }
 
+// ============================================================================
+// Small maps (up to 11x11): towers_kernel - the whole image in one pass, depthwise with lane = (row, channel)
+// ============================================================================
+// At 11x11 a tower half is 121 pixels.  The chunked kernel above, at one pixel per lane, reads every input value 25 times from
+// LDS (871 KB per job through one CU's LDS port: ~10 k cycles, measured) and goes through eleven barriers and five dependent
+// rounds of global loads per job: the four jobs of an image take 44 us even at batch 1.  Here:
+//   * the image is staged ONCE as it lies in memory ([pixel][72 channels]: one contiguous 35 KB run, fully coalesced);
+//   * depthwise: a lane = (output row y, channel c), 792 lane units = 13 wave units over eight waves (two per wave).  The
+//     lane reads the five input rows of its channel into registers (55 values, one LDS round trip) and slides the taps over
+//     them: an input value is read five times (once per output row it feeds) instead of 25, every read is 64 consecutive
+//     channels of one pixel (256 contiguous bytes: conflict-free), the 25 taps and the BN constants are per-lane registers
+//     read from the tap table the job's filter image brings into LDS;
+//   * exchange: BN + ReLU results as fp32 [pixel][76] (pitch 76 = 12 mod 64 banks: the pointwise phase's 16-byte reads of 16
+//     pixels x 4 lane groups are conflict-free), split into two fp16 terms by the reader;
+//   * pointwise (K = 72 in one go) and the transposed output conv as in towerh_kernel.
+// Three barriers per job.
+template <int MH>
+__global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
+  struct { int B, H, W; long long* trace; } a;
+  a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
+  constexpr int KC = TH_KC, C = TH_C, NQ = C / 4, MAXW = 11, CP = 76, MAXPX = 128;
+  constexpr int TAPS_FL = NQ * 27 * 4;
+  constexpr int LDS_IMG = th_lds_img(MH) + TAPS_FL;               // pointwise filter, constants, output-conv filter, tap table: one straight copy
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* WP_ = lds;
+  float* CS = lds + TH_CS;
+  float* WH = lds + TH_WH;
+  float* IN = lds + LDS_IMG;                                      // [row + 2][W][72]: two zero rows above and below the image
+  float* X32 = IN + (MAXW + 4) * MAXW * C;                        // [pixel][76]; rows past H*W stay zero
+  const int H = a.H, W = a.W, HW = H * W;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grid = gridDim.x;
+  YFV2_WSTAMP(0);
+  const int opix = 16 * wv + p;                                   // pointwise tile: 16 pixels per wave
+  const bool pv = opix < HW;
+  for (int i = tid; i < ((MAXW + 4) * MAXW * C + MAXPX * CP) / 4; i += 512) reinterpret_cast<f32x4*>(IN)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int N4 = LDS_IMG / 4, NIT = (N4 + 511) / 512;
+  const __attribute__((address_space(4))) TowerArgs* kj = (const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  f32x4 tmp[NIT];                                                 // the NEXT job's filter image, in flight while this job computes
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(kj[0].img16);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
+  }
+#pragma unroll 1
+  for (int ji = 0; ji < jobs.n; ++ji) {
+  const __attribute__((address_space(4))) TowerArgs& ja = kj[ji];
+  const float* tapsf = lds + th_lds_img(MH);                      // [quad][27][4]: 25 taps, BN scale x 16, BN shift x 16 (in LDS: as per-lane
+                                                                  // global gathers the 54 loads of a wave cost the job ~7 k cycles of address traffic)
+  constexpr int NPF = (MAXPX * NQ + 511) / 512;                   // 16-byte pieces of the image per thread (5)
+#pragma unroll 1
+  for (int b = blockIdx.x; b < a.B; b += grid) {
+    // ---- everything the job needs from memory is requested at once
+    const bool in_lds = (ja.chain & 1) != 0, out_lds = (ja.chain & 2) != 0;   // half a -> half b of a tower: the 72-channel tensor between them never leaves LDS
+    f32x4 pre[NPF];
+    if (!in_lds) {
+      const f32x4* img = reinterpret_cast<const f32x4*>(ja.in + (size_t)b * HW * C);
+#pragma unroll
+      for (int j = 0; j < NPF; ++j) { const int i = tid + j * 512; pre[j] = img[i < HW * NQ ? i : 0]; }
+    }
+    const bool first_image = b == (int)blockIdx.x;
+    // the two lane units of this wave
+    bool uon[2], ulane[2];
+    int uy[2], uc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int L = 64 * (wv + 8 * k) + lane;
+      uon[k] = 64 * (wv + 8 * k) < H * C;
+      ulane[k] = L < H * C;
+      const int Lc = ulane[k] ? L : 0;
+      uy[k] = yfv2_fdiv(Lc, 1.0f / (float)C); uc[k] = Lc - uy[k] * C;
+    }
+    __syncthreads();                                              // the previous job / image is done with LDS
+    if (!in_lds) {
+#pragma unroll
+      for (int j = 0; j < NPF; ++j) { const int i = tid + j * 512; if (i < HW * NQ) reinterpret_cast<f32x4*>(IN + 2 * W * C)[i] = pre[j]; }
+    }
+    if (first_image) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; if (i < N4) reinterpret_cast<f32x4*>(lds)[i] = tmp[k]; }
+    }
+    __syncthreads();                                              // image and filters in LDS
+    YFV2_WSTAMP(1);
+    if (first_image && ji + 1 < jobs.n) {                         // the next job's filter image: off its critical path
+      const f32x4* src = reinterpret_cast<const f32x4*>(kj[ji + 1].img16);
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
+    }
+
+    // ---- depthwise: lane units (row, channel); a unit's five input rows are requested at once (one LDS round trip)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!uon[k]) continue;                                      // wave-uniform
+      const bool on = ulane[k];
+      const int y = uy[k], c = uc[k];
+      float twk[27];
+      {
+        const float* tl = tapsf + ((c >> 2) * 27) * 4 + (c & 3);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) twk[t] = tl[4 * t];
+      }
+      float v[5][MAXW];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const float* rp = IN + (y + r) * W * C + c;               // row y + r - 2 of the image: the halo rows are zero, every read is inside the buffer
+#pragma unroll
+        for (int x = 0; x < MAXW; ++x) { const float t = rp[x * C]; v[r][x] = x < W ? t : 0.f; }
+      }
+      float acc[MAXW];
+#pragma unroll
+      for (int x = 0; x < MAXW; ++x) acc[x] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int x = 0; x < MAXW; ++x)
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) {
+            const int xi = x + kx - 2;
+            if (xi >= 0 && xi < MAXW) acc[x] = __builtin_fmaf(v[r][xi], twk[r * 5 + kx], acc[x]);
+          }
+      if (on) {
+#pragma unroll
+        for (int x = 0; x < MAXW; ++x)
+          if (x < W) { const float uu = __builtin_fmaf(acc[x], twk[25], twk[26]); X32[(y * W + x) * CP + c] = uu > 0.f ? uu : 0.f; }   // (the BN constants carry the 2^4)
+      }
+    }
+    __syncthreads();                                              // exchange complete
+    YFV2_WSTAMP(2);
+
+    // ---- pointwise: K = 72 in one go
+    f32x4 acc[KC];
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      u32x4 xb[KC];
+#pragma unroll
+      for (int sc = 0; sc < KC; ++sc) {
+        const f32x4 v = 16 * sc + 4 * g < C ? *reinterpret_cast<const f32x4*>(X32 + opix * CP + 16 * sc + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        xb[sc] = split4(v);
+      }
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        u32x4 wf[KC];
+#pragma unroll
+        for (int sc = 0; sc < KC; ++sc) wf[sc] = *reinterpret_cast<const u32x4*>(WP_ + ((mt * KC + sc) * 64 + lane) * 4);
+#pragma unroll
+        for (int sc = 0; sc < KC; ++sc) acc[mt] = mfma_cross(wf[sc], xb[sc], acc[mt]);
+#pragma unroll
+        for (int sc = 0; sc + 1 < KC; sc += 2) acc[mt] = mfma_main2(wf[sc], wf[sc + 1], (yfv2_u2){xb[sc][0], xb[sc][1]}, xb[sc + 1], acc[mt]);
+        acc[mt] = mfma_main1(wf[KC - 1], xb[KC - 1], acc[mt]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < KC; ++mt) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + 16 * mt + 4 * g);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + 16 * mt + 4 * g);
+      acc[mt] = __builtin_elementwise_fma(acc[mt], sc, sh);
+    }
+    YFV2_WSTAMP(3);
+    if (MH == 0 || !ja.has_head) {
+      if (pv) {                                                   // (every depthwise read of IN is behind the exchange barrier)
+        float* dst = out_lds ? IN + (2 * W + opix) * C : ja.out + ((size_t)b * HW + opix) * C;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt)
+          if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt];
+      }
+    } else {
+      u32x4 xs[KC];
+#pragma unroll
+      for (int sc = 0; sc < KC; ++sc) xs[sc] = split4(acc[sc] * 16.0f);
+      const float us = CS[3 * 96];
+      const bool vec = (HW & 3) == 0;
+#pragma unroll 1
+      for (int m = 0; m < MH; ++m) {
+        if (16 * m >= ja.mh) break;
+        u32x4 wf[KC];
+#pragma unroll
+        for (int sc = 0; sc < KC; ++sc) wf[sc] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + sc) * 64 + lane) * 4);
+        f32x4 hacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sc = 0; sc < KC; ++sc) hacc = mfma_cross(xs[sc], wf[sc], hacc);
+#pragma unroll
+        for (int sc = 0; sc + 1 < KC; sc += 2) hacc = mfma_main2(xs[sc], xs[sc + 1], (yfv2_u2){wf[sc][0], wf[sc][1]}, wf[sc + 1], hacc);
+        hacc = mfma_main1(xs[KC - 1], wf[KC - 1], hacc);
+        const int co = 16 * m + p;
+        if (co < ja.mh) {
+          const float bias = CS[2 * 96 + co];
+          float* plane = co < ja.split ? ja.nchw0 + ((size_t)b * ja.split + co) * HW : ja.nchw1 + ((size_t)b * (ja.mh - ja.split) + (co - ja.split)) * HW;
+          const int px0 = 16 * wv + 4 * g;
+          f32x4 y;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(hacc[r], us, bias);
+          if (vec) {
+            if (px0 < HW) *reinterpret_cast<f32x4*>(plane + px0) = y;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (px0 + r < HW) plane[px0 + r] = y[r];
+          }
+        }
+      }
+    }
+    YFV2_WSTAMP(4);
+  }
+  __syncthreads();                                                // the next job reads what this one wrote for the same image
+  }
+}
+
+template <int MH>
+static void launch_towers(const TowerJobs& jobs, hipStream_t s) {
+  const int B = jobs.j[0].B;
+  const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + (TH_C / 4) * 27 * 4 + 15 * 11 * TH_C + 128 * 76);
+  static std::atomic<unsigned long long> lds_ok{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towers_kernel<MH>), lds_ok);
+  hipLaunchKernelGGL((towers_kernel<MH>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
+}
+
 template <int MH, int PS, int NT, int NJ>
 static void launch_towerh(const TowerJobs& jobs, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + 4 * (4 * 16 * NT * 8 + ThGeom<PS>::TIN_SLOTS));
@@ -402,7 +621,7 @@ bool yfv2_towerh_supported(int H, int W) {
   if (H <= 11 && W <= 11) return true;
   return H <= 22 && W <= 22 && ((H + 1) / 2) * ((W + 1) / 2) <= 128;
 }
-// several tower halves in one launch: the single-pixel kernel only (see the kernel)
+// several tower halves in one launch: maps up to 11x11 only (towers_kernel)
 bool yfv2_towerh_multi(int H, int W) { return H >= 1 && W >= 1 && H <= 11 && W <= 11; }
 
 // The kernel is instantiated for 0, 1 or 6 output-conv tiles; every job's image must be packed for `mh_tiles` of them
@@ -415,8 +634,8 @@ bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
   if (!yfv2_towerh_supported(a.H, a.W) || (mh_tiles != 0 && mh_tiles != 1 && mh_tiles != 6)) return false;
   if (jobs.n > 1) {
     if (!yfv2_towerh_multi(a.H, a.W) || mh_tiles == 0) return false;
-    if (mh_tiles == 1) launch_towerh<1, 1, 1, 4>(jobs, s);
-    else launch_towerh<6, 1, 1, 4>(jobs, s);
+    if (mh_tiles == 1) launch_towers<1>(jobs, s);
+    else launch_towers<6>(jobs, s);
   } else if (a.H <= 11 && a.W <= 11) {
     if (mh_tiles == 0) launch_towerh<0, 1, 1, 1>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 1, 1, 1>(jobs, s);
