@@ -1422,7 +1422,6 @@ struct PlanBuilder {
   // workgroup: cls a, cls b, reg a, reg b of its image, in the order the separate launches had): runs of four consecutive
   // such steps become one step.
   void merge_tower_launches() {
-    { const char* env = std::getenv("YFV2_TOWERMERGE"); if (env && env[0] == '0') return; }   // debugging aid
     std::vector<Step> out;
     for (size_t i = 0; i < h->plan.size();) {
       auto mergeable = [&](const Step& t) { return t.kind == STEP_TOWER && t.img_off3 != 0 && yfv2_towerh_multi(t.tw.H, t.tw.W) && t.tw.H == h->plan[i].tw.H && t.tw.W == h->plan[i].tw.W; };
@@ -1552,7 +1551,7 @@ std::string step_kernel(const Step& st) {
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
       if (st.img_off3 && !st.jobs.empty()) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
-      if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4, 1>" : "1, 1, 1>");   // default plan
+      if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");   // default plan
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)

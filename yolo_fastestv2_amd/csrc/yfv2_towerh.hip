@@ -87,9 +87,8 @@ template <int PS> struct ThGeom {
   static constexpr int TIN_SLOTS = 4 * PS * SP;
 };
 
-template <int MH, int PS, int NT, int NJ>
-__global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {
-  constexpr bool MULTI = NJ > 1;                               // several jobs per launch (the 11x11 maps); else exactly jobs.j[0]
+template <int MH, int PS, int NT>
+__global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs jobs.j[0] (job LISTS are towers_kernel's, below)
   struct { int B, H, W; long long* trace; } a;                 // geometry, batch and trace buffer are the same for every job
   a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
   constexpr int KC = TH_KC, C = TH_C, WS = PS + 4, NPAR = PS * PS, Q = TH_Q, SP = ThGeom<PS>::SP, XOFF = TH_XOFF;
@@ -161,18 +160,10 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {
     opix[nt] = q;                                                           // < XP always: pixels past HW read the zeroed exchange tail
   }
 
-  // ---- the jobs of this launch, one after the other (NJ > 1: the 11x11 maps, where four 15 us launches of 25 k busy cycles
-  // each cost more in launch overhead than the jobs' own serialisation; at 22x22 a job is 60-75 k cycles either way and the
-  // wider kernel - every job on the six-tile LDS layout, both epilogues - spills: separate launches there).  A later job
-  // may read what an earlier one wrote for the SAME image (half b reads half a's output): made visible by the barrier
-  // between jobs (workgroup scope: same CU, same L1, stores waited for).
-#pragma unroll 1
-  for (int ji = 0; ji < (MULTI ? jobs.n : 1); ++ji) {
-  // the job's fields straight from the kernel-argument segment (the jobs are the kernel's only argument: offset 0) by
-  // scalar loads at a dynamic offset.  Indexing jobs.j[ji] makes the compiler copy the array to scratch and turns every
-  // pointer below into a per-lane value (vector loads of the taps: 4x the time); selecting among the four jobs' fields keeps
-  // all 4 x 8 of them in SGPRs (spills).
-  const __attribute__((address_space(4))) TowerArgs& ja = ((const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[MULTI ? ji : 0];
+  // (The four halves of a 22x22 level as a job list of ONE launch were measured: 145 us against 132 as four launches - a job is
+  // 60-75 k cycles either way, and the wider kernel - every job on the six-tile LDS layout, both epilogues - spills.)
+  {
+  const __attribute__((address_space(4))) TowerArgs& ja = *(const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const yfv2_cf4* taps = (const yfv2_cf4*)(ja.img16 + th_lds_img(MH));
   int b = blockIdx.x;
   f32x4 pre[NPF];
@@ -189,8 +180,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
     constexpr int NZ = 4 * XP + ThGeom<PS>::TIN_SLOTS;
-    if (!MULTI || ji == 0)
-      for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // the tap table of this wave's five quads -> scalar cache: one request per 64-byte line, all issued back to back (as C++
     // loads the compiler serialises them in groups of eight, a trip to L2 / HBM each)
     const float* tq = ja.img16 + th_lds_img(MH) + qq * 108;
@@ -320,7 +310,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
     }
     YFV2_WSTAMP(17);
-    if (MH == 0 || (MULTI && !ja.has_head)) {
+    if constexpr (MH == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if (!pv[nt]) continue;
@@ -383,7 +373,6 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {
     }
     YFV2_WSTAMP(18);
   }
-  if (MULTI && ji + 1 < jobs.n) __syncthreads();   // workgroup-scope release/acquire: this job's global stores are complete (an agent-scope __threadfence() would write back and invalidate L2 on every XCD: measured 4x the launch time)
   }
 }
 
@@ -593,7 +582,9 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
     }
     YFV2_WSTAMP(4);
   }
-  __syncthreads();                                                // the next job reads what this one wrote for the same image
+  __syncthreads();                                                // the next job reads what this one wrote for the same image: workgroup scope is
+                                                                  // enough (same CU, same L1); an agent-scope __threadfence() here wrote back and
+                                                                  // invalidated L2 on every XCD - 4x the launch time
   }
 }
 
@@ -606,13 +597,13 @@ static void launch_towers(const TowerJobs& jobs, hipStream_t s) {
   hipLaunchKernelGGL((towers_kernel<MH>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
 }
 
-template <int MH, int PS, int NT, int NJ>
+template <int MH, int PS, int NT>
 static void launch_towerh(const TowerJobs& jobs, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + 4 * (4 * 16 * NT * 8 + ThGeom<PS>::TIN_SLOTS));
   static std::atomic<unsigned long long> lds_ok{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerh_kernel<MH, PS, NT, NJ>), lds_ok);
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerh_kernel<MH, PS, NT>), lds_ok);
   const int B = jobs.j[0].B;
-  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT, NJ>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
+  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
 }
 
 // 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
@@ -637,13 +628,13 @@ bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
     if (mh_tiles == 1) launch_towers<1>(jobs, s);
     else launch_towers<6>(jobs, s);
   } else if (a.H <= 11 && a.W <= 11) {
-    if (mh_tiles == 0) launch_towerh<0, 1, 1, 1>(jobs, s);
-    else if (mh_tiles == 1) launch_towerh<1, 1, 1, 1>(jobs, s);
-    else launch_towerh<6, 1, 1, 1>(jobs, s);
+    if (mh_tiles == 0) launch_towerh<0, 1, 1>(jobs, s);
+    else if (mh_tiles == 1) launch_towerh<1, 1, 1>(jobs, s);
+    else launch_towerh<6, 1, 1>(jobs, s);
   } else {
-    if (mh_tiles == 0) launch_towerh<0, 2, 4, 1>(jobs, s);
-    else if (mh_tiles == 1) launch_towerh<1, 2, 4, 1>(jobs, s);
-    else launch_towerh<6, 2, 4, 1>(jobs, s);
+    if (mh_tiles == 0) launch_towerh<0, 2, 4>(jobs, s);
+    else if (mh_tiles == 1) launch_towerh<1, 2, 4>(jobs, s);
+    else launch_towerh<6, 2, 4>(jobs, s);
   }
   return true;
 }
