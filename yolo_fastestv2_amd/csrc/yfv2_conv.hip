@@ -396,13 +396,13 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
     if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_PLAIN>(a, s); return true; }
     if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_PLAIN, 256, true>(a, s); return true; }
     if (K == 72 && MT == 5) { pw_launch<72, 5, 2, PW_PLAIN>(a, s); return true; }
-    if (K == 192 && MT == 5) { pw_launch<192, 5, 2, PW_PLAIN, 512, true>(a, s); return true; }
+    if (K == 192 && MT == 5) { pw_launch<192, 5, 1, PW_PLAIN, 512, true>(a, s); return true; }   // one pixel tile per wave: 121 pixels x 256 images are 1936 tiles for 2048 waves (two tiles: 15 -> 13.4 us)
   } else if (mode == PW_SHUFFLE) {
     if (K == 24 && MT == 2) { pw_launch<24, 2, 4, PW_SHUFFLE>(a, s); return true; }
     if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_SHUFFLE>(a, s); return true; }
     if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_SHUFFLE>(a, s); return true; }
   } else if (mode == PW_FPN) {
-    if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }
+    if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }   // (four pixel tiles per wave: the same 31 us)
   } else if (mode == PW_HEAD) {
     if (K == 72 && MT == 1) { pw_launch<72, 1, 4, PW_HEAD>(a, s); return true; }
     if (K == 72 && MT <= 6) { pw_launch<72, 6, 2, PW_HEAD>(a, s); return true; }
