@@ -12,12 +12,17 @@ a strict subset of the timed work; its rate is reported as `forward_only_img_s`.
 Weights are seeded random-init of the reference architecture (no checkpoint
 download is possible) and data is torch.rand: with those, every image yields the
 maximum of 300 detections, i.e. NMS runs its WORST case inside `value`.
+Consecutive steps are independent batches: they alternate between two handles
+(own workspaces) on two HIP streams, so that one step's launches fill the idle
+slots of its neighbour's (all K steps complete inside the timed region);
+`single_stream_img_s` is the same K steps on one handle and one stream.
 The configs[2] variant the survey specifies (COCO weights, a 256-batch built from
 the shipped JPEGs, thresholds 0.3/0.4 and 0.01/0.4) is timed as well and reported
 in `coco_e2e` (extra fields, never `value`).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings):
-  value      whole-job images/s (all ranks' images / max-over-ranks time)
+  value      whole-job images/s (all ranks' images / max-over-ranks time), steps pipelined over two streams
+  single_stream_img_s   the same steps strictly one after the other
   roofline   the kernel that owns the most forward time (sum over its launches, the
              top row of a rocprofv3 --stats table): algorithmic bytes (SURVEY.md 8(d):
              EXTERNAL reads + writes for a fused launch) and flops of its launches /
@@ -162,6 +167,13 @@ def main():
         sd = yfv2.random_state_dict(0)
     eng = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
     eng.load_state_dict(sd)
+    # Consecutive steps (batches) are independent: they alternate between TWO handles (each with its own workspace) on two HIP
+    # streams, so that a step's decode + NMS launch and its neighbours' launches fill each other's idle slots - the
+    # one-workgroup-per-image kernels of this path are latency-bound.  `single_stream_img_s` reports the same steps on one
+    # handle and one stream.
+    eng2 = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
+    eng2.load_state_dict(sd)
+    engs, streams = [eng, eng2], [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.rand(a.batch, 3, 352, 352, device=dev, generator=g)  # resident in HBM before timing
     det_bufs = eng.new_det_buffers(a.batch)
@@ -169,7 +181,7 @@ def main():
 
     # N > 1: a rank's padded detections (8.4 KB/image, one flat buffer) are all-gathered once per step on RCCL's own
     # stream, overlapped with the next step's kernels: two buffer sets, a set is reused only after its gather was waited for
-    sets = [det_bufs, eng.new_det_buffers(a.batch)] if use_dist else [det_bufs]
+    sets = [det_bufs, eng2.new_det_buffers(a.batch)]
     recv = [torch.empty(world * a.batch * (300 * 7 + 1), dtype=torch.float32, device=dev) for _ in sets] if use_dist else []
     works = [None] * len(sets)
     nstep = [0]
@@ -180,9 +192,13 @@ def main():
         if works[j] is not None:
             works[j].wait_host()          # issued two steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
             works[j] = None
-        d, i, c = eng.detect(x, a.conf, a.iou, out=sets[j])
-        if use_dist:
-            works[j] = yfv2.gather_detections(d, i, c, force=True, async_op=True, out=recv[j])
+        with torch.cuda.stream(streams[j]):
+            d, i, c = engs[j].detect(x, a.conf, a.iou, out=sets[j])
+            if use_dist:
+                works[j] = yfv2.gather_detections(d, i, c, force=True, async_op=True, out=recv[j])
+
+    def step_single():
+        eng.detect(x, a.conf, a.iou, out=det_bufs)
 
     def finish():
         for j, w in enumerate(works):
@@ -199,6 +215,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     value = world * a.batch * a.steps / dt
+    # the same K steps on one handle and one stream (no collective): what a caller that does not pipeline its batches gets
+    for _ in range(2):
+        step_single()
+    dt_s = timed(step_single, a.steps, sync, barrier)
 
     # forward only (BASELINE.json configs[1]) - same batch, same buffers
     for _ in range(2):
@@ -352,6 +372,8 @@ def main():
                                    "(COCO weights, JPEG-derived batch) in coco_e2e"
                                    % (a.batch, a.conf, a.iou, " + one RCCL all-gather of the padded detections per step, overlapped with the next step" if use_dist else ""),
                        "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
+            "pipelining": "consecutive steps alternate between two handles (own workspaces) on two HIP streams; all K steps complete inside the timed region",
+            "single_stream_img_s": round(a.batch * a.steps / dt_s, 1), "single_stream_ms_per_step": round(1e3 * dt_s / a.steps, 4),
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
             "forward_from_uint8_hwc_img_s": round(fwd_u8_img_s, 1), "forward_from_uint8_hwc_ms": round(1e3 * dt_u / a.steps, 4),
             "roofline": roof, "cpu_baseline": cpu,
