@@ -427,9 +427,119 @@ def make_train_golden():
     np.savez_compressed(os.path.join(HERE, "golden_train.npz"), **out)
 
 
+CURVE = dict(classes=80, B=8, T=20, seed=131, lr=0.001, batches_per_epoch=2, iterations=12, perturbed_runs=3)
+
+
+def curve_inputs():
+    """fine-tuning set-up: the COCO checkpoint (weights_coco.npz), and the `batches_per_epoch` (images, labels) batches the loop
+    cycles through epoch after epoch - the six shipped JPEGs (images_u8.npz) rotated, the second pass mirrored with a seeded
+    gain, seeded labels"""
+    c = CURVE
+    w = oracle.load_weights(os.path.join(HERE, "weights_coco.npz"))
+    arr = list(np.load(os.path.join(HERE, "images_u8.npz"))["images"])
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    batches = []
+    for b in range(c["batches_per_epoch"]):
+        xs = []
+        for i in range(c["B"]):
+            a = arr[(i + b) % len(arr)].astype(np.float32) / 255.0
+            if i >= len(arr):
+                a = a[:, :, ::-1] * np.float32(rng.uniform(0.8, 1.2))
+            xs.append(np.ascontiguousarray(a, np.float32))
+        _, _, t = train_case_inputs(c["classes"], c["B"], c["T"] + 3 * b, c["seed"] + b)
+        batches.append((np.stack(xs), t))
+    return w, batches
+
+
+def make_curve_golden():
+    """golden_curve.npz: the reference's training LOOP (train.py:94-131, 146) executed with the reference's own modules on
+    CPU for CURVE["iterations"] iterations - warm-up of the learning rate by batch_num (the first step runs at lr 0), SGD
+    step + zero_grad every iteration (subdivisions 1), MultiStepLR stepped once per epoch - fine-tuning the COCO checkpoint
+    over a two-batch epoch: the four losses of every iteration, the learning rate used, a few tensors of the final state.
+
+    A training loop amplifies rounding: the SAME reference code started from weights perturbed by 1e-7 (relative, ~one fp32
+    ulp) leaves the curve by 1e-6 for the first iterations and by 1e-3 .. 1e-2 once the learning rate is up
+    (`spread`: the envelope of CURVE["perturbed_runs"] such runs, per iteration).  That envelope is the yardstick another
+    implementation's curve is held to (tests/test_train_gpu.py); the oracle's chained train_step is checked against it
+    here and in the CPU suite."""
+    import importlib.util
+    import math
+    det, _ = import_reference()
+    spec = importlib.util.spec_from_file_location("ref_loss", os.path.join(REF, "utils", "loss.py"))
+    L = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(L)
+    orig = torch.Tensor.clamp_
+
+    def clamp_(self, mn=None, mx=None):
+        fix = lambda v: int(v) if (torch.is_tensor(v) and not self.is_floating_point()) else v  # noqa: E731
+        return orig(self, fix(mn), fix(mx))
+    torch.Tensor.clamp_ = clamp_
+    c = CURVE
+    anchors = [float(a) for a in np.load(os.path.join(HERE, "cfg_coco.npz"))["anchors"]]
+    cfg = {"anchor_num": 3, "classes": c["classes"], "width": 352, "height": 352, "anchors": anchors, "learning_rate": c["lr"],
+           "subdivisions": 1, "steps": [150, 250]}
+    w, batches = curve_inputs()
+
+    def reference_loop(w0):
+        model = det.Detector(c["classes"], 3, True)
+        model.load_state_dict({k: v.clone() for k, v in w0.items()})
+        optimizer = torch.optim.SGD(params=model.parameters(), lr=cfg["learning_rate"], momentum=0.949, weight_decay=0.0005)
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=cfg["steps"], gamma=0.1)
+        curve, lrs, batch_num = [], [], 0
+        while batch_num < c["iterations"]:
+            model.train()
+            for x, t in batches:
+                if batch_num >= c["iterations"]:
+                    break
+                preds = model(torch.from_numpy(x))
+                iou_loss, obj_loss, cls_loss, total_loss = L.compute_loss(preds, torch.from_numpy(t), cfg, torch.device("cpu"))
+                total_loss.backward()
+                for g in optimizer.param_groups:
+                    warmup_num = 5 * len(batches)
+                    if batch_num <= warmup_num:
+                        g["lr"] = cfg["learning_rate"] * math.pow(batch_num / warmup_num, 4)
+                    lr = g["lr"]
+                if batch_num % cfg["subdivisions"] == 0:
+                    optimizer.step()
+                    optimizer.zero_grad()
+                curve.append([float(v.detach()) for v in (iou_loss, obj_loss, cls_loss, total_loss)])
+                lrs.append(lr)
+                batch_num += 1
+            scheduler.step()
+        return np.asarray(curve, np.float64), lrs, model.state_dict()
+
+    try:
+        curve, lrs, final = reference_loop(w)
+        spread = np.zeros_like(curve)
+        for r in range(c["perturbed_runs"]):
+            gen = torch.Generator().manual_seed(c["seed"] + 10 + r)
+            wp = {k: (v * (1 + 1e-7 * torch.randn(v.shape, generator=gen)) if v.is_floating_point() else v) for k, v in w.items()}
+            spread = np.maximum(spread, np.abs(reference_loop(wp)[0] - curve))
+        spread = np.maximum.accumulate(spread, axis=0)
+        ow, obuf, ocurve = w, None, []
+        for i in range(c["iterations"]):
+            x, t = batches[i % len(batches)]
+            assert oracle.warmup_lr(c["lr"], i, len(batches)) == lrs[i], (i, lrs[i])
+            r = oracle.train_step(ow, torch.from_numpy(x), torch.from_numpy(t), anchors, c["classes"], lrs[i], momentum_buf=obuf)
+            ow, obuf = r["new_w"], r["momentum_buf"]
+            ocurve.append(r["losses"])
+        ocurve = np.asarray(ocurve, np.float64)
+        for i in range(c["iterations"]):
+            print("iter %2d lr %.6f reference %s spread %.2e oracle-reference %.2e" % (i, lrs[i], np.round(curve[i], 6), spread[i, 3], abs(ocurve[i, 3] - curve[i, 3])))
+        assert (np.abs(ocurve - curve) <= 2e-6 * np.abs(curve) + 8 * spread).all(), np.abs(ocurve - curve).max()
+        out = {"curve": curve.astype(np.float32), "spread": spread.astype(np.float32), "lr": np.asarray(lrs, np.float64)}
+        for k in TRAIN_KEEP + tuple(b + ".running_var" for b in TRAIN_BN):
+            out["final:" + k] = final[k].detach().numpy()
+    finally:
+        torch.Tensor.clamp_ = orig
+    np.savez_compressed(os.path.join(HERE, "golden_curve.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         make_train_golden()   # only golden_train.npz
+    elif len(sys.argv) > 1 and sys.argv[1] == "curve":
+        make_curve_golden()   # only golden_curve.npz
     elif len(sys.argv) > 1 and sys.argv[1] == "loss":
         make_loss_golden()    # only golden_loss.npz
     elif len(sys.argv) > 1 and sys.argv[1] == "ap":

@@ -142,3 +142,64 @@ def test_gradient_accumulation_over_subdivisions():
     yfv2.compute_loss(model(xs), ts, cfg, dev)[3].backward()
     for k, p in model.named_parameters():
         assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-7 * float(g1[k].abs().max() + 1e-12)), k
+
+
+def test_training_loop_follows_the_reference_loss_curve(record_parity):
+    """train.py:94-131 line by line through the drop-in surface for 12 iterations (fine-tuning the COCO checkpoint over a
+    two-batch epoch, warm-up by batch_num, step + zero_grad every iteration, MultiStepLR per epoch) against
+    tests/golden/golden_curve.npz = the same loop run with the reference's own modules.  A training loop amplifies rounding:
+    the golden carries `spread`, how far the REFERENCE's curve moves when its starting weights are perturbed by one fp32 ulp;
+    the device's curve must stay within 8x that envelope (+ 1e-5 relative)."""
+    import math
+    import yolo_fastestv2_amd as yfv2
+    g = np.load(os.path.join(GOLDEN, "golden_curve.npz"))
+    c = make_golden.CURVE
+    w, batches = make_golden.curve_inputs()
+    dev = torch.device("cuda:0")
+    anchors = [float(a) for a in np.load(os.path.join(GOLDEN, "cfg_coco.npz"))["anchors"]]
+    cfg = {"anchor_num": 3, "classes": c["classes"], "width": 352, "height": 352, "anchors": anchors, "learning_rate": c["lr"],
+           "subdivisions": 1, "steps": [150, 250]}
+    model = yfv2.Detector(cfg["classes"], cfg["anchor_num"], True).to(dev)                   # train.py:70
+    model.load_state_dict({k: v.clone() for k, v in w.items()})
+    optimizer = yfv2.SGD(params=model.parameters(), lr=cfg["learning_rate"], momentum=0.949, weight_decay=0.0005)
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=cfg["steps"], gamma=0.1)
+    train_dataloader = [(torch.from_numpy(x), torch.from_numpy(t)) for x, t in batches]   # stored as float, already / 255
+    curve, batch_num = [], 0
+    while batch_num < c["iterations"]:
+        model.train()
+        for imgs, targets in train_dataloader:
+            if batch_num >= c["iterations"]:
+                break
+            imgs = imgs.to(dev).float()
+            targets = targets.to(dev)
+            preds = model(imgs)
+            iou_loss, obj_loss, cls_loss, total_loss = yfv2.compute_loss(preds, targets, cfg, dev)
+            total_loss.backward()
+            for pg in optimizer.param_groups:
+                warmup_num = 5 * len(train_dataloader)
+                if batch_num <= warmup_num:
+                    scale = math.pow(batch_num / warmup_num, 4)
+                    pg["lr"] = cfg["learning_rate"] * scale
+                lr = pg["lr"]
+            assert lr == float(g["lr"][batch_num])
+            if batch_num % cfg["subdivisions"] == 0:
+                optimizer.step()
+                optimizer.zero_grad()
+            curve.append([float(v.detach()) for v in (iou_loss, obj_loss, cls_loss, total_loss)])
+            batch_num += 1
+        scheduler.step()
+    curve = np.asarray(curve, np.float64)
+    ref, spread = g["curve"].astype(np.float64), g["spread"].astype(np.float64)
+    err = np.abs(curve - ref)
+    ratio = float((err / (1e-5 * np.abs(ref) + spread)).max())
+    record_parity("train_loss_curve", iterations=int(c["iterations"]), total_loss_reference=[round(float(v), 6) for v in ref[:, 3]],
+                  total_loss_device=[round(float(v), 6) for v in curve[:, 3]], reference_spread_under_one_ulp_perturbation=[float(v) for v in spread[:, 3]],
+                  worst_error_over_envelope=round(ratio, 3))
+    assert (err <= 1e-5 * np.abs(ref) + 8 * spread).all(), (err[:, 3], spread[:, 3])
+    assert curve[-1, 3] < 0.7 * curve[0, 3]
+    after = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for key in g.files:
+        if key.startswith("final:"):
+            k = key.split(":", 1)[1]
+            d = np.abs(after[k] - g[key]).max()
+            assert d <= 2e-3 * max(1e-3, np.abs(g[key]).max()), (k, d)

@@ -1,9 +1,9 @@
-"""SURVEY.md 8(f) row 3, groundwork for the next slice of the training path: the ORACLE's restatement of one training
+"""SURVEY.md 8(f) row 3, the checker of the training path: the ORACLE's restatement of one training
 iteration (train.py:93-112 - train-mode forward with batch-statistics BatchNorm, compute_loss, backward, one
 SGD(momentum 0.949, weight_decay 0.0005) step) against tests/golden/golden_train.npz, which tests/golden/make_golden.py
 `train` produced by running the reference's OWN modules (model.detector.Detector in train(), utils.loss.compute_loss,
-torch.optim.SGD) on the same seeded weights, images and labels.  These are the parity targets for backward / optimizer
-kernels that do not exist yet; nothing here touches the product path."""
+torch.optim.SGD) on the same seeded weights, images and labels.  These are the parity targets of the train-mode forward /
+backward / optimizer kernels (tests/test_train_gpu.py); nothing here touches the product path."""
 import os
 import sys
 
@@ -116,3 +116,29 @@ def test_relu_decision_replay_and_why_it_is_needed():
     def rel(a, b):
         return max(float((a["grads"][k].double() - b["grads"][k]).abs().max()) / max(float(b["grads"][k].abs().max()), 1e-12) for k in b["grads"] if float(b["grads"][k].abs().max()) > 1e-3)
     assert rel(r32, free64) > 10 * rel(r32, same64), (rel(r32, free64), rel(r32, same64))
+
+
+def test_chained_train_steps_follow_the_reference_loss_curve():
+    """golden_curve.npz = the reference's own loop (train.py:94-131) for 12 iterations of fine-tuning the COCO checkpoint,
+    warm-up included; the oracle's train_step chained on its own state follows it within the loop's measured sensitivity to a
+    one-ulp perturbation of the starting weights (`spread`; make_golden.py curve)."""
+    g = np.load(os.path.join(GOLDEN, "golden_curve.npz"))
+    c = make_golden.CURVE
+    w, batches = make_golden.curve_inputs()
+    anchors = [float(a) for a in np.load(os.path.join(GOLDEN, "cfg_coco.npz"))["anchors"]]
+    ow, buf = w, None
+    for i in range(c["iterations"]):
+        x, t = batches[i % len(batches)]
+        lr = oracle.warmup_lr(c["lr"], i, len(batches))
+        assert lr == float(g["lr"][i])
+        r = oracle.train_step(ow, torch.from_numpy(x), torch.from_numpy(t), anchors, c["classes"], lr, momentum_buf=buf)
+        ow, buf = r["new_w"], r["momentum_buf"]
+        for k in range(4):
+            ref = float(g["curve"][i, k])
+            assert abs(r["losses"][k] - ref) <= 2e-6 * abs(ref) + 8 * float(g["spread"][i, k]), (i, k, r["losses"][k], ref)
+    assert float(g["curve"][-1, 3]) < 0.7 * float(g["curve"][0, 3])          # the curve does move: 14.4 -> 9.5
+    for key in g.files:
+        if key.startswith("final:"):
+            k = key.split(":", 1)[1]
+            d = np.abs(ow[k].numpy() - g[key]).max()
+            assert d <= 2e-3 * max(1e-3, np.abs(g[key]).max()), (k, d)
