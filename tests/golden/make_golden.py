@@ -428,13 +428,14 @@ def make_train_golden():
 
 
 CURVE = dict(classes=80, B=8, T=20, seed=131, lr=0.001, batches_per_epoch=2, iterations=12, perturbed_runs=3)
+CURVE64 = dict(classes=80, B=64, T=150, seed=164, lr=0.001, batches_per_epoch=2, iterations=12, perturbed_runs=2)   # train.py's regime: SURVEY 8(f) row 3 names bs = 64
+CURVES = (("", CURVE), ("b64_", CURVE64))
 
 
-def curve_inputs():
+def curve_inputs(c=CURVE):
     """fine-tuning set-up: the COCO checkpoint (weights_coco.npz), and the `batches_per_epoch` (images, labels) batches the loop
     cycles through epoch after epoch - the six shipped JPEGs (images_u8.npz) rotated, the second pass mirrored with a seeded
     gain, seeded labels"""
-    c = CURVE
     w = oracle.load_weights(os.path.join(HERE, "weights_coco.npz"))
     arr = list(np.load(os.path.join(HERE, "images_u8.npz"))["images"])
     rng = np.random.Generator(np.random.PCG64(c["seed"]))
@@ -445,6 +446,8 @@ def curve_inputs():
             a = arr[(i + b) % len(arr)].astype(np.float32) / 255.0
             if i >= len(arr):
                 a = a[:, :, ::-1] * np.float32(rng.uniform(0.8, 1.2))
+            if i >= 2 * len(arr):
+                a = np.roll(a, int(rng.integers(-16, 17)), axis=1 + i % 2)
             xs.append(np.ascontiguousarray(a, np.float32))
         _, _, t = train_case_inputs(c["classes"], c["B"], c["T"] + 3 * b, c["seed"] + b)
         batches.append((np.stack(xs), t))
@@ -455,7 +458,8 @@ def make_curve_golden():
     """golden_curve.npz: the reference's training LOOP (train.py:94-131, 146) executed with the reference's own modules on
     CPU for CURVE["iterations"] iterations - warm-up of the learning rate by batch_num (the first step runs at lr 0), SGD
     step + zero_grad every iteration (subdivisions 1), MultiStepLR stepped once per epoch - fine-tuning the COCO checkpoint
-    over a two-batch epoch: the four losses of every iteration, the learning rate used, a few tensors of the final state.
+    over a two-batch epoch (8 images per batch, and 64 as train.py runs it): the four losses of every iteration, the learning
+    rate used, a few tensors of the final state.
 
     A training loop amplifies rounding: the SAME reference code started from weights perturbed by 1e-7 (relative, ~one fp32
     ulp) leaves the curve by 1e-6 for the first iterations and by 1e-3 .. 1e-2 once the learning rate is up
@@ -474,13 +478,9 @@ def make_curve_golden():
         fix = lambda v: int(v) if (torch.is_tensor(v) and not self.is_floating_point()) else v  # noqa: E731
         return orig(self, fix(mn), fix(mx))
     torch.Tensor.clamp_ = clamp_
-    c = CURVE
     anchors = [float(a) for a in np.load(os.path.join(HERE, "cfg_coco.npz"))["anchors"]]
-    cfg = {"anchor_num": 3, "classes": c["classes"], "width": 352, "height": 352, "anchors": anchors, "learning_rate": c["lr"],
-           "subdivisions": 1, "steps": [150, 250]}
-    w, batches = curve_inputs()
 
-    def reference_loop(w0):
+    def reference_loop(c, cfg, w0, batches):
         model = det.Detector(c["classes"], 3, True)
         model.load_state_dict({k: v.clone() for k, v in w0.items()})
         optimizer = torch.optim.SGD(params=model.parameters(), lr=cfg["learning_rate"], momentum=0.949, weight_decay=0.0005)
@@ -508,28 +508,34 @@ def make_curve_golden():
             scheduler.step()
         return np.asarray(curve, np.float64), lrs, model.state_dict()
 
+    out = {}
     try:
-        curve, lrs, final = reference_loop(w)
-        spread = np.zeros_like(curve)
-        for r in range(c["perturbed_runs"]):
-            gen = torch.Generator().manual_seed(c["seed"] + 10 + r)
-            wp = {k: (v * (1 + 1e-7 * torch.randn(v.shape, generator=gen)) if v.is_floating_point() else v) for k, v in w.items()}
-            spread = np.maximum(spread, np.abs(reference_loop(wp)[0] - curve))
-        spread = np.maximum.accumulate(spread, axis=0)
-        ow, obuf, ocurve = w, None, []
-        for i in range(c["iterations"]):
-            x, t = batches[i % len(batches)]
-            assert oracle.warmup_lr(c["lr"], i, len(batches)) == lrs[i], (i, lrs[i])
-            r = oracle.train_step(ow, torch.from_numpy(x), torch.from_numpy(t), anchors, c["classes"], lrs[i], momentum_buf=obuf)
-            ow, obuf = r["new_w"], r["momentum_buf"]
-            ocurve.append(r["losses"])
-        ocurve = np.asarray(ocurve, np.float64)
-        for i in range(c["iterations"]):
-            print("iter %2d lr %.6f reference %s spread %.2e oracle-reference %.2e" % (i, lrs[i], np.round(curve[i], 6), spread[i, 3], abs(ocurve[i, 3] - curve[i, 3])))
-        assert (np.abs(ocurve - curve) <= 2e-6 * np.abs(curve) + 8 * spread).all(), np.abs(ocurve - curve).max()
-        out = {"curve": curve.astype(np.float32), "spread": spread.astype(np.float32), "lr": np.asarray(lrs, np.float64)}
-        for k in TRAIN_KEEP + tuple(b + ".running_var" for b in TRAIN_BN):
-            out["final:" + k] = final[k].detach().numpy()
+        for prefix, c in CURVES:
+            cfg = {"anchor_num": 3, "classes": c["classes"], "width": 352, "height": 352, "anchors": anchors, "learning_rate": c["lr"],
+                   "subdivisions": 1, "steps": [150, 250]}
+            w, batches = curve_inputs(c)
+            curve, lrs, final = reference_loop(c, cfg, w, batches)
+            spread = np.zeros_like(curve)
+            for r in range(c["perturbed_runs"]):
+                gen = torch.Generator().manual_seed(c["seed"] + 10 + r)
+                wp = {k: (v * (1 + 1e-7 * torch.randn(v.shape, generator=gen)) if v.is_floating_point() else v) for k, v in w.items()}
+                spread = np.maximum(spread, np.abs(reference_loop(c, cfg, wp, batches)[0] - curve))
+            spread = np.maximum.accumulate(spread, axis=0)
+            ow, obuf, ocurve = w, None, []
+            for i in range(c["iterations"]):
+                x, t = batches[i % len(batches)]
+                assert oracle.warmup_lr(c["lr"], i, len(batches)) == lrs[i], (i, lrs[i])
+                r = oracle.train_step(ow, torch.from_numpy(x), torch.from_numpy(t), anchors, c["classes"], lrs[i], momentum_buf=obuf)
+                ow, obuf = r["new_w"], r["momentum_buf"]
+                ocurve.append(r["losses"])
+            ocurve = np.asarray(ocurve, np.float64)
+            for i in range(c["iterations"]):
+                print("%siter %2d lr %.6f reference %s spread %.2e oracle-reference %.2e" % (prefix, i, lrs[i], np.round(curve[i], 6), spread[i, 3], abs(ocurve[i, 3] - curve[i, 3])))
+            assert (np.abs(ocurve - curve) <= 2e-6 * np.abs(curve) + 8 * spread).all(), np.abs(ocurve - curve).max()
+            out.update({prefix + "curve": curve.astype(np.float32), prefix + "spread": spread.astype(np.float32), prefix + "lr": np.asarray(lrs, np.float64)})
+            if not prefix:
+                for k in TRAIN_KEEP + tuple(b + ".running_var" for b in TRAIN_BN):
+                    out["final:" + k] = final[k].detach().numpy()
     finally:
         torch.Tensor.clamp_ = orig
     np.savez_compressed(os.path.join(HERE, "golden_curve.npz"), **out)

@@ -466,3 +466,71 @@ def test_bench_quotes_counters_only_from_a_profile_of_the_same_tree(tmp_path, mo
     assert bench.profile_lookup(got, "tower2_kernel<0", "total_bytes", 2) is None                                  # ambiguous prefix: refuse
     assert bench.profile_lookup(got, "stem_px_kernel", "mfma_busy_pct", 1, mean=True) == 55.5
     assert bench.profile_lookup(None, "stem_px_kernel", "total_bytes", 1) is None
+
+
+def test_data_parallel_training_averages_the_gradient_bucket_world_size_2_gloo(tmp_path):
+    """SURVEY.md 8(e) "Training" on CPU: two processes, gloo.  (1) average_gradients_ = one all-reduce + 1/W over a flat
+    bucket; (2) Detector.data_parallel(): the train-mode backward averages the whole gradient bucket before autograd sees it
+    (a stand-in engine writes rank-dependent gradients through the SAME bind / forward / backward calls the device engine
+    gets), so every rank's .grad is the mean over ranks, and the SGD step keeps the replicas identical."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        import yolo_fastestv2_amd as yfv2
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        calls = []
+        real = dist.all_reduce
+        def counting(*a, **k):
+            calls.append(1); return real(*a, **k)
+        dist.all_reduce = counting
+        flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        out = yfv2.average_gradients_(flat)
+        assert out is flat and torch.equal(flat, torch.arange(10, dtype=torch.float32) * 1.5) and len(calls) == 1
+
+        class StandIn:                                   # the three calls _TrainForward makes on an Engine
+            _train_seq = 0
+            def train_bind(self, tensors, grads): self.grads = grads
+            def train_forward(self, x):
+                self._train_seq += 1
+                return tuple(torch.zeros(s) for s in self.logit_shapes(x.shape[0]))
+            def logit_shapes(self, B): return [(B, 12, 22, 22), (B, 3, 22, 22), (B, 80, 22, 22), (B, 12, 11, 11), (B, 3, 11, 11), (B, 80, 11, 11)]
+            def train_backward(self, g6):
+                for i, (k, v) in enumerate(self.grads.items()):
+                    v += (rank + 1) * (1.0 + 0.001 * i) * float(g6[0].flatten()[0])
+        torch.manual_seed(0)                             # same initial weights on both ranks
+        model = yfv2.Detector(80, 3, True)
+        eng = StandIn()
+        model.engine_for = lambda x, sync=True: eng
+        model.train()
+        model.data_parallel()
+        from yolo_fastestv2_amd.model.detector import _TrainForward
+        params = [p for _, p in model.named_parameters()]
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.949, weight_decay=0.0005)   # yfv2.SGD's kernel needs the device
+        before = [p.detach().clone() for p in params]
+        outs = _TrainForward.apply(model, torch.zeros(2, 3, 352, 352), *params)
+        (2.0 * sum(o.sum() for o in outs)).backward()
+        assert len(calls) == 2                           # ONE collective for all 225 gradients
+        for i, p in enumerate(params):
+            want = 1.5 * (1.0 + 0.001 * i) * 2.0         # mean over ranks of (rank+1) * ...
+            assert torch.allclose(p.grad, torch.full_like(p, want), rtol=1e-6), (i, float(p.grad.flatten()[0]), want)
+        opt.step()
+        mine = torch.cat([p.detach().flatten() for p in params])
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1])             # replicas stay identical
+        assert not torch.equal(mine, torch.cat([b.flatten() for b in before]))
+        model.data_parallel(enabled=False)
+        outs = _TrainForward.apply(model, torch.zeros(2, 3, 352, 352), *params)
+        opt.zero_grad(); sum(o.sum() for o in outs).backward()
+        assert len(calls) == 2 and abs(float(params[0].grad.flatten()[0]) - (rank + 1)) < 1e-6
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in o, o

@@ -144,17 +144,17 @@ def test_gradient_accumulation_over_subdivisions():
         assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-7 * float(g1[k].abs().max() + 1e-12)), k
 
 
-def test_training_loop_follows_the_reference_loss_curve(record_parity):
+@pytest.mark.parametrize("prefix,c", make_golden.CURVES, ids=["batch8", "batch64"])
+def test_training_loop_follows_the_reference_loss_curve(prefix, c, record_parity):
     """train.py:94-131 line by line through the drop-in surface for 12 iterations (fine-tuning the COCO checkpoint over a
-    two-batch epoch, warm-up by batch_num, step + zero_grad every iteration, MultiStepLR per epoch) against
+    two-batch epoch - 8 images per batch, and 64 as train.py runs it - warm-up by batch_num, step + zero_grad every iteration, MultiStepLR per epoch) against
     tests/golden/golden_curve.npz = the same loop run with the reference's own modules.  A training loop amplifies rounding:
     the golden carries `spread`, how far the REFERENCE's curve moves when its starting weights are perturbed by one fp32 ulp;
     the device's curve must stay within 8x that envelope (+ 1e-5 relative)."""
     import math
     import yolo_fastestv2_amd as yfv2
     g = np.load(os.path.join(GOLDEN, "golden_curve.npz"))
-    c = make_golden.CURVE
-    w, batches = make_golden.curve_inputs()
+    w, batches = make_golden.curve_inputs(c)
     dev = torch.device("cuda:0")
     anchors = [float(a) for a in np.load(os.path.join(GOLDEN, "cfg_coco.npz"))["anchors"]]
     cfg = {"anchor_num": 3, "classes": c["classes"], "width": 352, "height": 352, "anchors": anchors, "learning_rate": c["lr"],
@@ -181,7 +181,7 @@ def test_training_loop_follows_the_reference_loss_curve(record_parity):
                     scale = math.pow(batch_num / warmup_num, 4)
                     pg["lr"] = cfg["learning_rate"] * scale
                 lr = pg["lr"]
-            assert lr == float(g["lr"][batch_num])
+            assert lr == float(g[prefix + "lr"][batch_num])
             if batch_num % cfg["subdivisions"] == 0:
                 optimizer.step()
                 optimizer.zero_grad()
@@ -189,17 +189,27 @@ def test_training_loop_follows_the_reference_loss_curve(record_parity):
             batch_num += 1
         scheduler.step()
     curve = np.asarray(curve, np.float64)
-    ref, spread = g["curve"].astype(np.float64), g["spread"].astype(np.float64)
+    ref, spread = g[prefix + "curve"].astype(np.float64), g[prefix + "spread"].astype(np.float64)
     err = np.abs(curve - ref)
     ratio = float((err / (1e-5 * np.abs(ref) + spread)).max())
-    record_parity("train_loss_curve", iterations=int(c["iterations"]), total_loss_reference=[round(float(v), 6) for v in ref[:, 3]],
+    record_parity("train_loss_curve_batch%d" % c["B"], iterations=int(c["iterations"]), total_loss_reference=[round(float(v), 6) for v in ref[:, 3]],
                   total_loss_device=[round(float(v), 6) for v in curve[:, 3]], reference_spread_under_one_ulp_perturbation=[float(v) for v in spread[:, 3]],
                   worst_error_over_envelope=round(ratio, 3))
     assert (err <= 1e-5 * np.abs(ref) + 8 * spread).all(), (err[:, 3], spread[:, 3])
-    assert curve[-1, 3] < 0.7 * curve[0, 3]
+    assert curve[-1, 3] < 0.9 * curve[0, 3]                                  # the curve does move
     after = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     for key in g.files:
-        if key.startswith("final:"):
+        if key.startswith("final:") and not prefix:
             k = key.split(":", 1)[1]
             d = np.abs(after[k] - g[key]).max()
             assert d <= 2e-3 * max(1e-3, np.abs(g[key]).max()), (k, d)
+
+
+def test_data_parallel_backward_issues_one_rccl_all_reduce():
+    """SURVEY.md 8(e) "Training": Detector.data_parallel() on a one-rank nccl (= RCCL) group - the gradient bucket is all-reduced
+    on the device, once per backward, and the iteration's result is unchanged (tests/gpu_cases/train_dp.py; the two-rank
+    arithmetic runs under gloo in tests/test_abi_and_host.py)."""
+    import subprocess
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_cases", "train_dp.py")
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "train_dp ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..engine import Engine
+from ..sharded import average_gradients_
 
 STAGE_REPEATS = (4, 8, 4)        # shufflenetv2.py:69
 STAGE_CHANNELS = (24, 48, 96, 192)  # detector.py:11
@@ -106,7 +107,7 @@ class _TrainForward(torch.autograd.Function):
                 nb = mod._buffers.get("num_batches_tracked")
                 if nb is not None:
                     nb += 1
-        ctx.eng, ctx.seq, ctx.flat, ctx.views, ctx.names = eng, eng._train_seq, flat, views, names
+        ctx.eng, ctx.seq, ctx.flat, ctx.views, ctx.names, ctx.dp = eng, eng._train_seq, flat, views, names, module._dp
         return outs
 
     @staticmethod
@@ -116,6 +117,8 @@ class _TrainForward(torch.autograd.Function):
                                "train-mode forward ran on this engine in between")
         ctx.flat.zero_()
         ctx.eng.train_backward([g if g is not None else torch.zeros(s, device=ctx.flat.device) for g, s in zip(g6, ctx.eng.logit_shapes(g6[0].shape[0]))])
+        if ctx.dp is not None:       # data parallel: one all-reduce over the whole gradient bucket (sharded.average_gradients_)
+            average_gradients_(ctx.flat, group=ctx.dp[0], force=ctx.dp[1])
         return (None, None) + tuple(ctx.views[k].clone() for k in ctx.names)
 
 
@@ -128,6 +131,7 @@ class Detector(nn.Module):
         super().__init__()
         self._engines = {}      # (device, H, W) -> Engine
         self._synced = {}       # engine key -> weight version token
+        self._dp = None         # (process group, force) once data_parallel() was called
         self.classes, self.anchor_num = int(classes), int(anchor_num)
         self.export_onnx = export_onnx
         for key, shape, kind in state_spec(self.classes, self.anchor_num):
@@ -200,6 +204,14 @@ class Detector(nn.Module):
         if cached is None or cached[0] != ids:
             cached = self.__dict__["_tensors"] = (ids, [t for t in self.state_dict(keep_vars=True).values() if t.is_floating_point()])
         return ids, tuple(t._version for t in cached[1])
+
+    def data_parallel(self, group=None, enabled=True, force=False):
+        """Extension over the reference surface (train.py is single-GPU): after this call every train-mode backward averages
+        the gradients over the ranks of `group` (default: the world) with one all-reduce of the flat gradient bucket, so
+        train.py's loop, unchanged, trains data-parallel when each rank feeds its own shard of the batch (one process per
+        GPU, backend "nccl" = RCCL).  BatchNorm statistics stay per rank.  Returns self."""
+        self._dp = (group, bool(force)) if enabled else None
+        return self
 
     def _train_names(self):
         return [k for k, _ in self.named_parameters()]
