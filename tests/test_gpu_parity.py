@@ -566,7 +566,7 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
         assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)
 
 
-def test_uint8_hwc_input_matches_float_path(yfv2, model, dev, images_u8, coco_weights):
+def test_uint8_hwc_input_matches_float_path(yfv2, model, dev, images_u8, coco_weights, cfg):
     """the pre-process of test.py:34-38 (HWC uint8 -> NCHW fp32 / 255) inside the stem kernel.
     images_u8 is stored NCHW; the entry point takes the decoder's HWC layout.  Same logits as the oracle on the
     float()/255 tensor (the 1/255 is folded into the filter: rounding-level differences only), same survivors as
@@ -581,6 +581,7 @@ def test_uint8_hwc_input_matches_float_path(yfv2, model, dev, images_u8, coco_we
         err = float((g.cpu() - r).abs().max())
         assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)
     eng = model.engine_for(x_hwc.to(dev))
+    eng.set_anchors(cfg["anchors"])
     d8, i8, c8 = eng.detect(x_hwc.to(dev), 0.3, 0.4)
     df, if_, cf = eng.detect((x_chw.float() / 255.0).to(dev), 0.3, 0.4)
     assert torch.equal(c8, cf)

@@ -15,7 +15,7 @@ from yolo_fastestv2_amd import _lib
 from yolo_fastestv2_amd._lib import Config, TensorDesc
 
 OLD_IMG_FL = 11 * 64 + 24                  # image_stem (4x4x1 kernel), packed twice (fp32 and uint8 scale) before the fp16 image
-H16_FL = 2 * 2 * 64 * 4 + 32 + 1
+H16_FL = 2 * 2 * 64 * 4 + 36 + 36          # filter terms | fp32-input constants (32 shifts, unscale, pad) | uint8-input constants
 TAP = [(0, 1), (0, 2), (1, 1), (1, 2), (0, 0), (1, 0), (2, 0), (2, 1)]
 
 
@@ -52,9 +52,12 @@ def _split(x):
     return h1.astype(np.float32), h2.astype(np.float32)
 
 
-def _kernel_model(x, im):
-    """x (3, H, W) float32 -> (H/4, W/4, 24): the kernel's arithmetic, conv rows vectorised over the image"""
+def _kernel_model(x, im, u8=False):
+    """x (3, H, W) float32 -> (H/4, W/4, 24): the kernel's arithmetic, conv rows vectorised over the image.
+    u8: stem_h3u_kernel - x holds the integers 0..255 (one exact fp16 term each), two products per MAC, its own constants."""
     w1, w2, shift, unscale = _decode(im)
+    if u8:
+        shift, unscale = im[1060:1092], float(im[1092])
     _, H, W = x.shape
     CH, CW = H // 2, W // 2
     xp = np.zeros((3, H + 2, W + 6), np.float32)       # row -1 and column -1 are padding; columns past W only feed zero weights
@@ -74,9 +77,11 @@ def _kernel_model(x, im):
             slots[3, j] = xp[c][(2 * ys + 1 + 1)[:, None], (col + 1)[None, :]]
         # what group 3's other slots hold is data too (rows of other channels), but the filter is zero there: check that
         assert not w1[:, 3, [0, 1, 4, 5, 6]].any() and not w2[:, 3, [0, 1, 4, 5, 6]].any()
-        x1, x2 = _split(slots * np.float32(256.0))       # the kernel's exact 2^8 prescale of the image
+        x1, x2 = _split(slots if u8 else slots * np.float32(256.0))       # the kernel's exact 2^8 prescale of the image
+        if u8:
+            assert not x2.any() and (x1 == slots).all()  # a pixel is one fp16 term
         acc = np.broadcast_to(shift[:, None, None], (32, CH, n)).astype(np.float32).copy()
-        for wa, xb in ((w1, x2), (w2, x1), (w1, x1)):   # the kernel's product order; every product is exact in fp32
+        for wa, xb in (((w2, x1), (w1, x1)) if u8 else ((w1, x2), (w2, x1), (w1, x1))):   # the kernel's product order; every product is exact in fp32
             acc = (acc.astype(np.float64) + np.einsum("cgj,gjyn->cyn", wa.astype(np.float64), xb.astype(np.float64))).astype(np.float32)
         conv[:, :, parity::2] = acc
     # max-pool 3x3 s2 p1 on the raw accumulators (0 stands for the padding: ReLU follows), then ReLU and the unscale
@@ -104,6 +109,12 @@ def test_stem16_host_packing_and_dataflow_vs_oracle():
         assert got.shape == ref.shape
         err = np.abs(got - ref).max()
         assert err <= 2e-6 * max(1.0, np.abs(ref).max()), "stem16 dataflow model vs oracle: max abs err %g (max %g)" % (err, np.abs(ref).max())
+        # uint8 pixels (stem_h3u_kernel): the oracle sees test.py:38's float() / 255
+        xi = torch.randint(0, 256, (1, 3, H, W), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+        got = _kernel_model(xi[0].numpy().astype(np.float32), im, u8=True)
+        ref = oracle.forward_stages(w, xi.float() / 255.0)["stem"][0].permute(1, 2, 0).numpy()
+        err = np.abs(got - ref).max()
+        assert err <= 2e-6 * max(1.0, np.abs(ref).max()), "stem16 uint8 dataflow model vs oracle: max abs err %g (max %g)" % (err, np.abs(ref).max())
 
 
 def test_fp16x3_is_as_accurate_as_the_fp32_convolution():

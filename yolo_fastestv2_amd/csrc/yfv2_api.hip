@@ -845,6 +845,10 @@ struct WeightPacker {
     for (int co = 0; co < 32; ++co) im.push_back(co < 24 ? std::ldexp(blob[f.shift + co], sw + 8) : 0.f);
     im.push_back(std::ldexp(1.0f, -(sw + 8)));
     while (im.size() % 4) im.push_back(0.f);
+    // stem_h3u_kernel (uint8 pixels 0..255 as they are, one exact fp16 term): accumulators carry 2^sw 255
+    for (int co = 0; co < 32; ++co) im.push_back(co < 24 ? (float)(std::ldexp((double)blob[f.shift + co], sw) * 255.0) : 0.f);
+    im.push_back((float)(std::ldexp(1.0, -sw) / 255.0));
+    while (im.size() % 4) im.push_back(0.f);
     return put(im);
   }
 };
@@ -1546,7 +1550,7 @@ struct PlanBuilder {
 // kernel (family) a plan step launches, as it appears in a rocprofv3 kernel trace (prefix of the symbol name)
 std::string step_kernel(const Step& st) {
   switch (st.kind) {
-    case STEP_STEM: return "stem_h3_kernel";   // fp32 input, default plan (uint8 input / YFV2_BF6=0: stem_px_kernel)
+    case STEP_STEM: return "stem_h3_kernel";   // fp32 input, default plan (uint8 input: stem_h3u_kernel; YFV2_BF6=0: stem_px_kernel)
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:

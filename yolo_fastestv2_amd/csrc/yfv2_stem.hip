@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64, 1) void stem_px_kernel(StemArgs a) {
 }
 
 void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
-  if (!a.u8_in && a.img16) { yfv2_launch_stem16(a, s); return; }   // fp32 input: the f16-matrix-core kernel (yfv2_stem16.hip)
+  if (a.img16) { yfv2_launch_stem16(a, s); return; }   // the f16-matrix-core kernels (yfv2_stem16.hip): fp32 NCHW or uint8 HWC input
   StemArgs b = a;
   const int PH = a.H / 4, PW = a.W / 4;
   int nb = 8;                                       // bands per image: R must divide PH

@@ -1,7 +1,7 @@
 // yfv2_stem16.hip - the stem (conv3x3 s2 3->24 + BN + ReLU + maxpool3x3 s2, model/backbone/shufflenetv2.py:74-80,
 // 102-104; behaviour only) as an implicit GEMM on the f16 matrix cores, fp32 accuracy kept by splitting every operand
 // EXACTLY-to-2^-24 into two fp16 terms ("fp16x3"): round 3's replacement of yfv2_stem.hip's 4x4x1 fp32-MFMA kernel for
-// fp32 input (that kernel stays for the uint8 entry points and as the YFV2_BF6=0 plan).
+// fp32 input, and (stem_h3u_kernel, at the end of this file) for the uint8 entry points; the 4x4x1 kernel stays as the YFV2_BF6=0 plan.
 //
 // Why: gfx950's fp32 MFMA issues at the fp32 VECTOR rate and shares that datapath with the VALU (tools/ubench/shadow.hip),
 // so the old kernel's time was MFMA + VALU summed (PMC: MFMA busy 55 %, issue-wait 40 %, 144 us = 0.49 of the HBM roofline
@@ -18,6 +18,7 @@
 // 1/255; unscaled, a dark image's second terms would be subnormal and the result 100x less accurate than the fp32 conv -
 // tests/test_stem16_host_model.py).  Valid for |x| < 255.9: the reference feeds [0, 1] (test.py:38), raw 0..255 pixels fit too;
 // larger magnitudes overflow fp16 (stated in include/yfv2.h; the uint8 entry points and YFV2_BF6=0 have no such bound).
+// A carried row above the image / a band's first row: see the kernels.
 //
 // GEMM shape.  D[channel][pixel] += W[channel][k] X[k][pixel], 16 x 16 x 32 per instruction: 24 channels = two channel tiles
 // (the second half empty), K = 27 taps in 32 slots, N = 16 pixels.  A wave = ONE strip of 16 lanes' worth of pooled columns
@@ -44,11 +45,15 @@
 // stores (no conversion, no MFMA) 120-128 - reads alone 92, writes alone 38-45: the launch is bound by its HBM access
 // pattern (strips of 240 bytes per row and plane), not by arithmetic; every input value loaded once (lane group 3 by
 // ds_bpermute instead of three extra L2-hit loads, row 2y-1 carried instead of re-read) 118-124.  4 waves per SIMD by
-// register cap spills (258 us); 4, 2 or 11 bands per image instead of 8: 126-131.
+// register cap spills (258 us); by buffer stores with 32-bit offsets instead of 64-bit pointers (124 VGPRs, no spills): no
+// change (131-133 against 128-132 us, same box) - bytes in flight are not what limits it; 4, 2 or 11 bands per image
+// instead of 8: 126-131.
 #include "yfv2_internal.h"
 
 typedef _Float16 yfv2_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 yfv2_h2 __attribute__((ext_vector_type(2)));
+typedef unsigned yfv2_u3 __attribute__((ext_vector_type(3)));
+typedef unsigned yfv2_u2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -233,6 +238,159 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
   if (t < a.R) step(t, re0, ro0, re1, ro1);
 }
 
+// ---- uint8 (B,H,W,3) input (yfv2_forward_u8 / yfv2_detect_u8: test.py:34-38's reshape / permute / float() / 255 folded into the loads).
+// The same implicit GEMM with three simplifications: (1) a pixel 0..255 is EXACTLY one fp16 term, so a MAC is two products
+// (w1 x, w2 x) instead of three; the 1/255 rides in the final unscale (2^-sw / 255, one rounding), the BN shift enters the
+// accumulator as shift 2^sw 255; (2) HWC puts the three channels of a lane's four columns into ONE aligned 12-byte load, the
+// same for the four lane groups of a pooled column: lane group g picks its channel's bytes with v_perm_b32 (selector per
+// lane), and lane group 3 picks tap (2,2)'s six values out of its own load - no ds_bpermute; (3) u8 -> fp16 without a
+// conversion instruction: 0x6400 | n is the fp16 number 1024 + n, one packed subtract gives n.  381 MB of input become 95.
+
+namespace {
+struct Row8 { unsigned p01, p23, m; };   // (v0,v1), (v2,v3) as fp16 pairs; m: high half = the left neighbour's v3
+// bytes sel.b0 and sel.b2 of the eight bytes {hi, lo} -> two exact fp16 integers
+__device__ __forceinline__ unsigned u8pair(unsigned hi, unsigned lo, unsigned sel) {
+  const unsigned v = __builtin_amdgcn_perm(hi, lo, sel) | 0x64006400u;
+  const yfv2_h2 h = __builtin_bit_cast(yfv2_h2, v) - (yfv2_h2){(_Float16)1024.0f, (_Float16)1024.0f};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void split_row_u8(const yfv2_u3 d, unsigned sel_a, unsigned sel_b, Row8& o) {
+  o.p01 = u8pair(d[1], d[0], sel_a);
+  o.p23 = u8pair(d[2], d[1], sel_b);
+  o.m = dpp_row_shr1_u(o.p23);
+}
+}  // namespace
+
+template <bool PPOUT>
+__global__ __launch_bounds__(64, 4) void stem_h3u_kernel(StemArgs a) {
+  const int H = a.H, W = a.W, PH = H >> 2, PW = W >> 2;
+  const int strips = (PW - 1 + 14) / 15;
+  const int bands = PH / a.R;
+  const int wpi = strips * bands;
+  const int nwg = gridDim.x;
+  const int wid = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+  const int b = __builtin_amdgcn_readfirstlane(wid / wpi), wi = __builtin_amdgcn_readfirstlane(wid - b * wpi);
+  const int strip = wi % strips, band = wi / strips;
+  const int lane = threadIdx.x, p = lane & 15, g = lane >> 4;
+  const int px = 15 * strip + p;
+  const bool lvalid = px < PW;
+  const int py0 = band * a.R;
+  const bool st_ok = lvalid && (p > 0 || strip == 0);
+
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + (size_t)b * 3 * H * W), 0, 3 * H * W, 0x00020000);
+  const int rowb = W * 3;
+  constexpr int OOB = (int)0x80000000;
+  const int lane_off = lvalid ? 12 * px : OOB;      // columns 4px .. 4px+3, three channels each: 12 bytes, 4-byte aligned (W % 4 == 0)
+  // byte selectors (v_perm_b32: indices 0..3 = the low source, 4..7 = the high one, 0x0c = zero).  Stream byte 3 c + ch is
+  // channel ch of column 4px + c.  Pairs (v0, v1) come out of {d1, d0} (stream bytes 0..7), pairs (v2, v3) out of {d2, d1}
+  // (stream bytes 4..11).  Lane group g < 3: channel g of columns 0..3, for X1 (row 2y) and X2 (row 2y+1) alike; lane group
+  // 3: X1 = (ch0, ch1) of columns 1 | 3, X2 = (ch2, 0) of columns 1 | 3, both from row 2y+1 - tap (2,2) in slots 2, 3, 7.
+  constexpr unsigned Z = 0x0c;
+  const unsigned sel1a = g < 3 ? (unsigned)g | (Z << 8) | ((unsigned)(g + 3) << 16) | (Z << 24) : 3u | (Z << 8) | (4u << 16) | (Z << 24);
+  const unsigned sel1b = g < 3 ? (unsigned)(g + 2) | (Z << 8) | ((unsigned)(g + 5) << 16) | (Z << 24) : 5u | (Z << 8) | (6u << 16) | (Z << 24);
+  const unsigned sel2a = g < 3 ? sel1a : 5u | (Z << 8) | (Z << 16) | (Z << 24);
+  const unsigned sel2b = g < 3 ? sel1b : 7u | (Z << 8) | (Z << 16) | (Z << 24);
+
+  yfv2_h8 wa[2][2];
+  {
+    const u32x4* wimg = reinterpret_cast<const u32x4*>(a.img16);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) wa[t][k] = __builtin_bit_cast(yfv2_h8, wimg[(t * 2 + k) * 64 + lane]);
+  }
+  const float* cst = a.img16 + 2 * 2 * 64 * 4 + 36;   // the uint8 constants follow the fp32 ones: shift 2^sw 255 [32], 2^-sw / 255
+  const f32x4 sh0 = *reinterpret_cast<const f32x4*>(cst + 4 * g), sh1 = *reinterpret_cast<const f32x4*>(cst + 16 + 4 * g);
+  const float unscale = cst[32];
+
+  auto load_row = [&](int r) -> yfv2_u3 {
+    const int off = (lane_off != OOB && r >= 0) ? lane_off + r * rowb : OOB;
+    return __builtin_bit_cast(yfv2_u3, __builtin_amdgcn_raw_buffer_load_b96(rsrc, off, 0, 0));
+  };
+  auto load2 = [&](int y, yfv2_u3 (&raw)[2]) { raw[0] = load_row(2 * y); raw[1] = load_row(2 * y + 1); };
+
+  auto conv_row = [&](Row8& x0, const yfv2_u3 (&raw)[2], f32x4 (&hp)[2]) {
+    const yfv2_u3 s1 = g == 3 ? raw[1] : raw[0];
+    Row8 x1, x2;
+    split_row_u8(s1, sel1a, sel1b, x1);
+    split_row_u8(raw[1], sel2a, sel2b, x2);
+    const u32x4 e = {x0.p01, x1.p01, pack_hi_hi(x0.m, x1.m), pack_hi_lo(x2.m, x2.p01)};
+    const u32x4 o = {x0.p23, x1.p23, pack_hi_hi(x0.p01, x1.p01), pack_hi_lo(x2.p01, x2.p23)};
+    const yfv2_h8 be = __builtin_bit_cast(yfv2_h8, e), bo = __builtin_bit_cast(yfv2_h8, o);
+    x0 = x2;
+    f32x4 ae[2] = {sh0, sh1}, ao[2] = {sh0, sh1};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], be, ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], bo, ao[t], 0, 0, 0); }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], be, ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], bo, ao[t], 0, 0, 0); }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2)
+        hp[t][e2] = __builtin_fmaxf(__builtin_fmaxf(dpp_row_shr1_f(ao[t][e2]), ae[t][e2]), ao[t][e2]);
+  };
+
+  f32x4 up[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  Row8 carry;
+  yfv2_u3 re0[2], ro0[2], re1[2], ro1[2];
+  if (py0 > 0) {
+    yfv2_u3 hb[2];
+    const yfv2_u3 top = load_row(4 * py0 - 3);
+    load2(2 * py0 - 1, hb);
+    load2(2 * py0, re0);
+    load2(2 * py0 + 1, ro0);
+    split_row_u8(top, sel2a, sel2b, carry);        // a carried row is an X2
+    conv_row(carry, hb, up);
+  } else {
+    load2(0, re0);
+    load2(1, ro0);
+    carry.p01 = carry.p23 = carry.m = 0u;
+  }
+  // pair-plane output through a buffer resource: a 32-bit lane offset (plane pair of the lane group; lanes that do not store
+  // carry the out-of-range offset, the store is dropped) + a wave-uniform offset (plane, row) instead of two 64-bit pointers
+  float* __restrict__ ob = PPOUT ? nullptr : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
+  __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * 24 * PH * PW), 0, 24 * PH * PW * 4, 0x00020000);
+  const int plane = PH * PW * 8;                    // bytes of one pair plane
+  const int ovoff0 = st_ok ? (py0 * PW + px) * 8 + 2 * g * plane : OOB;
+  const int ovoff1 = g < 2 ? ovoff0 : OOB;         // channel tile 1 holds channels 16..23 in lane groups 0, 1
+  int osoff = 0;
+  const int ylast = (H >> 1) - 1;
+  auto step = [&](int t, const yfv2_u3 (&ce)[2], const yfv2_u3 (&co)[2], yfv2_u3 (&ne)[2], yfv2_u3 (&no)[2]) {
+    const int y = 2 * (py0 + t);
+    load2(min(y + 2, ylast - 1), ne);
+    load2(min(y + 3, ylast), no);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 h0[2], h1[2];
+    conv_row(carry, ce, h0);
+    conv_row(carry, co, h1);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m = __builtin_fmaxf(__builtin_fmaxf(up[tt][e], h0[tt][e]), h1[tt][e]);
+        o[e] = __builtin_fmaxf(m, 0.f) * unscale;
+      }
+      up[tt] = h1[tt];
+      if constexpr (PPOUT) {                         // channels 16 tt + 4 g .. +3 = pair planes 8 tt + 2 g, + 1
+        const int vo = tt ? ovoff1 : ovoff0;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(yfv2_u2, (f32x2){o[0], o[1]}), orsrc, vo, osoff + 8 * tt * plane, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(yfv2_u2, (f32x2){o[2], o[3]}), orsrc, vo, osoff + (8 * tt + 1) * plane, 0);
+      } else if (st_ok && (tt == 0 || g < 2)) {
+        *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;
+      }
+    }
+    if constexpr (PPOUT) osoff += PW * 8; else ob += (size_t)PW * 24;
+  };
+  int t = 0;
+#pragma unroll 1
+  for (; t + 1 < a.R; t += 2) {
+    step(t, re0, ro0, re1, ro1);
+    step(t + 1, re1, ro1, re0, ro0);
+  }
+  if (t < a.R) step(t, re0, ro0, re1, ro1);
+}
+
 void yfv2_launch_stem16(const StemArgs& a, hipStream_t s) {
   StemArgs b = a;
   const int PH = a.H / 4, PW = a.W / 4;
@@ -241,6 +399,11 @@ void yfv2_launch_stem16(const StemArgs& a, hipStream_t s) {
   b.R = PH / nb;
   const int strips = (PW - 1 + 14) / 15;
   const dim3 grid(a.B * strips * nb);
+  if (a.u8_in) {
+    if (a.pp_out) hipLaunchKernelGGL((stem_h3u_kernel<true>), grid, dim3(64), 0, s, b);
+    else hipLaunchKernelGGL((stem_h3u_kernel<false>), grid, dim3(64), 0, s, b);
+    return;
+  }
   if (a.pp_out) hipLaunchKernelGGL((stem_h3_kernel<true>), grid, dim3(64), 0, s, b);
   else hipLaunchKernelGGL((stem_h3_kernel<false>), grid, dim3(64), 0, s, b);
 }
