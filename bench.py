@@ -365,7 +365,7 @@ def main():
                           "reproduces them to 2^-24 (filters on the host, scaled by a power of two; activations scaled by 2^4 / 2^8), the three products "
                           "w1 x2 + w2 x1 + w1 x1 (each exact) accumulated in fp32 by v_mfma_f32_16x16x32_f16, the powers of two undone exactly; error vs "
                           "float64 within 2x of a plain fp32 convolution's (tests/test_stem16_host_model.py), valid for |activation| < 4094 (|pixel| < "
-                          "255.9).  The uint8 stem and the YFV2_BF6=0 plan run the fp32 MFMA.  Every parity test (logits 1e-4, scores 1e-5, identical NMS survivors) runs on this arithmetic.",
+                          "255.9).  The uint8 stem is fp16x2 (a pixel 0..255 is one exact fp16 term); the YFV2_BF6=0 plan runs the fp32 MFMA.  Every parity test (logits 1e-4, scores 1e-5, identical NMS survivors) runs on this arithmetic.",
             "config": {"workload": "batch %d/GPU synthetic 352x352x3 fp32 (torch.rand), seeded random-init weights, "
                                    "Detector forward + anchor decode + class-aware NMS(conf %.2f, iou %.2f; 300 detections/image = NMS worst case)%s; "
                                    "BASELINE.json configs[1] (forward only) is the subset reported in forward_only_img_s, configs[2] "

@@ -228,6 +228,8 @@ void yfv2_launch_s1h(const S1PxArgs& a0, hipStream_t s) {
   a.nstrips = a.W <= 16 ? 1 : (a.W - 2 + 13) / 14;
   a.nb = a.H >= 16 ? 4 : 1;   // (2, 3, 5, 6, 8, 11 bands measured 35-41 us against 31-33; a memory-only build of this kernel - same
                               // 8-byte loads and stores, no arithmetic - takes 29-30 us: the launch is bound by its access pattern)
+                              // (next row's loads issued BEFORE the pending stores, and two rows of look-ahead on top of that: 30-32 us
+                              // each, same box as 30-32 - neither the stores' place in the in-order vmcnt queue nor bytes in flight limit it)
   a.R = (a.H + a.nb - 1) / a.nb;
   a.nb = (a.H + a.R - 1) / a.R;
   hipLaunchKernelGGL(s1h_kernel, dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
