@@ -12,16 +12,16 @@ a strict subset of the timed work; its rate is reported as `forward_only_img_s`.
 Weights are seeded random-init of the reference architecture (no checkpoint
 download is possible) and data is torch.rand: with those, every image yields the
 maximum of 300 detections, i.e. NMS runs its WORST case inside `value`.
-Consecutive steps are independent batches: they alternate between two handles
-(own workspaces) on two HIP streams, so that one step's launches fill the idle
-slots of its neighbour's (all K steps complete inside the timed region);
-`single_stream_img_s` is the same K steps on one handle and one stream.
+Consecutive steps are independent batches: they rotate over three handles
+(own workspaces) on three HIP streams, so that one step's launches fill the
+under-filled tails of its neighbours' (all K steps complete inside the timed
+region); `single_stream_img_s` is the same K steps on one handle and one stream.
 The configs[2] variant the survey specifies (COCO weights, a 256-batch built from
 the shipped JPEGs, thresholds 0.3/0.4 and 0.01/0.4) is timed as well and reported
 in `coco_e2e` (extra fields, never `value`).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings):
-  value      whole-job images/s (all ranks' images / max-over-ranks time), steps pipelined over two streams
+  value      whole-job images/s (all ranks' images / max-over-ranks time), steps pipelined over three streams
   single_stream_img_s   the same steps strictly one after the other
   roofline   the kernel that owns the most forward time (sum over its launches, the
              top row of a rocprofv3 --stats table): algorithmic bytes (SURVEY.md 8(d):
@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.3)
     ap.add_argument("--iou", type=float, default=0.4)
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--pipeline", type=int, default=3, help="handles / HIP streams consecutive steps rotate over (1 = one handle, one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weights", choices=("random", "coco"), default="random")
@@ -167,13 +168,17 @@ def main():
         sd = yfv2.random_state_dict(0)
     eng = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
     eng.load_state_dict(sd)
-    # Consecutive steps (batches) are independent: they alternate between TWO handles (each with its own workspace) on two HIP
-    # streams, so that a step's decode + NMS launch and its neighbours' launches fill each other's idle slots - the
-    # one-workgroup-per-image kernels of this path are latency-bound.  `single_stream_img_s` reports the same steps on one
-    # handle and one stream.
-    eng2 = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
-    eng2.load_state_dict(sd)
-    engs, streams = [eng, eng2], [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    # Consecutive steps (batches) are independent: they rotate over a.pipeline handles (each with its own workspace) on as many
+    # HIP streams, so that a step's decode + NMS launch and the under-filled tail of every launch (one workgroup per image,
+    # a last round of waves on a third of the SIMDs) overlap the neighbours' launches.  tools/pipeline_probe.py: 1 / 2 / 3 / 4
+    # handles = 0.78-0.79 / 0.72-0.74 / 0.70-0.71 / 0.72-0.74 ms per step on one box.  `single_stream_img_s` reports the same
+    # steps on one handle and one stream.
+    engs = [eng]
+    for _ in range(1, max(1, a.pipeline)):
+        e = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
+        e.load_state_dict(sd)
+        engs.append(e)
+    streams = [torch.cuda.Stream(device=dev) for _ in engs]
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.rand(a.batch, 3, 352, 352, device=dev, generator=g)  # resident in HBM before timing
     det_bufs = eng.new_det_buffers(a.batch)
@@ -181,7 +186,7 @@ def main():
 
     # N > 1: a rank's padded detections (8.4 KB/image, one flat buffer) are all-gathered once per step on RCCL's own
     # stream, overlapped with the next step's kernels: two buffer sets, a set is reused only after its gather was waited for
-    sets = [det_bufs, eng2.new_det_buffers(a.batch)]
+    sets = [det_bufs] + [e.new_det_buffers(a.batch) for e in engs[1:]]
     recv = [torch.empty(world * a.batch * (300 * 7 + 1), dtype=torch.float32, device=dev) for _ in sets] if use_dist else []
     works = [None] * len(sets)
     nstep = [0]
@@ -190,7 +195,7 @@ def main():
         j = nstep[0] % len(sets)
         nstep[0] += 1
         if works[j] is not None:
-            works[j].wait_host()          # issued two steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
+            works[j].wait_host()          # issued len(sets) steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
             works[j] = None
         with torch.cuda.stream(streams[j]):
             d, i, c = engs[j].detect(x, a.conf, a.iou, out=sets[j])
@@ -206,6 +211,10 @@ def main():
                 w.wait(unpack=False)
                 works[j] = None
 
+    for j in range(1, len(engs)):          # set-up, not a step: every extra handle's first call (lazy one-time initialisation)
+        with torch.cuda.stream(streams[j]):
+            engs[j].detect(x, a.conf, a.iou, out=sets[j])
+    sync()
     for _ in range(a.warmup):
         step()
     finish()
@@ -225,6 +234,19 @@ def main():
         eng.forward(x, out=logit_bufs)
     dt_f = timed(lambda: eng.forward(x, out=logit_bufs), a.steps, sync, barrier)
     fwd_img_s = world * a.batch * a.steps / dt_f
+    # ... and pipelined over the handles like `value`
+    logit_sets = [logit_bufs] + [[torch.empty(s, device=dev) for s in eng.logit_shapes(a.batch)] for _ in engs[1:]]
+    nf = [0]
+
+    def fwd_step():
+        j = nf[0] % len(engs)
+        nf[0] += 1
+        with torch.cuda.stream(streams[j]):
+            engs[j].forward(x, out=logit_sets[j])
+    for _ in range(2 * len(engs)):
+        fwd_step()
+    dt_fp = timed(fwd_step, a.steps, sync, barrier)
+    del logit_sets[1:]
     # the same forward fed with uint8 (B,H,W,3) images (yfv2_forward_u8: test.py:34-38's pre-process inside the stem) -
     # an extra, never `value`: the contract's input is the fp32 tensor
     xu = (x.permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
@@ -372,7 +394,8 @@ def main():
                                    "(COCO weights, JPEG-derived batch) in coco_e2e"
                                    % (a.batch, a.conf, a.iou, " + one RCCL all-gather of the padded detections per step, overlapped with the next step" if use_dist else ""),
                        "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
-            "pipelining": "consecutive steps alternate between two handles (own workspaces) on two HIP streams; all K steps complete inside the timed region",
+            "pipelining": "consecutive steps rotate over %d handles (own workspaces) on as many HIP streams; all K steps complete inside the timed region" % len(engs),
+            "forward_only_pipelined_img_s": round(world * a.batch * a.steps / dt_fp, 1), "forward_only_pipelined_ms": round(1e3 * dt_fp / a.steps, 4),
             "single_stream_img_s": round(a.batch * a.steps / dt_s, 1), "single_stream_ms_per_step": round(1e3 * dt_s / a.steps, 4),
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
             "forward_from_uint8_hwc_img_s": round(fwd_u8_img_s, 1), "forward_from_uint8_hwc_ms": round(1e3 * dt_u / a.steps, 4),

@@ -17,11 +17,11 @@ if [ "$MODE" = "quick" ]; then exit 0; fi
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
 cd /tmp && export TMPDIR=/tmp
-echo "== rocprofv3 kernel stats"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
+echo "== rocprofv3 kernel stats"   # --pipeline 1: one stream, so that a launch's duration is its own (overlapped launches share the machine)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --pipeline 1 > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
 find $OUT/prof -name "*kernel_stats*" | head -1 | while read f; do cp "$f" $OUT/kernel_stats.csv; head -30 "$f" | cut -c1-150; done
 echo "== pmc SQ pass"
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc1 -o $TAG -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-iters 1 > $OUT/pmc1.log 2>&1; echo "pmc1 rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc1 -o $TAG -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-iters 1 --pipeline 1 > $OUT/pmc1.log 2>&1; echo "pmc1 rc=$?"
 python $ROOT/tools/pmc_table.py $OUT/pmc1 $OUT/pmc.json > $OUT/pmc_sq_summary.txt; head -40 $OUT/pmc_sq_summary.txt | cut -c1-140
 echo "== traffic passes"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- python $ROOT/tools/traffic_probe.py > $OUT/fetch.log 2>&1; echo "fetch rc=$?"
