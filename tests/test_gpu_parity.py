@@ -631,6 +631,28 @@ def test_small_and_strip_shaped_inputs(yfv2, dev, hw):
         assert err <= LOGIT_ATOL * scale, "%dx%d %s: max abs err %g (scale %g)" % (hw[0], hw[1], k, err, scale)
 
 
+@pytest.mark.parametrize("hw,B", [((32, 32), 3), ((64, 96), 3), ((352, 32), 2), ((96, 384), 2), ((288, 384), 2), ((320, 320), 5), ((352, 352), 9)])
+def test_uint8_entry_sizes_and_strips_vs_oracle(yfv2, dev, hw, B):
+    """stem_h3u_kernel (uint8 HWC pixels on the f16 matrix cores) at the sizes the fp32 stem is tested at: strips with a
+    partial last lane group, one-band images, the halo lane between strips, the first / last rows' padding - logits against
+    the oracle on test.py:38's float() / 255 tensor, extreme pixels (0 and 255 runs) included."""
+    w = yfv2.random_state_dict(13)
+    m = yfv2.Detector(80, 3, True).to(dev)
+    m.load_state_dict(w)
+    m.eval()
+    g = torch.Generator().manual_seed(hw[0] * 7 + hw[1])
+    x = torch.randint(0, 256, (B, hw[0], hw[1], 3), generator=g, dtype=torch.uint8)
+    x[0, : hw[0] // 2] = 255                      # saturated / black halves: the largest accumulators, exact zeros
+    x[B - 1, :, : hw[1] // 2] = 0
+    ref = oracle.forward(w, x.permute(0, 3, 1, 2).float() / 255.0)
+    got = m(x.to(dev))
+    for gg, r, k in zip(got, ref, LOGIT_KEYS):
+        assert tuple(gg.shape) == tuple(r.shape)
+        scale = max(1.0, float(r.abs().max()))
+        err = float((gg.cpu() - r).abs().max())
+        assert err <= LOGIT_ATOL * scale, "%dx%d %s: max abs err %g (scale %g)" % (hw[0], hw[1], k, err, scale)
+
+
 def test_batch_statistics_bit_exact_vs_reference_golden(yfv2, dev, golden_stats):
     """evaluation()'s matching loop (utils.py:194-230) as one kernel launch; flags identical to
     the ones the reference function produced on the same detections / targets (jittered copies, twins with tied
