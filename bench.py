@@ -166,39 +166,31 @@ def main():
         sd = {k: torch.from_numpy(z[k]) for k in z.files}
     else:
         sd = yfv2.random_state_dict(0)
-    eng = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
-    eng.load_state_dict(sd)
     # Consecutive steps (batches) are independent: they rotate over a.pipeline handles (each with its own workspace) on as many
-    # HIP streams, so that a step's decode + NMS launch and the under-filled tail of every launch (one workgroup per image,
-    # a last round of waves on a third of the SIMDs) overlap the neighbours' launches.  tools/pipeline_probe.py: 1 / 2 / 3 / 4
-    # handles = 0.78-0.79 / 0.72-0.74 / 0.70-0.71 / 0.72-0.74 ms per step on one box.  `single_stream_img_s` reports the same
-    # steps on one handle and one stream.
-    engs = [eng]
-    for _ in range(1, max(1, a.pipeline)):
-        e = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
-        e.load_state_dict(sd)
-        engs.append(e)
-    streams = [torch.cuda.Stream(device=dev) for _ in engs]
+    # HIP streams (yolo_fastestv2_amd.DetectPipeline), so that a step's decode + NMS launch and the under-filled tail of every
+    # launch (one workgroup per image, a last round of waves on a third of the SIMDs) overlap the neighbours' launches.
+    # tools/pipeline_probe.py: 1 / 2 / 3 / 4 handles = 0.78-0.79 / 0.72-0.74 / 0.70-0.71 / 0.72-0.74 ms per step on one box.
+    # `single_stream_img_s` reports the same steps on one handle and one stream.
+    pipe = yfv2.DetectPipeline(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch, depth=max(1, a.pipeline))
+    pipe.load_state_dict(sd)
+    eng, engs, streams = pipe.engines[0], pipe.engines, pipe.streams
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.rand(a.batch, 3, 352, 352, device=dev, generator=g)  # resident in HBM before timing
-    det_bufs = eng.new_det_buffers(a.batch)
+    det_bufs = pipe.buffers[0]
     logit_bufs = [torch.empty(s, device=dev) for s in eng.logit_shapes(a.batch)]
 
     # N > 1: a rank's padded detections (8.4 KB/image, one flat buffer) are all-gathered once per step on RCCL's own
     # stream, overlapped with the next step's kernels: two buffer sets, a set is reused only after its gather was waited for
-    sets = [det_bufs] + [e.new_det_buffers(a.batch) for e in engs[1:]]
+    sets = pipe.buffers
     recv = [torch.empty(world * a.batch * (300 * 7 + 1), dtype=torch.float32, device=dev) for _ in sets] if use_dist else []
     works = [None] * len(sets)
-    nstep = [0]
 
     def step():
-        j = nstep[0] % len(sets)
-        nstep[0] += 1
-        if works[j] is not None:
-            works[j].wait_host()          # issued len(sets) steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
-            works[j] = None
-        with torch.cuda.stream(streams[j]):
-            d, i, c = engs[j].detect(x, a.conf, a.iou, out=sets[j])
+        with pipe.slot() as (j, e, bufs):      # next handle in rotation, its stream current
+            if works[j] is not None:
+                works[j].wait_host()      # issued len(sets) steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
+                works[j] = None
+            d, i, c = e.detect(x, a.conf, a.iou, out=bufs)
             if use_dist:
                 works[j] = yfv2.gather_detections(d, i, c, force=True, async_op=True, out=recv[j])
 

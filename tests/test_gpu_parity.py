@@ -816,3 +816,37 @@ def test_other_class_counts_in_their_own_interpreter(classes):
     marks = [ln for ln in r.stdout.splitlines() if ln.startswith("[class_counts]")]
     assert r.returncode == 0, ("exit code %d after %r" % (r.returncode, marks[-1] if marks else "no marker"), r.stdout[-1500:], r.stderr[-3000:])
     assert "PARITY OK classes=%d" % classes in r.stdout
+
+
+def test_detect_pipeline_matches_one_handle_bit_for_bit(yfv2, dev, coco_weights, images_u8, cfg):
+    """DetectPipeline (bench.py's `value` loop as a product class): seven different batches - fp32 and uint8, full and partial -
+    rotating over three handles / streams give exactly what one handle gives batch by batch; a ticket whose slot was reused
+    is refused; results arrive on the caller's stream."""
+    pipe = yfv2.DetectPipeline(dev, 352, 352, 80, 3, anchors=cfg["anchors"], max_batch=12, depth=3)
+    pipe.load_state_dict(coco_weights)
+    one = yfv2.Engine(dev, 352, 352, 80, 3, anchors=cfg["anchors"], max_batch=12)
+    one.load_state_dict(coco_weights)
+    batches = []
+    for k in range(7):
+        xb = _batch_from_reference_images(images_u8, 12 if k % 3 else 7, seed=40 + k)
+        if k % 2:
+            xb = (xb * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()   # the uint8 HWC entry
+        batches.append(xb.to(dev))
+    want = [tuple(t.clone() for t in one.detect(x, 0.25, 0.4)) for x in batches]
+    tickets, got = [], []
+    for k, x in enumerate(batches):
+        tickets.append(pipe.submit(x, 0.25, 0.4))
+        if k >= 2:                                  # consume with two batches still in flight
+            got.append(tuple(t.clone() for t in pipe.result(tickets[k - 2])))
+    got += [tuple(t.clone() for t in pipe.result(t)) for t in tickets[-2:]]
+    torch.cuda.synchronize()
+    assert sum(int(w[2].sum()) for w in want) > 50
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert torch.equal(w[2], g[2]), k
+        for b in range(w[2].shape[0]):
+            n = int(w[2][b])
+            assert torch.equal(w[0][b, :n], g[0][b, :n]) and torch.equal(w[1][b, :n], g[1][b, :n]), (k, b)
+    with pytest.raises(RuntimeError):
+        pipe.result(tickets[0])                     # its slot now holds batch 6
+    d, i, c = pipe.result(tickets[6], host=True)
+    assert torch.equal(c, want[6][2])

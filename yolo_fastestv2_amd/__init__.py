@@ -20,6 +20,7 @@ from .utils.utils import (ap_per_class, compute_ap, evaluation, get_batch_statis
 from .utils.loss import compute_loss  # noqa: F401
 from .utils.optim import SGD  # noqa: F401
 from .weights import export_weights, random_state_dict  # noqa: F401
+from .pipeline import DetectPipeline  # noqa: F401
 from .sharded import average_gradients_, detect_sharded, gather_decoded, gather_detections, shard_range  # noqa: F401
 
 
