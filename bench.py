@@ -16,6 +16,8 @@ Consecutive steps are independent batches: they rotate over three handles
 (own workspaces) on three HIP streams, so that one step's launches fill the
 under-filled tails of its neighbours' (all K steps complete inside the timed
 region); `single_stream_img_s` is the same K steps on one handle and one stream.
+Before the W warm-up steps, `--spinup` (80) untimed steps bring the device out of
+its idle power state (a fresh process runs its first ~25 steps 8-10 % slower).
 The configs[2] variant the survey specifies (COCO weights, a 256-batch built from
 the shipped JPEGs, thresholds 0.3/0.4 and 0.01/0.4) is timed as well and reported
 in `coco_e2e` (extra fields, never `value`).
@@ -95,6 +97,7 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.3)
     ap.add_argument("--iou", type=float, default=0.4)
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--spinup", type=int, default=80, help="untimed steps before the warm-up that bring the device out of its idle power state (about 60 ms)")
     ap.add_argument("--pipeline", type=int, default=3, help="handles / HIP streams consecutive steps rotate over (1 = one handle, one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,6 +209,15 @@ def main():
     for j in range(1, len(engs)):          # set-up, not a step: every extra handle's first call (lazy one-time initialisation)
         with torch.cuda.stream(streams[j]):
             engs[j].detect(x, a.conf, a.iou, out=sets[j])
+    sync()
+    # set-up, not a step: bring the device out of its idle power state.  A fresh process runs its first ~25 steps 8-10 % slower
+    # than every later one (tools/stagger_probe.py: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each
+    # following 20), which would put a --warmup 5 --steps 20 run entirely inside the ramp.  a.spinup of the same steps run
+    # untimed first (a fixed COUNT, the same on every rank: the steps hold a collective), then the W warm-up steps, then the
+    # K timed ones; the count is reported as `spinup_steps`.
+    for _ in range(a.spinup):
+        step()
+    finish()
     sync()
     for _ in range(a.warmup):
         step()
@@ -319,12 +331,21 @@ def main():
             xc3 = batch_from_reference_images(np.load(os.path.join(gold, "images_u8.npz"))["images"], a.batch, seed=3).to(dev)
             coco = {"weights": "coco2017-0.241078ap-model.pth (tests/golden/weights_coco.npz)",
                     "input": "%d images derived from the 6 shipped JPEGs (flip / roll / gain variants, seed 3)" % a.batch}
+            pipe.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files})     # the pipeline's handles, COCO weights from here on
             for tag, ct in (("conf0.30_iou0.40", 0.3), ("conf0.01_iou0.40", 0.01)):
                 for _ in range(2):
                     eng_c.detect(xc3, ct, 0.4, out=det_bufs)
                 dt_c = timed(lambda: eng_c.detect(xc3, ct, 0.4, out=det_bufs), a.steps, sync, barrier)
                 cc = det_bufs[2].float().cpu()
-                coco[tag] = {"img_s": round(a.batch * a.steps / dt_c, 1), "ms_per_step": round(1e3 * dt_c / a.steps, 4),
+
+                def coco_step():
+                    with pipe.slot() as (_, e, bufs):
+                        e.detect(xc3, ct, 0.4, out=bufs)
+                for _ in range(2 * pipe.depth):
+                    coco_step()
+                dt_cp = timed(coco_step, a.steps, sync, barrier)
+                coco[tag] = {"img_s": round(a.batch * a.steps / dt_cp, 1), "ms_per_step": round(1e3 * dt_cp / a.steps, 4),
+                             "single_stream_img_s": round(a.batch * a.steps / dt_c, 1), "single_stream_ms_per_step": round(1e3 * dt_c / a.steps, 4),
                              "detections_per_image_mean": round(float(cc.mean()), 2), "detections_per_image_max": int(cc.max())}
             del eng_c, xc3
 
@@ -386,6 +407,7 @@ def main():
                                    "(COCO weights, JPEG-derived batch) in coco_e2e"
                                    % (a.batch, a.conf, a.iou, " + one RCCL all-gather of the padded detections per step, overlapped with the next step" if use_dist else ""),
                        "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
+            "spinup_steps": a.spinup,
             "pipelining": "consecutive steps rotate over %d handles (own workspaces) on as many HIP streams; all K steps complete inside the timed region" % len(engs),
             "forward_only_pipelined_img_s": round(world * a.batch * a.steps / dt_fp, 1), "forward_only_pipelined_ms": round(1e3 * dt_fp / a.steps, 4),
             "single_stream_img_s": round(a.batch * a.steps / dt_s, 1), "single_stream_ms_per_step": round(1e3 * dt_s / a.steps, 4),
