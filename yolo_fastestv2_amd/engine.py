@@ -122,7 +122,10 @@ class Engine:
                 raise ValueError("expected uint8 (B,%d,%d,3), got %s" % (self.height, self.width, tuple(x.shape)))
         elif x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (3, self.height, self.width):
             raise ValueError("expected fp32 (B,3,%d,%d) or uint8 (B,%d,%d,3), got %s %s" % (self.height, self.width, self.height, self.width, x.dtype, tuple(x.shape)))
-        return x.contiguous()
+        x = x.contiguous()
+        if x.data_ptr() % 16:        # a view into the middle of a storage: the stem kernels load 16-byte (fp32) / 4-byte-aligned 12-byte (uint8) records
+            x = x.clone()
+        return x
 
     # ---- the hot path ---------------------------------------------------------------------
     def forward(self, x, out=None):
