@@ -534,3 +534,74 @@ def test_data_parallel_training_averages_the_gradient_bucket_world_size_2_gloo(t
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "rank %d ok" % r in o, o
+
+
+def test_detect_pipeline_slot_rotation_and_ticket_rules(monkeypatch):
+    """DetectPipeline's host logic without a GPU (stand-ins for the Engine and for torch.cuda's streams / events): slots rotate,
+    a slot's stream is current while its batch is enqueued, a batch larger than max_batch is refused, a ticket whose slot
+    was reused is refused, result() orders the caller's stream behind the ticket's event (or blocks the host)."""
+    import contextlib
+    import yolo_fastestv2_amd.pipeline as P
+    log = []
+
+    class FakeStream:
+        def __init__(self, device=None): self.waited = []
+        def wait_stream(self, s): self.waited.append(("stream", s))
+        def wait_event(self, e): self.waited.append(("event", e))
+        def synchronize(self): log.append(("sync", self))
+
+    class FakeEvent:
+        def record(self, s): self.stream = s
+        def synchronize(self): log.append(("host_wait", self))
+
+    class FakeEngine:
+        def __init__(self, device, h, w, classes, anchor_num, anchors=None, max_batch=1): self.loaded = None
+        def new_det_buffers(self, B): return (torch.zeros(B, 300, 6), torch.zeros(B, 300, dtype=torch.int32), torch.zeros(B, dtype=torch.int32))
+        def load_state_dict(self, sd): self.loaded = sd
+        def set_anchors(self, a): self.anchors = a
+        def detect(self, x, conf, iou, out=None):
+            log.append(("detect", self, current[0], tuple(o.shape[0] for o in out)))
+            out[2][:] = int(x.sum())
+            return out
+
+    current = [None]
+    main = FakeStream()
+
+    @contextlib.contextmanager
+    def fake_stream_ctx(s):
+        prev, current[0] = current[0], s
+        try:
+            yield
+        finally:
+            current[0] = prev
+    monkeypatch.setattr(P, "Engine", FakeEngine)
+    monkeypatch.setattr(P.torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(P.torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(P.torch.cuda, "stream", fake_stream_ctx)
+    monkeypatch.setattr(P.torch.cuda, "current_stream", lambda device=None: current[0] or main)
+    monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s: None, raising=False)
+
+    pipe = P.DetectPipeline("cpu", 352, 352, 80, 3, anchors=[1.0] * 12, max_batch=4, depth=3)
+    pipe.load_state_dict({"w": 1})
+    assert all(e.loaded == {"w": 1} for e in pipe.engines) and len(pipe.streams) == 3
+    tickets = [pipe.submit(torch.full((2 + (k % 2), 1), float(k + 1)), 0.3, 0.4) for k in range(5)]
+    detects = [l for l in log if l[0] == "detect"]
+    assert [pipe.engines.index(l[1]) for l in detects] == [0, 1, 2, 0, 1]                  # rotation
+    assert [pipe.streams.index(l[2]) for l in detects] == [0, 1, 2, 0, 1]                  # the slot's stream was current
+    assert [l[3] for l in detects] == [(2, 2, 2), (3, 3, 3), (2, 2, 2), (3, 3, 3), (2, 2, 2)]   # views of the slot's buffers, B rows
+    assert all(s.waited and s.waited[0] == ("stream", main) for s in pipe.streams)         # ordered behind the producer of x
+    with pytest.raises(RuntimeError):
+        pipe.result(tickets[0])                                                           # slot 0 now holds batch 3
+    d, i, c = pipe.result(tickets[3])
+    assert ("event", tickets[3].event) in main.waited and int(c[0]) == 4 * 3               # batch 3: three rows of value 4
+    pipe.result(tickets[4], host=True)
+    assert ("host_wait", tickets[4].event) in log
+    with pytest.raises(ValueError):
+        pipe.submit(torch.zeros(5, 1), 0.3, 0.4)
+    n_wait = sum(len(s.waited) for s in pipe.streams)
+    pipe.submit(torch.ones(1, 1), 0.3, 0.4, wait_for_input=False)
+    assert sum(len(s.waited) for s in pipe.streams) == n_wait                              # no stream wait for a ready input
+    with pipe.slot() as (j, eng, bufs):                                                   # the raw form bench.py uses
+        assert current[0] is pipe.streams[j] and eng is pipe.engines[j] and bufs is pipe.buffers[j]
+    pipe.synchronize()
+    assert sum(1 for l in log if l[0] == "sync") == 3
