@@ -54,3 +54,37 @@ def test_routing_matches_the_oracle_blocks():
     assert np.array_equal(out[:6], a0[0::8])                              # untouched channels, bit for bit
     y1, y2 = acts[1][24:], acts[2][24:]
     assert np.array_equal(out[6:12], y1[0::4]) and np.array_equal(out[12:24], y2[0::2])
+
+
+def test_lane_group_assignment_needs_no_movement_between_lane_groups():
+    """The matrix-core layout of the strip kernels (yfv2_stage2h.hip): a 24-channel pointwise conv leaves lane group g of a pixel
+    with accumulators (tile 0: 4 per group g = 0..3; tile 1: 4 per group g = 0, 1) and wants its 24 inputs as K slots 8g..8g+7
+    of groups 0..2.  Which OUTPUT channel lands in which accumulator is the host's choice (filter rows), which INPUT channel
+    sits in which K slot too (filter columns).  A fused stage2.1-3 is free of cross-lane traffic if every intermediate channel
+    can be produced in the lane group that later consumes it - constructed and checked here."""
+    cap = {(0, g): 4 for g in range(4)}
+    cap.update({(1, 0): 4, (1, 1): 4})
+    # y1: odd channels feed block 2, channels 2 mod 4 feed block 3 (two rows later), channels 0 mod 4 are final
+    y1 = {(0, 0): [1, 3, 5, 7], (0, 1): [9, 11, 13, 15], (0, 2): [17, 19, 21, 23],          # -> block 2, K slots of groups 0, 1, 2
+          (1, 0): [2, 6, 10, 14], (1, 1): [18, 22, 0, 4],                                   # -> block 3 (six of them), two finals
+          (0, 3): [8, 12, 16, 20]}                                                           # finals
+    # y2: odd channels feed block 3, even channels are final
+    y2 = {(0, 0): [1, 3, 5, 7], (0, 1): [9, 11, 13, 15], (0, 2): [17, 19, 21, 23],
+          (1, 0): [0, 2, 4, 6], (1, 1): [8, 10, 12, 14], (0, 3): [16, 18, 20, 22]}
+    for y in (y1, y2):
+        assert sorted(c for v in y.values() for c in v) == list(range(24))
+        assert all(len(v) <= cap[k] for k, v in y.items())
+    group_of = lambda y, c: next(g for (t, g), v in y.items() if c in v)                  # noqa: E731
+    # block 2: 12 register inputs (y1 odd) + 12 from memory; block 3: 12 (y2 odd) + 6 (y1 2 mod 4) + 6 from memory
+    k2 = {g: [("y1", c) for c in range(1, 24, 2) if group_of(y1, c) == g] for g in range(3)}
+    k3 = {g: [("y2", c) for c in range(1, 24, 2) if group_of(y2, c) == g] + [("y1", c) for c in range(2, 24, 4) if group_of(y1, c) == g] for g in range(3)}
+    assert sum(len(v) for v in k2.values()) == 12 and sum(len(v) for v in k3.values()) == 18     # nothing needed sits in lane group 3
+    mem2 = {g: 8 - len(k2[g]) for g in range(3)}
+    mem3 = {g: 8 - len(k3[g]) for g in range(3)}
+    assert all(v >= 0 for v in mem2.values()) and all(v >= 0 for v in mem3.values())
+    assert sum(mem2.values()) == 12 and sum(mem3.values()) == 6                                    # = the channels the algebra test says come from memory
+    assert all(v % 2 == 0 for v in mem2.values()) and all(v % 2 == 0 for v in mem3.values())       # whole 8-byte pairs per lane
+    # stores: finals of y1 (0 mod 4) and y2 (even) pair up inside one lane's accumulators of one tile
+    for y, final in ((y1, set(range(0, 24, 4))), (y2, set(range(0, 24, 2)))):
+        for (t, g), v in y.items():
+            assert len([c for c in v if c in final]) % 2 == 0, (t, g, v)
