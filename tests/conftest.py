@@ -71,6 +71,22 @@ def golden_rand():
 
 
 @pytest.fixture(scope="session")
+def golden_floor():
+    """the reference's fp32 forward + decode against its own float64 evaluation on the bench workload (make_golden.py floor)"""
+    return _npz("golden_floor.npz")
+
+
+def floor_inputs(z):
+    """the workload golden_floor.npz was made on: (state_dict, images) - CPU generators, reproducible on every box"""
+    import torch
+    import yolo_fastestv2_amd as yfv2
+    sd = yfv2.random_state_dict(int(z["weight_seed"]))
+    x = torch.rand(int(z["images"]), 3, 352, 352, generator=torch.Generator().manual_seed(int(z["image_seed"])))
+    assert np.array_equal(x.flatten()[::1000003].numpy(), z["x_probe"]), "torch.rand(seed) differs from the generating machine's"
+    return sd, x
+
+
+@pytest.fixture(scope="session")
 def golden_kat():
     return _npz("golden_kat.npz")
 

@@ -20,6 +20,8 @@ Outputs (all small, committed):
                        -> reference non_max_suppression rows
   golden_stats.npz     NMS rows of the stress set + synthetic targets -> reference get_batch_statistics
   golden_ap.npz        synthetic detection statistics -> reference ap_per_class (python make_golden.py ap)
+  golden_floor.npz     the bench workload (random-init weights, seeded images): the reference's fp32 forward + decode against
+                       its own float64 evaluation - the noise floor a device path is held to (python make_golden.py floor)
   golden_loss.npz      seeded logits + targets -> reference utils/loss.py compute_loss values and its autograd
                        gradients w.r.t. the six logit maps (python make_golden.py loss)
 
@@ -541,6 +543,78 @@ def make_curve_golden():
     np.savez_compressed(os.path.join(HERE, "golden_curve.npz"), **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# noise floor of the BENCH regime (VERDICT r03 "what's weak" 1): random-init weights give logits of magnitude ~36, where an
+# absolute 1e-4 is below what fp32 arithmetic delivers - the reference's own fp32 forward is further than that from the exact
+# result.  This fixture records how far: the reference modules in fp32 against the SAME modules in float64 on the bench's
+# workload (random_state_dict(0), seeded U[0,1) images).  A device path is then held to a small multiple of the reference's
+# own error against float64 (tests/test_gpu_parity.py::test_bench_regime_within_the_reference_noise_floor) instead of a
+# tolerance scaled by the logit magnitude.
+# ---------------------------------------------------------------------------------------------------------------
+FLOOR = dict(weight_seed=0, image_seed=1000, images=16, keep=2)
+BENCH_ANCHORS = [12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87]   # bench.py ANCHORS = data/coco.data:17
+
+
+def floor_inputs(f=FLOOR):
+    """-> (state_dict, images): what the generator and the tests both build (CPU generators: reproducible everywhere)"""
+    import yolo_fastestv2_amd as yfv2
+    sd = yfv2.random_state_dict(f["weight_seed"])
+    x = torch.rand(f["images"], 3, 352, 352, generator=torch.Generator().manual_seed(f["image_seed"]))
+    return sd, x
+
+
+def floor_stats(got, exact):
+    """error statistics of one tensor against its float64 value: (max |d|, rms d)"""
+    d = np.asarray(got, np.float64) - np.asarray(exact, np.float64)
+    return np.asarray([np.abs(d).max(), np.sqrt((d * d).mean())], np.float64)
+
+
+def decoded_floor_stats(got, exact):
+    """box coordinates relative to max(1, |exact|), scores absolute: (max box, rms box, max score, rms score)"""
+    d = np.asarray(got, np.float64) - np.asarray(exact, np.float64)
+    db = d[..., :4] / np.maximum(1.0, np.abs(exact[..., :4]))
+    ds = d[..., 4:]
+    return np.asarray([np.abs(db).max(), np.sqrt((db * db).mean()), np.abs(ds).max(), np.sqrt((ds * ds).mean())], np.float64)
+
+
+def make_floor_golden():
+    import copy
+    torch.set_num_threads(1)
+    det, uu = import_reference()
+    sd, x = floor_inputs()
+    cfg = dict(uu.load_datafile(os.path.join(REF, "data/coco.data")))
+    assert [float(a) for a in cfg["anchors"]] == BENCH_ANCHORS
+    model = det.Detector(80, 3, True)
+    print(model.load_state_dict(sd))
+    model.eval()
+    model64 = copy.deepcopy(model).double()
+    with torch.no_grad():
+        p32 = model(x)
+        p64 = model64(x.double())
+    dec32 = uu.handel_preds(p32, cfg, torch.device("cpu")).numpy()
+    dec64 = oracle.decode64(p64, cfg["anchors"], cfg["height"])
+    # the oracle IS the reference here: fp32 bit for bit, float64 bit for bit
+    for a, b in zip(p32, oracle.forward(sd, x)):
+        assert torch.equal(a, b), "oracle.forward != reference forward"
+    for a, b in zip(p64, oracle.forward64(sd, x)):
+        assert a.dtype == torch.float64 and torch.equal(a, b), "oracle.forward64 != reference .double() forward"
+    out = {"x_probe": x.flatten()[::1000003].numpy(), "images": np.int64(FLOOR["images"]), "keep": np.int64(FLOOR["keep"]),
+           "weight_seed": np.int64(FLOOR["weight_seed"]), "image_seed": np.int64(FLOOR["image_seed"])}
+    for k, a, b in zip(("reg2", "obj2", "cls2", "reg3", "obj3", "cls3"), p32, p64):
+        out["err_" + k] = floor_stats(a.numpy(), b.numpy())
+        out["scale_" + k] = np.float64(b.abs().max().item())
+        out["logit64_" + k] = b[:FLOOR["keep"]].numpy()
+        print("%-5s |logit| max %7.3f   reference fp32 vs float64: max %.3e rms %.3e" % (k, out["scale_" + k], *out["err_" + k]))
+    out["err_decoded"] = decoded_floor_stats(dec32, dec64)
+    print("decoded: box rel max %.3e rms %.3e   score max %.3e rms %.3e" % tuple(out["err_decoded"]))
+    # what the reference reports on its own fp32 logits at the bench's thresholds (counts only: the rows are recomputed by the
+    # oracle in the test - NMS is pinned bit-exactly elsewhere)
+    rows, idx = ref_nms_per_image(uu, dec32, 0.3, 0.4)
+    out["n_det"] = np.asarray([r.shape[0] for r in rows], np.int64)
+    np.savez_compressed(os.path.join(HERE, "golden_floor.npz"), **out)
+    print("golden_floor.npz", os.path.getsize(os.path.join(HERE, "golden_floor.npz")), "bytes; detections per image", out["n_det"])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         make_train_golden()   # only golden_train.npz
@@ -548,6 +622,8 @@ if __name__ == "__main__":
         make_curve_golden()   # only golden_curve.npz
     elif len(sys.argv) > 1 and sys.argv[1] == "loss":
         make_loss_golden()    # only golden_loss.npz
+    elif len(sys.argv) > 1 and sys.argv[1] == "floor":
+        make_floor_golden()   # only golden_floor.npz
     elif len(sys.argv) > 1 and sys.argv[1] == "ap":
         make_ap_golden()      # only golden_ap.npz (the other files are left as committed)
     else:

@@ -115,7 +115,7 @@ def classify(dec_img, conf_thres, iou_thres, classes=None, eps_conf=None, eps_ti
     return pool, status, conf
 
 
-def _candidates(dec_img, conf_thres, classes, EPS_CONF, EPS_TIE):
+def _candidates(dec_img, conf_thres, classes, EPS_CONF, EPS_TIE, box_rtol=None):
     """rows that may take part (obj, conf within EPS_CONF of passing): ids, present (clearly passing), cls, conf, cls_open,
     fp32 offset boxes as float64, area, per-row quantisation term"""
     d = np.asarray(dec_img, dtype=np.float32)
@@ -141,11 +141,11 @@ def _candidates(dec_img, conf_thres, classes, EPS_CONF, EPS_TIE):
     # how far an edge of this box may sit from where the other execution has it: one fp32 bucket at the offset coordinate
     # (the class offset quantises: 1/64 pixel at class 36) plus the decode tolerance the parity tests grant on cx, cy, w, h
     bucket = np.spacing(np.abs(box32).max(1).astype(np.float32)).astype(np.float64) if pool.size else np.zeros(0)
-    delta = bucket + BOX_RTOL * 1.5 * np.maximum(1.0, np.abs(x[:, :4]).max(1).astype(np.float64))
+    delta = bucket + (BOX_RTOL * 1.5 if box_rtol is None else box_rtol) * np.maximum(1.0, np.abs(x[:, :4]).max(1).astype(np.float64))
     return pool, present, cls, conf, cls_open, raw, area, delta
 
 
-def check(dec_img, got_rows, conf_thres, iou_thres, classes=None, eps_conf=None, eps_tie=None, eps_iou=None):
+def check(dec_img, got_rows, conf_thres, iou_thres, classes=None, eps_conf=None, eps_tie=None, eps_iou=None, box_rtol=None):
     """The CERTIFICATE form of the rule, relative to the survivor list `got_rows` a device reported for this image (in its
     reported order) - no cascades, because every decision is checked against the device's own kept set K:
       * a kept row must be able to pass the thresholds, and no kept row that certainly precedes it may certainly suppress it
@@ -155,11 +155,12 @@ def check(dec_img, got_rows, conf_thres, iou_thres, classes=None, eps_conf=None,
     A greedy NMS result is exactly the set with these two properties, so a valid execution within the margins always passes
     and anything else is a wrong result.  `n_uncertain` counts the decisions that only hold thanks to a margin (a kept row's
     nearest certainly-preceding kept neighbour within eps of the threshold, a dropped row whose best suppressor is within eps,
-    a row within EPS_CONF of conf_thres)."""
+    a row within EPS_CONF of conf_thres).  `box_rtol`: how far (relative to max(1, |coordinate|)) a decoded cx, cy, w, h of the
+    execution under test may sit from `dec_img`'s (default 1.5 * BOX_RTOL)."""
     EPS_C = EPS_CONF if eps_conf is None else eps_conf
     EPS_T = EPS_TIE if eps_tie is None else eps_tie
     EPS_I = EPS_IOU if eps_iou is None else eps_iou
-    pool, present, cls, conf, cls_open, raw, area, delta = _candidates(dec_img, conf_thres, classes, EPS_C, EPS_T)
+    pool, present, cls, conf, cls_open, raw, area, delta = _candidates(dec_img, conf_thres, classes, EPS_C, EPS_T, box_rtol)
     pos = {int(r): i for i, r in enumerate(pool.tolist())}
     got = [int(v) for v in got_rows]
     forbidden = [r for r in got if r not in pos]          # clearly below a threshold (or filtered class)

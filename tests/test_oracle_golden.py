@@ -157,3 +157,37 @@ def test_oracle_resize_properties():
         return
     pil = np.asarray(Image.fromarray(img).resize((352, 352), Image.BILINEAR))
     assert np.abs(oracle.resize_linear_u8(img, 352, 352).astype(int) - pil.astype(int)).max() <= 1
+
+
+def test_noise_floor_golden_and_the_rule_built_on_it(golden_floor):
+    """golden_floor.npz (make_golden.py floor: the reference's modules in fp32 and in float64 on the bench workload).  On the
+    CPU: this host's float64 oracle reproduces the reference's float64 logits; the oracle's fp32 forward + decode sits at the
+    recorded floor; the noise-floor check of tests/test_gpu_parity.py accepts the oracle's own execution (with its survivors)
+    and REJECTS an execution whose logits carry three floors of extra error - the check can fail."""
+    import bench
+    import pytest
+    import test_gpu_parity as tg
+    from conftest import floor_inputs
+    sd, x = floor_inputs(golden_floor)
+    keep, n = int(golden_floor["keep"]), 4
+    xs = x[:n]
+    p64 = oracle.forward64(sd, xs)
+    for k, t in zip(tg.LOGIT_KEYS, p64):
+        assert t.dtype == torch.float64
+        assert np.abs(t[:keep].numpy() - golden_floor["logit64_" + k]).max() <= 1e-9, k
+    p32 = oracle.forward(sd, xs)
+    for k, a, b in zip(tg.LOGIT_KEYS, p32, p64):
+        e_max, e_rms = tg._err_stats(a.numpy(), b.numpy())
+        assert e_max <= 1.5 * golden_floor["err_" + k][0] and 0.5 * golden_floor["err_" + k][1] <= e_rms <= 1.5 * golden_floor["err_" + k][1], (k, e_max, e_rms)
+    assert max(float(golden_floor["err_" + k][0]) for k in tg.LOGIT_KEYS) < 1e-4      # the reference itself is inside 1e-4 absolute at logit scale 36
+    err_ref = {k: golden_floor["err_" + k] for k in tg.LOGIT_KEYS}
+    err_ref["decoded"] = golden_floor["err_decoded"]
+    o_dec = oracle.decode(p32, bench.ANCHORS, 352)
+    _, o_idx = oracle.non_max_suppression(o_dec, 0.3, 0.4)
+    fl = tg._bench_regime_floor_check(sd, xs, list(p32), o_dec, [[int(v) for v in i] for i in o_idx], err_ref)
+    assert not fl["violations"] and fl["record"]["end_to_end_n_diff"] == 0
+    assert fl["record"]["worst_logit_ratio_device_over_reference"] <= 1.5
+    g = torch.Generator().manual_seed(3)
+    noisy = [t + 3 * float(golden_floor["err_" + k][1]) * torch.randn(t.shape, generator=g) for k, t in zip(tg.LOGIT_KEYS, p32)]
+    with pytest.raises(AssertionError):
+        tg._bench_regime_floor_check(sd, xs, noisy, o_dec, [[int(v) for v in i] for i in o_idx], err_ref)

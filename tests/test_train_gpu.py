@@ -144,6 +144,80 @@ def test_gradient_accumulation_over_subdivisions():
         assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-7 * float(g1[k].abs().max() + 1e-12)), k
 
 
+def test_eval_after_training_runs_the_current_weights_every_time():
+    """yfv2.SGD and the train-mode forward write parameters / BatchNorm statistics through raw pointers; the
+    packed inference copy of the weights must be refreshed after EVERY such write, not only at the first evaluation.  train ->
+    eval -> train -> eval: both evaluations must equal a fresh Detector loaded from the state_dict of that moment, bit for bit,
+    and they must differ from each other (the second round of training really moved the weights).  Also a caller temporary as
+    the train-mode input (ADVICE medium: the library re-reads x in backward, the engine keeps it alive)."""
+    import yolo_fastestv2_amd as yfv2
+    dev = torch.device("cuda:0")
+    classes, B, T, seed, lr = make_golden.TRAIN_CASES[1]
+    w, x, t = make_golden.train_case_inputs(classes, B, T, seed)
+    anchors = [float(a) for a in np.load(os.path.join(GOLDEN, "cfg_coco.npz"))["anchors"]]
+    cfg = {"anchor_num": 3, "classes": classes, "width": 352, "height": 352, "anchors": anchors}
+    model = yfv2.Detector(classes, 3, True).to(dev)
+    model.load_state_dict(w)
+    opt = yfv2.SGD(model.parameters(), lr=lr, momentum=0.949, weight_decay=0.0005)
+    ts = torch.from_numpy(t).to(dev)
+
+    def train_once():
+        model.train()
+        loss = yfv2.compute_loss(model(torch.from_numpy(x).to(dev) * 1.0), ts, cfg, dev)[3]     # the input is a temporary
+        junk = [torch.empty(x.size, device=dev) for _ in range(3)]                             # invite the allocator to reuse its block
+        opt.zero_grad()
+        loss.backward()
+        del junk
+        opt.step()
+
+    def eval_now():
+        model.eval()
+        with torch.no_grad():
+            got = [o.clone() for o in model(torch.from_numpy(x).to(dev))]
+        fresh = yfv2.Detector(classes, 3, True).to(dev)
+        fresh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        fresh.eval()
+        with torch.no_grad():
+            want = fresh(torch.from_numpy(x).to(dev))
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), "eval mode ran stale weights"
+        return got
+
+    train_once()
+    first = eval_now()
+    train_once()
+    second = eval_now()
+    assert any(not torch.equal(a, b) for a, b in zip(first, second))
+    # the first-conv weight gradient with a temporary input equals the one with a tensor the caller keeps
+    model.load_state_dict(w)
+    model.train()
+    keep = torch.from_numpy(x).to(dev)
+    opt.zero_grad(); yfv2.compute_loss(model(keep), ts, cfg, dev)[3].backward()
+    g_keep = model.backbone.first_conv._modules["0"].weight.grad.clone()
+    model.load_state_dict(w)
+    opt.zero_grad()
+    loss = yfv2.compute_loss(model(torch.from_numpy(x).to(dev) * 1.0), ts, cfg, dev)[3]
+    junk = [torch.full((x.size,), 7.0, device=dev) for _ in range(3)]
+    loss.backward()
+    assert torch.equal(model.backbone.first_conv._modules["0"].weight.grad, g_keep)
+
+
+def test_train_bind_refuses_mis_sized_buffers():
+    """yfv2_train_bind checks every descriptor's element count against the handle's configuration."""
+    import yolo_fastestv2_amd as yfv2
+    dev = torch.device("cuda:0")
+    eng = yfv2.Engine(dev, 64, 64, 5, 3, max_batch=2)
+    sd = {k: v.to(dev) for k, v in yfv2.random_state_dict(1, classes=5).items() if v.is_floating_point()}
+    grads = {k: torch.zeros_like(v) for k, v in sd.items() if not k.endswith(("running_mean", "running_var"))}
+    eng.train_bind(sd, grads)                                              # the right sizes bind
+    bad = dict(sd); bad["output_cls_layers.weight"] = torch.zeros(4 * 72, device=dev)      # one class short
+    with pytest.raises(yfv2.Yfv2Error, match="output_cls_layers.weight"):
+        eng.train_bind(bad, grads)
+    badg = dict(grads); badg["backbone.stage3.0.branch_main.3.weight"] = torch.zeros(48 * 9 - 1, device=dev)
+    with pytest.raises(yfv2.Yfv2Error, match="gradient buffer"):
+        eng.train_bind(sd, badg)
+
+
 @pytest.mark.parametrize("prefix,c", make_golden.CURVES, ids=["batch8", "batch64"])
 def test_training_loop_follows_the_reference_loss_curve(prefix, c, record_parity):
     """train.py:94-131 line by line through the drop-in surface for 12 iterations (fine-tuning the COCO checkpoint over a

@@ -386,11 +386,63 @@ void yfv2_train_release(void* p) {
   delete t;
 }
 
+namespace {
+// element count of every floating-point state_dict entry of the architecture (model/detector.py:8-19 and the modules it builds:
+// shufflenetv2.py:19-46,66-100, fpn.py:5-49) for this configuration
+std::map<std::string, int64_t> expected_numels(const yfv2_config& cfg) {
+  std::map<std::string, int64_t> m;
+  auto conv = [&](const std::string& n, int co, int ci_per_group, int k) { m[n + ".weight"] = (int64_t)co * ci_per_group * k * k; };
+  auto bn = [&](const std::string& n, int c) { for (const char* leaf : {".weight", ".bias", ".running_mean", ".running_var"}) m[n + leaf] = c; };
+  conv("backbone.first_conv.0", 24, 3, 3); bn("backbone.first_conv.1", 24);
+  const int repeats[3] = {4, 8, 4}, chans[4] = {24, 48, 96, 192};
+  int cin = 24;
+  for (int si = 0; si < 3; ++si) {
+    const int cout = chans[si + 1], mid = cout / 2;
+    for (int i = 0; i < repeats[si]; ++i) {
+      const std::string p = "backbone.stage" + std::to_string(si + 2) + "." + std::to_string(i);
+      const int inp = i == 0 ? cin : cin / 2;
+      conv(p + ".branch_main.0", mid, inp, 1); bn(p + ".branch_main.1", mid);
+      conv(p + ".branch_main.3", mid, 1, 3); bn(p + ".branch_main.4", mid);
+      conv(p + ".branch_main.5", cout - inp, mid, 1); bn(p + ".branch_main.6", cout - inp);
+      if (i == 0) {
+        conv(p + ".branch_proj.0", inp, 1, 3); bn(p + ".branch_proj.1", inp);
+        conv(p + ".branch_proj.2", inp, inp, 1); bn(p + ".branch_proj.3", inp);
+      }
+      cin = cout;
+    }
+  }
+  conv("fpn.conv1x1_2.0", 72, 288, 1); bn("fpn.conv1x1_2.1", 72);
+  conv("fpn.conv1x1_3.0", 72, 192, 1); bn("fpn.conv1x1_3.1", 72);
+  for (const char* head : {"cls_head_2", "reg_head_2", "reg_head_3", "cls_head_3"}) {
+    const std::string p = std::string("fpn.") + head + ".block";
+    conv(p + ".0", 72, 1, 5); bn(p + ".1", 72); conv(p + ".3", 72, 72, 1); bn(p + ".4", 72);
+    conv(p + ".5", 72, 1, 5); bn(p + ".6", 72); conv(p + ".8", 72, 72, 1); bn(p + ".9", 72);
+  }
+  const int A = cfg.anchor_num;
+  const std::pair<const char*, int> outs[3] = {{"output_reg_layers", 4 * A}, {"output_obj_layers", A}, {"output_cls_layers", cfg.classes}};
+  for (const auto& o : outs) { m[std::string(o.first) + ".weight"] = (int64_t)o.second * 72; m[std::string(o.first) + ".bias"] = o.second; }
+  return m;
+}
+}  // namespace
+
 extern "C" {
 
 int yfv2_train_bind(yfv2_handle h, const yfv2_tensor_desc* tensors, int32_t n, const yfv2_tensor_desc* grads, int32_t ng) {
   if (!h || !tensors || n <= 0 || !grads || ng <= 0) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_train_bind: bad argument");
   Train* t = train_of(h, true);
+  // every bound buffer is indexed with the shapes the handle's configuration implies: a mis-sized one is refused here
+  // (YFV2_ERR_WEIGHTS, like yfv2_load_weights), not read or written out of bounds later
+  const std::map<std::string, int64_t> want = expected_numels(t->cfg);
+  auto check = [&](const yfv2_tensor_desc& d, const char* what) -> int {
+    auto it = want.find(d.name);
+    if (it == want.end()) return YFV2_OK;               // not a tensor of this model: never looked up
+    if (!d.data || d.numel != it->second)
+      return yfv2_ctx_fail(h, YFV2_ERR_WEIGHTS, (std::string("yfv2_train_bind: ") + what + " '" + d.name + "' has " + std::to_string((long long)d.numel) +
+                                                 " elements, expected " + std::to_string((long long)it->second)).c_str());
+    return YFV2_OK;
+  };
+  for (int i = 0; i < n; ++i) if (tensors[i].name) if (int rc = check(tensors[i], "tensor")) return rc;
+  for (int i = 0; i < ng; ++i) if (grads[i].name) if (int rc = check(grads[i], "gradient buffer")) return rc;
   t->param.clear(); t->pgrad.clear();
   for (int i = 0; i < n; ++i) if (tensors[i].name) t->param[tensors[i].name] = const_cast<float*>(tensors[i].data);
   for (int i = 0; i < ng; ++i) if (grads[i].name) t->pgrad[grads[i].name] = const_cast<float*>(grads[i].data);

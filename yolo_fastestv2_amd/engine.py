@@ -262,6 +262,10 @@ class Engine:
         ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in out])
         check(_lib.lib().yfv2_train_forward(self._h, _ptr(x), B, ptrs, _stream(self.device)), self._h)
         self._train_seq = getattr(self, "_train_seq", 0) + 1
+        # the library does NOT copy the input: the backward's first-conv weight gradient re-reads it through the raw pointer
+        # (yfv2_train.hip).  `x` may be a temporary made here (contiguous() / clone()) or by the caller: hold it until the next
+        # train-mode forward replaces the tape, or the caching allocator hands the block to somebody else before backward runs
+        self._train_x = x
         return tuple(out)
 
     def train_backward(self, grads6):

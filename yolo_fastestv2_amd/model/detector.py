@@ -102,6 +102,10 @@ class _TrainForward(torch.autograd.Function):
             off += n
         eng.train_bind({k: v.data for k, v in state.items()}, views)
         outs = eng.train_forward(x)
+        ctx.x = getattr(eng, "_train_x", x)         # the tensor the library really reads again in backward (see Engine.train_forward)
+        # the BatchNorm running statistics were just moved through raw pointers (no autograd version bump): every packed
+        # inference copy of the weights is stale from here on
+        module._synced.clear()
         with torch.no_grad():
             for mod in module.modules():
                 nb = mod._buffers.get("num_batches_tracked")

@@ -13,7 +13,9 @@ per batch than back to back on one MI355X (tools/pipeline_probe.py); more than t
     for t in tickets[-pipe.depth:]:
         dets, idx, cnt = pipe.result(t)                            # orders the CURRENT stream behind that batch
 
-A ticket's buffers belong to its slot: they are overwritten by the `depth`-th submit after it.
+A ticket's buffers belong to its slot: they are overwritten by the `depth`-th submit after it.  A consumer that reads them
+on its own stream calls `pipe.release(ticket)` after enqueueing its last reader; the slot's next submit then waits for that
+point (without it, only a `result()` issued AFTER the reuse is caught - by the serial check).
 """
 import contextlib
 
@@ -41,6 +43,7 @@ class DetectPipeline:
         self.max_batch = int(max_batch)
         self._serial = 0
         self._last = [None] * self.depth          # serial of the ticket that owns each slot's buffers
+        self._readers = [[] for _ in range(self.depth)]   # events recorded on the consumer streams result() ordered behind a slot
 
     def load_state_dict(self, state_dict):
         for e in self.engines:
@@ -69,6 +72,11 @@ class DetectPipeline:
             raise ValueError("batch %d exceeds max_batch %d" % (B, self.max_batch))
         cur = torch.cuda.current_stream(self.device)
         with self.slot() as (j, eng, (dets, idx, cnt)):
+            # write-after-read: streams that result() ordered behind this slot's previous batch may still be reading its
+            # detection buffers - the slot's stream waits for the marks they left before it overwrites them
+            for ev in self._readers[j]:
+                self.streams[j].wait_event(ev)
+            self._readers[j] = []
             if wait_for_input:
                 self.streams[j].wait_stream(cur)
                 x.record_stream(self.streams[j])
@@ -86,6 +94,14 @@ class DetectPipeline:
         else:
             torch.cuda.current_stream(self.device).wait_event(ticket.event)
         return ticket.out
+
+    def release(self, ticket):
+        """Mark the point on the CURRENT stream after which the ticket's buffers are no longer read there: the slot's next
+        submit waits for it.  Call after the last consumer kernel of `result(ticket)` was enqueued (a host=True consumer that
+        copied the tensors needs no mark)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._readers[ticket.slot].append(ev)
 
     def synchronize(self):
         for s in self.streams:

@@ -2,8 +2,8 @@
 ``(lbox, lobj, lcls, loss)`` of float32 tensors of shape (1,) on the logits' device, computed by libyfv2's HIP kernels
 (``yfv2_loss``: build_target, CIoU in float64, objectness BCE, class cross-entropy).  ``loss.backward()`` works as in
 ``train.py:108``: the kernels also produce the gradient of the total loss w.r.t. the six logit maps, which this
-autograd.Function hands on.  SURVEY.md 8(f) row 3, first slice: this package's ``Detector`` has no train-mode forward or
-convolution backward yet, so the gradients stop at the logits."""
+autograd.Function hands on to whatever produced the logits - this package's ``Detector`` in ``train()`` mode carries them
+down to every parameter (``yfv2_train_backward``, model/detector.py).  SURVEY.md 8(f) row 3."""
 import torch
 
 from ..engine import get_engine

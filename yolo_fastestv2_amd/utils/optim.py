@@ -31,4 +31,7 @@ class SGD(torch.optim.Optimizer):
                     st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 eng = get_engine(p.device, 32, 32, 1, 3)          # any handle of the device: the kernel only needs its error slot
                 eng.sgd_step(p.data, p.grad.contiguous(), st["momentum_buffer"], group["lr"], group["momentum"], group["weight_decay"], first)
+                # the kernel wrote through the raw pointer: move the autograd version counter as an in-place torch op would,
+                # so that Detector.engine_for() sees the change and re-packs the inference weights on the next eval forward
+                torch._C._increment_version(p)
         return loss
