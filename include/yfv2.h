@@ -21,6 +21,9 @@
  *     orders against ONE stream.  Off by default: measured no gain)
  *   - all pointers named x / out6 / boxes / dets / idx / count are DEVICE
  *     pointers; weights passed to yfv2_load_weights are HOST pointers.
+ *     (YFV2_LANES=N in the environment of yfv2_create: a forward / detect of a large batch is cut into N slices that run on
+ *     N streams owned by the handle - forked from and joined back into the caller's stream with events inside the call, same
+ *     ordering contract, bit-identical results)
  *   - one handle per device, not thread-safe, and ONE STREAM AT A TIME: the handle's workspace (activations, logits
  *     and candidate rows of yfv2_detect, the class-filter scratch of yfv2_nms) is shared by all calls on it, so calls
  *     issued on different streams must be ordered by the caller (events); use one handle per concurrent stream.
@@ -36,7 +39,7 @@
 extern "C" {
 #endif
 
-#define YFV2_ABI_VERSION 3 /* 2: yfv2_stage_info reports external bytes as well; 3: yfv2_train_*, yfv2_sgd_step */
+#define YFV2_ABI_VERSION 4 /* 2: yfv2_stage_info reports external bytes as well; 3: yfv2_train_*, yfv2_sgd_step; 4: yfv2_nonfinite, lanes */
 #define YFV2_API __attribute__((visibility("default")))
 #define YFV2_MAX_DET 300 /* utils/utils.py:243 max_det */
 
@@ -94,11 +97,23 @@ YFV2_API int yfv2_set_anchors(yfv2_handle h, const double anchors[12]);
 
 /* replaces: model/detector.py:21-47 Detector.forward (export_onnx=False).
  * x: (B,3,H,W) fp32 NCHW in [0,1] (test.py:38; any |x| < 255.9 is computed to fp32 accuracy, beyond that the default
- * plan's stem - two-term fp16 operands on the matrix cores, yfv2_stem16.hip - overflows; YFV2_BF6=0 at create time and
- * the uint8 entry point yfv2_forward_u8 have no such bound).  out6: six NCHW fp32 logit tensors in the
+ * plan's stem - two-term fp16 operands on the matrix cores, yfv2_stem16.hip - leaves fp16's range: DETECTED, see
+ * yfv2_nonfinite below; YFV2_BF6=0 at create time and the uint8 entry point yfv2_forward_u8 have no such bound).  out6: six NCHW fp32 logit tensors in the
  * reference's return order (reg_2, obj_2, cls_2, reg_3, obj_3, cls_3) with
  * shapes (B,4A,H/16,W/16) (B,A,..) (B,classes,..) and the same at H/32. */
 YFV2_API int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream);
+
+/* Range guard of the default plan.  Its channel contractions run as "fp16x3" (every fp32 operand split into two fp16 terms
+ * after an exact power-of-two scale: fp32-accurate) and are valid while |activation| < 4094 and, for
+ * yfv2_forward's fp32 input, |x| < 255.9 - two orders of magnitude above anything the COCO checkpoint or a He-initialised
+ * network produces.  Beyond that an operand becomes (+Inf, -Inf), its products NaN, and the ReLU behind the conv would turn
+ * the NaN into a silent 0; the reference's fp32 conv has no such cliff.  So every kernel of that plan tests its matrix-core
+ * accumulators BEFORE the ReLU and sets a sticky word in the handle when one is not a number (also true for non-finite
+ * values in x itself).  yfv2_nonfinite waits for `stream`, writes 1 to *flag if any forward / detect since the last query
+ * tripped the guard (0 otherwise) and clears the word.  A handle created with YFV2_BF6=0 in the environment computes every
+ * conv on the fp32 matrix instructions, has no such bound and never sets it.  The Python surface queries the word wherever it
+ * synchronises anyway (handel_preds, non_max_suppression's callers, evaluation) and raises. */
+YFV2_API int yfv2_nonfinite(yfv2_handle h, int32_t* flag, void* stream);
 
 /* Same forward from the image layout the reference's callers hold BEFORE their pre-process step
  * (test.py:34-38, utils/datasets.py:106-111): uint8 (B, height, width, 3) - HWC, channel order as decoded

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib_mod.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), "libyfv2.so does not export %s" % name
-    assert _lib_mod.lib().yfv2_abi_version() == _lib_mod.ABI_VERSION == 3
+    assert _lib_mod.lib().yfv2_abi_version() == _lib_mod.ABI_VERSION == 4
     # nothing else leaks out of the library's namespace
     syms = subprocess.run(["nm", "-D", "--defined-only", _lib_mod.LIB_PATH], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in syms.splitlines() if " T " in l}

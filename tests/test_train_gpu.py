@@ -199,7 +199,10 @@ def test_eval_after_training_runs_the_current_weights_every_time():
     loss = yfv2.compute_loss(model(torch.from_numpy(x).to(dev) * 1.0), ts, cfg, dev)[3]
     junk = [torch.full((x.size,), 7.0, device=dev) for _ in range(3)]
     loss.backward()
-    assert torch.equal(model.backbone.first_conv._modules["0"].weight.grad, g_keep)
+    g_tmp = model.backbone.first_conv._modules["0"].weight.grad
+    # (the weight-gradient reduction meets in float atomics: summation order varies run to run, so not bit-equal - but a stale
+    # or recycled input block - here filled with 7.0 - would move every entry by orders of magnitude)
+    assert torch.allclose(g_tmp, g_keep, rtol=1e-4, atol=1e-4 * float(g_keep.abs().max()))
 
 
 def test_train_bind_refuses_mis_sized_buffers():

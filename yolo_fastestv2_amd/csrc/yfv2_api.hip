@@ -8,6 +8,7 @@
 // model/detector.py:21-47.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 namespace {
 
 thread_local std::string g_tls_error;
+thread_local bool g_creating_lane = false;   // yfv2_create called for a child handle of a laned handle (create_lanes)
 
 struct Folded { size_t w = 0, scale = 0, shift = 0; };  // offsets (floats) into the param blob
 
@@ -87,6 +89,7 @@ struct yfv2_ctx {
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries), then one int32 of its own for the statistics overflow flag
   int32_t* d_stats_flag = nullptr;  // = d_classes + 256
+  int32_t* d_nonfinite = nullptr;   // = d_classes + 257 (a lane: its parent's word): the sticky range-guard word of the fp16x3 plan (yfv2_nonfinite)
   // training-loss workspace (yfv2_loss): match slots for loss_cap labels, objectness target maps for max_batch images,
   // counters and float64 sums; grown on demand (a growth waits for the device)
   void* d_loss_ws = nullptr;
@@ -98,6 +101,20 @@ struct yfv2_ctx {
   float* dbg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t dbg_per_img[6] = {0, 0, 0, 0, 0, 0};
   int dbg_c[6] = {0, 0, 0, 0, 0, 0};
+  // LANES (YFV2_LANES=N in the environment of yfv2_create): yfv2_forward / yfv2_detect (and their uint8
+  // forms) of at least lane_min images cut the batch into N contiguous slices; slice i is run by child handle lanes[i] (own
+  // workspace sized max_batch / N, own plan, its own copy of the 1 MB weight blob) on stream lane_stream[i] - lane 0 on the
+  // caller's stream - forked from and joined back into the caller's stream with events INSIDE the call: the caller still
+  // orders against one stream.  Images are independent, so the result is bit-identical to the unsliced call;
+  // what changes is that the one-workgroup-per-image launches of one slice (stages 3 / 4, towers, decode + NMS) share the
+  // machine with the streaming launches of another instead of each leaving it under-filled.
+  std::vector<yfv2_ctx*> lanes;
+  std::vector<hipStream_t> lane_stream;    // [n_lanes - 1]
+  std::vector<hipEvent_t> lane_join;       // [n_lanes - 1]
+  hipEvent_t lane_fork = nullptr;
+  int lane_min = 0;
+  bool in_lane = false;                    // this handle IS a lane of another one (never laned itself)
+  std::vector<int> last_split;             // slice sizes of the last forward if it ran on the lanes (yfv2_debug_activation)
 };
 
 namespace {
@@ -1606,12 +1623,14 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.img = params + st.img_off;
       a.img_u8 = params + st.img_off2;
       a.img16 = h->bf6 ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: the 4x4x1 fp32-MFMA stem
+      a.nonfinite = h->d_nonfinite;
       yfv2_launch_stem(a, s);
     } else if (st.kind == STEP_PW) {
       PwArgs a = st.pw;
       a.P = B * st.px_per_img;
       a.img = params + st.img_off;
       a.bf6 = h->bf6 ? 1 : 0;
+      a.nonfinite = h->d_nonfinite;
       if (st.mode == PW_HEAD) {
         a.nchw0 = out6[st.head0];
         a.nchw1 = st.head1 >= 0 ? out6[st.head1] : nullptr;
@@ -1625,6 +1644,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.bf6 = h->bf6 ? 1 : 0;
       a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
       a.img16 = (st.img_off3 && h->bf6) ? params + st.img_off3 : nullptr;
+      a.nonfinite = h->d_nonfinite;
       if (a.img16 && st.c2 == 48) yfv2_launch_s3h(a, s);
       else if (a.img16 && st.c2 == 96) yfv2_launch_s4h(a, s);
       else if (!yfv2_launch_block_s2(st.c2, a, s))
@@ -1639,6 +1659,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
         a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
         a.bf6 = h->bf6 ? 1 : 0;
         a.img16 = (t.img_off3 && h->bf6) ? params + t.img_off3 : nullptr;   // YFV2_BF6=0: tower2_kernel on the fp32 MFMA
+        a.nonfinite = h->d_nonfinite;
         if (t.has_head) {
           a.nchw0 = out6[t.head0];
           a.nchw1 = t.head1 >= 0 ? out6[t.head1] : nullptr;
@@ -1667,6 +1688,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.B = B;
       a.img = params + st.img_off;
       a.trace = nullptr;
+      a.nonfinite = h->d_nonfinite;
       if (!yfv2_launch_block_s1pool(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no pool-chain kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S1CHAIN) {
@@ -1674,6 +1696,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.B = B;
       a.img = params + st.img_off;
       a.trace = (h->trace_step < 0 || h->trace_step == (int)i) ? h->d_trace : nullptr;
+      a.nonfinite = h->d_nonfinite;
       if (!yfv2_launch_block_s1chain(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no chain kernel for step '" + st.name + "'");
     } else if (st.kind == STEP_S2PX) {
@@ -1682,12 +1705,14 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.img[0] = params + st.img_off;
       a.img[1] = params + st.img_off2;
       a.img16 = h->bf6 ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: the two role kernels on the 4x4x1 fp32 MFMA
+      a.nonfinite = h->d_nonfinite;
       yfv2_launch_s2px(a, s);
     } else if (st.kind == STEP_S1PX) {
       S1PxArgs a = st.s1px;
       a.B = B;
       a.img = params + st.img_off;
       a.img16 = h->bf6 ? params + st.img_off2 : nullptr;   // YFV2_BF6=0: s1px_kernel on the 4x4x1 fp32 MFMA
+      a.nonfinite = h->d_nonfinite;
       yfv2_launch_s1px(a, s);
     } else {
       DwArgs a = st.dw;
@@ -1755,6 +1780,70 @@ int setup_ctx(yfv2_ctx* h, const yfv2_config* cfg, int rows, Alloc alloc) {
   return rc;
 }
 
+constexpr int LANES_DEFAULT = 1, LANES_MAX = 8, LANE_MIN_IMAGES = 32;   // per slice: below that a slice is pure latency (tools/scale_probe.py)
+
+int create_lanes(yfv2_ctx* h) {
+  int n = LANES_DEFAULT;
+  if (const char* e = std::getenv("YFV2_LANES")) n = std::atoi(e);
+  if (h->d_trace || h->in_lane) n = 1;             // cycle stamps are taken on the parent's own launches
+  n = n < 1 ? 1 : (n > LANES_MAX ? LANES_MAX : n);
+  if (n == 1 || h->cfg.max_batch < n * LANE_MIN_IMAGES) return YFV2_OK;
+  h->lane_min = n * LANE_MIN_IMAGES;
+  yfv2_config c = h->cfg;
+  c.max_batch = (h->cfg.max_batch + n - 1) / n;
+  for (int i = 0; i < n; ++i) {
+    yfv2_ctx* lane = nullptr;
+    g_creating_lane = true;
+    const int rc = yfv2_create(&lane, &c);
+    g_creating_lane = false;
+    if (rc) return fail(h, rc, "lane " + std::to_string(i) + ": " + g_tls_error);
+    lane->d_nonfinite = h->d_nonfinite;
+    h->lanes.push_back(lane);
+  }
+  HIP_TRY(h, hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));
+  for (int i = 1; i < n; ++i) {
+    hipStream_t st; hipEvent_t ev;
+    HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));   // non-blocking: no implicit ordering against the NULL stream, events only
+    h->lane_stream.push_back(st);
+    HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    h->lane_join.push_back(ev);
+  }
+  return YFV2_OK;
+}
+
+// run `f(lane, first image, images, stream)` for every slice of a batch of B images; lane 0 on the caller's stream `s`
+template <class F>
+int run_lanes(yfv2_ctx* h, int B, hipStream_t s, F f) {
+  const int n = (int)h->lanes.size();
+  const int per = (B + n - 1) / n;
+  h->last_split.clear();
+  HIP_TRY(h, hipEventRecord(h->lane_fork, s));
+  int rc = YFV2_OK;
+  // lanes 1.. first: their launches are queued behind the fork before lane 0's own launches occupy the caller's stream
+  for (int i = 1; i < n && rc == YFV2_OK; ++i) {
+    const int off = i * per, cnt = std::min(per, B - off);
+    if (cnt <= 0) break;
+    HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[i - 1], h->lane_fork, 0));
+    rc = f(h->lanes[i], off, cnt, h->lane_stream[i - 1]);
+    if (rc) { h->err = h->lanes[i]->err; break; }
+    HIP_TRY(h, hipEventRecord(h->lane_join[i - 1], h->lane_stream[i - 1]));
+  }
+  if (rc == YFV2_OK) {
+    rc = f(h->lanes[0], 0, std::min(per, B), s);
+    if (rc) h->err = h->lanes[0]->err;
+  }
+  for (int i = 1; i < n; ++i) {
+    const int off = i * per, cnt = std::min(per, B - off);
+    if (cnt <= 0) break;
+    HIP_TRY(h, hipStreamWaitEvent(s, h->lane_join[i - 1], 0));   // also on the error path: whatever was enqueued is joined
+  }
+  if (rc == YFV2_OK)
+    for (int i = 0; i < n; ++i) { const int cnt = std::min(per, B - i * per); if (cnt > 0) h->last_split.push_back(cnt); }
+  return rc;
+}
+
+bool use_lanes(const yfv2_ctx* h, int B) { return !h->lanes.empty() && B >= h->lane_min; }
+
 }  // namespace
 
 void** yfv2_ctx_train_slot(yfv2_ctx* h) { return h ? &h->train : nullptr; }
@@ -1786,13 +1875,15 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     return fail(nullptr, YFV2_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
 
   yfv2_ctx* h = new yfv2_ctx();
+  h->in_lane = g_creating_lane;
   DeviceGuard guard(cfg->device);
   int rc = setup_ctx(h, cfg, rows, alloc_buf);
-  if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 257 * sizeof(int32_t)) != hipSuccess)
+  if (rc == YFV2_OK && hipMalloc(reinterpret_cast<void**>(&h->d_classes), 258 * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, YFV2_ERR_DEVICE, "hipMalloc(class filter) failed");
   if (rc == YFV2_OK) {
     h->d_stats_flag = h->d_classes + 256;
-    if (hipMemset(h->d_stats_flag, 0, sizeof(int32_t)) != hipSuccess) rc = fail(h, YFV2_ERR_DEVICE, "hipMemset(statistics flag) failed");
+    h->d_nonfinite = h->d_classes + 257;
+    if (hipMemset(h->d_stats_flag, 0, 2 * sizeof(int32_t)) != hipSuccess) rc = fail(h, YFV2_ERR_DEVICE, "hipMemset(flags) failed");
   }
   if (rc != YFV2_OK) {
     g_tls_error = h->err;
@@ -1802,6 +1893,7 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
   read_plan_switches(h);
   if (const char* tr = std::getenv("YFV2_TRACE"))
     if (tr[0] == '1') { if (const char* ts = std::getenv("YFV2_TRACE_STEP")) h->trace_step = std::atoi(ts); (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
+  if (int rc2 = create_lanes(h)) { g_tls_error = h->err; yfv2_destroy(h); return rc2; }
   *out = h;
   return YFV2_OK;
 }
@@ -1909,6 +2001,10 @@ void yfv2_destroy(yfv2_handle h) {
   if (h->d_loss_ws) (void)hipFree(h->d_loss_ws);
   if (h->train) { yfv2_train_release(h->train); h->train = nullptr; }
   if (h->d_params) (void)hipFree(h->d_params);
+  for (yfv2_ctx* lane : h->lanes) yfv2_destroy(lane);
+  for (hipStream_t st : h->lane_stream) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (hipEvent_t ev : h->lane_join) (void)hipEventDestroy(ev);
+  if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
   delete h;
 }
 
@@ -1936,6 +2032,8 @@ int yfv2_load_weights(yfv2_handle h, const yfv2_tensor_desc* tensors, int32_t n)
   }
   HIP_TRY(h, hipMemcpy(h->d_params, wp.blob.data(), wp.blob.size() * sizeof(float), hipMemcpyHostToDevice));
   h->weights_loaded = true;
+  for (yfv2_ctx* lane : h->lanes)
+    if (int rc = yfv2_load_weights(lane, tensors, n)) { h->weights_loaded = false; return fail(h, rc, lane->err); }
   return YFV2_OK;
 }
 
@@ -1943,6 +2041,7 @@ int yfv2_set_anchors(yfv2_handle h, const double anchors[12]) {
   if (!h) return fail(nullptr, YFV2_ERR_ARG, "null handle");
   if (!anchors) return fail(h, YFV2_ERR_ARG, "yfv2_set_anchors: null pointer");
   for (int i = 0; i < 12; ++i) h->cfg.anchors[i] = anchors[i];
+  for (yfv2_ctx* lane : h->lanes) (void)yfv2_set_anchors(lane, anchors);
   return YFV2_OK;
 }
 
@@ -1953,6 +2052,13 @@ int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6],
   for (int i = 0; i < 6; ++i)
     if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_forward: null output tensor");
   DeviceGuard guard(h->device);
+  if (use_lanes(h, B))
+    return run_lanes(h, B, static_cast<hipStream_t>(stream), [&](yfv2_ctx* lane, int off, int cnt, hipStream_t st) {
+      float* o6[6];
+      for (int i = 0; i < 6; ++i) o6[i] = out6[i] + (size_t)off * logit_elems(h, i);
+      return yfv2_forward(lane, x + (size_t)off * 3 * h->cfg.height * h->cfg.width, cnt, o6, st);
+    });
+  h->last_split.clear();
   return run_plan(h, x, false, B, out6, static_cast<hipStream_t>(stream), nullptr);
 }
 
@@ -1963,6 +2069,13 @@ int yfv2_forward_u8(yfv2_handle h, const uint8_t* x, int32_t B, float* const out
   for (int i = 0; i < 6; ++i)
     if (!out6[i]) return fail(h, YFV2_ERR_ARG, "yfv2_forward_u8: null output tensor");
   DeviceGuard guard(h->device);
+  if (use_lanes(h, B))
+    return run_lanes(h, B, static_cast<hipStream_t>(stream), [&](yfv2_ctx* lane, int off, int cnt, hipStream_t st) {
+      float* o6[6];
+      for (int i = 0; i < 6; ++i) o6[i] = out6[i] + (size_t)off * logit_elems(h, i);
+      return yfv2_forward_u8(lane, x + (size_t)off * 3 * h->cfg.height * h->cfg.width, cnt, o6, st);
+    });
+  h->last_split.clear();
   return run_plan(h, x, true, B, out6, static_cast<hipStream_t>(stream), nullptr);
 }
 
@@ -2041,6 +2154,14 @@ int yfv2_detect(yfv2_handle h, const float* x, int32_t B, float conf_thres, doub
                 int32_t* count, void* stream) {
   int rc = check_call(h, B, true);
   if (rc) return rc;
+  if (use_lanes(h, B)) {
+    if (!x || !dets || !idx || !count) return fail(h, YFV2_ERR_ARG, "yfv2_detect: null pointer");
+    DeviceGuard guard(h->device);
+    return run_lanes(h, B, static_cast<hipStream_t>(stream), [&](yfv2_ctx* lane, int off, int cnt, hipStream_t st) {
+      return yfv2_detect(lane, x + (size_t)off * 3 * h->cfg.height * h->cfg.width, cnt, conf_thres, iou_thres, dets + (size_t)off * YFV2_MAX_DET * 6,
+                         idx + (size_t)off * YFV2_MAX_DET, count + off, st);
+    });
+  }
   float* out6[6];
   for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
   rc = yfv2_forward(h, x, B, out6, stream);
@@ -2075,6 +2196,14 @@ int yfv2_detect_u8(yfv2_handle h, const uint8_t* x, int32_t B, float conf_thres,
                    int32_t* count, void* stream) {
   int rc = check_call(h, B, true);
   if (rc) return rc;
+  if (use_lanes(h, B)) {
+    if (!x || !dets || !idx || !count) return fail(h, YFV2_ERR_ARG, "yfv2_detect_u8: null pointer");
+    DeviceGuard guard(h->device);
+    return run_lanes(h, B, static_cast<hipStream_t>(stream), [&](yfv2_ctx* lane, int off, int cnt, hipStream_t st) {
+      return yfv2_detect_u8(lane, x + (size_t)off * 3 * h->cfg.height * h->cfg.width, cnt, conf_thres, iou_thres, dets + (size_t)off * YFV2_MAX_DET * 6,
+                            idx + (size_t)off * YFV2_MAX_DET, count + off, st);
+    });
+  }
   float* out6[6];
   for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
   rc = yfv2_forward_u8(h, x, B, out6, stream);
@@ -2107,6 +2236,19 @@ int yfv2_batch_statistics_overflow(yfv2_handle h, int32_t* overflowed, void* str
   HIP_TRY(h, hipMemsetAsync(h->d_stats_flag, 0, sizeof(int32_t), s));
   HIP_TRY(h, hipStreamSynchronize(s));
   *overflowed = over;
+  return YFV2_OK;
+}
+
+// the sticky range-guard word of the fp16x3 plan (yfv2_internal.h Yfv2Watch): waits for `stream`, reports and clears it
+int yfv2_nonfinite(yfv2_handle h, int32_t* flag, void* stream) {
+  if (!h || !flag) return fail(h, YFV2_ERR_ARG, "yfv2_nonfinite: null argument");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int32_t v = 0;
+  HIP_TRY(h, hipMemcpyAsync(&v, h->d_nonfinite, sizeof(v), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  if (v) HIP_TRY(h, hipMemsetAsync(h->d_nonfinite, 0, sizeof(v), s));
+  *flag = v ? 1 : 0;
   return YFV2_OK;
 }
 
@@ -2259,6 +2401,17 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
   DeviceGuard guard(h->device);
   const int64_t n = (int64_t)h->dbg_per_img[which] * B;
   if (!host_dst) return n;
+  if (!h->last_split.empty()) {   // the last forward ran on the lanes: every lane holds its slice
+    if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
+    int off = 0;
+    for (size_t i = 0; i < h->last_split.size() && off < B; ++i) {
+      const int cnt = std::min(h->last_split[i], B - off);
+      const int64_t got = yfv2_debug_activation(h->lanes[i], which, cnt, host_dst + (size_t)off * h->dbg_per_img[which], (int64_t)h->dbg_per_img[which] * cnt);
+      if (got < 0) return got;
+      off += cnt;
+    }
+    return n;
+  }
   if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
   if (which == 0 && h->stem_pp) {  // stem output in pair planes [12][PH*PW][2] -> NHWC
     const size_t per = h->dbg_per_img[0], hw = per / 24;

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   // program order): its barriers wait for the LDS counter, not for the global stores in flight - __syncthreads() would
   // also drain vmcnt, i.e. stall every block's exchange phase until its park stores are acknowledged by L2.
   auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  Yfv2Watch watch;   // range guard of the fp16x3 products (yfv2_internal.h): one accumulator element per pixel tile and pointwise conv
 
   // fp16x3 (round 3; yfv2_stem16.hip): every operand = two fp16 terms, w1 x2 + w2 x1 + w1 x1 with fp32 accumulation.
   // B operands of one pixel tile from its three chunk fragments (x 2^4 first): the pair (chunks 0, 1) as {x1, x1} and
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
       for (int mt = 0; mt < KC; ++mt) {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         mfma9(W1P, mt, b, acc);
+        if (mt == 0) { watch.see(acc[0][0]); watch.see(acc[1][0]); }
         const f32x4 sc1 = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
         const f32x4 sh1 = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
 #pragma unroll
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
       for (int mt = 0; mt < KC; ++mt) {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         mfma9(W2P, mt, b, acc);
+        if (mt == 0) { watch.see(acc[0][0]); watch.see(acc[1][0]); }
         const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
 #pragma unroll
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
     YFV2_WSTAMP(11);
     __syncthreads();                                      // tile and image buffer are rewritten by the next image
   }
+  watch.report(a.nonfinite);
 }
 
 static long s1chain_lds_floats(int H, int W) {
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
   float* POOL = lds;                                   // [H * W][P96_CPP]
   float* T = POOL + a.H * a.W * P96_CPP;               // [(H+2)][(W+2)][P96_TP], border zero
   float* IMG = T + (a.H + 2) * (a.W + 2) * P96_TP;     // one third's image
+  Yfv2Watch watch;                                     // range guard of the fp16x3 products (yfv2_internal.h)
   const int H = a.H, W = a.W, HW = H * W, WP = W + 2, NB = a.nblk;
   const float invW = 1.0f / (float)W;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -584,6 +589,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
               P96_PROD(a1, b1b[sp]) P96_PROD(a2, b1a[sp]) P96_PROD(a1, b1a[sp])
 #undef P96_PROD
             }
+            watch.see(acc1[0][0]);
           } else {
 #pragma unroll
           for (int s2 = 0; s2 < P96_KC; ++s2) {
@@ -675,6 +681,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
         }
         }
         if (th == P96_TH - 1) {                         // pw2's BN + ReLU (the vectors leave with this image)
+          if constexpr (PRE) watch.see(acc2[0][0]);
 #pragma unroll
           for (int mt = 0; mt < P96_KC; ++mt) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(CSV + 4 * P96_TC + 16 * mt + 4 * g);
@@ -730,6 +737,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
     }
     __syncthreads();
   }
+  watch.report(a.nonfinite);
 }
 
 static long s1pool_lds_floats(int H, int W, bool pre) { return (long)H * W * P96_CPP + (long)(H + 2) * (W + 2) * P96_TP + (pre ? P96_IMGP_FL : P96_IMG_FL); }

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
     sh[mt] = *reinterpret_cast<const f32x4*>(a.img + FILT_FL + MT * 16 + 16 * mt + 4 * g);
   }
 
+  Yfv2Watch watch;   // range guard of the fp16x3 form (yfv2_internal.h)
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
   for (int st = blockIdx.x * nwaves + wave; st < n_super; st += gridDim.x * nwaves) {
     const int pix0 = st * (NT * 16);
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int pix = pixv[nt];
+      if constexpr (PRE) watch.see(acc[0][nt][0]);
       if (pix >= a.P) continue;
       if constexpr (MODE == PW_HEAD) {
         const int b = pix / a.HW, hw = pix - b * a.HW;
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
       }
     }
   }
+  if constexpr (PRE) watch.report(a.nonfinite);
 }
 
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>

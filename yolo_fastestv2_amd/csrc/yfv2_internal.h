@@ -93,6 +93,23 @@ __device__ __forceinline__ void yfv2_mfma6_tiles(const Bf3A (&a)[MT_], const Bf3
 }
 #endif
 
+// ---- range guard of the fp16x3 arithmetic (include/yfv2.h yfv2_nonfinite)
+// An operand beyond fp16's range (|activation| * 2^4 or |pixel| * 2^8 >= 65520) splits into (+Inf, -Inf); the three
+// products of ANY filter entry with it are +-Inf or NaN and sum to NaN, for every output channel of that pixel - and the ReLU
+// behind almost every pointwise conv (v_max_f32 / v_med3_f32 return the non-NaN operand) would turn that NaN into a clean,
+// silent 0.  So every kernel of the fp16x3 plan looks at ONE accumulator element per lane of every pointwise product before
+// its ReLU: a v_cmp_u_f32 into a scalar register pair OR-ed into a sticky wave-uniform mask (no vector register, no branch),
+// and reports once at its end.  Non-finite INPUT values are caught by the same test.
+#ifdef __HIPCC__
+struct Yfv2Watch {
+  unsigned long long m = 0;
+  __device__ __forceinline__ void see(float v) { m |= __builtin_amdgcn_ballot_w64(v != v); }
+  __device__ __forceinline__ void report(int* flag) const {
+    if (m != 0 && flag != nullptr) atomicOr(flag, 1);   // the rare path: every active lane of the wave, one word
+  }
+};
+#endif
+
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
   const void* x;       // fp32 (B,3,H,W) in [0,1], or (u8_in) uint8 (B,H,W,3) in 0..255
@@ -105,6 +122,7 @@ struct StemArgs {
   int pp_out;          // 1: write pair planes [B][12][H/4][W/4][2] (stage 2 in lane-per-pixel form), 0: NHWC
   const float* img16;  // yfv2_stem16.hip (fp32 input on the f16 matrix cores): filter as two fp16 terms in MFMA A-operand order
                        // [tile 2][term 2][64 lanes][4 dwords] | shift * 2^sw [32] | 2^-sw (WeightPacker::image_stem16); null: use the 4x4x1 kernel
+  int* nonfinite;      // the handle's sticky range-guard word (Yfv2Watch), or null
 };
 
 // ---- pointwise 1x1 conv on the fp32 MFMA, NHWC
@@ -131,6 +149,7 @@ struct PwArgs {
   int split;
   int bf6;             // run the MFMAs as bf16x6 where the instantiation has that form (handle flag, YFV2_BF6=0 at create time clears it)
   int presplit;        // img holds the filter PRE-SPLIT into bf16 hi/mid/lo operand quads per chunk pair (WeightPacker::image_pw, streamed K = 192 / 288 forms; needs bf6)
+  int* nonfinite;      // range-guard word (Yfv2Watch), or null
 };
 
 // ---- depthwise kxk conv + BN (+ReLU), NHWC, float4 over channels
@@ -157,6 +176,7 @@ struct BlockS1Args {
   int R;             // rows per work item (H % R == 0)
   int nblk;          // block_s1chain_kernel: blocks in the chain (img = their images back to back)
   int presplit;      // block_s1pool_kernel: the images hold W1 / W2 pre-split for bf16x6 (yfv2_s1pool_image_floats(true) floats each)
+  int* nonfinite;    // range-guard word (Yfv2Watch), or null
 };
 
 // chain of N stride-1 blocks in one launch (block_s1chain6_kernel, C2 = 48, bf16x6 pointwise convs on host-pre-split
@@ -185,6 +205,7 @@ struct BlockS2Args {
   int bf6;           // pw1 as bf16x6 (pair-plane input form)
   long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (block_s2w_kernel; or null)
   const float* img16;  // s3h_kernel's image (stage3.0 from pair planes in streaming form, yfv2_stage2h.hip; WeightPacker::image_s3h) or null
+  int* nonfinite;      // range-guard word (Yfv2Watch), or null
 };
 bool yfv2_s3h_supported(int H, int W);
 void yfv2_launch_s3h(const BlockS2Args& a, hipStream_t s);
@@ -210,6 +231,7 @@ struct S1PxArgs {
   int src_off[12];     // byte offsets (from the image base in buffer 0) of the 12 branch pairs: where they are read ...
   int dst_off[12];     // ... and where the block's output for the same pairs is written (the other buffer)
   const float* img16;  // s1h_kernel's image (yfv2_stage2h.hip, WeightPacker::image_s1h); null: s1px_kernel
+  int* nonfinite;      // range-guard word (Yfv2Watch), or null
 };
 // stride-2 block of stage 2 (24 -> 48 channels) in lane-per-pixel form; two wave roles (proj / main branch)
 struct S2PxArgs {
@@ -223,6 +245,7 @@ struct S2PxArgs {
   int st2_off[2][8];   // per role: byte offsets of the 8 pair planes its output positions 0..15 fill (8-byte stores)
   int st1_off[2][8];   // per role: byte offsets (plane + element) of output positions 16..23 (4-byte stores)
   const float* img16;  // s2h_kernel's image (yfv2_stage2h.hip, WeightPacker::image_s2h: both branches in one wave); null: the two role kernels
+  int* nonfinite;      // range-guard word (Yfv2Watch), or null
 };
 void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // a.img16 set: yfv2_launch_s2h (one kernel); else two kernels (proj role, main role)
 void yfv2_launch_s2h(const S2PxArgs& a, hipStream_t s);
@@ -243,6 +266,7 @@ struct TowerArgs {
   int bf6;           // pointwise + chained output conv as bf16x6
   const float* img16;  // towerh_kernel's image (yfv2_towerh.hip), or null: tower2_kernel
   int chain;           // towers_kernel job list: bit 0 = the input is what the previous job left in LDS, bit 1 = the output stays in LDS for the next job (no global round trip)
+  int* nonfinite;      // range-guard word (Yfv2Watch), or null
 };
 
 // ---- decode (handel_preds) and NMS

@@ -75,7 +75,7 @@ __device__ __forceinline__ void split2(f32x2 v, unsigned& h1, unsigned& h2) {
 }
 // 24 -> 24 pointwise conv of 16 pixels: in = the lane's eight K slots as four pairs (already carrying their 2^4), init = BN
 // shift (scaled) of the lane's output channels; w[tile][term].  w1 x2, w2 x1, w1 x1: smallest terms first.
-__device__ __forceinline__ void pw_h3(const yfv2_h8 (&w)[2][2], const f32x2 (&in)[4], const f32x4 (&init)[2], f32x4 (&acc)[2]) {
+__device__ __forceinline__ void pw_h3(const yfv2_h8 (&w)[2][2], const f32x2 (&in)[4], const f32x4 (&init)[2], f32x4 (&acc)[2], Yfv2Watch& watch) {
   u32x4 b1, b2;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { unsigned h1, h2; split2(in[k], h1, h2); b1[k] = h1; b2[k] = h2; }
@@ -86,6 +86,7 @@ __device__ __forceinline__ void pw_h3(const yfv2_h8 (&w)[2][2], const f32x2 (&in
   for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t][1], x1, acc[t], 0, 0, 0);
 #pragma unroll
   for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t][0], x1, acc[t], 0, 0, 0);
+  watch.see(acc[0][0]);   // range guard (yfv2_internal.h): an operand beyond fp16's range makes every output channel of its pixel NaN
 }
 
 }  // namespace
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(64, 3) void s1h_kernel(S1PxArgs a) {
         w2[t][k] = __builtin_bit_cast(yfv2_h8, q[(S1H_W2 / 4) + (t * 2 + k) * 64 + lane]);
       }
   }
+  Yfv2Watch watch;
   float tq[18];
 #pragma unroll
   for (int q = 0; q < 18; ++q) tq[q] = img[S1H_TAPS + q * 64 + lane];
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64, 3) void s1h_kernel(S1PxArgs a) {
       f32x2 in[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) in[k] = cur[k] * 16.0f;
-      pw_h3(w1, in, sh1, acc);
+      pw_h3(w1, in, sh1, acc, watch);
     }
     const float lim = (xok && r >= 0 && r < H) ? __builtin_inff() : 0.f;
 #pragma unroll
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64, 3) void s1h_kernel(S1PxArgs a) {
       d[c >> 1][c & 1] = a1 + row_shr1(a0) + row_shl1(a2);
     };
     [&]<int... Cs>(std::integer_sequence<int, Cs...>) { (dw_ch(std::integral_constant<int, Cs>{}), ...); }(std::make_integer_sequence<int, 8>{});
-    pw_h3(w2, d, bi2, acc);
+    pw_h3(w2, d, bi2, acc, watch);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       pend[k][0] = __builtin_fmaxf(acc[k >> 1][2 * (k & 1)], 0.f) * unscale2;
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(64, 3) void s1h_kernel(S1PxArgs a) {
     for (int k = 0; k < 4; ++k)
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pend[k]), rsrc, (pok && doff[k] != OOB) ? doff[k] + pend_row * rowb : OOB, 0, 0);
   }
+  watch.report(a.nonfinite);
 }
 
 void yfv2_launch_s1h(const S1PxArgs& a0, hipStream_t s) {
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
         w2[t][k] = __builtin_bit_cast(yfv2_h8, q[(S2H_W2 / 4) + (t * 2 + k) * 64 + lane]);
       }
   }
+  Yfv2Watch watch;
   float tm[18], tp[18];
 #pragma unroll
   for (int q = 0; q < 18; ++q) { tm[q] = img[S2H_TM + q * 64 + lane]; tp[q] = img[S2H_TP + q * 64 + lane]; }
@@ -319,8 +323,8 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
       xe[2 * k] = v[0]; xe[2 * k + 1] = v[1]; xo[2 * k] = v[2]; xo[2 * k + 1] = v[3];
     }
     f32x4 ae[2], ao[2];
-    pw_h3(w1, ine, sh1, ae);
-    pw_h3(w1, ino, sh1, ao);
+    pw_h3(w1, ine, sh1, ae, watch);
+    pw_h3(w1, ino, sh1, ao, watch);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       te[c] = __builtin_amdgcn_fmed3f(ae[c >> 2][c & 3], 0.f, lim);
@@ -375,8 +379,8 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
       dp[c >> 1][c & 1] = Sp[c] + row_shr1(Qp[c]);
     }
     f32x4 am[2], ap[2];
-    pw_h3(wp, dp, bip, ap);
-    pw_h3(w2, dm, bi2, am);
+    pw_h3(wp, dp, bip, ap, watch);
+    pw_h3(w2, dm, bi2, am, watch);
     const bool rowok = oy < y1;                    // wave-uniform
     f32x4 op[2], om[2];
 #pragma unroll
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) st(4 + e, op[1][e], om[1][e]);     // positions 16 + 4g + e: proj | main halves of a mixed pair
   }
+  watch.report(a.nonfinite);
 #undef YFV2_TQ
 #undef YFV2_TK
 }
@@ -424,7 +429,7 @@ constexpr int S3H_WFL = 3072, S3H_TM = 9216, S3H_TP = 9216 + 1728, S3H_CST = 921
 
 namespace {
 // 48 -> 48 pointwise conv of 16 pixels, filter operands from LDS
-__device__ __forceinline__ void pw_h3_48(const float* W, int lane, const f32x2 (&in)[6], const f32x4 (&init)[3], f32x4 (&acc)[3]) {
+__device__ __forceinline__ void pw_h3_48(const float* W, int lane, const f32x2 (&in)[6], const f32x4 (&init)[3], f32x4 (&acc)[3], Yfv2Watch& watch) {
   u32x4 b1[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, b2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
   for (int k = 0; k < 6; ++k) { unsigned h1, h2; split2(in[k], h1, h2); b1[k >> 2][k & 3] = h1; b2[k >> 2][k & 3] = h2; }
@@ -446,6 +451,7 @@ __device__ __forceinline__ void pw_h3_48(const float* W, int lane, const f32x2 (
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], x1, acc[t], 0, 0, 0);
   }
+  watch.see(acc[0][0]);
 }
 }  // namespace
 
@@ -481,6 +487,7 @@ __global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
   // input: stage 2's two pair-plane buffers of this image (a.in = buffer 0; buffer 1 follows at + pp_bufstride floats)
   __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * 48 * IH * IW), 0,
                                                                    (int)((a.pp_bufstride + 48LL * IH * IW) * 4), 0x00020000);
+  Yfv2Watch watch;
   float tm[27], tp[27];
 #pragma unroll
   for (int q = 0; q < 27; ++q) { tm[q] = img[S3H_TM + q * 64 + lane]; tp[q] = img[S3H_TP + q * 64 + lane]; }
@@ -516,8 +523,8 @@ __global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
       xe[2 * k] = v[0]; xe[2 * k + 1] = v[1]; xo[2 * k] = v[2]; xo[2 * k + 1] = v[3];
     }
     f32x4 ae[3], ao[3];
-    pw_h3_48(W1, lane, ine, sh1, ae);
-    pw_h3_48(W1, lane, ino, sh1, ao);
+    pw_h3_48(W1, lane, ine, sh1, ae, watch);
+    pw_h3_48(W1, lane, ino, sh1, ao, watch);
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
       te[c] = __builtin_amdgcn_fmed3f(ae[c >> 2][c & 3], 0.f, lim);
@@ -571,8 +578,8 @@ __global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
       dp[c >> 1][c & 1] = Sp[c] + row_shr1(Qp[c]);
     }
     f32x4 am[3], ap[3];
-    pw_h3_48(WP, lane, dp, bip, ap);
-    pw_h3_48(W2, lane, dm, bi2, am);
+    pw_h3_48(WP, lane, dp, bip, ap, watch);
+    pw_h3_48(W2, lane, dm, bi2, am, watch);
     if (st_lane && oy < y1) {
       float* o = outp + (size_t)oy * OW * 96;
 #pragma unroll
@@ -585,6 +592,7 @@ __global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
       }
     }
   }
+  watch.report(a.nonfinite);
 #undef YFV2_TQ
 #undef YFV2_TK
 }
@@ -620,7 +628,7 @@ constexpr int S4H_WFL = 9216, S4H_TM = 27648, S4H_TP = 27648 + 3456, S4H_CST = 2
 
 namespace {
 // 96 -> 96 pointwise conv of 16 pixels, filter operands from LDS (one 16-byte read per (tile, chunk, term), used at once)
-__device__ __forceinline__ void pw_h3_96(const float* W, int lane, const f32x2 (&in)[12], const f32x4 (&init)[6], f32x4 (&acc)[6]) {
+__device__ __forceinline__ void pw_h3_96(const float* W, int lane, const f32x2 (&in)[12], const f32x4 (&init)[6], f32x4 (&acc)[6], Yfv2Watch& watch) {
   const u32x4* Wq = reinterpret_cast<const u32x4*>(W) + lane;
 #pragma unroll
   for (int t = 0; t < 6; ++t) acc[t] = init[t];
@@ -642,6 +650,7 @@ __device__ __forceinline__ void pw_h3_96(const float* W, int lane, const f32x2 (
 #pragma unroll
     for (int t = 0; t < 6; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], x1, acc[t], 0, 0, 0);
   }
+  watch.see(acc[0][0]);
 }
 
 template <bool MAIN>
@@ -657,6 +666,7 @@ __device__ __forceinline__ void s4h_body(const BlockS2Args& a, const float* lds,
   const float* W1 = lds; const float* WB = lds + (MAIN ? 2 : 1) * S4H_WFL;   // this role's second filter: W2 (main) / Wproj
 
   __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * 96 * IH * IW), 0, 96 * IH * IW * 4, 0x00020000);
+  Yfv2Watch watch;
   float tq[54];
 #pragma unroll
   for (int q = 0; q < 54; ++q) tq[q] = img[(MAIN ? S4H_TM : S4H_TP) + q * 64 + lane];
@@ -688,12 +698,12 @@ __device__ __forceinline__ void s4h_body(const BlockS2Args& a, const float* lds,
       f32x4 acc[6];
 #pragma unroll
       for (int t = 0; t < 6; ++t) { const f32x4 v = X[t] * 16.0f; in[2 * t] = (f32x2){v[0], v[1]}; in[2 * t + 1] = (f32x2){v[2], v[3]}; }
-      pw_h3_96(W1, lane, in, sh1, acc);
+      pw_h3_96(W1, lane, in, sh1, acc, watch);
 #pragma unroll
       for (int c = 0; c < 24; ++c) ve[c] = __builtin_amdgcn_fmed3f(acc[c >> 2][c & 3], 0.f, lim);
 #pragma unroll
       for (int t = 0; t < 6; ++t) { const f32x4 v = X[6 + t] * 16.0f; in[2 * t] = (f32x2){v[0], v[1]}; in[2 * t + 1] = (f32x2){v[2], v[3]}; }
-      pw_h3_96(W1, lane, in, sh1, acc);
+      pw_h3_96(W1, lane, in, sh1, acc, watch);
 #pragma unroll
       for (int c = 0; c < 24; ++c) vo[c] = __builtin_amdgcn_fmed3f(acc[c >> 2][c & 3], 0.f, lim);
     } else {
@@ -744,7 +754,7 @@ __device__ __forceinline__ void s4h_body(const BlockS2Args& a, const float* lds,
 #pragma unroll
     for (int c = 0; c < 24; ++c) { dpp_src_ready(Q[c]); d[c >> 1][c & 1] = S[c] + row_shr1(Q[c]); }
     f32x4 acc[6];
-    pw_h3_96(WB, lane, d, bib, acc);
+    pw_h3_96(WB, lane, d, bib, acc, watch);
     if (st_lane && oy < y1) {
       float* o = outp + (size_t)oy * OW * 192;
 #pragma unroll
@@ -756,6 +766,7 @@ __device__ __forceinline__ void s4h_body(const BlockS2Args& a, const float* lds,
       }
     }
   }
+  watch.report(a.nonfinite);
 #undef YFV2_TQ
 #undef YFV2_TK
 }

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
 
   // conv row y from the carried row 2y-1 (x0) and the freshly loaded rows 2y, 2y+1 -> horizontally pooled raw values
   // hp[tile][4] = max(O[p-1], E[p], O[p]) (BN shift inside, pre-ReLU, x 2^(sw+8)); x0 <- the split row 2y+1
+  Yfv2Watch watch;
   auto conv_row = [&](Row16& x0, const f32x4 (&raw)[2], f32x4 (&hp)[2]) {
     f32x4 r1 = raw[0], r2 = raw[1];
     {   // lane group 3: (ch0, ch1) of columns 4px+1 | 4px+3 into X1's v0 v1 | v2 v3, ch2 into X2's v0 | v2
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
     for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], be[0], ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], bo[0], ao[t], 0, 0, 0); }
 #pragma unroll
     for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], be[0], ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], bo[0], ao[t], 0, 0, 0); }
+    watch.see(ae[0][0]); watch.see(ao[0][0]);   // every input column sits in an even or an odd window: a pixel beyond fp16's range makes both NaN
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
     step(t + 1, re1, ro1, re0, ro0);
   }
   if (t < a.R) step(t, re0, ro0, re1, ro1);
+  watch.report(a.nonfinite);
 }
 
 // ---- uint8 (B,H,W,3) input (yfv2_forward_u8 / yfv2_detect_u8: test.py:34-38's reshape / permute / float() / 255 folded into the loads).

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
   const __attribute__((address_space(4))) TowerArgs& ja = *(const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const yfv2_cf4* taps = (const yfv2_cf4*)(ja.img16 + th_lds_img(MH));
   int b = blockIdx.x;
+  Yfv2Watch watch;                                             // range guard of the fp16x3 products (yfv2_internal.h)
   f32x4 pre[NPF];
   stage_load(ja.in, b < a.B ? b : 0, 0, pre);                  // the first slice flies during the job's prologue
 
@@ -309,6 +310,8 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) watch.see(acc[0][nt][0]);   // a depthwise result beyond fp16's range: NaN in every channel of its pixel
     YFV2_WSTAMP(17);
     if constexpr (MH == 0) {
 #pragma unroll
@@ -350,6 +353,8 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
           for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main2(xs[s][nt], xs[s + 1][nt], (yfv2_u2){wf[s][0], wf[s][1]}, wf[s + 1], hacc[nt]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main1(xs[KC - 1][nt], wf[KC - 1], hacc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) watch.see((hacc[nt][0] + hacc[nt][1]) + (hacc[nt][2] + hacc[nt][3]));   // transposed: a lane's four values are four PIXELS
         const int co = 16 * m + p;
         if (co < ja.mh) {
           const float bias = CS[2 * 96 + co];
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
     }
     YFV2_WSTAMP(18);
   }
+  watch.report(ja.nonfinite);
   }
 }
 
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
 
   constexpr int N4 = LDS_IMG / 4, NIT = (N4 + 511) / 512;
   const __attribute__((address_space(4))) TowerArgs* kj = (const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  Yfv2Watch watch;                                                // range guard of the fp16x3 products (yfv2_internal.h)
   f32x4 tmp[NIT];                                                 // the NEXT job's filter image, in flight while this job computes
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(kj[0].img16);
@@ -536,6 +543,7 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
       const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + 16 * mt + 4 * g);
       acc[mt] = __builtin_elementwise_fma(acc[mt], sc, sh);
     }
+    watch.see(acc[0][0]);
     YFV2_WSTAMP(3);
     if (MH == 0 || !ja.has_head) {
       if (pv) {                                                   // (every depthwise read of IN is behind the exchange barrier)
@@ -562,6 +570,7 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
 #pragma unroll
         for (int sc = 0; sc + 1 < KC; sc += 2) hacc = mfma_main2(xs[sc], xs[sc + 1], (yfv2_u2){wf[sc][0], wf[sc][1]}, wf[sc + 1], hacc);
         hacc = mfma_main1(xs[KC - 1], wf[KC - 1], hacc);
+        watch.see((hacc[0] + hacc[1]) + (hacc[2] + hacc[3]));      // transposed: a lane's four values are four PIXELS
         const int co = 16 * m + p;
         if (co < ja.mh) {
           const float bias = CS[2 * 96 + co];
@@ -586,6 +595,7 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
                                                                   // enough (same CU, same L1); an agent-scope __threadfence() here wrote back and
                                                                   // invalidated L2 on every XCD - 4x the launch time
   }
+  watch.report(kj[0].nonfinite);
 }
 
 template <int MH>

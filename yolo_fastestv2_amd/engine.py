@@ -296,6 +296,21 @@ class Engine:
         check(_lib.lib().yfv2_batch_statistics_overflow(self._h, C.byref(over), _stream(self.device)), self._h)
         return bool(over.value)
 
+    def nonfinite(self):
+        """Waits for the stream; True if any forward / detect on this handle since the last query tripped the range guard of the
+        fp16x3 plan (an activation beyond +-4094, an fp32 input beyond +-255.9, or a non-finite value: include/yfv2.h
+        yfv2_nonfinite).  Clears the word."""
+        flag = C.c_int32(0)
+        check(_lib.lib().yfv2_nonfinite(self._h, C.byref(flag), _stream(self.device)), self._h)
+        return bool(flag.value)
+
+    def check_finite(self, what="forward"):
+        """Raise if the range guard tripped (call where the host waits for the device anyway)."""
+        if self.nonfinite():
+            raise _lib.Yfv2Error(-7, "%s: an activation left the range of the default (fp16x3) plan - |activation| >= 4094 or a non-finite "
+                                     "input; the result is invalid.  Create the handle with YFV2_BF6=0 in the environment (every conv on the "
+                                     "fp32 matrix instructions, no such bound) for this model / input" % what)
+
     # ---- introspection --------------------------------------------------------------------
     def stages(self):
         L = _lib.lib()

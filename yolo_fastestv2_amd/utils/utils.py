@@ -59,6 +59,7 @@ def handel_preds(preds, cfg, device):
     eng.set_anchors(cfg["anchors"])
     dev = eng.decode([p.detach().float() for p in preds])
     out = dev.cpu()
+    eng.check_finite("handel_preds (the forward that produced these logits)")   # the host has just waited for the device: free
     out._yfv2_dev = (dev, eng, out._version)
     return out
 
@@ -192,8 +193,12 @@ def evaluation(val_dataloader, cfg, model, device, conf_thres=0.01, nms_thresh=0
     # the sticky overflow word of EVERY engine used is read (and thereby cleared) before any return path, so that a flag set
     # here can never surface in a later, unrelated evaluation on the cached handle
     over = [eng.stats_overflowed() for eng in engines]
+    bad = [eng.nonfinite() for eng in engines]
     if any(over):
         raise RuntimeError("evaluation: an image has more than 1024 targets (yfv2_batch_statistics limit)")
+    if any(bad):
+        raise RuntimeError("evaluation: an activation left the range of the default (fp16x3) plan (include/yfv2.h yfv2_nonfinite); "
+                           "run with YFV2_BF6=0 in the environment")
     if not kept:
         print("---- No detections over whole validation set ----")
         return None
