@@ -98,12 +98,17 @@ __device__ __forceinline__ void yfv2_mfma6_tiles(const Bf3A (&a)[MT_], const Bf3
 // products of ANY filter entry with it are +-Inf or NaN and sum to NaN, for every output channel of that pixel - and the ReLU
 // behind almost every pointwise conv (v_max_f32 / v_med3_f32 return the non-NaN operand) would turn that NaN into a clean,
 // silent 0.  So every kernel of the fp16x3 plan looks at ONE accumulator element per lane of every pointwise product before
-// its ReLU: a v_cmp_u_f32 into a scalar register pair OR-ed into a sticky wave-uniform mask (no vector register, no branch),
+// its ReLU: a shift and an unsigned compare into a scalar register pair OR-ed into a sticky wave-uniform mask (no branch),
 // and reports once at its end.  Non-finite INPUT values are caught by the same test.
 #ifdef __HIPCC__
 struct Yfv2Watch {
   unsigned long long m = 0;
-  __device__ __forceinline__ void see(float v) { m |= __builtin_amdgcn_ballot_w64(v != v); }
+  // an integer test of the exponent field (all ones: NaN or Inf), two VALU instructions: the kernel files are compiled with
+  // -fno-honor-nans (bare v_max for the ReLUs), under which `v != v` and the class intrinsics fold to false
+  __device__ __forceinline__ void see(float v) {
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    m |= __builtin_amdgcn_ballot_w64((b << 1) >= 0xff000000u);
+  }
   __device__ __forceinline__ void report(int* flag) const {
     if (m != 0 && flag != nullptr) atomicOr(flag, 1);   // the rare path: every active lane of the wave, one word
   }
