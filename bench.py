@@ -16,8 +16,8 @@ Consecutive steps are independent batches: they rotate over three handles
 (own workspaces) on three HIP streams, so that one step's launches fill the
 under-filled tails of its neighbours' (all K steps complete inside the timed
 region); `single_stream_img_s` is the same K steps on one handle and one stream.
-Before the W warm-up steps, `--spinup` (80) untimed steps bring the device out of
-its idle power state (a fresh process runs its first ~25 steps 8-10 % slower).
+The untimed warm-up is max(W, 80) steps (`warmup_steps_run`): a fresh process runs its
+first ~25 steps 8-10 % slower, until the device has left its idle power state.
 The configs[2] variant the survey specifies (COCO weights, a 256-batch built from
 the shipped JPEGs, thresholds 0.3/0.4 and 0.01/0.4) is timed as well and reported
 in `coco_e2e` (extra fields, never `value`).
@@ -33,8 +33,13 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings):
              intensity.  `traffic` = HBM bytes per launch from the PMC passes under
              profiles/ (tools/gpu_traffic.sh) IF that profile was taken on this very
              source tree (fingerprint match), else null.
-  kernel_table  the same figures for every kernel of the forward (+ mfma_busy from
-             the SQ counter pass, same fingerprint rule)
+  kernel_table  the same figures for every kernel of the forward: hbm_frac_external (of the nominal
+             8 TB/s) and hbm_frac_of_achievable (of the ~6.3 TB/s the guide calls achievable);
+             mfma_pipe_frac = matrix-pipe flops issued / that pipe's dense peak - on the default
+             plan 3 x algorithmic flops / 2.5 PFLOP/s (fp16x3: three f16 products per MAC; the
+             depthwise flops, which run on the VALU, are included in `flops`: an upper bound) -
+             next to mfma_busy from the SQ counter pass (same fingerprint rule); no fraction
+             can exceed 1
   cpu_baseline  the CPU oracle (same ATen CPU ops as the reference + numpy
              decode/NMS) timed on this box's host cores on a bounded sample
 """
@@ -49,9 +54,15 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (= fp32 vector peak)
-RIDGE_FLOP_PER_BYTE = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)   # 19.7
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec ...
+HBM_ACHIEVABLE_GBS = 6300.0    # ... of which ~6.3 TB/s are achievable (same guide, HBM section)
+MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (= fp32 vector peak): the pipe of the YFV2_BF6=0 plan
+MFMA_F16_PEAK_TF = 2500.0      # dense fp16 MFMA peak: the pipe the default plan's fp16x3 contractions run on
+# The default plan spends THREE f16 products per algorithmic MAC (w1 x2 + w2 x1 + w1 x1), so its ceiling in algorithmic
+# flops is a third of the f16 peak; the ridge that decides `bound` follows from that ceiling.
+FP16X3 = os.environ.get("YFV2_BF6", "1") != "0"
+PIPE_PEAK_TF, PIPE_COST = (MFMA_F16_PEAK_TF, 3.0) if FP16X3 else (MFMA_F32_PEAK_TF, 1.0)
+RIDGE_FLOP_PER_BYTE = (PIPE_PEAK_TF / PIPE_COST) * 1e12 / (HBM_PEAK_GBS * 1e9)   # 104 flop/B (fp16x3), 19.7 (fp32 MFMA)
 sys.path.insert(0, os.path.join(REPO, "tools"))
 from srchash import source_hash  # noqa: E402
 
@@ -97,7 +108,7 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.3)
     ap.add_argument("--iou", type=float, default=0.4)
     ap.add_argument("--profile-iters", type=int, default=5)
-    ap.add_argument("--spinup", type=int, default=80, help="untimed steps before the warm-up that bring the device out of its idle power state (about 60 ms)")
+    ap.add_argument("--min-warmup", type=int, default=80, help="the untimed warm-up runs max(--warmup, this) steps: a fresh process needs ~60 ms of work to leave the device's idle power state")
     ap.add_argument("--pipeline", type=int, default=3, help="handles / HIP streams consecutive steps rotate over (1 = one handle, one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -212,16 +223,14 @@ def main():
     sync()
     # set-up, not a step: bring the device out of its idle power state.  A fresh process runs its first ~25 steps 8-10 % slower
     # than every later one (tools/stagger_probe.py: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each
-    # following 20), which would put a --warmup 5 --steps 20 run entirely inside the ramp.  a.spinup of the same steps run
-    # untimed first (a fixed COUNT, the same on every rank: the steps hold a collective), then the W warm-up steps, then the
-    # K timed ones; the count is reported as `spinup_steps`.
-    for _ in range(a.spinup):
+    # following 20), which would put a --warmup 5 --steps 20 run entirely inside the ramp.  So the untimed warm-up is
+    # max(W, --min-warmup = 80) of the same steps (a fixed COUNT, the same on every rank: the steps hold a collective), then
+    # the K timed ones; the count actually run is reported as `warmup_steps_run`.
+    warm_steps = max(a.warmup, a.min_warmup)
+    for _ in range(warm_steps):
         step()
     finish()
     sync()
-    for _ in range(a.warmup):
-        step()
-    finish()
     dt = timed(step, a.steps, sync, barrier, finish)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
@@ -232,6 +241,20 @@ def main():
     for _ in range(2):
         step_single()
     dt_s = timed(step_single, a.steps, sync, barrier)
+
+    # ONE call per batch on ONE handle whose calls cut the batch into two slices on internal streams (YFV2_LANES=2)
+    os.environ["YFV2_LANES"] = "2"
+    try:
+        eng_l = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
+    finally:
+        os.environ.pop("YFV2_LANES", None)
+    eng_l.load_state_dict(sd)
+    for _ in range(3):
+        eng_l.detect(x, a.conf, a.iou, out=det_bufs)
+    dt_l = timed(lambda: eng_l.detect(x, a.conf, a.iou, out=det_bufs), a.steps, sync, barrier)
+    del eng_l
+    for _ in range(2):
+        step_single()          # det_bufs again hold the one-handle result (detections_per_image below)
 
     # forward only (BASELINE.json configs[1]) - same batch, same buffers
     for _ in range(2):
@@ -289,8 +312,9 @@ def main():
             traffic = profile_lookup(prof_t, name, "total_bytes", k["launches"])
             r = {"kernel": name, "launches": k["launches"], "ms": round(k["ms"], 4), "share": round(k["ms"] / tot_ms, 4),
                  "external_bytes": k["ext"], "moved_gbs": round(moved, 1), "hbm_frac_external": round(moved / HBM_PEAK_GBS, 4),
+                 "hbm_frac_of_achievable": round(moved / HBM_ACHIEVABLE_GBS, 4),
                  "per_layer_gbs": round(k["bytes"] / sec / 1e9, 1),
-                 "tflops": round(tf, 2), "flops_frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+                 "tflops": round(tf, 2), "mfma_pipe_frac": round(PIPE_COST * tf / PIPE_PEAK_TF, 4),
                  "flop_per_external_byte": round(ai, 1), "bound": "mfma" if ai > RIDGE_FLOP_PER_BYTE else "hbm",
                  "mfma_busy": profile_lookup(prof_p, name, "mfma_busy_pct", 1, mean=True),
                  "traffic_bytes": traffic, "traffic_over_external": round(traffic / k["ext"], 3) if traffic else None}
@@ -302,8 +326,8 @@ def main():
         # left of the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B) HBM, right of it the fp32 MFMA peak
         if drow["bound"] == "hbm":
             ach, peak, unit = drow["moved_gbs"], HBM_PEAK_GBS, "GB/s"
-        else:
-            ach, peak, unit = drow["tflops"], MFMA_F32_PEAK_TF, "TFLOP/s"
+        else:     # matrix-pipe flops actually issued (3 per algorithmic flop on fp16x3) against that pipe's dense peak
+            ach, peak, unit = round(PIPE_COST * drow["tflops"], 2), PIPE_PEAK_TF, "TFLOP/s"
         tot_ext = sum(k["ext"] for k in table.values()); tot_fl = sum(k["flops"] for k in table.values())
         roof = {"kernel": dom_name, "covers": dom["covers"], "launches_per_forward": dom["launches"], "bound": drow["bound"],
                 "achieved": ach, "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
@@ -313,12 +337,15 @@ def main():
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "sum_ms_per_forward": round(dom["ms"], 4),
                 "share_of_forward": round(dom["ms"] / tot_ms, 4),
                 "algorithmic_bytes_per_launch": dom["ext"] / dom["launches"], "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
-                "hbm_frac_external": drow["hbm_frac_external"], "flops_frac_of_fp32_mfma_peak": drow["flops_frac_of_fp32_mfma_peak"],
+                "hbm_frac_external": drow["hbm_frac_external"], "hbm_frac_of_achievable": drow["hbm_frac_of_achievable"],
+                "mfma_pipe_frac": drow["mfma_pipe_frac"],
+                "mfma_pipe": ("f16 dense %.0f TFLOP/s, %g products per algorithmic MAC (fp16x3)" if FP16X3 else "fp32 dense %.1f TFLOP/s, %g product per MAC") % (PIPE_PEAK_TF, PIPE_COST),
                 "mfma_busy": drow["mfma_busy"], "src_hash": src_hash,
                 "whole_forward": {"external_gbs": round(tot_ext / (tot_ms * 1e-3) / 1e9, 1), "hbm_frac_external": round(tot_ext / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                   "per_layer_gbs": round(sum(k["bytes"] for k in table.values()) / (tot_ms * 1e-3) / 1e9, 1),
+                                  "hbm_frac_of_achievable": round(tot_ext / (tot_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4),
                                   "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                  "flops_frac_of_fp32_mfma_peak": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}}
+                                  "mfma_pipe_frac": round(PIPE_COST * tot_fl / (tot_ms * 1e-3) / 1e12 / PIPE_PEAK_TF, 4)}}
 
         # ---- BASELINE configs[2] as the survey specifies it: COCO weights, JPEG-derived batch, both threshold pairs ----
         coco = None
@@ -407,10 +434,11 @@ def main():
                                    "(COCO weights, JPEG-derived batch) in coco_e2e"
                                    % (a.batch, a.conf, a.iou, " + one RCCL all-gather of the padded detections per step, overlapped with the next step" if use_dist else ""),
                        "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
-            "spinup_steps": a.spinup,
+            "warmup_steps_run": warm_steps,
             "pipelining": "consecutive steps rotate over %d handles (own workspaces) on as many HIP streams; all K steps complete inside the timed region" % len(engs),
             "forward_only_pipelined_img_s": round(world * a.batch * a.steps / dt_fp, 1), "forward_only_pipelined_ms": round(1e3 * dt_fp / a.steps, 4),
             "single_stream_img_s": round(a.batch * a.steps / dt_s, 1), "single_stream_ms_per_step": round(1e3 * dt_s / a.steps, 4),
+            "single_call_two_lanes_img_s": round(a.batch * a.steps / dt_l, 1), "single_call_two_lanes_ms_per_step": round(1e3 * dt_l / a.steps, 4),
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
             "forward_from_uint8_hwc_img_s": round(fwd_u8_img_s, 1), "forward_from_uint8_hwc_ms": round(1e3 * dt_u / a.steps, 4),
             "roofline": roof, "cpu_baseline": cpu,

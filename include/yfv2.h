@@ -59,10 +59,10 @@ typedef struct yfv2_ctx* yfv2_handle;
  * (utils/utils.py:13-65: classes, anchor_num, width, height, anchors) plus
  * the workspace size. */
 typedef struct yfv2_config {
-  int32_t classes;     /* 80  */
+  int32_t classes;     /* 80; 1..255 */
   int32_t anchor_num;  /* 3 (the reference hard-codes 3: utils/utils.py:300,326) */
   int32_t height;      /* 352; multiple of 32 */
-  int32_t width;       /* 352; multiple of 32, <= 384 */
+  int32_t width;       /* 352; multiple of 32; at most 4096 decode rows = 3 (H/16 W/16 + H/32 W/32), i.e. up to 512x512 */
   double anchors[12];  /* data/coco.data:17, float64 like utils/utils.py:305 */
   int32_t max_batch;   /* workspace is sized for this many images */
   int32_t device;      /* HIP device ordinal */

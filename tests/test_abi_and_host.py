@@ -391,7 +391,7 @@ def _dryrun(classes, H, W, drop=None, max_batch=4, weights_classes=None):
     from yolo_fastestv2_amd import _lib
     from yolo_fastestv2_amd._lib import Config, TensorDesc
 
-    w = yfv2.random_state_dict(1, classes=weights_classes or min(max(classes, 1), 93))
+    w = yfv2.random_state_dict(1, classes=weights_classes or min(max(classes, 1), 255))
     host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point() and k != drop}
     arr = (TensorDesc * len(host))()
     for i, (k, t) in enumerate(host.items()):
@@ -410,14 +410,18 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
     WEIGHTS code - codes, not crashes."""
     from yolo_fastestv2_amd import _lib
 
-    sizes = [(352, 352), (320, 320), (288, 384), (32, 32), (64, 96), (352, 32)]
-    for classes in (80, 20, 1, 2, 17, 93):
+    sizes = [(352, 352), (320, 320), (288, 384), (32, 32), (64, 96), (352, 32), (416, 416), (384, 384), (512, 512), (640, 384), (96, 1024)]
+    for classes in (80, 20, 1, 2, 17, 93, 94, 100, 255):
         blobs = set()
         for H, W in sizes:
             rc, steps, blob, _ = _dryrun(classes, H, W)
             assert rc == 0 and steps >= 13 and blob > 400000, (classes, H, W, rc, steps, blob)
             blobs.add(blob)
-        assert len(blobs) <= 6      # the packed blob depends on which kernels a size selects, not on the size itself
+        assert len(blobs) <= 11     # the packed blob depends on which kernels a size selects, not on the size itself
+    # more than 93 classes: the class head no longer fits one chained output conv - it runs as slices of 96 channels
+    # (22x22: + objectness head + two class slices; 11x11: its four tower halves no longer form one launch: 1 -> 4 + 3)
+    assert _dryrun(100, 352, 352)[1] == _dryrun(80, 352, 352)[1] + 3 + 6
+    assert _dryrun(255, 352, 352)[1] == _dryrun(100, 352, 352)[1] + 2                # a third class slice per level
     # the two alternative plans (layer by layer: 77 launches; every pointwise conv on the fp32 MFMA: the stage-3 chain and
     # stage4.0, which exist only as bf16x6 kernels, then run layer by layer) are planned and packed by the same code
     import os
@@ -431,11 +435,11 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
         finally:
             del os.environ[var]
     ERR_CONFIG, ERR_WEIGHTS = _lib.ERR_CONFIG, _lib.ERR_WEIGHTS
-    assert _dryrun(80, 384, 384)[0] == ERR_CONFIG      # 2160 decode rows > the NMS kernel's 2048
-    assert _dryrun(94, 352, 352)[0] == ERR_CONFIG
+    assert _dryrun(80, 544, 544)[0] == ERR_CONFIG      # 4335 decode rows > the NMS kernel's 4096
+    assert _dryrun(80, 640, 640)[0] == ERR_CONFIG
+    assert _dryrun(256, 352, 352)[0] == ERR_CONFIG     # the class index travels as one byte
     assert _dryrun(0, 352, 352)[0] == ERR_CONFIG
     assert _dryrun(80, 350, 352)[0] == ERR_CONFIG
-    assert _dryrun(80, 352, 416)[0] == ERR_CONFIG
     assert _dryrun(80, 352, 352, drop="fpn.conv1x1_2.0.weight")[0] == ERR_WEIGHTS
     assert _dryrun(80, 352, 352, weights_classes=20)[0] == ERR_WEIGHTS     # a 20-class checkpoint into an 80-class handle
     assert _dryrun(20, 352, 352)[2] < _dryrun(80, 352, 352)[2]

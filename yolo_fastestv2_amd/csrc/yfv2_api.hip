@@ -236,6 +236,17 @@ struct WeightPacker {
     return true;
   }
 
+  // rows [r0, r0 + n) of one biased output conv (the class head of a model with more classes than one launch's 96 rows)
+  bool heads_range(const std::string& name, int rows_total, int r0, int n, int ci, Folded* f) {
+    const float* w = get(name + ".weight", (int64_t)rows_total * ci);
+    const float* b = get(name + ".bias", rows_total);
+    if (!w || !b || r0 < 0 || r0 + n > rows_total) return false;
+    f->w = reserve((size_t)n * ci); f->scale = reserve(n); f->shift = reserve(n);
+    std::memcpy(&blob[f->w], w + (size_t)r0 * ci, sizeof(float) * n * ci);
+    for (int i = 0; i < n; ++i) { blob[f->scale + i] = 1.0f; blob[f->shift + i] = b[r0 + i]; }
+    return true;
+  }
+
   // ---- LDS images: the exact, zero-padded block of floats a kernel copies into LDS (or its
   // registers) in its prologue.  Built from the arrays packed above.
   // fragment-major filter: frag (mt, s), lane l -> W[16mt + (l&15)][16s + 4(l>>4) .. +3]  (zero outside M x K)
@@ -911,7 +922,7 @@ struct PlanBuilder {
     s.pw.relu = relu ? 1 : 0;
     s.pw.copy = nullptr; s.pw.copy_stride = 0; s.pw.copy_off = 0;
     s.pw.H = 0; s.pw.W = 0; s.pw.HW = px;
-    s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0;
+    s.pw.nchw0 = nullptr; s.pw.nchw1 = nullptr; s.pw.split = 0; s.pw.ctot0 = 0; s.pw.coff0 = 0;
     s.px_per_img = px;
     s.pw.presplit = (h->bf6 && yfv2_pw_presplit_supported(K, mode, M)) ? 1 : 0;
     s.img_off = wp.image_pw(f, M, K, yfv2_pw_tiles(K, mode, M), s.pw.presplit != 0);
@@ -1378,7 +1389,9 @@ struct PlanBuilder {
     s.img_off = wp.image_tower(fd, fp, fh, mh);
     // one LDS layout per launch: where the four halves of a map size share a launch (merge_tower_launches) every image is
     // packed for the widest output conv of the level (obj + cls), else for the step's own
-    s.tw_tiles = yfv2_towerh_multi(H, W) ? ((h->cfg.anchor_num + h->cfg.classes + 15) / 16 <= 1 ? 1 : 6) : (fh ? ((mh + 15) / 16 <= 1 ? 1 : 6) : 0);
+    // (with more than 93 classes the class head runs as separate launches: the level's halves are never merged)
+    const bool merged_level = yfv2_towerh_multi(H, W) && h->cfg.anchor_num + h->cfg.classes <= 96;
+    s.tw_tiles = merged_level ? ((h->cfg.anchor_num + h->cfg.classes + 15) / 16 <= 1 ? 1 : 6) : (fh ? ((mh + 15) / 16 <= 1 ? 1 : 6) : 0);
     if (yfv2_towerh_supported(H, W)) s.img_off3 = wp.image_towerh(fd, fp, fh, mh, s.tw_tiles);
     s.has_head = fh != nullptr;
     s.head0 = head0; s.head1 = head1;
@@ -1386,6 +1399,25 @@ struct PlanBuilder {
     s.flops = 2.0 * H * W * (25.0 * 72 + 72.0 * 72 + (fh ? 72.0 * mh : 0.0));
     s.bytes = 4.0 * H * W * (72.0 + (fh ? mh : 72.0));
     h->plan.push_back(s);
+  }
+
+  // obj + cls output convs of a model with more than 93 classes, from the finished cls tower in h->tb: the objectness head
+  // and the class head in slices of up to 96 output channels, each a PW_HEAD launch writing its channel range of the NCHW tensor
+  void wide_cls_heads(const std::string& p, int px, int scale_idx) {
+    const int A = h->cfg.anchor_num, nc = h->cfg.classes;
+    Folded f;
+    ok &= wp.heads({{"output_obj_layers", A}}, 72, &f);
+    {
+      Step& s = add_pw(p + " -> output_obj (bias, NCHW)", 72, PW_HEAD, A, px, h->tb.p, 72, 0, nullptr, 0, 0, false, f);
+      s.pw.split = A; s.head0 = scale_idx * 3 + 1; s.head1 = -1;
+    }
+    for (int c0 = 0; c0 < nc; c0 += 96) {
+      const int n = std::min(96, nc - c0);
+      ok &= wp.heads_range("output_cls_layers", nc, c0, n, 72, &f);
+      Step& s = add_pw(p + " -> output_cls channels " + std::to_string(c0) + ".." + std::to_string(c0 + n - 1) + " (bias, NCHW)", 72, PW_HEAD, n, px,
+                       h->tb.p, 72, 0, nullptr, 0, 0, false, f);
+      s.pw.split = n; s.pw.ctot0 = nc; s.pw.coff0 = c0; s.head0 = scale_idx * 3 + 2; s.head1 = -1;
+    }
   }
 
   void tower(const std::string& p, int H, int W, const Buf& s_in, bool is_cls, int scale_idx) {
@@ -1402,7 +1434,10 @@ struct PlanBuilder {
         const int A = h->cfg.anchor_num, nc = h->cfg.classes;
         float* mid = h->ta.p;
         tower_half(p + " half a: dw5x5+bn+relu -> pw+bn", H, W, s_in.p, mid, fd1, fp1, nullptr, 0, 0, -1, -1);
-        if (is_cls) {
+        if (is_cls && A + nc > 96) {   // more output channels than a chained output conv holds: the tower ends in memory, the heads follow as launches
+          tower_half(p + " half b: dw5x5+bn+relu -> pw+bn", H, W, mid, h->tb.p, fd2, fp2, nullptr, 0, 0, -1, -1);
+          wide_cls_heads(p, px, scale_idx);
+        } else if (is_cls) {
           ok &= wp.heads({{"output_obj_layers", A}, {"output_cls_layers", nc}}, 72, &fh);
           tower_half(p + " half b: dw5x5+bn+relu -> pw+bn -> output_obj+output_cls (bias, NCHW)", H, W, mid, nullptr, fd2,
                      fp2, &fh, A + nc, A, scale_idx * 3 + 1, scale_idx * 3 + 2);
@@ -1423,7 +1458,9 @@ struct PlanBuilder {
     ok &= wp.pw(p + ".8", p + ".9", 72, 72, &f);
     add_pw(p + ".pw+bn(b)", 72, PW_PLAIN, 72, px, h->ta.p, 72, 0, h->tb.p, 72, 0, false, f);
     const int A = h->cfg.anchor_num, nc = h->cfg.classes;
-    if (is_cls) {
+    if (is_cls && A + nc > 96) {
+      wide_cls_heads(p, px, scale_idx);
+    } else if (is_cls) {
       ok &= wp.heads({{"output_obj_layers", A}, {"output_cls_layers", nc}}, 72, &f);
       Step& s = add_pw(p + " -> output_obj+output_cls (bias, NCHW)", 72, PW_HEAD, A + nc, px, h->tb.p, 72, 0, nullptr,
                        0, 0, false, f);
@@ -1445,7 +1482,8 @@ struct PlanBuilder {
   void merge_tower_launches() {
     std::vector<Step> out;
     for (size_t i = 0; i < h->plan.size();) {
-      auto mergeable = [&](const Step& t) { return t.kind == STEP_TOWER && t.img_off3 != 0 && yfv2_towerh_multi(t.tw.H, t.tw.W) && t.tw.H == h->plan[i].tw.H && t.tw.W == h->plan[i].tw.W; };
+      auto mergeable = [&](const Step& t) { return t.kind == STEP_TOWER && t.img_off3 != 0 && yfv2_towerh_multi(t.tw.H, t.tw.W) && t.tw.H == h->plan[i].tw.H && t.tw.W == h->plan[i].tw.W &&
+                                                   h->cfg.anchor_num + h->cfg.classes <= 96; };
       size_t n = 0;
       while (i + n < h->plan.size() && n < 4 && mergeable(h->plan[i + n])) ++n;
       if (n == 4) {
@@ -1739,13 +1777,20 @@ int check_call(yfv2_ctx* h, int B, bool need_weights) {
 int check_config(const yfv2_config* cfg, int* rows_out) {
   if (cfg->anchor_num != 3)
     return fail(nullptr, YFV2_ERR_CONFIG, "anchor_num must be 3 (the reference decode hard-codes 3 anchors per scale)");
-  if (cfg->classes < 1 || cfg->classes + cfg->anchor_num > 96)
-    return fail(nullptr, YFV2_ERR_CONFIG, "classes must be in [1, 93]");
-  if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32 || cfg->width > 384)
-    return fail(nullptr, YFV2_ERR_CONFIG, "height/width must be multiples of 32 and width <= 384");
+  // The reference sizes everything from its .data file (utils/utils.py:13-65).  What is static here: the class index travels
+  // as one byte through the NMS kernel (255 classes), and that kernel sorts an image's candidates in LDS (4096 decode rows =
+  // any input up to 512x512, or e.g. 640x384).  Shapes and class counts outside the fused kernels' own bounds run on the
+  // general plan, block by block (PlanBuilder); decode + NMS then run as two launches.
+  if (cfg->classes < 1 || cfg->classes > 255)
+    return fail(nullptr, YFV2_ERR_CONFIG, "classes must be in [1, 255]");
+  if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)
+    return fail(nullptr, YFV2_ERR_CONFIG, "height/width must be multiples of 32");
   if (cfg->max_batch < 1) return fail(nullptr, YFV2_ERR_CONFIG, "max_batch must be >= 1");
-  const int rows = 3 * ((cfg->height / 16) * (cfg->width / 16) + (cfg->height / 32) * (cfg->width / 32));
-  if (rows > 2048) return fail(nullptr, YFV2_ERR_CONFIG, "more than 2048 decode rows per image is not supported by the NMS kernel");
+  const long long rows_ll = 3LL * ((long long)(cfg->height / 16) * (cfg->width / 16) + (long long)(cfg->height / 32) * (cfg->width / 32));
+  if (rows_ll > yfv2_nms_max_rows())
+    return fail(nullptr, YFV2_ERR_CONFIG, "more than " + std::to_string(yfv2_nms_max_rows()) + " decode rows per image (" + std::to_string(rows_ll) +
+                                          ": inputs beyond 512x512) is not supported by the NMS kernel");
+  const int rows = (int)rows_ll;
   *rows_out = rows;
   return YFV2_OK;
 }
@@ -2173,7 +2218,7 @@ static int post_impl(yfv2_handle h, int32_t B, float conf_thres, double iou_thre
   if (!dets || !idx || !count) return fail(h, YFV2_ERR_ARG, "yfv2_detect: null pointer");
   float* out6[6];
   for (int i = 0; i < 6; ++i) out6[i] = h->logits[i].p;
-  if (!h->postfuse) {
+  if (!h->postfuse || !yfv2_post_fusable(h->cfg.classes, h->rows)) {
     // compact candidate rows instead of the (B,1815,85) tensor: same arithmetic, 10x less traffic
     const int rc = decode_impl(h, out6, B, nullptr, h->cand.p, stream);
     if (rc) return rc;

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
             if (co < a.M) {
               const float y = __builtin_fmaf(acc[mt][nt][r], sc[mt][r], sh[mt][r]);
               if (co < a.split)
-                a.nchw0[((size_t)b * a.split + co) * a.HW + hw] = y;
+                a.nchw0[((size_t)b * (a.ctot0 ? a.ctot0 : a.split) + a.coff0 + co) * a.HW + hw] = y;
               else
                 a.nchw1[((size_t)b * (a.M - a.split) + (co - a.split)) * a.HW + hw] = y;
             }

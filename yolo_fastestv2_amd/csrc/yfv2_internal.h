@@ -152,6 +152,8 @@ struct PwArgs {
   float* nchw0;        // PW_HEAD: co <  split -> nchw0[b][co][hw]
   float* nchw1;        // PW_HEAD: co >= split -> nchw1[b][co-split][hw]
   int split;
+  int ctot0, coff0;    // PW_HEAD writing a channel RANGE of a wider tensor (more than 93 classes: the class head in slices of 96):
+                       // nchw0 has ctot0 channels per image (0: = split) and this launch's channel co lands at coff0 + co
   int bf6;             // run the MFMAs as bf16x6 where the instantiation has that form (handle flag, YFV2_BF6=0 at create time clears it)
   int presplit;        // img holds the filter PRE-SPLIT into bf16 hi/mid/lo operand quads per chunk pair (WeightPacker::image_pw, streamed K = 192 / 288 forms; needs bf6)
   int* nonfinite;      // range-guard word (Yfv2Watch), or null
@@ -363,6 +365,8 @@ void yfv2_launch_resize(const ResizeArgs& a, hipStream_t s);
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s);
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);
 void yfv2_launch_decode_nms(const DecodeArgs& d, const NmsArgs& a, hipStream_t s);   // yfv2_detect: decode + NMS in one launch
+bool yfv2_post_fusable(int classes, int rows);   // ... which exists for up to 96 classes and 2048 decode rows; beyond: two launches
+int yfv2_nms_max_rows();                         // decode rows per image nms_kernel handles (4096)
 
 // ---- training path (yfv2_train.hip): its state hangs off the handle through an opaque slot owned by yfv2_api.hip
 struct yfv2_ctx;

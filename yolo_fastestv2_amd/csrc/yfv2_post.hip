@@ -18,12 +18,13 @@ __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, _
 // fetched one pass ahead - the class slice is not read at all: non_max_suppression drops rows with obj <= conf_thres before it
 // looks at a class (utils.py:254), so conf / class of such rows are never used (they are written as 0).  With trained weights
 // that is nearly every cell: the launch's decode phase stops being a 164 MB read.
-template <bool SKIP = false>
+// MAXPER >= ceil(classes / 4): 24 for up to 96 classes (every register count and schedule note below refers to that form), 64
+// for up to 255 (the general form: only reached through decode_kernel, 256 threads per workgroup).
+template <bool SKIP = false, int MAXPER = 24>
 __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int sc, int cc, int part, f32x4& r0, f32x4& r1,
                                                  const float (&objl)[3] = {0.f, 0.f, 0.f}, float skip_ct = 0.f) {
   const int fh = a.fh[sc], fw = a.fw[sc], hw = fh * fw;
   const int nc = a.classes;
-  constexpr int MAXPER = 24;  // >= ceil(classes / 4), classes <= 93
   const int per = (nc + 3) >> 2;
   const int c_lo = part * per, c_hi = min(nc, c_lo + per);
   const float* cls = a.cls[sc] + (size_t)b * nc * hw;   // wave-uniform base: the per-lane part stays a 32-bit offset (24 addresses live)
@@ -114,17 +115,18 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
 constexpr int DEC_CELLS = 64;
 constexpr int DEC_THREADS = 256;
 
-template <bool COMPACT>
+template <bool COMPACT, int MAXPER = 24>
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int blocks0, int blocks1) {
-  extern __shared__ float stage[];  // [DEC_CELLS][3][5+classes]
+  constexpr int CELLS = MAXPER > 24 ? 32 : DEC_CELLS, THREADS = 4 * CELLS;   // (the wide form halves the cells: [32][3][260] floats of LDS)
+  extern __shared__ float stage[];  // [CELLS][3][5+classes]
   const int per_img = blocks0 + blocks1;
   const int b = blockIdx.x / per_img;
   int blk = blockIdx.x - b * per_img;
   const int sc = blk >= blocks0 ? 1 : 0;
   if (sc) blk -= blocks0;
   const int fh = a.fh[sc], fw = a.fw[sc], hw = fh * fw;
-  const int cell0 = blk * DEC_CELLS;
-  const int ncell = min(DEC_CELLS, hw - cell0);
+  const int cell0 = blk * CELLS;
+  const int ncell = min(CELLS, hw - cell0);
   const int nc = a.classes, rowlen = 5 + nc;
   const int tid = threadIdx.x;
   const int lc = tid >> 2, part = tid & 3;  // local cell, quarter
@@ -134,7 +136,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
 
   // ---- class softmax (fp32): exp(x - max) / sum.  The lane's logits are fetched with one
   // batch of independent loads (fixed trip count, masked) instead of a load per loop turn.
-  constexpr int MAXPER = 24;  // >= ceil(classes / 4), classes <= 93
   const int per = (nc + 3) >> 2;
   const int c_lo = part * per, c_hi = min(nc, c_lo + per);
   const float* cls = a.cls[sc] + (size_t)b * nc * hw;   // wave-uniform base: the per-lane part stays a 32-bit offset (24 addresses live)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
   if constexpr (COMPACT) {
     // compact candidate rows (8 floats) instead of the 85-wide tensor: what the two-launch form of yfv2_detect consumes
     f32x4 r0, r1;
-    yfv2_compact_row(a, b, sc, cc, part, r0, r1);
+    yfv2_compact_row<false, MAXPER>(a, b, sc, cc, part, r0, r1);
     if (ok && part < 3) {
       float* d = a.cand + (row0 + (size_t)lc * 3 + part) * 8;
       *reinterpret_cast<f32x4*>(d) = r0;
@@ -214,23 +215,35 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeArgs a, int b
     __syncthreads();
     float* dst = a.boxes + row0 * rowlen;
     const int n = ncell * 3 * rowlen;
-    for (int i = tid; i < n; i += DEC_THREADS) dst[i] = stage[i];
+    for (int i = tid; i < n; i += THREADS) dst[i] = stage[i];
   }
 }
 
 void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
-  const int b0 = (a.fh[0] * a.fw[0] + DEC_CELLS - 1) / DEC_CELLS;
-  const int b1 = (a.fh[1] * a.fw[1] + DEC_CELLS - 1) / DEC_CELLS;
-  const size_t lds = (size_t)DEC_CELLS * 3 * (5 + a.classes) * sizeof(float);
-  static std::atomic<unsigned long long> lds_ok0{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<false>), lds_ok0);
-  static std::atomic<unsigned long long> lds_ok1{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<true>), lds_ok1);
-  if (a.cand)
-    hipLaunchKernelGGL(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), 0, s, a, b0, b1);
-  else
-    hipLaunchKernelGGL(decode_kernel<false>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
+  const int cells = a.classes <= 96 ? DEC_CELLS : 32;
+  const int b0 = (a.fh[0] * a.fw[0] + cells - 1) / cells;
+  const int b1 = (a.fh[1] * a.fw[1] + cells - 1) / cells;
+  const size_t lds = (size_t)cells * 3 * (5 + a.classes) * sizeof(float);
+  static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0}, lds_ok2{0}, lds_ok3{0};
+  if (a.classes <= 96) {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<false>), lds_ok0);
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<true>), lds_ok1);
+    if (a.cand)
+      hipLaunchKernelGGL(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), 0, s, a, b0, b1);
+    else
+      hipLaunchKernelGGL(decode_kernel<false>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
+  } else {   // up to 255 classes: 64 class slots per lane, 32 cells per workgroup ([32][3][260] floats of LDS)
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<false, 64>), lds_ok2);
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<true, 64>), lds_ok3);
+    if (a.cand)
+      hipLaunchKernelGGL((decode_kernel<true, 64>), dim3(a.B * (b0 + b1)), dim3(4 * cells), 0, s, a, b0, b1);
+    else
+      hipLaunchKernelGGL((decode_kernel<false, 64>), dim3(a.B * (b0 + b1)), dim3(4 * cells), lds, s, a, b0, b1);
+  }
 }
+// the fused decode + NMS launch (nms_kernel<2>) holds a lane's class slice in 24 registers and the image's rows in LDS
+bool yfv2_post_fusable(int classes, int rows) { return classes <= 96 && rows <= 2048; }
+int yfv2_nms_max_rows() { return 4096; }
 
 // ============================================================================
 // class-aware greedy NMS  (non_max_suppression + torchvision.ops.nms)
@@ -247,21 +260,29 @@ void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
 //               (the reference truncates the full result to 300, same set)
 constexpr int NMS_THREADS = 1024;  // 16 waves: one workgroup per image is latency-bound, occupancy is what hides it
 constexpr int NMS_NQ = NMS_THREADS / 64;  // thread groups per 64-candidate chunk
-constexpr int NMS_CAP = 2048;      // >= rows (1815); power of two for the bitonic network
+constexpr int NMS_CAP = 2048;      // >= rows (1815); power of two for the bitonic network (KPT = 2 keys per thread; KPT = 4: 4096 rows)
 constexpr int NMS_MAX_DET = 300;   // utils/utils.py:243 (== YFV2_MAX_DET)
 
 // SRC 0: the (B, rows, 5 + classes) decoded tensor (yfv2_nms); 1: compact candidate rows in global memory (decode_kernel<true>);
 // 2: the logits themselves - the workgroup decodes its image into compact rows in LDS first (yfv2_detect: one launch for
 // handel_preds + non_max_suppression, the candidate rows never exist in HBM)
 #define NMS_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
-template <int SRC>
+// KPT = sort keys per thread: 2 (up to 2048 rows: everything the notes below measured) or 4 (up to 4096 rows - inputs beyond
+// 352x352, e.g. 416x416 = 2535 rows, 512x512 = 3840; the sort's second exchange buffer then shares LDS with the box arrays,
+// which are written after it, so that 4096 candidates fit into 132 KB)
+template <int SRC, int KPT = 2>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a, DecodeArgs dec) {
   constexpr bool COMPACT = SRC >= 1;
+  constexpr int CAP = KPT * NMS_THREADS;
+  static_assert(KPT == 2 || (KPT == 4 && SRC != 2), "two keys per thread, or four without the in-LDS decode");
   extern __shared__ __attribute__((aligned(16))) float crow[];   // SRC == 2: [rows][8]
-  __shared__ unsigned long long key[NMS_CAP], key2[NMS_CAP];   // key2: second exchange buffer of the sort
-  __shared__ float bx1[NMS_CAP], by1[NMS_CAP], bx2[NMS_CAP], by2[NMS_CAP], area[NMS_CAP];
-  __shared__ unsigned char supp[NMS_CAP];
-  __shared__ unsigned char cls_of_row[NMS_CAP];
+  __shared__ unsigned long long key[CAP];
+  __shared__ __attribute__((aligned(16))) float geo[(KPT == 2 ? 7 : 5) * CAP];
+  unsigned long long* const key2 = reinterpret_cast<unsigned long long*>(geo);   // second exchange buffer of the sort
+  float* const bx1 = geo + (KPT == 2 ? 2 * CAP : 0);
+  float* const by1 = bx1 + CAP; float* const bx2 = by1 + CAP; float* const by2 = bx2 + CAP; float* const area = by2 + CAP;
+  __shared__ unsigned char supp[CAP];
+  __shared__ unsigned char cls_of_row[CAP];
   __shared__ int keep[NMS_MAX_DET];
   __shared__ float kx1[NMS_MAX_DET], kx2[NMS_MAX_DET];   // x interval of the kept boxes, in kept order (greedy step's first test)
   __shared__ unsigned long long pmask[NMS_NQ][64];
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a, DecodeArgs 
   while (np2 < n) np2 <<= 1;
   for (int i = n + tid; i < np2; i += NMS_THREADS) key[i] = 0ull;
   __syncthreads();
-  {
+  if constexpr (KPT == 2) {
     static_assert(NMS_CAP == 2 * NMS_THREADS, "two keys per thread");
     const int i0 = tid, i1 = tid + NMS_THREADS;
     unsigned long long k0 = i0 < np2 ? key[i0] : 0ull, k1 = i1 < np2 ? key[i1] : 0ull;
@@ -426,6 +447,52 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a, DecodeArgs 
     __syncthreads();                                                // readers of either buffer are done
     if (i0 < np2) key[i0] = k0;
     if (i1 < np2) key[i1] = k1;
+    __syncthreads();
+  } else {
+    // the same network with KPT keys per thread: thread t owns indices t + 1024 r; a distance >= 1024 pairs two of its own keys
+    unsigned long long k[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) { const int i = tid + r * NMS_THREADS; k[r] = i < np2 ? key[i] : 0ull; }
+    auto cx = [](unsigned long long x, unsigned long long y, bool take_max) { return take_max == (x > y) ? x : y; };
+    int pb = 0;
+    for (int kk = 2; kk <= np2; kk <<= 1) {
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        if (j >= NMS_THREADS) {
+          const int jr = j / NMS_THREADS;                           // 1 or 2: partner key r ^ jr of the same thread
+#pragma unroll
+          for (int r = 0; r < KPT; ++r) {
+            if ((r & jr) == 0) {
+              const int r2 = r | jr;
+              const bool desc = ((tid + r * NMS_THREADS) & kk) == 0;  // (the same for both keys: jr * 1024 < kk)
+              const unsigned long long hi = k[r] > k[r2] ? k[r] : k[r2], lo = k[r] > k[r2] ? k[r2] : k[r];
+              k[r] = desc ? hi : lo; k[r2] = desc ? lo : hi;
+            }
+          }
+        } else if (j >= 64) {
+          unsigned long long* buf = pb ? key2 : key;
+#pragma unroll
+          for (int r = 0; r < KPT; ++r) buf[tid + r * NMS_THREADS] = k[r];
+          __syncthreads();
+          const bool low = (tid & j) == 0;
+#pragma unroll
+          for (int r = 0; r < KPT; ++r) {
+            const int i = tid + r * NMS_THREADS;
+            k[r] = cx(k[r], buf[i ^ j], low == ((i & kk) == 0));
+          }
+          pb ^= 1;
+        } else {
+          const bool low = (tid & j) == 0;
+#pragma unroll
+          for (int r = 0; r < KPT; ++r) {
+            const int i = tid + r * NMS_THREADS;
+            k[r] = cx(k[r], __shfl_xor(k[r], j), low == ((i & kk) == 0));
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) { const int i = tid + r * NMS_THREADS; if (i < np2) key[i] = k[r]; }
     __syncthreads();
   }
 
@@ -573,10 +640,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsArgs a, DecodeArgs 
 
 void yfv2_launch_nms(const NmsArgs& a, hipStream_t s) {
   const DecodeArgs none{};
-  if (a.compact)
-    hipLaunchKernelGGL(nms_kernel<1>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
-  else
-    hipLaunchKernelGGL(nms_kernel<0>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+  if (a.rows <= NMS_CAP) {
+    if (a.compact)
+      hipLaunchKernelGGL(nms_kernel<1>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+    else
+      hipLaunchKernelGGL(nms_kernel<0>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+  } else {   // up to 4096 rows: four sort keys per thread (the configuration check admits no more)
+    if (a.compact)
+      hipLaunchKernelGGL((nms_kernel<1, 4>), dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+    else
+      hipLaunchKernelGGL((nms_kernel<0, 4>), dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+  }
 }
 
 // handel_preds + non_max_suppression of yfv2_detect as ONE launch: a.boxes is unused, the rows are decoded into LDS

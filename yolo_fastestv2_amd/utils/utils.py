@@ -210,10 +210,10 @@ def evaluation(val_dataloader, cfg, model, device, conf_thres=0.01, nms_thresh=0
 
 def _engine_for_rows(device, rows, classes):
     for h in range(32, 2049, 32):  # square inputs first (the reference only ever uses H == W)
-        if 3 * ((h // 16) ** 2 + (h // 32) ** 2) == rows and h <= 384:
+        if 3 * ((h // 16) ** 2 + (h // 32) ** 2) == rows:
             return get_engine(device, h, h, classes, 3)
     for h in range(32, 2049, 32):
-        for w in range(32, 385, 32):
+        for w in range(32, 2049, 32):
             if 3 * ((h // 16) * (w // 16) + (h // 32) * (w // 32)) == rows:
                 return get_engine(device, h, w, classes, 3)
     raise ValueError("cannot infer the input size from %d decode rows" % rows)
