@@ -78,7 +78,7 @@ struct yfv2_ctx {
   Buf s2pp;  // stage 2 in pair planes: two buffers back to back, [2][max_batch][24 pairs][H/8][W/8][2]
   // pair-plane bookkeeping at the END of stage 2 (for the stride-2 consumer and for yfv2_debug_activation)
   bool s2_px = false;
-  bool stem_pp = false;     // the stem writes pair planes [12][H/4][W/4][2] (consumed by s2px_kernel)
+  bool stem_pp = false;     // the stem writes channel planes for stage2.0's streaming kernels: quad planes [6][H/4][W/4][4] (stem_h3 -> s2h_kernel), pair planes [12][H/4][W/4][2] on the YFV2_BF6=0 plan (stem_px -> s2px kernels)
   int s2_label[48] = {0};   // logical channel stored in slot 2*pair + element
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
   bool bf6 = true;          // pointwise convs on the bf16 matrix cores where a kernel has that form (YFV2_BF6=0 at create time: fp32 MFMA)
@@ -2458,7 +2458,20 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
     return n;
   }
   if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
-  if (which == 0 && h->stem_pp) {  // stem output in pair planes [12][PH*PW][2] -> NHWC
+  if (which == 0 && h->stem_pp && h->bf6) {  // stem output in quad planes [6][PH*PW][4] (stem_h3 / stem_h3u kernels) -> NHWC
+    const size_t per = h->dbg_per_img[0], hw = per / 24;
+    std::vector<float> tmp((size_t)n);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(tmp.data(), h->dbg[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+      fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");
+      return YFV2_ERR_DEVICE;
+    }
+    for (int b = 0; b < B; ++b)
+      for (int q = 0; q < 6; ++q)
+        for (size_t px = 0; px < hw; ++px)
+          for (int e = 0; e < 4; ++e) host_dst[((size_t)b * hw + px) * 24 + 4 * q + e] = tmp[(size_t)b * per + ((size_t)q * hw + px) * 4 + e];
+    return n;
+  }
+  if (which == 0 && h->stem_pp) {  // stem output in pair planes [12][PH*PW][2] (stem_px_kernel, YFV2_BF6=0) -> NHWC
     const size_t per = h->dbg_per_img[0], hw = per / 24;
     std::vector<float> tmp((size_t)n);
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(tmp.data(), h->dbg[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {

@@ -68,26 +68,58 @@ __device__ __forceinline__ void yfv2_compact_row(const DecodeArgs& a, int b, int
       best[an] = -INFINITY;
       bj[an] = 0x7fffffff;
     }
+    // conf = max_j fl32(fl32(e_j / sum) * obj) and its FIRST maximal j (utils.py:261,267).  The map e -> fl32(fl32(e / sum) * obj)
+    // is non-decreasing (division by and multiplication with a non-negative constant, round to nearest), and the largest
+    // exponential is exactly 1 (its logit IS the maximum), so conf = fl32(fl32(1 / sum) * obj) - one division per cell instead
+    // of one per class - and a class can only tie with it if its exponential is within two roundings of 1: >= 1 - 2^-20 is
+    // a safe superset while the products are normal numbers.  Round 4: this sweep was a division, three multiplications and
+    // three compare-selects per class, two thirds of the launch's decode phase (VALU-bound: 68 k of its 163 k ticks).
+    // One such class in the cell (the usual case): it is the answer for all three anchors.  More than one (a near-tie of two
+    // logits) or a product down among the denormals (ties reach further there; conf <= 2^-100 only matters for
+    // conf_thres <= 0): the exact sweep, as before - rare, so its wave-level divergence costs nothing.
+    const float ev1 = __fdiv_rn(1.0f, sum);
+    int first = 0x7fffffff, cnt = 0;
 #pragma unroll
     for (int i = 0; i < MAXPER; ++i) {
-      if (c_lo + i < c_hi) {
-        const float ev = __fdiv_rn(lv[i], sum);   // the class probability, as decode_kernel<false> stores it
-#pragma unroll
-        for (int an = 0; an < 3; ++an) {
-          const float pj = __fmul_rn(ev, obj3[an]);
-          if (pj > best[an]) { best[an] = pj; bj[an] = c_lo + i; }  // strict: first maximal index of this slice
-        }
-      }
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      const bool near_max = c_lo + i < c_hi && lv[i] >= 0.99999904632568359375f;   // 1 - 2^-20
+      first = near_max ? min(first, c_lo + i) : first;
+      cnt += near_max ? 1 : 0;
     }
+    cnt += __shfl_xor(cnt, 1);
+    cnt += __shfl_xor(cnt, 2);
+    first = min(first, __shfl_xor(first, 1));
+    first = min(first, __shfl_xor(first, 2));
+    bool exact = cnt != 1;
 #pragma unroll
-    for (int an = 0; an < 3; ++an)
+    for (int an = 0; an < 3; ++an) {
+      best[an] = __fmul_rn(ev1, obj3[an]);
+      bj[an] = first;
+      exact |= !(best[an] > 7.888609052210118e-31f);   // 2^-100 (also catches a NaN logit: every comparison false, as in the exact sweep)
+    }
+    if (exact) {   // the four lanes of a cell agree on this (cnt and obj3 are cell-wide)
 #pragma unroll
-      for (int msk = 1; msk < 4; msk <<= 1) {
-        const float ob_ = __shfl_xor(best[an], msk);
-        const int oi = __shfl_xor(bj[an], msk);
-        if (ob_ > best[an] || (ob_ == best[an] && oi < bj[an])) { best[an] = ob_; bj[an] = oi; }
+      for (int an = 0; an < 3; ++an) { best[an] = -INFINITY; bj[an] = 0x7fffffff; }
+#pragma unroll
+      for (int i = 0; i < MAXPER; ++i) {
+        if (c_lo + i < c_hi) {
+          const float ev = __fdiv_rn(lv[i], sum);   // the class probability, as decode_kernel<false> stores it
+#pragma unroll
+          for (int an = 0; an < 3; ++an) {
+            const float pj = __fmul_rn(ev, obj3[an]);
+            if (pj > best[an]) { best[an] = pj; bj[an] = c_lo + i; }  // strict: first maximal index of this slice
+          }
+        }
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int an = 0; an < 3; ++an)
+#pragma unroll
+        for (int msk = 1; msk < 4; msk <<= 1) {
+          const float ob_ = __shfl_xor(best[an], msk);
+          const int oi = __shfl_xor(bj[an], msk);
+          if (ob_ > best[an] || (ob_ == best[an] && oi < bj[an])) { best[an] = ob_; bj[an] = oi; }
+        }
+    }
   }
   const int an = part < 3 ? part : 0;
   const int y = cc / fw, x = cc - y * fw;

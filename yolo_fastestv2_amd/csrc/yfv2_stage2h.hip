@@ -296,31 +296,37 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
   const f32x4 bip[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 32 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 48 + 4 * g)};
   const f32x4 bi2[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 64 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 80 + 4 * g)};
   const float unscale_p = img[S2H_CST + 96], unscale_2 = img[S2H_CST + 97];
-  int loff[4], soff[8];
+  // input: the stem's QUAD planes [6][IH][IW][4] (round 4; yfv2_stem16.hip) - this lane's eight channel positions are plane g
+  // (all lane groups: the stem's channel tile 0) and plane 4 + g (lane groups 0, 1: tile 1), two adjacent pixels of each
+  int loff[2], soff[8];
+  loff[0] = xok ? (g * IH * IW + 2 * ox) * 16 : OOB;
+  loff[1] = (xok && g < 2) ? ((4 + g) * IH * IW + 2 * ox) * 16 : OOB;
   {
     const int* po = reinterpret_cast<const int*>(img + S2H_OFFS);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int v = po[k * 64 + lane]; loff[k] = (xok && v != OOB) ? v + 2 * ox * 8 : OOB; }
-#pragma unroll
     for (int k = 0; k < 8; ++k) { const int v = po[(4 + k) * 64 + lane]; soff[k] = (st_lane && v != OOB) ? v + ox * 8 : OOB; }
   }
-  const int irowb = IW * 8, orowb = OW * 8;
+  const int irowb = IW * 16, orowb = OW * 8;
 
-  // one input row: X[k] = {col 2ox: the pair's two channels ; col 2ox+1: the same}, times 2^4 later
+  // one input row: X[2t + c] = the four channel positions 4t .. 4t+3 of column 2ox + c, times 2^4 later - four 16-byte loads
   auto load_row = [&](int iy, f32x4 (&X)[4]) {
     const bool rok = iy >= 0 && iy < IH;           // wave-uniform
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      X[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rok && loff[k] != OOB) ? loff[k] + iy * irowb : OOB, 0, 0));
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        X[2 * t + c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rok && loff[t] != OOB) ? loff[t] + iy * irowb : OOB, 16 * c, 0));   // (an out-of-range voffset stays out of range)
   };
   // the two branches' depthwise inputs of one input row: raw values x 2^4 (proj) and relu(pw1) x 2^(sw1+4) (main, 0 outside the image)
   auto columns = [&](const f32x4 (&X)[4], float lim, float (&xe)[8], float (&xo)[8], float (&te)[8], float (&to)[8]) {
     f32x2 ine[4], ino[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 v = X[k] * 16.0f;
-      ine[k] = (f32x2){v[0], v[1]}; ino[k] = (f32x2){v[2], v[3]};
-      xe[2 * k] = v[0]; xe[2 * k + 1] = v[1]; xo[2 * k] = v[2]; xo[2 * k + 1] = v[3];
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 ve = X[2 * t] * 16.0f, vo = X[2 * t + 1] * 16.0f;
+      ine[2 * t] = (f32x2){ve[0], ve[1]}; ine[2 * t + 1] = (f32x2){ve[2], ve[3]};
+      ino[2 * t] = (f32x2){vo[0], vo[1]}; ino[2 * t + 1] = (f32x2){vo[2], vo[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xe[4 * t + e] = ve[e]; xo[4 * t + e] = vo[e]; }
     }
     f32x4 ae[2], ao[2];
     pw_h3(w1, ine, sh1, ae, watch);

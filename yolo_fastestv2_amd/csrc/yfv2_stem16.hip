@@ -199,7 +199,11 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
     load2(1, ro0);
     split_row((f32x4){0.f, 0.f, 0.f, 0.f}, carry);
   }
-  float* __restrict__ ob = PPOUT ? a.out + (size_t)b * 24 * PH * PW + ((size_t)py0 * PW + (st_ok ? px : 0)) * 2
+  // PPOUT (round 4): QUAD planes [6][PH][PW][4] - channel tile t of lane group g = channels 16 t + 4 g .. +3 = plane 4 t + g, ONE
+  // 16-byte store per tile.  (Rounds 1-3 wrote 8-byte pair-plane records, two stores per tile: tools/ubench/stem_pattern.hip -
+  // this kernel's loads and stores without its arithmetic - takes 139 us with those and 123 with these; stage2.0's loads,
+  // two pixels of a plane per lane, cost the same from either layout.)
+  float* __restrict__ ob = PPOUT ? a.out + (size_t)b * 24 * PH * PW + ((size_t)py0 * PW + (st_ok ? px : 0)) * 4
                                  : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
   const int ylast = (H >> 1) - 1;
   auto step = [&](int t, const f32x4 (&ce)[2], const f32x4 (&co)[2], f32x4 (&ne)[2], f32x4 (&no)[2]) {
@@ -221,15 +225,13 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
       up[tt] = h1[tt];
       if (st_ok && (tt == 0 || g < 2)) {           // channel tile 1 holds channels 16..23 in lane groups 0, 1
         if constexpr (PPOUT) {
-          const int q = 8 * tt + 2 * g;            // channels 16 tt + 4 g .. +3 = pairs q, q + 1
-          *reinterpret_cast<f32x2*>(ob + (size_t)q * PH * PW * 2) = (f32x2){o[0], o[1]};
-          *reinterpret_cast<f32x2*>(ob + (size_t)(q + 1) * PH * PW * 2) = (f32x2){o[2], o[3]};
+          *reinterpret_cast<f32x4*>(ob + (size_t)(4 * tt + g) * PH * PW * 4) = o;
         } else {
           *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;
         }
       }
     }
-    ob += PPOUT ? (size_t)PW * 2 : (size_t)PW * 24;
+    ob += PPOUT ? (size_t)PW * 4 : (size_t)PW * 24;
   };
   int t = 0;
 #pragma unroll 1
@@ -349,12 +351,12 @@ __global__ __launch_bounds__(64, 4) void stem_h3u_kernel(StemArgs a) {
     load2(1, ro0);
     carry.p01 = carry.p23 = carry.m = 0u;
   }
-  // pair-plane output through a buffer resource: a 32-bit lane offset (plane pair of the lane group; lanes that do not store
+  // plane output through a buffer resource: a 32-bit lane offset (plane pair of the lane group; lanes that do not store
   // carry the out-of-range offset, the store is dropped) + a wave-uniform offset (plane, row) instead of two 64-bit pointers
   float* __restrict__ ob = PPOUT ? nullptr : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
   __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * 24 * PH * PW), 0, 24 * PH * PW * 4, 0x00020000);
-  const int plane = PH * PW * 8;                    // bytes of one pair plane
-  const int ovoff0 = st_ok ? (py0 * PW + px) * 8 + 2 * g * plane : OOB;
+  const int plane = PH * PW * 16;                   // bytes of one quad plane (four channels; see stem_h3_kernel)
+  const int ovoff0 = st_ok ? (py0 * PW + px) * 16 + g * plane : OOB;
   const int ovoff1 = g < 2 ? ovoff0 : OOB;         // channel tile 1 holds channels 16..23 in lane groups 0, 1
   int osoff = 0;
   const int ylast = (H >> 1) - 1;
@@ -375,15 +377,14 @@ __global__ __launch_bounds__(64, 4) void stem_h3u_kernel(StemArgs a) {
         o[e] = __builtin_fmaxf(m, 0.f) * unscale;
       }
       up[tt] = h1[tt];
-      if constexpr (PPOUT) {                         // channels 16 tt + 4 g .. +3 = pair planes 8 tt + 2 g, + 1
+      if constexpr (PPOUT) {                         // channels 16 tt + 4 g .. +3 = quad plane 4 tt + g
         const int vo = tt ? ovoff1 : ovoff0;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(yfv2_u2, (f32x2){o[0], o[1]}), orsrc, vo, osoff + 8 * tt * plane, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(yfv2_u2, (f32x2){o[2], o[3]}), orsrc, vo, osoff + (8 * tt + 1) * plane, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, vo, osoff + 4 * tt * plane, 0);
       } else if (st_ok && (tt == 0 || g < 2)) {
         *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;
       }
     }
-    if constexpr (PPOUT) osoff += PW * 8; else ob += (size_t)PW * 24;
+    if constexpr (PPOUT) osoff += PW * 16; else ob += (size_t)PW * 24;
   };
   int t = 0;
 #pragma unroll 1
