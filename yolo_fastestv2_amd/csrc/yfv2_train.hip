@@ -289,6 +289,235 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
   p[i] = p[i] - lr * bb;
 }
 
+
+// ---- round 4: the pointwise (1x1, stride 1) convolutions - 51 of the 79 convs and 73 % of the step's arithmetic - as GEMMs on
+// the fp32 matrix instruction (v_mfma_f32_16x16x4_f32), straight on the NCHW views (channel planes are contiguous pixel runs).
+// Round 3 ran them on conv_fwd / conv_bwd_data / conv_bwd_weight_kernel above: one thread per output element looping over the
+// channels, one BLOCK per filter entry for the weight gradient (every block re-read the whole activation and gradient: 250-300 us
+// per layer whatever its size) - 13.6 + 21.2 ms of the 42 ms iteration at batch 64 (rocprofv3, tools/train_probe.py).
+typedef float yfv2_f4 __attribute__((ext_vector_type(4)));
+
+// out[b][r][p] (+)= sum_k Wm(r, k) in[b][k][p] (+ bias[r]);  Wm(r, k) = TRANS ? w[k * wld + r] : w[r * wld + k]
+//   forward:        in = x,     out = y,      w = (Cout, Cin), wld = Cin
+//   data gradient:  in = dy,    out = dx (+=), TRANS, w = the same (Cout, Cin) array, wld = Cin: dx[ci] += sum_co w[co][ci] dy[co]
+// A wave = one image x 64 pixels x up to four 16-row tiles of output channels; lane (l, g): B operand = in[k0 + g][p0 + 16 e + l]
+// for the four pixel tiles e (four coalesced dword loads), A operand = Wm(16 t + l, k0 + g); D lane (l, g) reg r = out row
+// 16 t + 4 g + r, pixel p0 + 16 e + l.
+template <bool TRANS, bool ACCUM>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(V in, V out, const float* __restrict__ w, const float* __restrict__ bias, int wld, int B) {
+  constexpr int MT = 4;
+  const int HW = out.H * out.W, K = in.C, M = out.C;
+  const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  const int p0 = (blockIdx.x * 4 + wave) * 64, b = blockIdx.y, r0 = blockIdx.z * (16 * MT);
+  if (p0 >= HW) return;
+  yfv2_f4 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = (yfv2_f4){0.f, 0.f, 0.f, 0.f};
+  const float* inb = in.p + ((size_t)b * in.Ctot + in.coff) * HW;
+  const size_t kstride = (size_t)in.cstride * HW;
+  // the operands of step k0 + 4 are requested before the sixteen MFMAs of step k0 run (one global round trip per step otherwise:
+  // the loop has 6 .. 72 steps and nothing else to hide it behind)
+  auto fetch = [&](int k0, float (&bv)[4], float (&av)[MT]) {
+    const int k = k0 + g;
+    const bool kok = k < K;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int p = p0 + 16 * e + l; bv[e] = (kok && p < HW) ? inb[(size_t)k * kstride + p] : 0.f; }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { const int r = r0 + 16 * t + l; av[t] = (kok && r < M) ? (TRANS ? w[(size_t)k * wld + r] : w[(size_t)r * wld + k]) : 0.f; }
+  };
+  auto mac = [&](const float (&bv)[4], const float (&av)[MT]) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[e], acc[t][e], 0, 0, 0);
+  };
+  float b0[4], a0[MT], b1[4], a1[MT];
+  fetch(0, b0, a0);
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    fetch(k0 + 4, b1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(b0, a0);
+    if (k0 + 4 >= K) break;
+    fetch(k0 + 8, b0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(b1, a1);
+  }
+  float* outb = out.p + ((size_t)b * out.Ctot + out.coff) * HW;
+  const size_t rstride = (size_t)out.cstride * HW;
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = r0 + 16 * t + 4 * g + rr;
+      if (r >= M) continue;
+      const float bi = bias ? bias[r] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = p0 + 16 * e + l;
+        if (p < HW) { float* d = outb + (size_t)r * rstride + p; *d = ACCUM ? *d + acc[t][e][rr] : acc[t][e][rr] + bi; }
+      }
+    }
+}
+
+// weight gradient: scratch[co * Cin + ci] += sum over one image's pixel segment of dy[b][co][p] x[b][ci][p] (double atomics: the
+// fp32 accumulation runs over at most `seg` pixels).  A wave = (image, segment, up to 3 x 3 tiles of 16 co x 16 ci); per 16 pixels
+// lane (l, g) holds pixels q + 4 g .. + 3 of channel row l of every tile: MFMA step e contracts pixel q + 4 g + e.
+__global__ __launch_bounds__(64) void pw_wgrad_kernel(V x, V dy, double* __restrict__ scratch, int seg, int ci_blocks) {
+  constexpr int T = 3;
+  const int HW = x.H * x.W, Cin = x.C, Cout = dy.C;
+  const int lane = threadIdx.x, l = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y, q0 = blockIdx.x * seg, q1 = min(HW, q0 + seg);
+  const int co0 = (blockIdx.z / ci_blocks) * (16 * T), ci0 = (blockIdx.z % ci_blocks) * (16 * T);
+  yfv2_f4 acc[T][T];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[i][j] = (yfv2_f4){0.f, 0.f, 0.f, 0.f};
+  const float* xb = x.p + ((size_t)b * x.Ctot + x.coff) * HW;
+  const float* gb = dy.p + ((size_t)b * dy.Ctot + dy.coff) * HW;
+  const size_t xs = (size_t)x.cstride * HW, gs = (size_t)dy.cstride * HW;
+  auto fetch = [&](int q, float (&av)[T][4], float (&bv)[T][4]) {
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const int co = co0 + 16 * i + l, ci = ci0 + 16 * i + l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = q + 4 * g + e;
+        av[i][e] = (co < Cout && p < q1) ? gb[(size_t)co * gs + p] : 0.f;
+        bv[i][e] = (ci < Cin && p < q1) ? xb[(size_t)ci * xs + p] : 0.f;
+      }
+    }
+  };
+  auto mac = [&](const float (&av)[T][4], const float (&bv)[T][4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+  };
+  float a0[T][4], b0[T][4], a1[T][4], b1[T][4];
+  fetch(q0, a0, b0);
+  for (int q = q0; q < q1; q += 32) {
+    fetch(q + 16, a1, b1);                        // (past q1: zeros)
+    __builtin_amdgcn_sched_barrier(0);
+    mac(a0, b0);
+    if (q + 16 >= q1) break;
+    fetch(q + 32, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(a1, b1);
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = co0 + 16 * i + 4 * g + rr, ci = ci0 + 16 * j + l;
+        if (co < Cout && ci < Cin) atomicAdd(&scratch[(size_t)co * Cin + ci], (double)acc[i][j][rr]);
+      }
+}
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(double* scratch, float* dw, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { dw[i] += (float)scratch[i]; scratch[i] = 0.0; }
+}
+
+// the stem's weight gradient (3 x 3, stride 2, pad 1, 3 -> 24 channels, 176 x 176 outputs per image: the longest reduction of
+// the network - 2 M terms per filter entry at batch 64; conv_bwd_weight_kernel: 3.9 ms): a thread walks output pixels with a
+// stride, holds 8 output channels x 9 taps of one input channel as fp32 partial sums over at most 16 pixels, the block meets in
+// LDS, one double atomic per entry and block.  grid (pixel blocks, 3 input channels, 3 groups of 8 output channels)
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(ConvP a, double* __restrict__ scratch) {
+  const int OH = a.out.H, OW = a.out.W, IH = a.in.H, IW = a.in.W;
+  const int ci = blockIdx.y, cog = blockIdx.z;
+  const long long n = (long long)a.B * OH * OW;
+  float acc[8][9];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  const long long i0 = (long long)blockIdx.x * 4096;
+  for (int it = 0; it < 16; ++it) {
+    const long long i = i0 + it * 256 + threadIdx.x;
+    if (i >= n) break;
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), b = (int)(i / ((long long)OW * OH));
+    float xv[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+        xv[ky * 3 + kx] = (iy >= 0 && iy < IH && ix >= 0 && ix < IW) ? a.in.p[a.in.at(b, ci, iy, ix)] : 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float gv = a.out.p[a.out.at(b, 8 * cog + c, oy, ox)];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[c][t] = __builtin_fmaf(gv, xv[t], acc[c][t]);
+    }
+  }
+  __shared__ float red[4][72];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = acc[c][t];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+      if (lane == 0) red[wave][c * 9 + t] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 72) {
+    const int c = threadIdx.x / 9, t = threadIdx.x % 9;
+    const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+    atomicAdd(&scratch[((size_t)(8 * cog + c) * a.in.C + ci) * 9 + t], v);
+  }
+}
+
+
+// depthwise weight gradient (k x k, stride 1 or 2): dW[c][ky][kx] += sum_{b, oy, ox} dy[b][c][oy][ox] x[b][c][s oy - pad + ky][..].
+// grid (pixel blocks of 4096, channels): a thread walks 16 output pixels of its channel with k*k fp32 partial sums, the block
+// meets by wave shuffles + LDS, one double atomic per tap and block (conv_bwd_weight_kernel: a double LDS tree per tap, 98 us per
+// layer at batch 64)
+template <int KS>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(ConvP a, double* __restrict__ scratch) {
+  constexpr int KK = KS * KS;
+  const int OH = a.out.H, OW = a.out.W, IH = a.in.H, IW = a.in.W, c = blockIdx.y;
+  const long long n = (long long)a.B * OH * OW;
+  float acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+  const long long i0 = (long long)blockIdx.x * 4096;
+  for (int it = 0; it < 16; ++it) {
+    const long long i = i0 + it * 256 + threadIdx.x;
+    if (i >= n) break;
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), b = (int)(i / ((long long)OW * OH));
+    const float gv = a.out.p[a.out.at(b, c, oy, ox)];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+        const float xv = (iy >= 0 && iy < IH && ix >= 0 && ix < IW) ? a.in.p[a.in.at(b, c, iy, ix)] : 0.f;
+        acc[ky * KS + kx] = __builtin_fmaf(gv, xv, acc[ky * KS + kx]);
+      }
+  }
+  __shared__ float red[4][KK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    float v = acc[t];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    if (lane == 0) red[wave][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < KK)
+    atomicAdd(&scratch[(size_t)c * KK + threadIdx.x], (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x]);
+}
+
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 struct Tens { size_t off = 0; int C = 0, H = 0, W = 0; };   // offset (floats) into the activation arena; its gradient sits at the same offset of the gradient arena
@@ -300,6 +529,7 @@ struct Train {
   int* pool_arg = nullptr; size_t pool_arg_n = 0;
   double* dscr = nullptr; size_t dscr_n = 0, dscr_used = 0;   // four doubles per BatchNorm channel: sum, sum of squares, the two backward sums (zeroed per forward)
   std::map<std::string, float*> param, pgrad;
+  double* wscr = nullptr; size_t wscr_n = 0;   // double partial sums of one layer's weight gradient (zero between uses: wgrad_finish_kernel)
   std::vector<std::function<void(hipStream_t)>> tape;
   std::map<std::string, V> relu_out;   // conv name -> the view its ReLU wrote (yfv2_debug_train_relu_output)
   std::string err;
@@ -317,6 +547,24 @@ struct Train {
   float* P(const std::string& n) { auto it = param.find(n); if (it == param.end() || !it->second) { if (err.empty()) err = "yfv2_train: tensor '" + n + "' is not bound"; return nullptr; } return it->second; }
   float* G(const std::string& n) { auto it = pgrad.find(n); if (it == pgrad.end() || !it->second) { if (err.empty()) err = "yfv2_train: gradient of '" + n + "' is not bound"; return nullptr; } return it->second; }
 
+  // pointwise conv launchers (round 4): forward / data gradient as one GEMM, weight gradient = GEMM into the double scratch + finish
+  void pw_forward(const V& in, const V& out, const float* w, const float* bias, hipStream_t s) const {
+    const int HW = out.H * out.W;
+    hipLaunchKernelGGL((pw_gemm_kernel<false, false>), dim3((HW + 255) / 256, B, (out.C + 63) / 64), dim3(256), 0, s, in, out, w, bias, in.C, B);
+  }
+  void pw_data_grad(const V& din, const V& dout, const float* w, int Bc, hipStream_t s) const {   // din += w^T dout
+    const int HW = din.H * din.W;
+    hipLaunchKernelGGL((pw_gemm_kernel<true, true>), dim3((HW + 255) / 256, Bc, (din.C + 63) / 64), dim3(256), 0, s, dout, din, w, (const float*)nullptr, din.C, Bc);
+  }
+  void pw_weight_grad(const V& x, const V& dout, float* dw, int Bc, hipStream_t s) const {
+    const int HW = x.H * x.W, cob = (dout.C + 47) / 48, cib = (x.C + 47) / 48;
+    int seg = 256;                                     // pixels per wave: enough waves for the machine, fp32 partial sums over few terms
+    while (seg > 64 && (long long)((HW + seg - 1) / seg) * Bc * cob * cib < 2048) seg >>= 1;
+    hipLaunchKernelGGL(pw_wgrad_kernel, dim3((HW + seg - 1) / seg, Bc, cob * cib), dim3(64), 0, s, x, dout, wscr, seg, cib);
+    const int n = dout.C * x.C;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, wscr, dw, n);
+  }
+
   // conv (no bias) + BatchNorm (batch statistics) [+ ReLU]: in view -> zout view (a channel slice of some tensor)
   void conv_bn(const Tens& tin, int in_coff, int in_cstride, int Cin, const Tens& tout, int out_coff, int Cout, const std::string& conv, const std::string& bn,
                int k, int stride, int pad, bool dw, bool relu, bool need_din, hipStream_t s) {
@@ -329,7 +577,9 @@ struct Train {
     if (!w || !gam || !bet || !rm || !rv || !gw || !gg || !gb) return;
     float* mean = acts + st.off; float* invstd = mean + Cout; float* sums = invstd + Cout;
     ConvP c{view(tin, false, in_coff, in_cstride, Cin), view(y, false), w, nullptr, k, stride, pad, dw ? 1 : 0, B};
-    hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, c);
+    const bool pw = k == 1 && stride == 1 && pad == 0 && !dw;
+    if (pw) pw_forward(c.in, c.out, w, nullptr, s);
+    else hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, c);
     double* ds = dscr + dscr_used; dscr_used += 4 * (size_t)Cout;
     if (dscr_used > dscr_n) { if (err.empty()) err = "yfv2_train: BatchNorm scratch exhausted"; return; }
     const unsigned nseg = reduce_segments((size_t)B * OH * OW, Cout);
@@ -345,10 +595,17 @@ struct Train {
       hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, st2, Cout, ds, sums, gg, gb);
       hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)Bc * Cout * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, Bc, mean, invstd, gam, relu ? 1 : 0, sums);
       ConvP cw{view(tin, false, in_coff, in_cstride, Cin), view(y, true), nullptr, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
-      hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(Cout, dw ? 1 : Cin, reduce_segments((size_t)Bc * OH * OW, (size_t)Cout * (dw ? 1 : Cin))), dim3(256), 0, st2, cw, gw);
+      if (pw) pw_weight_grad(cw.in, cw.out, gw, Bc, st2);
+      else if (dw && (k == 3 || k == 5)) {
+        const dim3 grid((unsigned)(((size_t)Bc * OH * OW + 4095) / 4096), Cout);
+        if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3>), grid, dim3(256), 0, st2, cw, wscr);
+        else hipLaunchKernelGGL((dw_wgrad_kernel<5>), grid, dim3(256), 0, st2, cw, wscr);
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3((Cout * k * k + 255) / 256), dim3(256), 0, st2, wscr, gw, Cout * k * k);
+      } else hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(Cout, dw ? 1 : Cin, reduce_segments((size_t)Bc * OH * OW, (size_t)Cout * (dw ? 1 : Cin))), dim3(256), 0, st2, cw, gw);
       if (need_din) {
         ConvP cd{view(tin, true, in_coff, in_cstride, Cin), view(y, true), w, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
-        hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)Bc * Cin * tin.H * tin.W)), dim3(256), 0, st2, cd);
+        if (pw) pw_data_grad(cd.in, cd.out, w, Bc, st2);
+        else hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)Bc * Cin * tin.H * tin.W)), dim3(256), 0, st2, cd);
       }
     });
   }
@@ -361,8 +618,7 @@ struct Train {
     float* w = P(name + ".weight"); float* bi = P(name + ".bias");
     if (!w || !bi) return;
     V o{out, Cout, 0, 1, Cout, tin.H, tin.W};
-    ConvP c{view(tin, false), o, w, bi, 1, 1, 0, 0, B};
-    hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * tin.H * tin.W)), dim3(256), 0, s, c);
+    pw_forward(view(tin, false), o, w, bi, s);
     heads.push_back(HeadUse{tin, name, Cout, out, nullptr});
   }
 };
@@ -383,6 +639,7 @@ void yfv2_train_release(void* p) {
   if (t->grads) (void)hipFree(t->grads);
   if (t->pool_arg) (void)hipFree(t->pool_arg);
   if (t->dscr) (void)hipFree(t->dscr);
+  if (t->wscr) (void)hipFree(t->wscr);
   delete t;
 }
 
@@ -489,7 +746,8 @@ int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const ou
             hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(256), 0, st2, 24, ds, sums, gg, gb);
             hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, B, mean, invstd, gam, 1, sums);
             ConvP cw{xin, tt->view(y, true), nullptr, nullptr, 3, 2, 1, 0, B};
-            hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(24, 3, reduce_segments((size_t)B * OH * OW, 72)), dim3(256), 0, st2, cw, gw);
+            hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)(((size_t)B * OH * OW + 4095) / 4096), 3, 3), dim3(256), 0, st2, cw, tt->wscr);
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(3), dim3(256), 0, st2, tt->wscr, gw, 24 * 3 * 9);
           });
           // maxpool
           const size_t np = (size_t)B * 24 * (H / 4) * (W / 4);
@@ -602,6 +860,11 @@ int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const ou
   }
   if (hipMemsetAsync(t->dscr, 0, t->dscr_n * sizeof(double), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: memset failed");
   t->dscr_used = 0;
+  if (!t->wscr) {
+    t->wscr_n = (size_t)288 * 256;   // the largest weight matrix: conv1x1_2 (72 x 288); the class head: classes (<= 255) x 72
+    if (hipMalloc(reinterpret_cast<void**>(&t->wscr), t->wscr_n * sizeof(double)) != hipSuccess) { t->wscr = nullptr; return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: out of device memory"); }
+    if (hipMemsetAsync(t->wscr, 0, t->wscr_n * sizeof(double), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: memset failed");
+  }
   build(false);
   if (!t->err.empty()) { t->tape.clear(); return yfv2_ctx_fail(h, YFV2_ERR_WEIGHTS, t->err.c_str()); }
   if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: launch failed");
@@ -623,10 +886,8 @@ int yfv2_train_backward(yfv2_handle h, const float* const grad6[6], void* stream
     if (!w || !gw || !gb) return yfv2_ctx_fail(h, YFV2_ERR_WEIGHTS, t->err.c_str());
     V go{const_cast<float*>(grad6[i]), u.Cout, 0, 1, u.Cout, u.tin.H, u.tin.W};
     hipLaunchKernelGGL(bias_bwd_kernel, dim3(u.Cout), dim3(256), 0, s, go, B, gb);
-    ConvP cw{t->view(u.tin, false), go, nullptr, nullptr, 1, 1, 0, 0, B};
-    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(u.Cout, 72, reduce_segments((size_t)B * u.tin.H * u.tin.W, (size_t)u.Cout * 72)), dim3(256), 0, s, cw, gw);
-    ConvP cd{t->view(u.tin, true), go, w, nullptr, 1, 1, 0, 0, B};
-    hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)B * 72 * u.tin.H * u.tin.W)), dim3(256), 0, s, cd);
+    t->pw_weight_grad(t->view(u.tin, false), go, gw, B, s);
+    t->pw_data_grad(t->view(u.tin, true), go, w, B, s);
   }
   for (size_t i = t->tape.size(); i-- > 0;) t->tape[i](s);
   t->tape.clear(); t->heads.clear();
