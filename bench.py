@@ -222,7 +222,7 @@ def main():
             engs[j].detect(x, a.conf, a.iou, out=sets[j])
     sync()
     # set-up, not a step: bring the device out of its idle power state.  A fresh process runs its first ~25 steps 8-10 % slower
-    # than every later one (tools/stagger_probe.py: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each
+    # than every later one (measured in round 3: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each
     # following 20), which would put a --warmup 5 --steps 20 run entirely inside the ramp.  So the untimed warm-up is
     # max(W, --min-warmup = 80) of the same steps (a fixed COUNT, the same on every rank: the steps hold a collective), then
     # the K timed ones; the count actually run is reported as `warmup_steps_run`.

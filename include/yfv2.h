@@ -213,6 +213,16 @@ YFV2_API int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float*
 YFV2_API int yfv2_train_backward(yfv2_handle h, const float* const grad6[6], void* stream);
 YFV2_API int yfv2_sgd_step(yfv2_handle h, float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                            float weight_decay, int32_t first_step, void* stream);
+/* The same update for MANY parameter tensors in a few launches (the network has 225: one launch each is 225 kernels of two
+ * microseconds and as many gaps).  items: HOST array, one entry per tensor (device pointers inside); the entries travel in the
+ * kernel-argument segment, 96 per launch. */
+typedef struct yfv2_sgd_item {
+  float* param; const float* grad; float* momentum_buf; /* device pointers */
+  int64_t n;                                            /* elements */
+  int32_t first_step; int32_t reserved;                 /* first_step: momentum_buf is uninitialised (buf = d) */
+} yfv2_sgd_item;
+YFV2_API int yfv2_sgd_step_multi(yfv2_handle h, const yfv2_sgd_item* items, int32_t n_items, float lr, float momentum, float weight_decay,
+                                 void* stream);
 
 /* ---- introspection / measurement (bench.py, tests) ------------------------- */
 

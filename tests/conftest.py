@@ -23,7 +23,7 @@ def pytest_configure(config):
 # ---- parity records: the margin counts of the end-to-end tests (how many detections, how many survivor differences, how
 # many of them on a numerical margin, how many unexplained) are part of the evidence, not just pass/fail: tests add them
 # through the `record_parity` fixture, the terminal summary prints them (so they land in every pytest log, -s or not) and
-# they are written to gpurun_out/parity_counts.json (copied to profiles/ by tools/gpu_r3.sh).
+# they are written to gpurun_out/parity_counts.json (copied to profiles/ by tools/gpu_r4.sh).
 PARITY_RECORDS = {}
 
 

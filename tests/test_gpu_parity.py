@@ -1042,3 +1042,29 @@ def test_range_guard_of_the_fp16x3_plan(yfv2, dev, cfg):
         yfv2.handel_preds(m(x.to(dev)), cfg, dev)
     m.load_state_dict(w)
     assert tuple(yfv2.handel_preds(m(x.to(dev)), cfg, dev).shape) == (3, 1815, 85)
+
+
+def test_two_handles_on_two_streams_stay_bit_identical(yfv2, dev, coco_weights, images_u8, cfg):
+    """Two independent handles working at the same time on two streams (what DetectPipeline and the lanes do at batch sizes
+    that fill the machine) must each give what they give alone - uint8 and fp32 input, twelve rounds.  Round 4 found the
+    uint8 stem's 16-byte buffer stores corrupted in 4-5 of 12 such rounds (a store-data WAR hazard hipcc does not cover when
+    the store's soffset is a register: yfv2_internal.h, yfv2_after_wide_buffer_store); one kernel at a time never showed it."""
+    B = 70
+    one = yfv2.Engine(dev, 352, 352, 80, 3, anchors=cfg["anchors"], max_batch=B)
+    two = yfv2.Engine(dev, 352, 352, 80, 3, anchors=cfg["anchors"], max_batch=B)
+    one.load_state_dict(coco_weights); two.load_state_dict(coco_weights)
+    x = _batch_from_reference_images(images_u8, B, seed=77).to(dev)
+    xu = (x * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for src in (xu, x):
+        torch.cuda.synchronize(dev)
+        full = [t.clone() for t in one.forward(src)]
+        for rep in range(12):
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(s1):
+                a = one.forward(src[:35])
+            with torch.cuda.stream(s2):
+                b = two.forward(src[35:])
+            torch.cuda.synchronize(dev)
+            for f, p, q in zip(full, a, b):
+                assert torch.equal(f[:35], p) and torch.equal(f[35:], q), (str(src.dtype), rep)

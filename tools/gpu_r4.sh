@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4 evidence call (as round 3: one tree, one fingerprint): GPU parity tests (+ parity counts), bench line, rocprofv3 kernel stats, SQ counter pass, HBM
 # traffic passes - all on ONE tree, summarised with the tree's source fingerprint so that bench.py can quote them.
-# usage (from the repo root on the GPU box): bash tools/gpu_r3.sh TAG [quick]
+# usage (from the repo root on the GPU box): bash tools/gpu_r4.sh TAG [quick]
 TAG=${1:-r04a}
 MODE=${2:-full}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

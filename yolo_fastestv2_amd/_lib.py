@@ -26,6 +26,10 @@ class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
 
+class SgdItem(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("n", C.c_int64), ("first_step", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Yfv2Error(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libyfv2 error %d: %s" % (code, msg))
@@ -60,6 +64,7 @@ _PROTOTYPES = {
     "yfv2_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),
     "yfv2_train_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "yfv2_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "yfv2_sgd_step_multi": (C.c_int, [C.c_void_p, C.POINTER(SgdItem), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "yfv2_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "yfv2_debug_plan_dryrun": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "yfv2_debug_plan_image": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64]),

@@ -115,6 +115,22 @@ struct Yfv2Watch {
 };
 #endif
 
+// A 16-byte BUFFER store whose soffset is an SGPR needs wait states before a VALU instruction overwrites its data registers.
+// Round 4, measured (two handles on two streams, uint8 input: element 0 of the store of lanes 12..15 of every lane group came
+// back holding the NEXT value of that register, in 4-5 of 12 runs; never with one kernel on the machine at a time): hipcc put
+//     buffer_store_dwordx4 v[2:5], v63, s[12:15], s19 offen ; v_max3_f32 v2, v1, v10, 0
+// back to back at the end of stem_h3u_kernel.  LLVM's hazard recognizer covers "VMEM store of more than 64 bits, then a VALU
+// write of its data" only when soffset is NOT a register (GCNHazardRecognizer::createsVALUHazard); with a register soffset it
+// assumes the hardware is safe, and under back-pressure from a second kernel's memory traffic it is not.  Every such store is
+// followed by yfv2_after_wide_buffer_store(): four wait states nothing may be scheduled into.
+#ifdef __HIPCC__
+__device__ __forceinline__ void yfv2_after_wide_buffer_store() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 3" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
   const void* x;       // fp32 (B,3,H,W) in [0,1], or (u8_in) uint8 (B,H,W,3) in 0..255

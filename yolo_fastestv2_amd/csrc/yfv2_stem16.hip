@@ -380,6 +380,7 @@ __global__ __launch_bounds__(64, 4) void stem_h3u_kernel(StemArgs a) {
       if constexpr (PPOUT) {                         // channels 16 tt + 4 g .. +3 = quad plane 4 tt + g
         const int vo = tt ? ovoff1 : ovoff0;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, vo, osoff + 4 * tt * plane, 0);
+        yfv2_after_wide_buffer_store();   // (the next tile's values are formed in the same registers: yfv2_internal.h)
       } else if (st_ok && (tt == 0 || g < 2)) {
         *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;
       }

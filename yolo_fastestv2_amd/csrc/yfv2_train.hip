@@ -518,6 +518,17 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(ConvP a, double* __restri
     atomicAdd(&scratch[(size_t)c * KK + threadIdx.x], (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x]);
 }
 
+struct SgdChunk { yfv2_sgd_item it[96]; };
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdChunk c, float lr, float momentum, float wd) {
+  const yfv2_sgd_item& t = c.it[blockIdx.y];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= t.n) return;
+  const float d = t.grad[i] + wd * t.param[i];
+  const float bb = t.first_step ? d : momentum * t.momentum_buf[i] + d;
+  t.momentum_buf[i] = bb;
+  t.param[i] = t.param[i] - lr * bb;
+}
+
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 struct Tens { size_t off = 0; int C = 0, H = 0, W = 0; };   // offset (floats) into the activation arena; its gradient sits at the same offset of the gradient arena
@@ -922,6 +933,25 @@ int yfv2_sgd_step(yfv2_handle h, float* param, const float* grad, float* momentu
   hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, momentum_buf, (long long)n, lr, momentum,
                      weight_decay, first_step ? 1 : 0);
   if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_sgd_step: launch failed");
+  return YFV2_OK;
+}
+
+int yfv2_sgd_step_multi(yfv2_handle h, const yfv2_sgd_item* items, int32_t n_items, float lr, float momentum, float weight_decay, void* stream) {
+  if (!h || !items || n_items < 0) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_sgd_step_multi: bad argument");
+  for (int i0 = 0; i0 < n_items; i0 += 96) {
+    SgdChunk c{};
+    const int m = n_items - i0 < 96 ? n_items - i0 : 96;
+    int64_t nmax = 0;
+    for (int k = 0; k < m; ++k) {
+      const yfv2_sgd_item& t = items[i0 + k];
+      if (!t.param || !t.grad || !t.momentum_buf || t.n < 0) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_sgd_step_multi: bad item");
+      c.it[k] = t;
+      if (t.n > nmax) nmax = t.n;
+    }
+    if (nmax == 0) continue;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(blocks_for((size_t)nmax), m), dim3(256), 0, static_cast<hipStream_t>(stream), c, lr, momentum, weight_decay);
+  }
+  if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_sgd_step_multi: launch failed");
   return YFV2_OK;
 }
 

@@ -289,6 +289,10 @@ class Engine:
         check(_lib.lib().yfv2_sgd_step(self._h, _ptr(param), _ptr(grad), _ptr(buf), param.numel(), float(lr), float(momentum), float(weight_decay),
                                        1 if first else 0, _stream(self.device)), self._h)
 
+    def sgd_step_multi(self, items, lr, momentum, weight_decay):
+        """items: a prepared (SgdItem * n) table (see utils/optim.py) - one entry per parameter tensor, a few launches in all."""
+        check(_lib.lib().yfv2_sgd_step_multi(self._h, items, len(items), float(lr), float(momentum), float(weight_decay), _stream(self.device)), self._h)
+
     def stats_overflowed(self):
         """Waits for the stream; True if any batch_statistics(sync=False) call since the last query met an image with
         more than 1024 targets (its flags are then invalid).  Clears the flag."""

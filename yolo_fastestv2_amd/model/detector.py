@@ -84,23 +84,38 @@ def state_spec(classes, anchor_num):
 
 
 class _TrainForward(torch.autograd.Function):
-    """Detector.forward in train() mode: forward = yfv2_train_forward, backward = yfv2_train_backward (train.py:105-110)."""
+    """Detector.forward in train() mode: forward = yfv2_train_forward, backward = yfv2_train_backward (train.py:105-110).
+
+    Gradients without copies: the library ADDS every parameter's gradient into a bound buffer; those buffers are views of one
+    flat work bucket (zeroed per backward, all-reduced once under data_parallel()), which is then copied / added into a second,
+    persistent bucket that the parameters' ``.grad`` tensors are views of - two kernels per backward where 225 ``clone()`` calls
+    and autograd's per-parameter accumulation used to be.  ``.grad`` set to None (``optimizer.zero_grad()``) or replaced by the
+    caller is handled: a missing one becomes a view again, a foreign tensor is added into."""
 
     @staticmethod
     def forward(ctx, module, x, *params):
         eng = module.engine_for(x, sync=False)
         names = module._train_names()
         state = {k: v for k, v in module.state_dict(keep_vars=True).items() if v.is_floating_point()}
-        for k, v in state.items():
-            if v.device != x.device or v.dtype != torch.float32 or not v.is_contiguous():
-                raise RuntimeError("training needs every parameter / buffer as a contiguous fp32 tensor on %s ('%s' is not): model.to(device).float()" % (x.device, k))
-        flat = torch.zeros(sum(state[k].numel() for k in names), device=x.device, dtype=torch.float32)
-        views, off = {}, 0
-        for k in names:
-            n = state[k].numel()
-            views[k] = flat[off:off + n].view_as(state[k])
-            off += n
-        eng.train_bind({k: v.data for k, v in state.items()}, views)
+        key = (id(eng), str(x.device)) + tuple(v.data_ptr() for v in state.values())
+        bound = module.__dict__.get("_train_bound")
+        if bound is None or bound["key"] != key:
+            for k, v in state.items():
+                if v.device != x.device or v.dtype != torch.float32 or not v.is_contiguous():
+                    raise RuntimeError("training needs every parameter / buffer as a contiguous fp32 tensor on %s ('%s' is not): model.to(device).float()" % (x.device, k))
+            total = sum(state[k].numel() for k in names)
+            work = torch.zeros(total, device=x.device, dtype=torch.float32)
+            keep = torch.zeros(total, device=x.device, dtype=torch.float32)
+
+            def views_of(flat):
+                out, off = {}, 0
+                for k in names:
+                    n = state[k].numel()
+                    out[k] = flat[off:off + n].view_as(state[k])
+                    off += n
+                return out
+            bound = module.__dict__["_train_bound"] = {"key": key, "work": work, "keep": keep, "work_views": views_of(work), "keep_views": views_of(keep)}
+            eng.train_bind({k: v.data for k, v in state.items()}, bound["work_views"])
         outs = eng.train_forward(x)
         ctx.x = getattr(eng, "_train_x", x)         # the tensor the library really reads again in backward (see Engine.train_forward)
         # the BatchNorm running statistics were just moved through raw pointers (no autograd version bump): every packed
@@ -111,7 +126,7 @@ class _TrainForward(torch.autograd.Function):
                 nb = mod._buffers.get("num_batches_tracked")
                 if nb is not None:
                     nb += 1
-        ctx.eng, ctx.seq, ctx.flat, ctx.views, ctx.names, ctx.dp = eng, eng._train_seq, flat, views, names, module._dp
+        ctx.eng, ctx.seq, ctx.module, ctx.bound, ctx.names, ctx.dp = eng, eng._train_seq, module, bound, names, module._dp
         return outs
 
     @staticmethod
@@ -119,11 +134,34 @@ class _TrainForward(torch.autograd.Function):
         if ctx.eng._train_seq != ctx.seq:
             raise RuntimeError("Detector (train mode): backward must follow the forward that produced these logits - another "
                                "train-mode forward ran on this engine in between")
-        ctx.flat.zero_()
-        ctx.eng.train_backward([g if g is not None else torch.zeros(s, device=ctx.flat.device) for g, s in zip(g6, ctx.eng.logit_shapes(g6[0].shape[0]))])
+        b = ctx.bound
+        work, keep = b["work"], b["keep"]
+        work.zero_()
+        ctx.eng.train_backward([g if g is not None else torch.zeros(s, device=work.device) for g, s in zip(g6, ctx.eng.logit_shapes(g6[0].shape[0]))])
         if ctx.dp is not None:       # data parallel: one all-reduce over the whole gradient bucket (sharded.average_gradients_)
-            average_gradients_(ctx.flat, group=ctx.dp[0], force=ctx.dp[1])
-        return (None, None) + tuple(ctx.views[k].clone() for k in ctx.names)
+            average_gradients_(work, group=ctx.dp[0], force=ctx.dp[1])
+        params = dict(ctx.module.named_parameters())
+        mine = {k: params[k].grad is not None and params[k].grad.data_ptr() == b["keep_views"][k].data_ptr() and params[k].grad.shape == b["keep_views"][k].shape
+                for k in ctx.names}
+        if all(mine.values()):
+            keep.add_(work)                          # accumulation over `subdivisions` batches (train.py:122), one kernel
+        else:
+            foreign = {k: params[k].grad for k in ctx.names if params[k].grad is not None and not mine[k]}
+            if any(mine.values()):                   # a mixed state: keep what is there, parameter by parameter
+                for k in ctx.names:
+                    if mine[k]:
+                        b["keep_views"][k].add_(b["work_views"][k])
+                    else:
+                        b["keep_views"][k].copy_(b["work_views"][k])
+            else:
+                keep.copy_(work)
+            for k in ctx.names:
+                if not mine[k]:
+                    if k in foreign:                 # somebody else's gradient tensor: add ours, as autograd would
+                        foreign[k].add_(b["keep_views"][k])
+                    else:
+                        params[k].grad = b["keep_views"][k]
+        return (None, None) + (None,) * len(ctx.names)
 
 
 class _Node(nn.Module):

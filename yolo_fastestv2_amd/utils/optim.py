@@ -1,9 +1,11 @@
 """torch.optim.SGD as train.py:81-85 builds it (momentum 0.949, weight_decay 0.0005, dampening 0, no Nesterov), stepping the
-parameters with libyfv2's ``yfv2_sgd_step`` kernel: d = g + wd p; buf = d (first step) | momentum buf + d; p -= lr buf.
+parameters with libyfv2's SGD kernel: d = g + wd p; buf = d (first step) | momentum buf + d; p -= lr buf.
 A ``torch.optim.Optimizer`` subclass, so ``param_groups`` (train.py:113-117 rewrites ``lr`` during the warm-up) and
-``torch.optim.lr_scheduler.MultiStepLR`` (train.py:88-90) work on it unchanged."""
+``torch.optim.lr_scheduler.MultiStepLR`` (train.py:88-90) work on it unchanged.  All tensors of a parameter group travel in one
+table (``yfv2_sgd_step_multi``): three launches for the network's 225 tensors instead of 225."""
 import torch
 
+from .. import _lib
 from ..engine import get_engine
 
 
@@ -20,6 +22,7 @@ class SGD(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
+            todo = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -29,9 +32,26 @@ class SGD(torch.optim.Optimizer):
                 first = "momentum_buffer" not in st
                 if first:
                     st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                eng = get_engine(p.device, 32, 32, 1, 3)          # any handle of the device: the kernel only needs its error slot
-                eng.sgd_step(p.data, p.grad.contiguous(), st["momentum_buffer"], group["lr"], group["momentum"], group["weight_decay"], first)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                todo.append((p, g, st["momentum_buffer"], first))
+            if not todo:
+                continue
+            # the table is rebuilt only when a pointer in it changed (gradients that are views of the Detector's persistent
+            # bucket keep their addresses from step to step)
+            key = tuple((p.data_ptr(), g.data_ptr(), b.data_ptr(), first) for p, g, b, first in todo)
+            cache = group.setdefault("_yfv2_table", {})
+            if cache.get("key") != key:
+                items = (_lib.SgdItem * len(todo))()
+                for i, (p, g, b, first) in enumerate(todo):
+                    items[i].param, items[i].grad, items[i].momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()
+                    items[i].n, items[i].first_step = p.numel(), 1 if first else 0
+                cache["key"], cache["items"] = key, items
+            dev = todo[0][0].device
+            eng = get_engine(dev, 32, 32, 1, 3)          # any handle of the device: the kernel only needs its error slot
+            eng.sgd_step_multi(cache["items"], group["lr"], group["momentum"], group["weight_decay"])
+            for p, g, _, _ in todo:
                 # the kernel wrote through the raw pointer: move the autograd version counter as an in-place torch op would,
                 # so that Detector.engine_for() sees the change and re-packs the inference weights on the next eval forward
                 torch._C._increment_version(p)
+                del g
         return loss
