@@ -417,6 +417,37 @@ def main():
                              "the GPU box - the oracle runs the same ATen CPU ops and is bit-identical to the reference's own modules "
                              "where both exist (asserted by tests/golden/make_golden.py)" % (n_img, bs, el, cands)}
 
+        # ---- BASELINE configs[4]: one train.py iteration at batch 64 - train-mode forward, compute_loss,
+        # backward to all 225 parameters, SGD - through the drop-in surface; an extra, never `value`
+        train = None
+        if world == 1:
+            import numpy as np
+            cfg_t = {"anchor_num": 3, "classes": 80, "width": 352, "height": 352, "anchors": ANCHORS}
+            model = yfv2.Detector(80, 3, True).to(dev)
+            model.load_state_dict(yfv2.random_state_dict(1))
+            model.train()
+            opt = yfv2.SGD(params=model.parameters(), lr=1e-3, momentum=0.949, weight_decay=0.0005)
+            Bt = 64
+            rng = np.random.default_rng(Bt)
+            xt = torch.from_numpy(rng.random((Bt, 3, 352, 352), dtype=np.float32)).to(dev)
+            tg = np.zeros((4 * Bt, 6), np.float32)
+            tg[:, 0] = rng.integers(0, Bt, 4 * Bt); tg[:, 1] = rng.integers(0, 80, 4 * Bt)
+            tg[:, 2:4] = rng.random((4 * Bt, 2)) * 0.9 + 0.05; tg[:, 4:6] = rng.random((4 * Bt, 2)) * 0.5 + 0.03
+            tgt = torch.from_numpy(tg).to(dev)
+
+            def train_step():
+                loss = yfv2.compute_loss(model(xt), tgt, cfg_t, dev)[3]
+                loss.backward(); opt.step(); opt.zero_grad()
+            for _ in range(3):
+                train_step()
+            dt_t = timed(train_step, 10, sync, barrier)
+            fl = 3.0 * 212764464.0 * Bt          # forward + data gradients + weight gradients: 3 x SURVEY.md 8(d)'s 212.8 MFLOP per image
+            train = {"batch": Bt, "ms_per_iteration": round(1e3 * dt_t / 10, 3), "img_s": round(Bt * 10 / dt_t, 1),
+                     "algorithmic_tflops": round(fl / (dt_t / 10) / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl / (dt_t / 10) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                     "note": "train.py:96-123 on the device (Detector.train(), compute_loss, backward, yfv2.SGD), fp32 MFMA for the pointwise convs; "
+                             "launch- and pass-count bound (about 900 kernels per iteration: DESIGN.md 4.3), not a throughput path"}
+            del model, opt, xt
+
         out = {
             "metric": "images/sec at 352x352 bs=256 per GPU (forward+decode+NMS)", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
@@ -444,7 +475,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "detections_per_image": {"mean": round(float(cnt_h.mean()), 1), "max": int(cnt_h.max())},
             "forward_launches": len(stages), "forward_sum_of_launch_ms": round(tot_ms, 4), "kernel_table": kernel_table,
-            "coco_e2e": coco,
+            "coco_e2e": coco, "train_iteration": train,
         }
         print(json.dumps(out), flush=True)
     barrier()
