@@ -82,6 +82,9 @@ constexpr int CH_TBL_FL = 64;
 constexpr int CH6_WP_FL = 3 * 3 * 256;
 constexpr int CH6_IMG_FL = 2 * CH6_WP_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL + CH_TBL_FL;
 
+// row pitch of the patch-parity tile in 16-byte slots: both column parities of a haloed row (2 (PW + 1) slots), = PW mod 16
+__host__ __device__ constexpr int s1chain_pitch(int PW) { return 2 * (PW + 1) + ((PW - 2 * (PW + 1)) % 16 + 16) % 16; }
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args a) {
   constexpr int C2 = 48;
@@ -97,26 +100,35 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   const float* WD = IM + 2 * CH6_WP_FL;
   const float* CS = WD + Cfg::DW_FL;
   const int H = a.H, W = a.W, HW = H * W, NB = a.nblk;
-  const int RP = W + 1;
-  const int PL = ((H + 2) * RP + 1 + 15) & ~15;
-  const float invRP = 1.0f / (float)RP;
+  // Tile geometry (round 4): a lane owns a 2x2 PATCH of pixels - its four pixel tiles nt = 2 dy + dx are the patch's four pixels -
+  // so that phase B's depthwise reads the patch's 4x4 window once (16 quads for four outputs instead of 36) and a chunk's taps
+  // once for all four.  A plane is kept as [row parity][haloed row / 2][column parity][haloed column / 2] (the towers'
+  // layout, yfv2_towerh.hip): every read or write instruction addresses ONE parity pair, where consecutive lanes = consecutive
+  // patches sit in consecutive 16-byte slots; the row pitch is = PW mod 16, so that the 16 lanes ds_read_b128 is serviced
+  // in stay on 16 different slot residues when they wrap into the next patch row.
+  const int PH = H >> 1, PW = W >> 1;
+  const int CP1 = PW + 1;                                   // slots of one column parity (haloed columns 0 .. 2 PW + 1)
+  const int RPT = s1chain_pitch(PW);
+  const int PL = 2 * (PH + 1) * RPT;                        // slots per plane
+  const float invPW = 1.0f / (float)PW;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const int s_first = RP + 1;
-  const int n_slots = (H - 1) * RP + W;                   // <= 16 * NT * NW (launcher)
   YFV2_WSTAMP(0);
 
   for (int i = tid; i < NQ * PL; i += THREADS) reinterpret_cast<f32x4*>(T1)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};  // halo rows / columns stay zero
 
+  const int patch = 16 * wave + p;
+  const bool pvalid = patch < PH * PW;
+  const int pi = pvalid ? yfv2_fdiv(patch, invPW) : 0, pj = pvalid ? patch - pi * PW : 0;
+  // haloed row hr -> (hr & 1) * (PH + 1) + (hr >> 1), haloed column hc -> (hc & 1) * CP1 + (hc >> 1); pixel (r, c) = haloed (r + 1, c + 1)
+  const int wbase = pi * RPT + pj;                          // window position (0, 0) = haloed (2 pi, 2 pj): both parities 0
   int sl[NT], pix[NT];
   bool valid[NT], real[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int q = 16 * (wave + NW * nt) + p;
-    valid[nt] = q < n_slots;
-    sl[nt] = s_first + (valid[nt] ? q : n_slots - 1);
-    const int r1 = yfv2_fdiv(sl[nt], invRP), xs = sl[nt] - r1 * RP;
-    real[nt] = valid[nt] && xs >= 1;                      // column 0 of a haloed row is the shared zero column
-    pix[nt] = real[nt] ? (r1 - 1) * W + (xs - 1) : 0;
+    const int dy = nt >> 1, dx = nt & 1;                    // haloed row 2 pi + dy + 1, haloed column 2 pj + dx + 1
+    sl[nt] = wbase + ((dy ^ 1) * (PH + 1) + dy) * RPT + (dx ^ 1) * CP1 + dx;
+    valid[nt] = pvalid; real[nt] = pvalid;
+    pix[nt] = pvalid ? (2 * pi + dy) * W + 2 * pj + dx : 0;
   }
   float* Tg = T1 + (size_t)g * PL * 4;                    // plane of quad g; quad 4 s + g is 4 s planes further
   // (a slot index goes through an opaque register wherever an LDS address is formed from it: addresses hoisted out of the
@@ -151,14 +163,14 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
     b.s = __builtin_bit_cast(yfv2_h8c, (u32x4){l[2][0], l[2][1], h[2][0], h[2][1]});
     return b;
   };
-  // acc[n] += W[mt] x B[n] for two pixel tiles: five products, the small ones first, the two tiles interleaved (the three
-  // filter operands of ONE output tile in registers at a time)
-  auto mfma9 = [&](const float* WP, int mt, const BOps (&b)[2], f32x4 (&acc)[2]) __attribute__((always_inline)) {
+  // acc[n] += W[mt] x B[n] for the lane's four pixel tiles: five products, the small ones first, the tiles interleaved (the
+  // three filter operands of ONE output tile in registers at a time, read once for all four tiles)
+  auto mfma9 = [&](const float* WP, int mt, const BOps (&b)[NT], f32x4 (&acc)[NT]) __attribute__((always_inline)) {
     const float* wq = WP + ((mt * 3) * 64 + lane) * 4;
     const u32x4 q1 = *reinterpret_cast<const u32x4*>(wq), q2 = *reinterpret_cast<const u32x4*>(wq + 256), qs = *reinterpret_cast<const u32x4*>(wq + 512);
     const yfv2_h8c w1p = __builtin_bit_cast(yfv2_h8c, q1), w2p = __builtin_bit_cast(yfv2_h8c, q2), ws = __builtin_bit_cast(yfv2_h8c, qs);
     const yfv2_h8c wm = __builtin_bit_cast(yfv2_h8c, (u32x4){0u, 0u, qs[0], qs[1]});
-#define CH6_EACH(EXPR) _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[n] = EXPR;
+#define CH6_EACH(EXPR) _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n] = EXPR;
     CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(w1p, b[n].p2, acc[n], 0, 0, 0))
     CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(w2p, b[n].p1, acc[n], 0, 0, 0))
     CH6_EACH(__builtin_amdgcn_mfma_f32_16x16x32_f16(ws, b[n].s, acc[n], 0, 0, 0))
@@ -168,94 +180,101 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   };
 
   auto phase_a = [&]() __attribute__((always_inline)) {
+    BOps b[NT];
+    int slo[NT];
 #pragma unroll
-    for (int tp = 0; tp < NT / 2; ++tp) {
-      if (16 * (wave + NW * (2 * tp)) >= n_slots) continue;   // wave-uniform: neither tile of the pair exists
-      BOps b[2];
-      const int slo[2] = {opq(sl[2 * tp]), opq(sl[2 * tp + 1])};
+    for (int n = 0; n < NT; ++n) slo[n] = opq(sl[n]);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        f32x4 bf[KC];
+    for (int n = 0; n < NT; ++n) {
+      f32x4 bf[KC];
 #pragma unroll
-        for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + slo[n]) * 4);
-        b[n] = make_b(bf[0], bf[1], bf[2]);
-      }
+      for (int s2 = 0; s2 < KC; ++s2) bf[s2] = *reinterpret_cast<const f32x4*>(Tg + ((size_t)(4 * s2) * PL + slo[n]) * 4);
+      b[n] = make_b(bf[0], bf[1], bf[2]);
+    }
 #pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        mfma9(W1P, mt, b, acc);
-        if (mt == 0) { watch.see(acc[0][0]); watch.see(acc[1][0]); }
-        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
-        const f32x4 sh1 = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+    for (int mt = 0; mt < KC; ++mt) {
+      f32x4 acc[NT];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const int nt = 2 * tp + n;
-          if (valid[nt]) {
-            f32x4 y;
+      for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mfma9(W1P, mt, b, acc);
+      if (mt == 0) { watch.see(acc[0][0]); watch.see(acc[1][0]); watch.see(acc[2][0]); watch.see(acc[3][0]); }
+      const f32x4 sc1 = *reinterpret_cast<const f32x4*>(CS + 0 * KC * 16 + 16 * mt + 4 * g);
+      const f32x4 sh1 = *reinterpret_cast<const f32x4*>(CS + 1 * KC * 16 + 16 * mt + 4 * g);
+      if (pvalid) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float uu = __builtin_fmaf(acc[n][c], sc1[c], sh1[c]);
-              y[c] = (real[nt] && uu > 0.f) ? uu : 0.f;     // the zero column stays zero (depthwise padding)
-            }
-            // (in place: a tile's three input quads were read above, before its first output quad is stored - and only this
-            // lane reads or writes this slot in phase A)
-            *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + slo[n]) * 4) = y;
+        for (int n = 0; n < NT; ++n) {
+          f32x4 y;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float uu = __builtin_fmaf(acc[n][c], sc1[c], sh1[c]);
+            y[c] = uu > 0.f ? uu : 0.f;
           }
+          // (in place: the lane's twelve input quads were read above, before its first output quad is stored - and only this
+          // lane reads or writes these slots in phase A)
+          *reinterpret_cast<f32x4*>(T1 + ((size_t)(4 * mt + g) * PL + slo[n]) * 4) = y;
         }
-        __builtin_amdgcn_sched_barrier(0);                  // one output tile's operands at a time
       }
+      __builtin_amdgcn_sched_barrier(0);                  // one output tile's operands at a time
     }
   };
+  // window row wr (haloed row 2 pi + wr) / column wc of the patch, as slot offsets from wbase: wave-uniform
+  const int wro[4] = {0, (PH + 1) * RPT, RPT, (PH + 2) * RPT};
+  const int wco[4] = {0, CP1, 1, CP1 + 1};
   auto phase_b = [&](f32x4 (&bo)[KC][NT]) __attribute__((always_inline)) {
+    f32x4 dwv[KC][NT];
+    const int wb = opq(wbase);
 #pragma unroll
-    for (int tp = 0; tp < NT / 2; ++tp) {
+    for (int s = 0; s < KC; ++s) {
+      const int cb = 16 * s + 4 * g;
+      f32x4 wl[9];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);   // once per chunk, for the four outputs
+      const f32x4 lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
+      const f32x4 lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+      const float* pl = Tg + ((size_t)(4 * s) * PL + wb) * 4;
+      f32x4 d[NT];
 #pragma unroll
-        for (int mt = 0; mt < KC; ++mt) bo[mt][2 * tp + n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (16 * (wave + NW * (2 * tp)) >= n_slots) continue;   // wave-uniform
-      f32x4 dwv[KC][2];
-      const int slo[2] = {opq(sl[2 * tp]), opq(sl[2 * tp + 1])};
+      for (int n = 0; n < NT; ++n) d[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int cb = 16 * s + 4 * g;
-        f32x4 wl[9];
+      for (int wr = 0; wr < 4; ++wr) {
+        f32x4 row[4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wl[k] = *reinterpret_cast<const f32x4*>(WD + k * KC * 16 + cb);   // once per pair of tiles
-        const f32x4 lsc = *reinterpret_cast<const f32x4*>(CS + 2 * KC * 16 + cb);
-        const f32x4 lsh = *reinterpret_cast<const f32x4*>(CS + 3 * KC * 16 + cb);
+        for (int wc = 0; wc < 4; ++wc) row[wc] = *reinterpret_cast<const f32x4*>(pl + (size_t)(wro[wr] + wco[wc]) * 4);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const float* win0 = Tg + (size_t)(slo[n] - RP - 1) * 4;
-          f32x4 win[9];
+        for (int dy = 0; dy < 2; ++dy) {
+          const int ky = wr - dy;
+          if (ky < 0 || ky > 2) continue;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) win[k] = *reinterpret_cast<const f32x4*>(win0 + ((size_t)(4 * s) * PL + (k / 3) * RP + (k % 3)) * 4);
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+          for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-          for (int k = 0; k < 9; ++k) d = __builtin_elementwise_fma(win[k], wl[k], d);   // packed: two v_pk_fma_f32 per tap
-          dwv[s][n] = __builtin_elementwise_fma(d, lsc, lsh);
+            for (int kx = 0; kx < 3; ++kx)
+              d[2 * dy + dx] = __builtin_elementwise_fma(row[dx + kx], wl[3 * ky + kx], d[2 * dy + dx]);   // packed: two v_pk_fma_f32 per tap
         }
-        __builtin_amdgcn_sched_barrier(0);                  // one chunk's taps and windows at a time
       }
-      BOps b[2];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) b[n] = make_b(dwv[0][n], dwv[1][n], dwv[2][n]);
+      for (int n = 0; n < NT; ++n) dwv[s][n] = __builtin_elementwise_fma(d[n], lsc, lsh);
+      __builtin_amdgcn_sched_barrier(0);                  // one chunk's taps and window at a time
+    }
+    BOps b[NT];
 #pragma unroll
-      for (int mt = 0; mt < KC; ++mt) {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        mfma9(W2P, mt, b, acc);
-        if (mt == 0) { watch.see(acc[0][0]); watch.see(acc[1][0]); }
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
+    for (int n = 0; n < NT; ++n) b[n] = make_b(dwv[0][n], dwv[1][n], dwv[2][n]);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+    for (int mt = 0; mt < KC; ++mt) {
+      f32x4 acc[NT];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float u = __builtin_fmaf(acc[n][k], sc[k], sh[k]);
-            bo[mt][2 * tp + n][k] = u > 0.f ? u : 0.f;
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mfma9(W2P, mt, b, acc);
+      if (mt == 0) { watch.see(acc[0][0]); watch.see(acc[1][0]); watch.see(acc[2][0]); watch.see(acc[3][0]); }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 4 * KC * 16 + 16 * mt + 4 * g);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 5 * KC * 16 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = __builtin_fmaf(acc[n][k], sc[k], sh[k]);
+          bo[mt][n][k] = u > 0.f ? u : 0.f;
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // the three quads of the next block's branch input (planes g, 4 + g, 8 + g) at this lane's slots
@@ -417,15 +436,15 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
 }
 
 static long s1chain_lds_floats(int H, int W) {
-  const long pl = (((long)(H + 2) * (W + 1) + 1 + 15) & ~15L);
+  const long pl = 2L * (H / 2 + 1) * s1chain_pitch(W / 2);   // 16-byte slots per plane: [row parity][haloed row / 2][pitch]
   return (long)CH6_IMG_FL + 12L * pl * 4;
 }
 
 int yfv2_s1chain_image_floats() { return CH6_IMG_FL; }
 
 bool yfv2_s1chain_supported(int c2, int H, int W) {
-  if (c2 != 48 || H < 2) return false;
-  if ((H - 1) * (W + 1) + W > 16 * 4 * 8) return false;   // slots <= 4 tiles x 8 waves
+  if (c2 != 48 || H < 2 || (H & 1) || (W & 1)) return false;
+  if ((H / 2) * (W / 2) > 16 * 8) return false;            // one 2x2 patch per (wave, lane & 15): 8 waves
   return s1chain_lds_floats(H, W) * 4 <= 160 * 1024;
 }
 
