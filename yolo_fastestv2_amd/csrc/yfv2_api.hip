@@ -1293,6 +1293,8 @@ struct PlanBuilder {
     s.s1.in = x.p; s.s1.out = y.p;
     s.s1.H = H; s.s1.W = W; s.s1.R = H; s.s1.nblk = NB;
     s.s1.presplit = 1;
+    s.s1.park = h->t1.p;     // a temporary of the layer-by-layer blocks: nothing else runs while the chain does
+    if ((size_t)yfv2_s1chain_park_floats(H, W, NB) > h->t1.per_img) ok = false;
     s.img_off = wp.put(im);
     s.name = names.front() + " .. " + names.back().substr(names.back().rfind('.') + 1) + " chain of " + std::to_string(NB) +
              " fused s1 blocks in one launch (activations between them stay on chip)";

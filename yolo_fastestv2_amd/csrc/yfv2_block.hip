@@ -121,6 +121,12 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   const int pi = pvalid ? yfv2_fdiv(patch, invPW) : 0, pj = pvalid ? patch - pi * PW : 0;
   // haloed row hr -> (hr & 1) * (PH + 1) + (hr >> 1), haloed column hc -> (hc & 1) * CP1 + (hc >> 1); pixel (r, c) = haloed (r + 1, c + 1)
   const int wbase = pi * RPT + pj;                          // window position (0, 0) = haloed (2 pi, 2 pj): both parities 0
+  // Parked values (see above) that a later block consumes - positions 0 .. NPARK of Z - do not go to Z any more (round 4) but to a
+  // scratch laid out for the lanes: [position][patch][the patch's four pixels], ONE 16-byte store / load per lane and position
+  // (16 lanes = 256 contiguous bytes) where the NHWC positions of Z took four dword accesses to four different lines.  Values
+  // no block consumes (positions >= NPARK) are still stored at their final place in Z.
+  const int NPARK = 12 * (NB - 2);
+  const int PP4 = ((PH * PW + 15) & ~15) * 4;
   int sl[NT], pix[NT];
   bool valid[NT], real[NT];
 #pragma unroll
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const float* ximg = a.in + (size_t)b * HW * C;
     float* zimg = a.out + (size_t)b * HW * C;
+    float* pimg = a.park + (size_t)b * NPARK * PP4;       // this image's park scratch: [position 0 .. NPARK)[patch][4 pixels of the patch]
     // ---- everything this image needs from memory up front is requested at once: the image of block 0, and X
     float hold2[6][NT];                                   // X[16 c + 4 g + 2]: branch input 4 c + g of the second block
     {
@@ -345,9 +352,14 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const int pos = tbl(3 + c);
+        if (pvalid) {
+          if (pos < NPARK) {
+            *reinterpret_cast<f32x4*>(pimg + (size_t)pos * PP4 + 4 * patch) = (f32x4){xq[0][c][0], xq[1][c][0], xq[2][c][0], xq[3][c][0]};
+          } else {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          if (real[nt]) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
+            for (int nt = 0; nt < NT; ++nt) zimg[(size_t)pix[nt] * C + pos] = xq[nt][c][0];
+          }
+        }
       }
     }
     YFV2_WSTAMP(1);
@@ -374,14 +386,19 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
       const int ps0 = tbl(0), ps1 = tbl(1), ps2 = tbl(2);   // this block's park positions: read before the tables are replaced
       f32x4 n2[NI2];
       part_issue(kb + 1, P1_4, P2_4, n2);                 // the rest of the next image flies during phase B
-      float plv[3][NT];
+      float plq[3][NT];                                   // parked input i of the patch's pixel nt (consumed in the exchange)
       if constexpr (!FIRST) {
-        // the three parked inputs of the next block (group kb - 1 of Z: parked two or more blocks ago), used in the exchange
+        // the three parked inputs of the next block (group kb - 1: parked two or more blocks ago), used in the exchange
+        if (more) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float* zp = zimg + (size_t)pix[nt] * C + 12 * (kb - 1) + 3 * g;
+          for (int i = 0; i < 3; ++i) {
+            // FOUR dword loads of the 16-byte record, through opaque offsets so that they are not merged into one: a
+            // 4-register tuple held across phase B gets split by the register allocator - v_movs behind a vmcnt(0), i.e.
+            // every wave waiting out the load latency here (measured: +19 us per launch)
+            const float* rec = pimg + (size_t)(12 * (kb - 1) + 3 * g + i) * PP4;
 #pragma unroll
-          for (int i = 0; i < 3; ++i) plv[i][nt] = zp[i];   // (halo slots: pixel 0's values, zeroed by write_tile; last block: unused)
+            for (int nt = 0; nt < NT; ++nt) plq[i][nt] = rec[opq(4 * patch + nt)];   // (lanes without a patch: in bounds, unused)
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -399,16 +416,24 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
                          (f32x4){hold2[4][nt], hold2[5][nt], bo[0][nt][1], bo[0][nt][3]},
                          (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
             else
-              write_tile(nt, (f32x4){Hd[0][nt], Hd[1][nt], Hd[2][nt], plv[0][nt]},
-                         (f32x4){plv[1][nt], plv[2][nt], bo[0][nt][1], bo[0][nt][3]},
+              write_tile(nt, (f32x4){Hd[0][nt], Hd[1][nt], Hd[2][nt], plq[0][nt]},
+                         (f32x4){plq[1][nt], plq[2][nt], bo[0][nt][1], bo[0][nt][3]},
                          (f32x4){bo[1][nt][1], bo[1][nt][3], bo[2][nt][1], bo[2][nt][3]});
-            if (real[nt]) {
-              float* zp = zimg + (size_t)pix[nt] * C;
-              zp[ps0] = bo[0][nt][2]; zp[ps1] = bo[1][nt][2]; zp[ps2] = bo[2][nt][2];
-            }
           }
 #pragma unroll
           for (int mt = 0; mt < KC; ++mt) Hd[mt][nt] = bo[mt][nt][0];
+        }
+        if (pvalid) {   // elements 2: parked for the block after next (one 16-byte store per position), or - nobody consumes them - at their final place
+          const int ps[3] = {ps0, ps1, ps2};
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            if (ps[i] < NPARK) {
+              *reinterpret_cast<f32x4*>(pimg + (size_t)ps[i] * PP4 + 4 * patch) = (f32x4){bo[i][0][2], bo[i][1][2], bo[i][2][2], bo[i][3][2]};
+            } else {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) zimg[(size_t)pix[nt] * C + ps[i]] = bo[i][nt][2];
+            }
+          }
         }
         lds_barrier();
         if (kb == 1) YFV2_WSTAMP(9);
@@ -440,11 +465,14 @@ static long s1chain_lds_floats(int H, int W) {
   return (long)CH6_IMG_FL + 12L * pl * 4;
 }
 
+long yfv2_s1chain_park_floats(int H, int W, int nblk) { return 12L * (nblk - 2) * ((((H / 2) * (W / 2) + 15) & ~15) * 4); }
+
 int yfv2_s1chain_image_floats() { return CH6_IMG_FL; }
 
 bool yfv2_s1chain_supported(int c2, int H, int W) {
   if (c2 != 48 || H < 2 || (H & 1) || (W & 1)) return false;
   if ((H / 2) * (W / 2) > 16 * 8) return false;            // one 2x2 patch per (wave, lane & 15): 8 waves
+  if (yfv2_s1chain_park_floats(H, W, 7) > 24L * (4 * H) * (4 * W)) return false;   // the park scratch is a stem-sized temporary (yfv2_api.hip: t1)
   return s1chain_lds_floats(H, W) * 4 <= 160 * 1024;
 }
 

@@ -200,12 +200,14 @@ struct BlockS1Args {
   int nblk;          // block_s1chain_kernel: blocks in the chain (img = their images back to back)
   int presplit;      // block_s1pool_kernel: the images hold W1 / W2 pre-split for bf16x6 (yfv2_s1pool_image_floats(true) floats each)
   int* nonfinite;    // range-guard word (Yfv2Watch), or null
+  float* park;       // block_s1chain6_kernel: scratch for the parked values, yfv2_s1chain_park_floats() floats per image (any dead buffer)
 };
 
 // chain of N stride-1 blocks in one launch (block_s1chain6_kernel, C2 = 48, bf16x6 pointwise convs on host-pre-split
 // filters); see PlanBuilder::s1chain_block for the channel bookkeeping shared by host and kernel
 bool yfv2_s1chain_supported(int c2, int H, int W);
 int yfv2_s1chain_image_floats();                                    // floats per block image (incl. the two int tables)
+long yfv2_s1chain_park_floats(int H, int W, int nblk);              // park scratch per image
 bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s);
 // chain of stride-1 blocks with the whole 192-channel activation resident in LDS (block_s1pool_kernel, stage 4 at 11x11):
 // natural channel order, no bookkeeping; img = per block three images of yfv2_s1pool_image_floats() floats (one per third)
