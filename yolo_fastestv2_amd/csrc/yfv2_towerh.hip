@@ -334,9 +334,15 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
       // channels) - both operands have the same lane layout, so this is the same registers with the arguments swapped - and
       // lane (c = lane & 15, g) ends up with pixels 4g..4g+3 of the tile for ONE channel: a 16-byte run of the NCHW tensor.
       const bool vec = (HW & 3) == 0;                                       // (alignment of every channel plane)
+      // (both plane pointers in scalar registers BEFORE the lane-dependent choice: left to itself the compiler turns the choice
+      // between two kernel-argument fields into ONE vector load from a chosen address - a full load latency in front of every
+      // output tile's stores)
+      float* hn0 = ja.nchw0; float* hn1 = ja.nchw1;
+      asm volatile("" : "+s"(hn0), "+s"(hn1));
+      const int hmh = ja.mh, hsplit = ja.split;
 #pragma unroll 1
       for (int m = 0; m < MH; ++m) {
-        if (16 * m >= ja.mh) break;
+        if (16 * m >= hmh) break;
         u32x4 wf[KC];
 #pragma unroll
         for (int s = 0; s < KC; ++s) wf[s] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
@@ -356,9 +362,9 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) watch.see((hacc[nt][0] + hacc[nt][1]) + (hacc[nt][2] + hacc[nt][3]));   // transposed: a lane's four values are four PIXELS
         const int co = 16 * m + p;
-        if (co < ja.mh) {
+        if (co < hmh) {
           const float bias = CS[2 * 96 + co];
-          float* plane = co < ja.split ? ja.nchw0 + ((size_t)b * ja.split + co) * HW : ja.nchw1 + ((size_t)b * (ja.mh - ja.split) + (co - ja.split)) * HW;
+          float* plane = co < hsplit ? hn0 + ((size_t)b * hsplit + co) * HW : hn1 + ((size_t)b * (hmh - hsplit) + (co - hsplit)) * HW;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int px0 = 16 * (wv * NT + nt) + 4 * g;
@@ -558,9 +564,15 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
       for (int sc = 0; sc < KC; ++sc) xs[sc] = split4(acc[sc] * 16.0f);
       const float us = CS[3 * 96];
       const bool vec = (HW & 3) == 0;
+      // (both plane pointers in scalar registers BEFORE the lane-dependent choice: left to itself the compiler turns the choice
+      // between two kernel-argument fields into ONE vector load from a chosen address - a full load latency in front of every
+      // output tile's stores)
+      float* hn0 = ja.nchw0; float* hn1 = ja.nchw1;
+      asm volatile("" : "+s"(hn0), "+s"(hn1));
+      const int hmh = ja.mh, hsplit = ja.split;
 #pragma unroll 1
       for (int m = 0; m < MH; ++m) {
-        if (16 * m >= ja.mh) break;
+        if (16 * m >= hmh) break;
         u32x4 wf[KC];
 #pragma unroll
         for (int sc = 0; sc < KC; ++sc) wf[sc] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + sc) * 64 + lane) * 4);
@@ -572,9 +584,9 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
         hacc = mfma_main1(xs[KC - 1], wf[KC - 1], hacc);
         watch.see((hacc[0] + hacc[1]) + (hacc[2] + hacc[3]));      // transposed: a lane's four values are four PIXELS
         const int co = 16 * m + p;
-        if (co < ja.mh) {
+        if (co < hmh) {
           const float bias = CS[2 * 96 + co];
-          float* plane = co < ja.split ? ja.nchw0 + ((size_t)b * ja.split + co) * HW : ja.nchw1 + ((size_t)b * (ja.mh - ja.split) + (co - ja.split)) * HW;
+          float* plane = co < hsplit ? hn0 + ((size_t)b * hsplit + co) * HW : hn1 + ((size_t)b * (hmh - hsplit) + (co - hsplit)) * HW;
           const int px0 = 16 * wv + 4 * g;
           f32x4 y;
 #pragma unroll
