@@ -5,6 +5,7 @@
 //   bit 0: loads      bit 1: stores      bit 2: strips of 16 pooled columns on 256-byte boundaries instead of 15 (240-byte stride)
 //   bit 3: NHWC-24 output with 16-byte stores instead of pair planes
 //   bit 4: pair planes padded to 96 columns per row, strips of 16 -> every store instruction writes whole aligned 128-byte lines
+//   bit 5: quad planes (what the kernel does since round 4)      bit 6: non-temporal loads      bit 7: non-temporal stores
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -12,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int V>
 __global__ __launch_bounds__(64, 3) void k(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int R) {
-  constexpr bool LD = V & 1, ST = V & 2, AL = (V & 4) || (V & 16), NHWC = V & 8, PADPP = V & 16, QUAD = V & 32;
+  constexpr bool LD = V & 1, ST = V & 2, AL = (V & 4) || (V & 16), NHWC = V & 8, PADPP = V & 16, QUAD = V & 32, NTL = V & 64, NTS = V & 128;
   const int PH = H >> 2, PW = W >> 2;
   const int SW = AL ? 16 : 15;
   const int strips = AL ? (PW + 15) / 16 : (PW - 1 + 14) / 15;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(64, 3) void k(const float* __restrict__ x, float* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = min(4 * y + r, H - 1);
-      v[r] = (LD && ldl) ? *reinterpret_cast<const f32x4*>(src + (size_t)row * W) : (f32x4){1.f, 2.f, 3.f, 4.f};
+      v[r] = (LD && ldl) ? (NTL ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)row * W)) : *reinterpret_cast<const f32x4*>(src + (size_t)row * W)) : (f32x4){1.f, 2.f, 3.f, 4.f};
     }
   };
   load4(py0, cur);
@@ -57,8 +58,13 @@ __global__ __launch_bounds__(64, 3) void k(const float* __restrict__ x, float* _
         ob += (size_t)PW * 24;
       } else if (QUAD) {   // [6 planes of four channels][PH][PW][4]: one 16-byte store per channel tile
         if (st_ok) {
+          if (NTS) {
+            __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(ob + (size_t)g * PH * PW * 4));
+            if (g < 2) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(ob + (size_t)(4 + g) * PH * PW * 4));
+          } else {
           *reinterpret_cast<f32x4*>(ob + (size_t)g * PH * PW * 4) = acc;
           if (g < 2) *reinterpret_cast<f32x4*>(ob + (size_t)(4 + g) * PH * PW * 4) = acc;
+          }
         }
         ob += (size_t)PW * 4;
       } else {
@@ -77,11 +83,21 @@ __global__ __launch_bounds__(64, 3) void k(const float* __restrict__ x, float* _
   }
   if (!ST && acc[0] == 12345.678f) out[lane] = acc[1];   // keep the loads alive
 }
+template <int NT>
 __global__ void copyk(const f32x4* __restrict__ a, f32x4* __restrict__ o, size_t nin, size_t nout) {   // the same byte counts, fully coalesced
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
   f32x4 s = {0, 0, 0, 0};
-  for (size_t j = i; j < nin; j += n) s += a[j];
-  for (size_t j = i; j < nout; j += n) o[j] = s;
+  for (size_t j = i; j < nin; j += n) s += (NT & 1) ? __builtin_nontemporal_load(a + j) : a[j];
+  for (size_t j = i; j < nout; j += n) { if (NT & 2) __builtin_nontemporal_store(s, o + j); else o[j] = s; }
+}
+// reads and writes interleaved per thread (two quads in, one out), as a streaming kernel with a 2:1 ratio does it
+template <int NT>
+__global__ void copyk2(const f32x4* __restrict__ a, f32x4* __restrict__ o, size_t nout) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = i; j < nout; j += n) {
+    const f32x4 u = (NT & 1) ? __builtin_nontemporal_load(a + 2 * j) : a[2 * j], v = (NT & 1) ? __builtin_nontemporal_load(a + 2 * j + 1) : a[2 * j + 1];
+    if (NT & 2) __builtin_nontemporal_store(u + v, o + j); else o[j] = u + v;
+  }
 }
 template <int V> float run(const float* x, float* out, int B, int H, int W, int iters) {
   const int PH = H / 4, PW = W / 4, R = 11;
@@ -161,14 +177,28 @@ int main() {
     printf("15-column strips, QUAD planes (16-byte stores)     loads+stores %6.1f us                       stores only %6.1f\n", run<35>(x, out, B, H, W, 20), run<34>(x, out, B, H, W, 20));
     printf("16-column strips, pair planes padded to 96 columns loads+stores %6.1f us                      stores only %6.1f\n", run<19>(x, out, B, H, W, 20), run<18>(x, out, B, H, W, 20));
     printf("stage2.0's pattern (190 MB in, 95 MB out): input in pair planes %6.1f us   in quad planes %6.1f us\n", run2<0>(out, x, B, 20), run2<1>(out, x, B, 20));
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("QUAD planes with non-temporal loads %6.1f us   stores %6.1f   both %6.1f\n", run<35 + 64>(x, out, B, H, W, 20), run<35 + 128>(x, out, B, H, W, 20), run<35 + 192>(x, out, B, H, W, 20));
+    printf("non-temporal loads ALONE: 15-column strips %6.1f us   16-column strips %6.1f;   16-column strips + NHWC-24 stores, non-temporal loads %6.1f\n",
+           run<1 + 64>(x, out, B, H, W, 20), run<5 + 64>(x, out, B, H, W, 20), run<15 + 64>(x, out, B, H, W, 20));
     const size_t n4i = nin / 4, n4o = (size_t)B * 24 * 88 * 88 / 4;
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(copyk, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4i, n4o);
-    hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(copyk, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4i, n4o);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    printf("plain streaming kernel, the same 381 MB in + 190 MB out: %6.1f us\n", 1e3f * ms / 20);
+    auto timeit = [&](auto launch) {
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int i = 0; i < 3; ++i) launch();
+      hipEventRecord(e0);
+      for (int i = 0; i < 20; ++i) launch();
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+      return 1e3f * ms / 20;
+    };
+    const float c0 = timeit([&] { hipLaunchKernelGGL(copyk<0>, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4i, n4o); });
+    const float c1 = timeit([&] { hipLaunchKernelGGL(copyk<1>, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4i, n4o); });
+    const float c2 = timeit([&] { hipLaunchKernelGGL(copyk<2>, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4i, n4o); });
+    const float c3 = timeit([&] { hipLaunchKernelGGL(copyk<3>, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4i, n4o); });
+    printf("plain streaming kernel, the same 381 MB in + 190 MB out: %6.1f us   nt loads %6.1f   nt stores %6.1f   both %6.1f\n", c0, c1, c2, c3);
+    const float d0 = timeit([&] { hipLaunchKernelGGL(copyk2<0>, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4o); });
+    const float d3 = timeit([&] { hipLaunchKernelGGL(copyk2<3>, dim3(256 * 8), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4o); });
+    const float d4 = timeit([&] { hipLaunchKernelGGL(copyk2<0>, dim3(256 * 32), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)out, n4o); });
+    printf("the same bytes with reads and writes interleaved per thread: %6.1f us   non-temporal %6.1f   four times the workgroups %6.1f\n", d0, d3, d4);
   }
   return 0;
 }
