@@ -15,6 +15,7 @@
 // the CALLER's device tensors in the reference's own layouts ((co, ci, k, k), (c,)): nothing is copied or re-laid-out.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -63,6 +64,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP a) {
       }
   }
   a.out.p[a.out.at(b, co, oy, ox)] = acc;
+}
+
+// The stem conv (3 x 3, stride 2, pad 1, 3 -> 24 channels): conv_fwd_kernel read its 27 inputs once per OUTPUT CHANNEL (0.96 ms at
+// batch 64); here a thread owns an output pixel, reads them once and keeps the 24 sums in registers - the same fmaf chain per
+// channel (input channel, then row, then column; padded taps skipped), the filter through the scalar cache.
+__global__ __launch_bounds__(256) void stem_fwd_kernel(ConvP a) {
+  const int OH = a.out.H, OW = a.out.W, IH = a.in.H, IW = a.in.W;
+  const size_t n = (size_t)a.B * OH * OW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ox = i % OW, oy = (i / OW) % OH, b = i / ((size_t)OW * OH);
+  float acc[24];
+#pragma unroll
+  for (int co = 0; co < 24; ++co) acc[co] = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= IH) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= IW) continue;
+        const float v = a.in.p[a.in.at(b, ci, iy, ix)];
+#pragma unroll
+        for (int co = 0; co < 24; ++co) acc[co] = __builtin_fmaf(a.w[((co * 3 + ci) * 3 + ky) * 3 + kx], v, acc[co]);
+      }
+    }
+#pragma unroll
+  for (int co = 0; co < 24; ++co) a.out.p[a.out.at(b, co, oy, ox)] = acc[co];
 }
 
 // d in += conv^T(d out): a.in = gradient view of the input (accumulated into), a.out = gradient of the output
@@ -159,25 +190,41 @@ __global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* y, int 
   for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; } __syncthreads(); }
   if (threadIdx.x == 0) { atomicAdd(&acc[4 * c + 0], r0[0]); atomicAdd(&acc[4 * c + 1], r1[0]); }
 }
-// mean, 1 / sqrt(biased variance + eps) (variance = E[y^2] - mean^2 in double: the inputs are fp32), running statistics
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(int C, int n, const double* acc, float* mean, float* invstd, float* run_mean, float* run_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const double m = acc[4 * c] / n;
-  double var = acc[4 * c + 1] / n - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / sqrt(var + 1e-5));
-  run_mean[c] = (float)(0.9 * (double)run_mean[c] + 0.1 * m);
-  run_var[c] = (float)(0.9 * (double)run_var[c] + 0.1 * (n > 1 ? var * n / (n - 1) : var));
-}
-
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, V z, int B, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu) {
-  const int HW = z.H * z.W;
-  const size_t n = (size_t)B * z.C * HW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+// mean, 1 / sqrt(biased variance + eps) (variance = E[y^2] - mean^2 in double: the inputs are fp32), running statistics - folded
+// into the apply kernel (round 4: it was a launch of its own per layer): a block of 256 consecutive NCHW elements touches at
+// most BN_CH channels (H * W >= 1), its first threads finish those channels' statistics into LDS; the block that holds a
+// channel's FIRST element (image 0) also stores mean / invstd for the backward pass and moves the running statistics - exactly
+// once per channel and forward.
+constexpr int BN_CH = 258;   // channels a block of 256 elements can touch when H * W == 1 (+ slack)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, V z, int B, const double* acc, float* mean, float* invstd, float* run_mean, float* run_var,
+                                                       const float* gamma, const float* beta, int relu) {
+  __shared__ float s_mean[BN_CH], s_inv[BN_CH], s_gamma[BN_CH], s_beta[BN_CH];
+  const int HW = z.H * z.W, C = z.C;
+  const size_t n = (size_t)B * C * HW, i0 = (size_t)blockIdx.x * 256, i = i0 + threadIdx.x;
+  const size_t ilast = i0 + 255 < n ? i0 + 255 : n - 1;
+  const size_t ch0 = i0 / HW, nch = ilast / HW - ch0 + 1;               // (image, channel) planes this block touches
+  const int nb = B * HW;
+  for (size_t k = threadIdx.x; k < nch; k += 256) {
+    const int c = (int)((ch0 + k) % C);
+    const double m = acc[4 * c] / nb;
+    double var = acc[4 * c + 1] / nb - m * m;
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)m, fi = (float)(1.0 / sqrt(var + 1e-5));
+    s_mean[k] = fm; s_inv[k] = fi; s_gamma[k] = gamma[c]; s_beta[k] = beta[c];
+    if (ch0 + k < (size_t)C) {                                            // this plane belongs to image 0: the channel's one writer
+      const size_t first = (ch0 + k) * HW;
+      if (first >= i0 && first <= ilast) {
+        mean[c] = fm; invstd[c] = fi;
+        run_mean[c] = (float)(0.9 * (double)run_mean[c] + 0.1 * m);
+        run_var[c] = (float)(0.9 * (double)run_var[c] + 0.1 * (nb > 1 ? var * nb / (nb - 1) : var));
+      }
+    }
+  }
+  __syncthreads();
   if (i >= n) return;
-  const int c = (i / HW) % z.C, b = i / ((size_t)HW * z.C), r = i % HW;
-  float v = (y[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+  const size_t pl = i / HW;
+  const int k = (int)(pl - ch0), c = (int)(pl % C), b = (int)(pl / C), r = (int)(i - pl * HW);
+  float v = (y[i] - s_mean[k]) * s_inv[k] * s_gamma[k] + s_beta[k];
   if (relu && !(v > 0.f)) v = 0.f;
   z.p[z.at(b, c, r / z.W, r % z.W)] = v;
 }
@@ -201,24 +248,33 @@ __global__ __launch_bounds__(256) void bn_bwd_part_kernel(const float* y, V z, V
   for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; } __syncthreads(); }
   if (threadIdx.x == 0) { atomicAdd(&acc[4 * c + 2], r0[0]); atomicAdd(&acc[4 * c + 3], r1[0]); }
 }
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(int C, const double* acc, float* sums, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  sums[2 * c] = (float)acc[4 * c + 2]; sums[2 * c + 1] = (float)acc[4 * c + 3];
-  dbeta[c] += (float)acc[4 * c + 2]; dgamma[c] += (float)acc[4 * c + 3];
-}
-
 // dy = gamma * invstd * (dz' - sum(dz') / N - xhat * sum(dz' xhat) / N)   (dy is the conv output's gradient: single consumer, overwritten)
+// The two sums arrive in double (bn_bwd_part_kernel); a block converts those of the channels it touches (as bn_apply_kernel does
+// with the statistics), and the block that holds a channel's first element adds them to d beta / d gamma - once per channel.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* y, V z, V dz, float* dy, int B, const float* mean, const float* invstd, const float* gamma,
-                                                          int relu, const float* sums) {
-  const int HW = z.H * z.W;
-  const size_t n = (size_t)B * z.C * HW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                          int relu, const double* acc, float* dgamma, float* dbeta) {
+  __shared__ float s_mean[BN_CH], s_inv[BN_CH], s_gamma[BN_CH], s_s0[BN_CH], s_s1[BN_CH];
+  const int HW = z.H * z.W, C = z.C;
+  const size_t n = (size_t)B * C * HW, i0 = (size_t)blockIdx.x * 256, i = i0 + threadIdx.x;
+  const size_t ilast = i0 + 255 < n ? i0 + 255 : n - 1;
+  const size_t ch0 = i0 / HW, nch = ilast / HW - ch0 + 1;
+  for (size_t k = threadIdx.x; k < nch; k += 256) {
+    const int c = (int)((ch0 + k) % C);
+    const float s0 = (float)acc[4 * c + 2], s1 = (float)acc[4 * c + 3];
+    s_mean[k] = mean[c]; s_inv[k] = invstd[c]; s_gamma[k] = gamma[c]; s_s0[k] = s0; s_s1[k] = s1;
+    if (ch0 + k < (size_t)C) {
+      const size_t first = (ch0 + k) * HW;
+      if (first >= i0 && first <= ilast) { dbeta[c] += s0; dgamma[c] += s1; }
+    }
+  }
+  __syncthreads();
   if (i >= n) return;
-  const int c = (i / HW) % z.C, b = i / ((size_t)HW * z.C), r = i % HW;
+  const size_t pl = i / HW;
+  const int k = (int)(pl - ch0), c = (int)(pl % C), b = (int)(pl / C), r = (int)(i - pl * HW);
   float g = dz.p[dz.at(b, c, r / z.W, r % z.W)];
   if (relu && !(z.p[z.at(b, c, r / z.W, r % z.W)] > 0.f)) g = 0.f;
-  const float xh = (y[i] - mean[c]) * invstd[c], inv_n = 1.0f / (float)(B * HW);
-  dy[i] = gamma[c] * invstd[c] * (g - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+  const float xh = (y[i] - s_mean[k]) * s_inv[k], inv_n = 1.0f / (float)(B * HW);
+  dy[i] = s_gamma[k] * s_inv[k] * (g - s_s0[k] * inv_n - xh * s_s1[k] * inv_n);
 }
 
 // max_pool2d(3, 2, 1) as ATen's CPU kernel scans it: window rows then columns, a later value replaces the maximum only if it is
@@ -253,7 +309,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dout, con
   for (int oy = iy / 2; oy <= (iy + 1) / 2 && oy < OH; ++oy)
     for (int ox = ix / 2; ox <= (ix + 1) / 2 && ox < OW; ++ox)
       if (arg[plane * OH * OW + oy * OW + ox] == iy * W + ix) acc += dout[plane * OH * OW + oy * OW + ox];
-  dx[i] += acc;
+  dx[i] = acc;   // (the stem's ReLU output has this one consumer; the arena was zeroed)
 }
 
 // dst view (+)= src view, same (C, H, W)
@@ -419,9 +475,14 @@ __global__ __launch_bounds__(64) void pw_wgrad_kernel(V x, V dy, double* __restr
         if (co < Cout && ci < Cin) atomicAdd(&scratch[(size_t)co * Cin + ci], (double)acc[i][j][rr]);
       }
 }
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(double* scratch, float* dw, int n) {
+// Every layer's weight gradient is summed in double in its own range of one scratch (zeroed per backward) and added to the bound
+// gradient tensors by ONE launch at the end of the backward pass (round 4: it was a launch per layer, 79 of them).
+struct FinishItem { const double* scr; float* dw; int n; int pad; };
+struct FinishChunk { FinishItem it[96]; };
+__global__ __launch_bounds__(256) void wgrad_finish_multi_kernel(FinishChunk c) {
+  const FinishItem& t = c.it[blockIdx.y];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { dw[i] += (float)scratch[i]; scratch[i] = 0.0; }
+  if (i < t.n) t.dw[i] += (float)t.scr[i];
 }
 
 // the stem's weight gradient (3 x 3, stride 2, pad 1, 3 -> 24 channels, 176 x 176 outputs per image: the longest reduction of
@@ -540,7 +601,16 @@ struct Train {
   int* pool_arg = nullptr; size_t pool_arg_n = 0;
   double* dscr = nullptr; size_t dscr_n = 0, dscr_used = 0;   // four doubles per BatchNorm channel: sum, sum of squares, the two backward sums (zeroed per forward)
   std::map<std::string, float*> param, pgrad;
-  double* wscr = nullptr; size_t wscr_n = 0;   // double partial sums of one layer's weight gradient (zero between uses: wgrad_finish_kernel)
+  double* wscr = nullptr; size_t wscr_n = 0, wscr_used = 0;   // double partial sums of every layer's weight gradient (zeroed per backward)
+  std::vector<FinishItem> fin;                                // what wgrad_finish_multi_kernel adds where, collected while the tape runs
+  // a layer's range of the scratch; a tensor used twice in one backward (the output convs serve both scales) keeps ONE range
+  double* wgrad_scratch(float* dw, int n) {
+    for (const auto& f : fin) if (f.dw == dw) return const_cast<double*>(f.scr);
+    if (wscr_used + (size_t)n > wscr_n) { if (err.empty()) err = "yfv2_train: weight-gradient scratch exhausted"; return nullptr; }
+    double* p = wscr + wscr_used; wscr_used += ((size_t)n + 1) & ~(size_t)1;
+    fin.push_back(FinishItem{p, dw, n, 0});
+    return p;
+  }
   std::vector<std::function<void(hipStream_t)>> tape;
   std::map<std::string, V> relu_out;   // conv name -> the view its ReLU wrote (yfv2_debug_train_relu_output)
   std::string err;
@@ -567,13 +637,12 @@ struct Train {
     const int HW = din.H * din.W;
     hipLaunchKernelGGL((pw_gemm_kernel<true, true>), dim3((HW + 255) / 256, Bc, (din.C + 63) / 64), dim3(256), 0, s, dout, din, w, (const float*)nullptr, din.C, Bc);
   }
-  void pw_weight_grad(const V& x, const V& dout, float* dw, int Bc, hipStream_t s) const {
+  void pw_weight_grad(const V& x, const V& dout, float* dw, int Bc, hipStream_t s) {
     const int HW = x.H * x.W, cob = (dout.C + 47) / 48, cib = (x.C + 47) / 48;
     int seg = 256;                                     // pixels per wave: enough waves for the machine, fp32 partial sums over few terms
     while (seg > 64 && (long long)((HW + seg - 1) / seg) * Bc * cob * cib < 2048) seg >>= 1;
-    hipLaunchKernelGGL(pw_wgrad_kernel, dim3((HW + seg - 1) / seg, Bc, cob * cib), dim3(64), 0, s, x, dout, wscr, seg, cib);
-    const int n = dout.C * x.C;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, wscr, dw, n);
+    double* scr = wgrad_scratch(dw, dout.C * x.C);
+    if (scr) hipLaunchKernelGGL(pw_wgrad_kernel, dim3((HW + seg - 1) / seg, Bc, cob * cib), dim3(64), 0, s, x, dout, scr, seg, cib);
   }
 
   // conv (no bias) + BatchNorm (batch statistics) [+ ReLU]: in view -> zout view (a channel slice of some tensor)
@@ -595,23 +664,21 @@ struct Train {
     if (dscr_used > dscr_n) { if (err.empty()) err = "yfv2_train: BatchNorm scratch exhausted"; return; }
     const unsigned nseg = reduce_segments((size_t)B * OH * OW, Cout);
     hipLaunchKernelGGL(bn_stats_part_kernel, dim3(Cout, nseg), dim3(256), 0, s, acts + y.off, B, Cout, OH * OW, ds);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, Cout, B * OH * OW, ds, mean, invstd, rm, rv);
     const V z = view(tout, false, out_coff, 1, Cout), dz = view(tout, true, out_coff, 1, Cout);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, acts + y.off, z, B, mean, invstd, gam, bet, relu ? 1 : 0);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, acts + y.off, z, B, ds, mean, invstd, rm, rv, gam, bet, relu ? 1 : 0);
     if (relu) relu_out[conv] = z;
     const int Bc = B;
     tape.push_back([=, this](hipStream_t st2) {
       float* yv = acts + y.off; float* dy = grads + y.off;
       hipLaunchKernelGGL(bn_bwd_part_kernel, dim3(Cout, nseg), dim3(256), 0, st2, yv, z, dz, Bc, mean, invstd, relu ? 1 : 0, ds);
-      hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, st2, Cout, ds, sums, gg, gb);
-      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)Bc * Cout * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, Bc, mean, invstd, gam, relu ? 1 : 0, sums);
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)Bc * Cout * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, Bc, mean, invstd, gam, relu ? 1 : 0, ds, gg, gb);
       ConvP cw{view(tin, false, in_coff, in_cstride, Cin), view(y, true), nullptr, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
       if (pw) pw_weight_grad(cw.in, cw.out, gw, Bc, st2);
       else if (dw && (k == 3 || k == 5)) {
         const dim3 grid((unsigned)(((size_t)Bc * OH * OW + 4095) / 4096), Cout);
-        if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3>), grid, dim3(256), 0, st2, cw, wscr);
-        else hipLaunchKernelGGL((dw_wgrad_kernel<5>), grid, dim3(256), 0, st2, cw, wscr);
-        hipLaunchKernelGGL(wgrad_finish_kernel, dim3((Cout * k * k + 255) / 256), dim3(256), 0, st2, wscr, gw, Cout * k * k);
+        double* scr = wgrad_scratch(gw, Cout * k * k);
+        if (scr && k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3>), grid, dim3(256), 0, st2, cw, scr);
+        else if (scr) hipLaunchKernelGGL((dw_wgrad_kernel<5>), grid, dim3(256), 0, st2, cw, scr);
       } else hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(Cout, dw ? 1 : Cin, reduce_segments((size_t)Bc * OH * OW, (size_t)Cout * (dw ? 1 : Cin))), dim3(256), 0, st2, cw, gw);
       if (need_din) {
         ConvP cd{view(tin, true, in_coff, in_cstride, Cin), view(y, true), w, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
@@ -742,23 +809,21 @@ int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const ou
           float* mean = t->acts + st.off; float* invstd = mean + 24; float* sums = invstd + 24;
           V xin{const_cast<float*>(x), 3, 0, 1, 3, H, W};
           ConvP c{xin, t->view(y, false), w, nullptr, 3, 2, 1, 0, B};
-          hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, c);
+          hipLaunchKernelGGL(stem_fwd_kernel, dim3(blocks_for((size_t)B * OH * OW)), dim3(256), 0, s, c);
           double* ds = t->dscr + t->dscr_used; t->dscr_used += 4 * 24;
           const unsigned nseg = reduce_segments((size_t)B * OH * OW, 24);
           hipLaunchKernelGGL(bn_stats_part_kernel, dim3(24, nseg), dim3(256), 0, s, t->acts + y.off, B, 24, OH * OW, ds);
-          hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(256), 0, s, 24, B * OH * OW, ds, mean, invstd, rm, rv);
           const V z = t->view(stem, false), dz = t->view(stem, true);
-          hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, t->acts + y.off, z, B, mean, invstd, gam, bet, 1);
+          hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, t->acts + y.off, z, B, ds, mean, invstd, rm, rv, gam, bet, 1);
           t->relu_out["backbone.first_conv.0"] = z;
           Train* tt = t;
           t->tape.push_back([=](hipStream_t st2) {
             float* yv = tt->acts + y.off; float* dy = tt->grads + y.off;
             hipLaunchKernelGGL(bn_bwd_part_kernel, dim3(24, nseg), dim3(256), 0, st2, yv, z, dz, B, mean, invstd, 1, ds);
-            hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(256), 0, st2, 24, ds, sums, gg, gb);
-            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, B, mean, invstd, gam, 1, sums);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, B, mean, invstd, gam, 1, ds, gg, gb);
             ConvP cw{xin, tt->view(y, true), nullptr, nullptr, 3, 2, 1, 0, B};
-            hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)(((size_t)B * OH * OW + 4095) / 4096), 3, 3), dim3(256), 0, st2, cw, tt->wscr);
-            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(3), dim3(256), 0, st2, tt->wscr, gw, 24 * 3 * 9);
+            double* scr = tt->wgrad_scratch(gw, 24 * 3 * 9);
+            if (scr) hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)(((size_t)B * OH * OW + 4095) / 4096), 3, 3), dim3(256), 0, st2, cw, scr);
           });
           // maxpool
           const size_t np = (size_t)B * 24 * (H / 4) * (W / 4);
@@ -872,9 +937,8 @@ int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const ou
   if (hipMemsetAsync(t->dscr, 0, t->dscr_n * sizeof(double), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: memset failed");
   t->dscr_used = 0;
   if (!t->wscr) {
-    t->wscr_n = (size_t)288 * 256;   // the largest weight matrix: conv1x1_2 (72 x 288); the class head: classes (<= 255) x 72
+    t->wscr_n = (size_t)1 << 19;   // every conv weight of the network (~0.24 M entries; the class head: classes (<= 255) x 72) in double
     if (hipMalloc(reinterpret_cast<void**>(&t->wscr), t->wscr_n * sizeof(double)) != hipSuccess) { t->wscr = nullptr; return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: out of device memory"); }
-    if (hipMemsetAsync(t->wscr, 0, t->wscr_n * sizeof(double), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_forward: memset failed");
   }
   build(false);
   if (!t->err.empty()) { t->tape.clear(); return yfv2_ctx_fail(h, YFV2_ERR_WEIGHTS, t->err.c_str()); }
@@ -890,6 +954,8 @@ int yfv2_train_backward(yfv2_handle h, const float* const grad6[6], void* stream
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int B = t->B;
   if (hipMemsetAsync(t->grads, 0, t->used * sizeof(float), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_backward: memset failed");
+  if (hipMemsetAsync(t->wscr, 0, t->wscr_n * sizeof(double), s) != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_backward: memset failed");
+  t->wscr_used = 0; t->fin.clear();
   // the output convs: weights shared by the two scales -> their gradients accumulate (the caller zeroed the parameter gradients)
   for (int i = 0; i < 6; ++i) {
     const auto& u = t->heads[i];
@@ -902,6 +968,15 @@ int yfv2_train_backward(yfv2_handle h, const float* const grad6[6], void* stream
   }
   for (size_t i = t->tape.size(); i-- > 0;) t->tape[i](s);
   t->tape.clear(); t->heads.clear();
+  if (!t->err.empty()) return yfv2_ctx_fail(h, YFV2_ERR_STATE, t->err.c_str());
+  for (size_t i0 = 0; i0 < t->fin.size(); i0 += 96) {   // every weight gradient: scratch (double) -> the bound tensors
+    FinishChunk c{};
+    const int m = (int)std::min<size_t>(96, t->fin.size() - i0);
+    int nmax = 0;
+    for (int k = 0; k < m; ++k) { c.it[k] = t->fin[i0 + k]; nmax = std::max(nmax, c.it[k].n); }
+    hipLaunchKernelGGL(wgrad_finish_multi_kernel, dim3(blocks_for((size_t)nmax), m), dim3(256), 0, s, c);
+  }
+  t->fin.clear();
   if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_train_backward: launch failed");
   return YFV2_OK;
 }

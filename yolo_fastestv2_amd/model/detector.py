@@ -121,11 +121,10 @@ class _TrainForward(torch.autograd.Function):
         # the BatchNorm running statistics were just moved through raw pointers (no autograd version bump): every packed
         # inference copy of the weights is stale from here on
         module._synced.clear()
-        with torch.no_grad():
-            for mod in module.modules():
-                nb = mod._buffers.get("num_batches_tracked")
-                if nb is not None:
-                    nb += 1
+        with torch.no_grad():   # one multi-tensor launch for the 73 counters
+            nbs = [mod._buffers["num_batches_tracked"] for mod in module.modules() if mod._buffers.get("num_batches_tracked") is not None]
+            if nbs:
+                torch._foreach_add_(nbs, 1)
         ctx.eng, ctx.seq, ctx.module, ctx.bound, ctx.names, ctx.dp = eng, eng._train_seq, module, bound, names, module._dp
         return outs
 
