@@ -66,6 +66,60 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP a) {
   a.out.p[a.out.at(b, co, oy, ox)] = acc;
 }
 
+// Depthwise convs (3 x 3 and 5 x 5, stride 1 or 2; pad K / 2), forward and data gradient: a block stays inside ONE (image, channel)
+// plane - the filter and the plane bases are wave-uniform, a thread divides once - with the generic kernels' summation order
+// (row, then column; padded taps skipped), so the results are theirs bit for bit.  grid (position chunks of 256, B * C planes)
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(ConvP a) {
+  constexpr int P = K / 2;
+  const int OH = a.out.H, OW = a.out.W, IH = a.in.H, IW = a.in.W, C = a.out.C;
+  const int pl = blockIdx.y, b = pl / C, c = pl - b * C;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= OH * OW) return;
+  const int oy = o / OW, ox = o - oy * OW;
+  const float* ip = a.in.p + a.in.at(b, c, 0, 0);
+  const float* w = a.w + c * K * K;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy * S - P + ky;
+    if (iy < 0 || iy >= IH) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int ix = ox * S - P + kx;
+      if (ix >= 0 && ix < IW) acc = __builtin_fmaf(w[ky * K + kx], ip[iy * IW + ix], acc);
+    }
+  }
+  a.out.p[a.out.at(b, c, 0, 0) + o] = acc;
+}
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(ConvP a) {   // a.in = gradient view of the input (accumulated into), a.out = gradient of the output
+  constexpr int P = K / 2;
+  const int OH = a.out.H, OW = a.out.W, IH = a.in.H, IW = a.in.W, C = a.in.C;
+  const int pl = blockIdx.y, b = pl / C, c = pl - b * C;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= IH * IW) return;
+  const int iy = i / IW, ix = i - iy * IW;
+  const float* gp = a.out.p + a.out.at(b, c, 0, 0);
+  const float* w = a.w + c * K * K;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int ny = iy + P - ky;
+    if (ny < 0 || (S > 1 && (ny % S))) continue;
+    const int oy = ny / S;
+    if (oy >= OH) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int nx = ix + P - kx;
+      if (nx < 0 || (S > 1 && (nx % S))) continue;
+      const int ox = nx / S;
+      if (ox >= OW) continue;
+      acc = __builtin_fmaf(w[ky * K + kx], gp[oy * OW + ox], acc);
+    }
+  }
+  a.in.p[a.in.at(b, c, 0, 0) + i] += acc;
+}
 // The stem conv (3 x 3, stride 2, pad 1, 3 -> 24 channels): conv_fwd_kernel read its 27 inputs once per OUTPUT CHANNEL (0.96 ms at
 // batch 64); here a thread owns an output pixel, reads them once and keeps the 24 sums in registers - the same fmaf chain per
 // channel (input channel, then row, then column; padded taps skipped), the filter through the scalar cache.
@@ -178,30 +232,47 @@ __global__ __launch_bounds__(256) void bias_bwd_kernel(V g, int B, float* db) {
 
 // BatchNorm2d, training mode: per-channel batch mean / biased variance of y (B, C, H, W contiguous); saves mean and
 // 1/sqrt(var + eps); running = 0.9 running + 0.1 (mean | unbiased variance)
+// (All four kernels walk (plane, position) incrementally - no division per element - and the two elementwise ones take 1024
+// elements per block; round 3's forms divided four times per element and spent a launch per layer on the per-channel finish.)
 // per channel and segment: sum and sum of squares of y in double, into acc[4 c + 0, 1] (zeroed per forward)
 __global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* y, int B, int C, int HW, double* acc) {
   __shared__ double r0[256], r1[256];
   const int c = blockIdx.x, n = B * HW, nseg = gridDim.y, len = (n + nseg - 1) / nseg;
   const int i0 = blockIdx.y * len, i1 = i0 + len < n ? i0 + len : n;
   double a0 = 0.0, a1 = 0.0;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) { const double v = (double)y[((size_t)(i / HW) * C + c) * HW + i % HW]; a0 += v; a1 += v * v; }
+  int i = i0 + threadIdx.x;
+  if (i < i1) {
+    int b = i / HW, r = i - b * HW;
+    const size_t pstride = (size_t)C * HW;
+    const float* p = y + ((size_t)b * C + c) * HW;
+    for (; i < i1; i += 256) {
+      const double v = (double)p[r];
+      a0 += v; a1 += v * v;
+      r += 256;
+      while (r >= HW) { r -= HW; p += pstride; }
+    }
+  }
   r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; } __syncthreads(); }
   if (threadIdx.x == 0) { atomicAdd(&acc[4 * c + 0], r0[0]); atomicAdd(&acc[4 * c + 1], r1[0]); }
 }
-// mean, 1 / sqrt(biased variance + eps) (variance = E[y^2] - mean^2 in double: the inputs are fp32), running statistics - folded
-// into the apply kernel (round 4: it was a launch of its own per layer): a block of 256 consecutive NCHW elements touches at
-// most BN_CH channels (H * W >= 1), its first threads finish those channels' statistics into LDS; the block that holds a
-// channel's FIRST element (image 0) also stores mean / invstd for the backward pass and moves the running statistics - exactly
-// once per channel and forward.
-constexpr int BN_CH = 258;   // channels a block of 256 elements can touch when H * W == 1 (+ slack)
+// mean, 1 / sqrt(biased variance + eps) (variance = E[y^2] - mean^2 in double: the inputs are fp32) and the running statistics are
+// finished inside the apply kernel: a block of BN_EPB consecutive NCHW elements touches a few (image, channel) planes, its first
+// threads finish those planes' statistics into LDS; the block that holds a channel's FIRST element (image 0) also stores
+// mean / invstd for the backward pass and moves the running statistics - exactly once per channel and forward.
+constexpr int BN_EPB = 1024, BN_CH = BN_EPB + 2;   // elements per block; planes a block can touch when H * W == 1 (+ slack)
+struct BnWalk {     // (plane, position) of element i0 + tid + 256 j, advanced without divisions
+  size_t pl; int k, c, b, r;
+  __device__ BnWalk(size_t i, size_t ch0, int HW, int C) { pl = i / HW; r = (int)(i - pl * HW); k = (int)(pl - ch0); c = (int)(pl % C); b = (int)(pl / C); }
+  __device__ void step(int HW, int C) { r += 256; while (r >= HW) { r -= HW; ++pl; ++k; if (++c == C) { c = 0; ++b; } } }
+};
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, V z, int B, const double* acc, float* mean, float* invstd, float* run_mean, float* run_var,
                                                        const float* gamma, const float* beta, int relu) {
   __shared__ float s_mean[BN_CH], s_inv[BN_CH], s_gamma[BN_CH], s_beta[BN_CH];
   const int HW = z.H * z.W, C = z.C;
-  const size_t n = (size_t)B * C * HW, i0 = (size_t)blockIdx.x * 256, i = i0 + threadIdx.x;
-  const size_t ilast = i0 + 255 < n ? i0 + 255 : n - 1;
+  const size_t n = (size_t)B * C * HW, i0 = (size_t)blockIdx.x * BN_EPB;
+  const size_t ilast = i0 + BN_EPB - 1 < n ? i0 + BN_EPB - 1 : n - 1;
   const size_t ch0 = i0 / HW, nch = ilast / HW - ch0 + 1;               // (image, channel) planes this block touches
   const int nb = B * HW;
   for (size_t k = threadIdx.x; k < nch; k += 256) {
@@ -221,12 +292,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, V z, int 
     }
   }
   __syncthreads();
-  if (i >= n) return;
-  const size_t pl = i / HW;
-  const int k = (int)(pl - ch0), c = (int)(pl % C), b = (int)(pl / C), r = (int)(i - pl * HW);
-  float v = (y[i] - s_mean[k]) * s_inv[k] * s_gamma[k] + s_beta[k];
-  if (relu && !(v > 0.f)) v = 0.f;
-  z.p[z.at(b, c, r / z.W, r % z.W)] = v;
+  size_t i = i0 + threadIdx.x;
+  if (i > ilast) return;
+  BnWalk w(i, ch0, HW, C);
+  for (; i <= ilast; i += 256) {
+    float v = (y[i] - s_mean[w.k]) * s_inv[w.k] * s_gamma[w.k] + s_beta[w.k];
+    if (relu && !(v > 0.f)) v = 0.f;
+    z.p[z.at(w.b, w.c, 0, 0) + w.r] = v;
+    w.step(HW, C);
+  }
 }
 
 // per channel: sum of dz' and of dz' * xhat (dz' = dz where the ReLU let the value through); -> d beta, d gamma, and the two
@@ -236,12 +310,18 @@ __global__ __launch_bounds__(256) void bn_bwd_part_kernel(const float* y, V z, V
   const int c = blockIdx.x, HW = z.H * z.W, n = B * HW, nseg = gridDim.y, len = (n + nseg - 1) / nseg;
   const int i0 = blockIdx.y * len, i1 = i0 + len < n ? i0 + len : n;
   double a0 = 0.0, a1 = 0.0;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-    const int b = i / HW, r = i % HW;
-    float g = dz.p[dz.at(b, c, r / z.W, r % z.W)];
-    if (relu && !(z.p[z.at(b, c, r / z.W, r % z.W)] > 0.f)) g = 0.f;
-    const float xh = (y[((size_t)b * z.C + c) * HW + r] - mean[c]) * invstd[c];
-    a0 += (double)g; a1 += (double)g * (double)xh;
+  int i = i0 + threadIdx.x;
+  if (i < i1) {
+    int b = i / HW, r = i - b * HW;
+    const float mc = mean[c], ic = invstd[c];
+    for (; i < i1; i += 256) {
+      float g = dz.p[dz.at(b, c, 0, 0) + r];
+      if (relu && !(z.p[z.at(b, c, 0, 0) + r] > 0.f)) g = 0.f;
+      const float xh = (y[((size_t)b * z.C + c) * HW + r] - mc) * ic;
+      a0 += (double)g; a1 += (double)g * (double)xh;
+      r += 256;
+      while (r >= HW) { r -= HW; ++b; }
+    }
   }
   r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
   __syncthreads();
@@ -249,14 +329,14 @@ __global__ __launch_bounds__(256) void bn_bwd_part_kernel(const float* y, V z, V
   if (threadIdx.x == 0) { atomicAdd(&acc[4 * c + 2], r0[0]); atomicAdd(&acc[4 * c + 3], r1[0]); }
 }
 // dy = gamma * invstd * (dz' - sum(dz') / N - xhat * sum(dz' xhat) / N)   (dy is the conv output's gradient: single consumer, overwritten)
-// The two sums arrive in double (bn_bwd_part_kernel); a block converts those of the channels it touches (as bn_apply_kernel does
+// The two sums arrive in double (bn_bwd_part_kernel); a block converts those of the planes it touches (as bn_apply_kernel does
 // with the statistics), and the block that holds a channel's first element adds them to d beta / d gamma - once per channel.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* y, V z, V dz, float* dy, int B, const float* mean, const float* invstd, const float* gamma,
                                                           int relu, const double* acc, float* dgamma, float* dbeta) {
   __shared__ float s_mean[BN_CH], s_inv[BN_CH], s_gamma[BN_CH], s_s0[BN_CH], s_s1[BN_CH];
   const int HW = z.H * z.W, C = z.C;
-  const size_t n = (size_t)B * C * HW, i0 = (size_t)blockIdx.x * 256, i = i0 + threadIdx.x;
-  const size_t ilast = i0 + 255 < n ? i0 + 255 : n - 1;
+  const size_t n = (size_t)B * C * HW, i0 = (size_t)blockIdx.x * BN_EPB;
+  const size_t ilast = i0 + BN_EPB - 1 < n ? i0 + BN_EPB - 1 : n - 1;
   const size_t ch0 = i0 / HW, nch = ilast / HW - ch0 + 1;
   for (size_t k = threadIdx.x; k < nch; k += 256) {
     const int c = (int)((ch0 + k) % C);
@@ -268,13 +348,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* y, V z, 
     }
   }
   __syncthreads();
-  if (i >= n) return;
-  const size_t pl = i / HW;
-  const int k = (int)(pl - ch0), c = (int)(pl % C), b = (int)(pl / C), r = (int)(i - pl * HW);
-  float g = dz.p[dz.at(b, c, r / z.W, r % z.W)];
-  if (relu && !(z.p[z.at(b, c, r / z.W, r % z.W)] > 0.f)) g = 0.f;
-  const float xh = (y[i] - s_mean[k]) * s_inv[k], inv_n = 1.0f / (float)(B * HW);
-  dy[i] = s_gamma[k] * s_inv[k] * (g - s_s0[k] * inv_n - xh * s_s1[k] * inv_n);
+  size_t i = i0 + threadIdx.x;
+  if (i > ilast) return;
+  const float inv_n = 1.0f / (float)(B * HW);
+  BnWalk w(i, ch0, HW, C);
+  for (; i <= ilast; i += 256) {
+    float g = dz.p[dz.at(w.b, w.c, 0, 0) + w.r];
+    if (relu && !(z.p[z.at(w.b, w.c, 0, 0) + w.r] > 0.f)) g = 0.f;
+    const float xh = (y[i] - s_mean[w.k]) * s_inv[w.k];
+    dy[i] = s_gamma[w.k] * s_inv[w.k] * (g - s_s0[w.k] * inv_n - xh * s_s1[w.k] * inv_n);
+    w.step(HW, C);
+  }
 }
 
 // max_pool2d(3, 2, 1) as ATen's CPU kernel scans it: window rows then columns, a later value replaces the maximum only if it is
@@ -591,6 +675,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdChunk c, float lr, fl
 }
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+inline unsigned bn_blocks(size_t n) { return (unsigned)((n + BN_EPB - 1) / BN_EPB); }
 
 struct Tens { size_t off = 0; int C = 0, H = 0, W = 0; };   // offset (floats) into the activation arena; its gradient sits at the same offset of the gradient arena
 
@@ -659,19 +744,25 @@ struct Train {
     ConvP c{view(tin, false, in_coff, in_cstride, Cin), view(y, false), w, nullptr, k, stride, pad, dw ? 1 : 0, B};
     const bool pw = k == 1 && stride == 1 && pad == 0 && !dw;
     if (pw) pw_forward(c.in, c.out, w, nullptr, s);
-    else hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, c);
+    else if (dw && pad == k / 2 && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+      const dim3 grid((OH * OW + 255) / 256, B * Cout);
+      if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_kernel<3, 1>), grid, dim3(256), 0, s, c);
+      else if (k == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, 2>), grid, dim3(256), 0, s, c);
+      else if (stride == 1) hipLaunchKernelGGL((dw_fwd_kernel<5, 1>), grid, dim3(256), 0, s, c);
+      else hipLaunchKernelGGL((dw_fwd_kernel<5, 2>), grid, dim3(256), 0, s, c);
+    } else hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, c);
     double* ds = dscr + dscr_used; dscr_used += 4 * (size_t)Cout;
     if (dscr_used > dscr_n) { if (err.empty()) err = "yfv2_train: BatchNorm scratch exhausted"; return; }
     const unsigned nseg = reduce_segments((size_t)B * OH * OW, Cout);
     hipLaunchKernelGGL(bn_stats_part_kernel, dim3(Cout, nseg), dim3(256), 0, s, acts + y.off, B, Cout, OH * OW, ds);
     const V z = view(tout, false, out_coff, 1, Cout), dz = view(tout, true, out_coff, 1, Cout);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, acts + y.off, z, B, ds, mean, invstd, rm, rv, gam, bet, relu ? 1 : 0);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_blocks((size_t)B * Cout * OH * OW)), dim3(256), 0, s, acts + y.off, z, B, ds, mean, invstd, rm, rv, gam, bet, relu ? 1 : 0);
     if (relu) relu_out[conv] = z;
     const int Bc = B;
     tape.push_back([=, this](hipStream_t st2) {
       float* yv = acts + y.off; float* dy = grads + y.off;
       hipLaunchKernelGGL(bn_bwd_part_kernel, dim3(Cout, nseg), dim3(256), 0, st2, yv, z, dz, Bc, mean, invstd, relu ? 1 : 0, ds);
-      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)Bc * Cout * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, Bc, mean, invstd, gam, relu ? 1 : 0, ds, gg, gb);
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_blocks((size_t)Bc * Cout * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, Bc, mean, invstd, gam, relu ? 1 : 0, ds, gg, gb);
       ConvP cw{view(tin, false, in_coff, in_cstride, Cin), view(y, true), nullptr, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
       if (pw) pw_weight_grad(cw.in, cw.out, gw, Bc, st2);
       else if (dw && (k == 3 || k == 5)) {
@@ -683,7 +774,13 @@ struct Train {
       if (need_din) {
         ConvP cd{view(tin, true, in_coff, in_cstride, Cin), view(y, true), w, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
         if (pw) pw_data_grad(cd.in, cd.out, w, Bc, st2);
-        else hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)Bc * Cin * tin.H * tin.W)), dim3(256), 0, st2, cd);
+        else if (dw && pad == k / 2 && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+          const dim3 grid((tin.H * tin.W + 255) / 256, Bc * Cin);
+          if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_bwd_data_kernel<3, 1>), grid, dim3(256), 0, st2, cd);
+          else if (k == 3) hipLaunchKernelGGL((dw_bwd_data_kernel<3, 2>), grid, dim3(256), 0, st2, cd);
+          else if (stride == 1) hipLaunchKernelGGL((dw_bwd_data_kernel<5, 1>), grid, dim3(256), 0, st2, cd);
+          else hipLaunchKernelGGL((dw_bwd_data_kernel<5, 2>), grid, dim3(256), 0, st2, cd);
+        } else hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)Bc * Cin * tin.H * tin.W)), dim3(256), 0, st2, cd);
       }
     });
   }
@@ -814,13 +911,13 @@ int yfv2_train_forward(yfv2_handle h, const float* x, int32_t B, float* const ou
           const unsigned nseg = reduce_segments((size_t)B * OH * OW, 24);
           hipLaunchKernelGGL(bn_stats_part_kernel, dim3(24, nseg), dim3(256), 0, s, t->acts + y.off, B, 24, OH * OW, ds);
           const V z = t->view(stem, false), dz = t->view(stem, true);
-          hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, s, t->acts + y.off, z, B, ds, mean, invstd, rm, rv, gam, bet, 1);
+          hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_blocks((size_t)B * 24 * OH * OW)), dim3(256), 0, s, t->acts + y.off, z, B, ds, mean, invstd, rm, rv, gam, bet, 1);
           t->relu_out["backbone.first_conv.0"] = z;
           Train* tt = t;
           t->tape.push_back([=](hipStream_t st2) {
             float* yv = tt->acts + y.off; float* dy = tt->grads + y.off;
             hipLaunchKernelGGL(bn_bwd_part_kernel, dim3(24, nseg), dim3(256), 0, st2, yv, z, dz, B, mean, invstd, 1, ds);
-            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)B * 24 * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, B, mean, invstd, gam, 1, ds, gg, gb);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_blocks((size_t)B * 24 * OH * OW)), dim3(256), 0, st2, yv, z, dz, dy, B, mean, invstd, gam, 1, ds, gg, gb);
             ConvP cw{xin, tt->view(y, true), nullptr, nullptr, 3, 2, 1, 0, B};
             double* scr = tt->wgrad_scratch(gw, 24 * 3 * 9);
             if (scr) hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)(((size_t)B * OH * OW + 4095) / 4096), 3, 3), dim3(256), 0, st2, cw, scr);
