@@ -419,14 +419,20 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
             blobs.add(blob)
         assert len(blobs) <= 11     # the packed blob depends on which kernels a size selects, not on the size itself
     # more than 93 classes: the class head no longer fits one chained output conv - it runs as slices of 96 channels
-    # (22x22: + objectness head + two class slices; 11x11: its four tower halves no longer form one launch: 1 -> 4 + 3)
-    assert _dryrun(100, 352, 352)[1] == _dryrun(80, 352, 352)[1] + 3 + 6
+    # (22x22: its tower halves no longer pair up, + objectness head + two class slices: 2 -> 4 + 3; 11x11: its four tower
+    # halves no longer form one launch: 1 -> 4 + 3)
+    assert _dryrun(100, 352, 352)[1] == _dryrun(80, 352, 352)[1] + 5 + 6
     assert _dryrun(255, 352, 352)[1] == _dryrun(100, 352, 352)[1] + 2                # a third class slice per level
     # the two alternative plans (layer by layer: 77 launches; every pointwise conv on the fp32 MFMA: the stage-3 chain and
     # stage4.0, which exist only as bf16x6 kernels, then run layer by layer) are planned and packed by the same code
     import os
-    assert _dryrun(80, 352, 352)[1] == 16      # eleven backbone + FPN launches, one launch for the four 11x11 tower halves, four at 22x22
-    for var, steps_min in (("YFV2_FUSED", 70), ("YFV2_BF6", 40)):
+    assert _dryrun(80, 352, 352)[1] == 14      # eleven backbone + FPN launches, one launch for the four 11x11 tower halves, two at 22x22 (cls | reg side by side)
+    os.environ["YFV2_TPAIR"] = "0"
+    try:
+        assert _dryrun(80, 352, 352)[1] == 16  # the 22x22 tower halves as four launches
+    finally:
+        del os.environ["YFV2_TPAIR"]
+    for var, steps_min in (("YFV2_FUSED", 70), ("YFV2_BF6", 38)):
         os.environ[var] = "0"
         try:
             for classes in (80, 20, 1):

@@ -606,8 +606,8 @@ def test_other_input_size_320(yfv2, dev):
         assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)) and np.array_equal(idx[b].numpy(), o_idx[b])
 
 
-@pytest.mark.parametrize("env", [{"YFV2_FUSED": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}],
-                         ids=["layer-by-layer", "fp32-mfma-everywhere", "two-launch-post"])
+@pytest.mark.parametrize("env", [{"YFV2_FUSED": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_TPAIR": "0"}],
+                         ids=["layer-by-layer", "fp32-mfma-everywhere", "two-launch-post", "tower-halves-as-four-launches"])
 def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     """The three plan switches that remain: everything layer by layer - also what a shape outside a fused
     kernel's static bounds gets, block by block; every pointwise conv on the fp32 MFMA; decode and NMS as two launches.
@@ -631,8 +631,10 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
         assert len(names) >= 70 and not any("chain of" in n or "lane-per-pixel" in n for n in names), names
     elif "YFV2_BF6" in env:
         assert not any("chain of 7" in n for n in names) and any("resident in LDS" in n for n in names), names
+    elif "YFV2_TPAIR" in env:
+        assert len(names) == 16 and not any("side by side" in n for n in names), names   # cls a, cls b, reg a, reg b at 22x22
     else:
-        assert len(names) == 16
+        assert len(names) == 14 and sum("side by side" in n for n in names) == 2, names
         eng.set_anchors([12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87])
         r1, i1 = yfv2.unpack_detections(*eng.detect(x.to(dev), 0.3, 0.4))                 # decode_kernel<compact> + nms_kernel<1>
         r2, i2 = yfv2.unpack_detections(*eng.nms(eng.decode(eng.forward(x.to(dev))), 0.3, 0.4))

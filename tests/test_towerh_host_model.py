@@ -35,6 +35,11 @@ def _images(w, classes):
     for st in range(ns.value):
         n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st, nm, 256, buf.ctypes.data_as(C.c_void_p), cap)
         out[nm.value.decode()] = buf[:max(n, 0)].copy()
+        for job in range(4):                                                    # launches that run several tower halves: each half's own image
+            n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st + 1000 * (job + 1), nm, 256, buf.ctypes.data_as(C.c_void_p), cap)
+            if n < 0:
+                break
+            out[nm.value.decode()] = buf[:n].copy()
     return out
 
 
@@ -99,7 +104,8 @@ def test_towerh_host_packing_and_arithmetic_vs_oracle(classes, tiles):
             w[k] = torch.rand_like(w[k]) + 0.5
     ims = _images(w, classes)
     torch.manual_seed(3)
-    # 22x22: one launch per half, each image packed for its own output conv
+    # 22x22: the a halves of the two towers side by side in one launch, the b halves in another: the b halves' images are both
+    # packed for the wider output conv of the level (`tiles`; tower2_kernel's image in front keeps the half's own)
     for tower, head_keys, mh in (("cls_head_2", ("output_obj_layers", "output_cls_layers"), 3 + classes), ("reg_head_2", ("output_reg_layers",), 12)):
         p = "fpn.%s.block" % tower
         name_a = [n for n in ims if n.startswith(p + " half a")][0]
@@ -113,7 +119,7 @@ def test_towerh_host_packing_and_arithmetic_vs_oracle(classes, tiles):
         assert np.abs(got - ref[0].numpy()).max() <= 3e-6 * max(1.0, float(ref.abs().max()))
         # the filter's power of two: largest entry in (2^13, 2^14]
         assert 2.0 ** 13 < np.abs(wp).max() <= 2.0 ** 14
-        wp, cs, wh, taps = _decode(ims[name_b], own, own)
+        wp, cs, wh, taps = _decode(ims[name_b], own, tiles)
         t, logit = _model(ref[0].numpy(), wp, cs, wh, taps)
         ref_t = oracle._conv_bn(w, p + ".8", p + ".9", oracle._conv_bn(w, p + ".5", p + ".6", ref, 1, 2, 72, relu=True))
         assert np.abs(t - ref_t[0].numpy()).max() <= 3e-6 * max(1.0, float(ref_t.abs().max()))

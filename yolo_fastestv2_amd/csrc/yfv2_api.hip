@@ -54,6 +54,7 @@ struct Step {
   double flops = 0, bytes = 0;  // algorithmic, per image; bytes = per-LAYER accounting (every reference layer the launch covers reads its input and writes its output once)
   double bytes_ext = -1;        // SURVEY.md 8(d) for fused launches: EXTERNAL reads + writes of the launch only (-1: same as bytes)
   std::vector<Step> jobs;       // STEP_TOWER on towerh_kernel: the tower halves this ONE launch runs one after the other (empty: the step is its own job)
+  bool par = false;             // ... or (par) side by side: independent halves (cls a | reg a, cls b | reg b) as workgroup ranges of one launch
   int tw_tiles = 0;             // STEP_TOWER on towerh_kernel: output-conv tiles the images of the launch are packed for (0, 1 or 6)
 };
 
@@ -1380,6 +1381,19 @@ struct PlanBuilder {
     add_pw(p + ".main.pw2+bn+relu", c2, PW_PLAIN, c2, H * W, h->t2.p, c2, 0, y.p, c, c2, true, f);
   }
 
+  // Maps larger than 11x11 run a tower half per launch (towerh_kernel's 2x2-patch form).  The cls and the reg tower of a level are
+  // independent of each other, so their a halves (both read the FPN map) and their b halves (each reads its own a half) go side
+  // by side as workgroup ranges of ONE launch each: four launches -> two, and a CU starts its next workgroup when its current one
+  // ends instead of waiting for the slowest image of the launch (YFV2_TPAIR=0: four launches).  Needs the chained output convs
+  // on both towers (anchors + classes <= 96) and a second intermediate buffer (tb: unused on this path otherwise).
+  bool pair_level(int H, int W) const {
+    const char* env = std::getenv("YFV2_TPAIR");
+    if (env && env[0] == '0') return false;
+    const char* envf = std::getenv("YFV2_FUSED");
+    if (envf && envf[0] == '0') return false;
+    return yfv2_tower2_supported(H, W) && yfv2_towerh_supported(H, W) && !yfv2_towerh_multi(H, W) && h->cfg.anchor_num + h->cfg.classes <= 96;
+  }
+
   // DWConvblock (fpn.py:12-25) + the output convs fed by this tower (detector.py:25-31)
   void tower_half(const std::string& name, int H, int W, const float* in, float* out, const Folded& fd, const Folded& fp,
                   const Folded* fh, int mh, int split, int head0, int head1) {
@@ -1394,6 +1408,8 @@ struct PlanBuilder {
     // (with more than 93 classes the class head runs as separate launches: the level's halves are never merged)
     const bool merged_level = yfv2_towerh_multi(H, W) && h->cfg.anchor_num + h->cfg.classes <= 96;
     s.tw_tiles = merged_level ? ((h->cfg.anchor_num + h->cfg.classes + 15) / 16 <= 1 ? 1 : 6) : (fh ? ((mh + 15) / 16 <= 1 ? 1 : 6) : 0);
+    // paired level (pair_level): the two b halves share a launch, so both are packed for the wider of the two output convs
+    if (pair_level(H, W) && fh) s.tw_tiles = ((h->cfg.anchor_num + h->cfg.classes + 15) / 16 <= 1 && (4 * h->cfg.anchor_num + 15) / 16 <= 1) ? 1 : 6;
     if (yfv2_towerh_supported(H, W)) s.img_off3 = wp.image_towerh(fd, fp, fh, mh, s.tw_tiles);
     s.has_head = fh != nullptr;
     s.head0 = head0; s.head1 = head1;
@@ -1434,7 +1450,7 @@ struct PlanBuilder {
         ok &= wp.dw(p + ".5", p + ".6", 72, 5, &fd2);
         ok &= wp.pw(p + ".8", p + ".9", 72, 72, &fp2);
         const int A = h->cfg.anchor_num, nc = h->cfg.classes;
-        float* mid = h->ta.p;
+        float* mid = (!is_cls && pair_level(H, W)) ? h->tb.p : h->ta.p;   // (paired level: both towers' a halves are alive at once)
         tower_half(p + " half a: dw5x5+bn+relu -> pw+bn", H, W, s_in.p, mid, fd1, fp1, nullptr, 0, 0, -1, -1);
         if (is_cls && A + nc > 96) {   // more output channels than a chained output conv holds: the tower ends in memory, the heads follow as launches
           tower_half(p + " half b: dw5x5+bn+relu -> pw+bn", H, W, mid, h->tb.p, fd2, fp2, nullptr, 0, 0, -1, -1);
@@ -1501,12 +1517,34 @@ struct PlanBuilder {
         m.bytes_ext = ext;
         out.push_back(m);
         i += 4;
+      } else if (i + 4 <= h->plan.size() && h->plan[i].kind == STEP_TOWER && pair_level(h->plan[i].tw.H, h->plan[i].tw.W) && pairable(i)) {
+        // cls a, cls b, reg a, reg b  ->  (cls a | reg a), (cls b | reg b)
+        for (int half = 0; half < 2; ++half) {
+          Step m = h->plan[i + half];
+          m.jobs = {h->plan[i + half], h->plan[i + 2 + half]};
+          m.par = true;
+          m.name = "fpn towers " + std::to_string(m.tw.H) + "x" + std::to_string(m.tw.W) + (half == 0 ? ": cls_head half a | reg_head half a (dw5x5+bn+relu -> pw+bn), side by side in one launch"
+                                                                                                        : ": cls_head half b -> output_obj+output_cls | reg_head half b -> output_reg, side by side in one launch");
+          m.flops = 0; m.bytes = 0;
+          for (const Step& j : m.jobs) { m.flops += j.flops; m.bytes += j.bytes; }
+          m.bytes_ext = -1;   // every job reads and writes memory: external = bytes
+          out.push_back(m);
+        }
+        i += 4;
       } else {
         out.push_back(h->plan[i]);
         ++i;
       }
     }
     h->plan.swap(out);
+  }
+  // four consecutive tower steps of one level in the order tower() emits them, all on towerh_kernel with the same image layout per pair
+  bool pairable(size_t i) const {
+    const Step *ca = &h->plan[i], *cb = &h->plan[i + 1], *ra = &h->plan[i + 2], *rb = &h->plan[i + 3];
+    for (const Step* t : {ca, cb, ra, rb})
+      if (t->kind != STEP_TOWER || !t->img_off3 || t->tw.H != ca->tw.H || t->tw.W != ca->tw.W) return false;
+    return !ca->has_head && !ra->has_head && cb->has_head && rb->has_head && ca->tw_tiles == ra->tw_tiles && cb->tw_tiles == rb->tw_tiles &&
+           cb->tw.in == ca->tw.out && rb->tw.in == ra->tw.out && ca->tw.out != ra->tw.out;
   }
 
   void build() {
@@ -1611,7 +1649,7 @@ std::string step_kernel(const Step& st) {
     case STEP_PW: return "pw_kernel<" + std::to_string(st.K) + ",";
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
-      if (st.img_off3 && !st.jobs.empty()) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
+      if (st.img_off3 && !st.jobs.empty() && !st.par) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
       if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");   // default plan
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
@@ -1629,6 +1667,8 @@ std::string step_kernel(const Step& st) {
 //   YFV2_BF6=0       every pointwise conv on the fp32 MFMA; blocks whose fused kernel exists only in the bf16x6 form
 //                    (the stage-3 chain, stage4.0) then run layer by layer
 //   YFV2_POSTFUSE=0  yfv2_detect decodes and suppresses in two launches
+//   YFV2_TPAIR=0     the tower halves of a level larger than 11x11 as four launches instead of two side-by-side pairs
+//                                                                                       - read by PlanBuilder::pair_level
 void read_plan_switches(yfv2_ctx* h) {
   if (const char* e = std::getenv("YFV2_BF6")) h->bf6 = !(e[0] == '0');
   if (const char* e = std::getenv("YFV2_POSTFUSE")) h->postfuse = !(e[0] == '0');
@@ -1713,7 +1753,8 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
         else { jobs.n = (int)st.jobs.size(); for (int k = 0; k < jobs.n; ++k) jobs.j[k] = args_of(st.jobs[k]); }
         // half a -> half b of a tower inside one launch: the tensor between them stays in the workgroup's LDS - as long as every
         // workgroup has ONE image (the job loop is outside the image loop)
-        for (int k = 0; k + 1 < jobs.n; ++k)
+        jobs.par = st.par ? 1 : 0;
+        for (int k = 0; k + 1 < jobs.n && !st.par; ++k)
           if (B <= 256 && !jobs.j[k].has_head && jobs.j[k].out == jobs.j[k + 1].in) { jobs.j[k].chain |= 2; jobs.j[k + 1].chain |= 1; }
         done = yfv2_launch_towerh(jobs, st.tw_tiles, s);
       }
@@ -1975,7 +2016,7 @@ int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tenso
   return YFV2_OK;
 }
 
-// Host-only test hook: the packed LDS image of launch `step` of the plan the dry run builds (at most `cap` floats from the
+// Host-only test hook: the packed LDS image of launch `step` (or of one of its jobs, see below) of the plan the dry run builds (at most `cap` floats from the
 // image's start to the end of the blob), and the launch's name.  Lets the CPU suite check host packing against a
 // numpy model of a kernel's dataflow.  Returns the number of floats copied or a negative error code.
 int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t step, char* name, int32_t name_cap,
@@ -1999,8 +2040,12 @@ int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* te
   PlanBuilder pb{&ctx, wp};
   pb.build();
   if (!pb.ok || !wp.missing.empty()) return fail(nullptr, YFV2_ERR_WEIGHTS, wp.missing.empty() ? "weight packing failed" : wp.missing);
+  // step + 1000 (k + 1): job k of a launch that runs several tower halves (towers_kernel's list, towerh_kernel's side-by-side pair)
+  const int job = step >= 1000 ? step / 1000 - 1 : -1;
+  if (step >= 1000) step %= 1000;
   if (step < 0 || step >= (int32_t)ctx.plan.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: step out of range");
-  const Step& st = ctx.plan[step];
+  if (job >= (int)ctx.plan[step].jobs.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: job out of range");
+  const Step& st = job >= 0 ? ctx.plan[step].jobs[job] : ctx.plan[step];
   if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", st.name.c_str());
   const int64_t avail = (int64_t)wp.blob.size() - (int64_t)st.img_off;
   const int64_t cnt = avail < cap ? avail : cap;

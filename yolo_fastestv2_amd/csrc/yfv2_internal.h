@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define YFV2_VARIANT_DEFAULT 0
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));   // three floats at any dword address (global_load/store_dwordx3)
@@ -15,6 +17,17 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 #ifdef __HIPCC__
 __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 #endif
+
+// Kernel-variant switches for same-box A/B measurements (YFV2_VARIANT = bit mask, read once per process; unset = the defaults):
+//   1  s1h_kernel at four waves per SIMD (launch bound 4: the compiler spills ten loop invariants)
+//   2  stem_h3_kernel at four waves per SIMD (five spilled registers)
+//   4  fpn.conv1x1_2 (pw_kernel<288>) as 1024-thread workgroups, one pixel tile per wave (16 waves per CU instead of 8)
+//   8  the two FPN reduces on pwf_kernel (a pixel tile's whole K in flight, two register sets) instead of pw_kernel's one-chunk-pair look-ahead
+#include <cstdlib>
+inline int yfv2_variant() {
+  static const int v = [] { const char* e = std::getenv("YFV2_VARIANT"); return e ? std::atoi(e) : YFV2_VARIANT_DEFAULT; }();
+  return v;
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-(function, device) attribute: raise it to the 160 KiB cap the first
 // time a function is launched on each device (`done` = the call site's bit mask of devices already served).
@@ -336,7 +349,13 @@ bool yfv2_tower2_supported(int H, int W);                    // whole-image towe
 bool yfv2_launch_tower2(const TowerArgs& a, hipStream_t s);
 bool yfv2_towerh_supported(int H, int W);
 bool yfv2_towerh_multi(int H, int W);
-struct TowerJobs { TowerArgs j[4]; int n; };   // towerh_kernel: up to four tower halves of one map size, run one after the other by every workgroup
+struct TowerJobs {   // up to four tower halves of one map size in ONE launch
+  TowerArgs j[4];
+  int n;
+  int par;   // 0: a job LIST - every workgroup runs the jobs one after the other on its image (towers_kernel, maps up to 11x11);
+             // 1: INDEPENDENT jobs side by side - workgroups [k gpj, (k + 1) gpj) run job k (towerh_kernel)
+  int gpj;   // par: workgroups per job (set by the launcher)
+};
 bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s);
 // ---- evaluation statistics (get_batch_statistics): which detections are true positives
 struct StatsArgs {

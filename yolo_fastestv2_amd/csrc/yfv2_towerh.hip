@@ -88,7 +88,9 @@ template <int PS> struct ThGeom {
 };
 
 template <int MH, int PS, int NT>
-__global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs jobs.j[0] (job LISTS are towers_kernel's, below)
+__global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs jobs.j[0], or (jobs.par) INDEPENDENT jobs side by side:
+                                                                        // workgroups [k gpj, (k + 1) gpj) run job k (job LISTS - one workgroup running
+                                                                        // dependent jobs in turn - are towers_kernel's, below)
   struct { int B, H, W; long long* trace; } a;                 // geometry, batch and trace buffer are the same for every job
   a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
   constexpr int KC = TH_KC, C = TH_C, WS = PS + 4, NPAR = PS * PS, Q = TH_Q, SP = ThGeom<PS>::SP, XOFF = TH_XOFF;
@@ -104,7 +106,12 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
   const float invW = 1.0f / (float)W;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grid = gridDim.x;
+  // Independent jobs in one launch (the a halves of the cls and reg towers both read the FPN map, the b halves each their own a
+  // half): a CU's next workgroup starts the moment its current one ends, instead of the whole chip draining between two launches.
+  const int gpj = jobs.par ? jobs.gpj : (int)gridDim.x;        // workgroups per job = the image loop's stride
+  const int bid = blockIdx.x;
+  const int jidx = __builtin_amdgcn_readfirstlane(jobs.par ? (bid >= gpj) + (bid >= 2 * gpj) + (bid >= 3 * gpj) : 0);
+  const int grid = gpj;
   YFV2_WSTAMP(0);
 
   // ---- staging map: piece i of a chunk -> (pixel, quad): eight consecutive lanes = eight consecutive pixels of one quad, the
@@ -163,9 +170,9 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
   // (The four halves of a 22x22 level as a job list of ONE launch were measured: 145 us against 132 as four launches - a job is
   // 60-75 k cycles either way, and the wider kernel - every job on the six-tile LDS layout, both epilogues - spills.)
   {
-  const __attribute__((address_space(4))) TowerArgs& ja = *(const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const __attribute__((address_space(4))) TowerArgs& ja = ((const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[jidx];
   const yfv2_cf4* taps = (const yfv2_cf4*)(ja.img16 + th_lds_img(MH));
-  int b = blockIdx.x;
+  int b = bid - jidx * gpj;
   Yfv2Watch watch;                                             // range guard of the fp16x3 products (yfv2_internal.h)
   f32x4 pre[NPF];
   stage_load(ja.in, b < a.B ? b : 0, 0, pre);                  // the first slice flies during the job's prologue
@@ -620,12 +627,13 @@ static void launch_towers(const TowerJobs& jobs, hipStream_t s) {
 }
 
 template <int MH, int PS, int NT>
-static void launch_towerh(const TowerJobs& jobs, hipStream_t s) {
+static void launch_towerh(TowerJobs jobs, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + 4 * (4 * 16 * NT * 8 + ThGeom<PS>::TIN_SLOTS));
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerh_kernel<MH, PS, NT>), lds_ok);
   const int B = jobs.j[0].B;
-  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
+  jobs.gpj = B < 256 ? B : 256;
+  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT>), dim3(jobs.gpj * (jobs.par ? jobs.n : 1)), dim3(512), lds, s, jobs);
 }
 
 // 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
@@ -645,7 +653,7 @@ bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
   for (int i = 0; i < jobs.n; ++i)
     if (!jobs.j[i].img16 || jobs.j[i].H != a.H || jobs.j[i].W != a.W || jobs.j[i].B != a.B) return false;
   if (!yfv2_towerh_supported(a.H, a.W) || (mh_tiles != 0 && mh_tiles != 1 && mh_tiles != 6)) return false;
-  if (jobs.n > 1) {
+  if (jobs.n > 1 && !jobs.par) {
     if (!yfv2_towerh_multi(a.H, a.W) || mh_tiles == 0) return false;
     if (mh_tiles == 1) launch_towers<1>(jobs, s);
     else launch_towers<6>(jobs, s);
