@@ -85,10 +85,11 @@ def _model(x, wp, cs, wh, taps):
     t = acc * cs[0, :72, None] + cs[1, :72, None]
     out = [t.reshape(x.shape)]
     if wh is not None:
-        t1, t2 = _split((t * np.float32(16.0)).astype(np.float32))
+        # a half that ends in an output conv: the kernel applies the host-merged matrix (output conv x BN x pointwise conv) to the
+        # depthwise result's two fp16 terms directly - `wh` IS that matrix, cs[2] its bias (the 72 x 72 filter is not used)
         h1 = wh[:, :72].astype(np.float16).astype(np.float64)
         h2 = wh[:, :72] - h1
-        logit = (h1 @ t2 + h2 @ t1 + h1 @ t1).astype(np.float32) * cs[3, 0] + cs[2, :wh.shape[0], None]
+        logit = (h1 @ u2 + h2 @ u1 + h1 @ u1).astype(np.float32) * cs[3, 0] + cs[2, :wh.shape[0], None]
         out.append(logit)
     return out
 

@@ -473,13 +473,33 @@ struct WeightPacker {
     for (int i = 0; i < 72 * 72; ++i) mp = std::fmax(mp, std::fabs(wpw[i]));
     const int sw = pow2_for(mp);
     push_a16(im, [&](int r, int c) { return (r < 72 && c < 72) ? std::ldexp(wpw[(size_t)r * 72 + c], sw) : 0.f; }, 5);
+    // A half that ends in an output conv: pointwise conv, its BatchNorm and the biased output conv are three linear maps in a row
+    // (fpn.py:16-17,23-24 - no activation behind the block's last BN; detector.py:25-31), so the kernels apply their PRODUCT to the
+    // depthwise result: M = Wh diag(scale) Wp (mh x 72), bias = Wh shift + b, both formed here in double and rounded once - closer
+    // to the exact value than the reference's own two fp32 steps.  (The 72 x 72 filter above stays in the image: a launch has one
+    // LDS layout for all its jobs, and the halves WITHOUT an output conv use it.)
+    std::vector<float> mw, mb;
     int swh = 0;
-    if (fh) { for (int i = 0; i < mh * 72; ++i) mhd = std::fmax(mhd, std::fabs(blob[fh->w + i])); swh = pow2_for(mhd); }
+    if (fh) {
+      mw.assign((size_t)mh * 72, 0.f); mb.assign((size_t)mh, 0.f);
+      for (int o = 0; o < mh; ++o) {
+        double bacc = blob[fh->shift + o];
+        for (int k = 0; k < 72; ++k) bacc += (double)blob[fh->w + (size_t)o * 72 + k] * (double)blob[fp.shift + k];
+        mb[o] = (float)bacc;
+        for (int c = 0; c < 72; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < 72; ++k) acc += (double)blob[fh->w + (size_t)o * 72 + k] * (double)blob[fp.scale + k] * (double)wpw[(size_t)k * 72 + c];
+          mw[(size_t)o * 72 + c] = (float)acc;
+          mhd = std::fmax(mhd, std::fabs((float)acc));
+        }
+      }
+      swh = pow2_for(mhd);
+    }
     for (int c = 0; c < 96; ++c) im.push_back(c < 72 ? std::ldexp(blob[fp.scale + c], -(sw + 4)) : 0.f);
     push_vec(im, &blob[fp.shift], 72, 96);
-    push_vec(im, fh ? &blob[fh->shift] : nullptr, mh, 96);
+    push_vec(im, fh ? mb.data() : nullptr, mh, 96);
     for (int c = 0; c < 96; ++c) im.push_back(c == 0 ? std::ldexp(1.0f, -(swh + 4)) : 0.f);
-    push_a16(im, [&](int r, int c) { return (fh && r < mh && c < 72) ? std::ldexp(blob[fh->w + (size_t)r * 72 + c], swh) : 0.f; }, mh_tiles);   // zero tiles where a job has no (or a narrower) output conv: one LDS layout per launch
+    push_a16(im, [&](int r, int c) { return (fh && r < mh && c < 72) ? std::ldexp(mw[(size_t)r * 72 + c], swh) : 0.f; }, mh_tiles);   // zero tiles where a job has no (or a narrower) output conv: one LDS layout per launch
     for (int s = 0; s < 5; ++s)
       for (int q = 0; q < 4; ++q)
         for (int t = 0; t < 27; ++t)

@@ -349,157 +349,6 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   if constexpr (PRE) watch.report(a.nonfinite);
 }
 
-// ============================================================================
-// pwf_kernel: the two FPN reduces (fpn.conv1x1_3: K = 192, fpn.conv1x1_2: K = 288 with upsample + concat folded in) with a
-// pixel tile's WHOLE K in flight
-// ============================================================================
-// pw_kernel's streamed form fetches one chunk pair (32 channels) ahead: a 16-pixel tile is K / 32 dependent round trips to
-// memory, each hidden behind 15 MFMAs of the pair before - with two waves per SIMD the launch is the sum of those latencies
-// (SQ counters: 54 % / 68 % of the wave cycles waiting).  Here a wave owns ONE pixel tile at a time, requests all K / 16
-// 16-byte pieces of the NEXT tile (288 channels: 18 per lane, 18 KB per wave) before it starts the arithmetic of the current
-// one, and ping-pongs between two register sets: one round trip per tile, overlapped with a whole tile of work.  Same packed
-// filter image (WeightPacker::image_pw, PRE form), same fp16x3 arithmetic and epilogue as pw_kernel<.., PRE = true>.
-template <int K, int MODE>
-__global__ __launch_bounds__(512) void pwf_kernel(PwArgs a) {
-  constexpr int MT = 5, K16 = K / 16, KP = K16 / 2, THREADS = 512;
-  static_assert(K % 32 == 0 && (MODE == PW_PLAIN || MODE == PW_FPN), "whole chunk pairs; plain / fpn");
-  constexpr int FILT_FL = MT * K16 * 256;
-  constexpr int SPLIT = MODE == PW_FPN ? 12 : K16;
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  const int tid = threadIdx.x;
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
-    f32x4* dst = reinterpret_cast<f32x4*>(wl);
-    constexpr int N4 = (FILT_FL + 2 * MT * 16) / 4;                 // filter + BN scale [80] + BN shift [80] (read from LDS in the epilogue: 40
-                                                                    // registers a lane does not hold across two tiles of operands)
-    constexpr int PER = (N4 + THREADS - 1) / THREADS;
-    constexpr int BATCH = PER < 9 ? PER : 9;
-#pragma unroll 1
-    for (int k0 = 0; k0 < PER; k0 += BATCH) {
-      f32x4 t[BATCH];
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) { const int i = tid + (k0 + k) * THREADS; t[k] = src[i < N4 ? i : 0]; }
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) { const int i = tid + (k0 + k) * THREADS; if (i < N4) dst[i] = t[k]; }
-    }
-  }
-  __syncthreads();
-  const int lane = tid & 63, p = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NW = THREADS / 64;
-  const float* CS = wl + FILT_FL;
-  Yfv2Watch watch;
-  const int n_tiles = (a.P + 15) / 16;
-  const int stride = (int)gridDim.x * NW;
-  const float inv_hw = 1.0f / (float)(a.H * a.W), inv_w = 1.0f / (float)a.W;
-
-  // every load of a tile is issued here, in one go; a pixel past the end re-reads the last one (never stored)
-  auto load = [&](int tile, f32x4 (&q)[K16]) __attribute__((always_inline)) {
-    const int pix = tile * 16 + p;
-    const int pc = pix < a.P ? pix : a.P - 1;
-    const float *s0, *s1;
-    if constexpr (MODE == PW_FPN) {
-      const int hw = a.H * a.W;
-      const int b = pc / hw, rem = pc - b * hw;
-      const int y = rem / a.W, x = rem - y * a.W;
-      s0 = a.in + ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * 192 + 4 * g;   // chunks 0..11: C3 at (y / 2, x / 2)
-      s1 = a.in2 + (size_t)pc * 96 + 4 * g - 16 * 12;                                          // chunks 12..17: C2
-    } else {
-      s0 = a.in + (size_t)pc * a.in_stride + a.in_off + 4 * g;
-      s1 = s0;
-    }
-#pragma unroll
-    for (int c = 0; c < K16; ++c) q[c] = *reinterpret_cast<const f32x4*>((c < SPLIT ? s0 : s1) + 16 * c);
-  };
-  auto tile_body = [&](int tile, const f32x4 (&q)[K16]) __attribute__((always_inline)) {
-    f32x4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int lo = lane * 4;
-    asm volatile("" : "+v"(lo));   // an opaque lane offset per tile: the filter reads are loop-invariant, and hoisted out of the tile
-                                   // loop they are 90 live operand quads (324 spilled registers)
-#pragma unroll
-    for (int sp = 0; sp < KP; ++sp) {
-      yfv2_h8 a1[MT], a2[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float* wq2 = wl + ((mt * KP + sp) * 2) * 256 + lo;
-        a1[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2));
-        a2[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2 + 256));
-      }
-      u32x4 t1, t2;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const f32x4 v = q[2 * sp + e] * 16.0f;                                          // fp16's absolute floor: 2^-25 -> 2^-29
-        const yfv2_h4 h1 = __builtin_convertvector(v, yfv2_h4);                         // v_cvt_pk_f16_f32 (RN)
-        const yfv2_h4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4), yfv2_h4);   // the difference is exact
-        const yfv2_u2 u1 = __builtin_bit_cast(yfv2_u2, h1), u2 = __builtin_bit_cast(yfv2_u2, h2);
-        t1[2 * e] = u1[0]; t1[2 * e + 1] = u1[1];
-        t2[2 * e] = u2[0]; t2[2 * e + 1] = u2[1];
-      }
-      const yfv2_h8 b1 = __builtin_bit_cast(yfv2_h8, t1), b2 = __builtin_bit_cast(yfv2_h8, t2);
-      // three products, the small ones first (the order pw_kernel<PRE> uses: identical results)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[mt], b2, acc[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[mt], b1, acc[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[mt], b1, acc[mt], 0, 0, 0);
-    }
-    watch.see(acc[0][0]);
-    const int pix = tile * 16 + p;
-    if (pix < a.P) {
-      float* dst = a.out + (size_t)pix * a.out_stride + a.out_off;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (16 * mt + 4 * g < a.M) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 16 * mt + 4 * g), sh = *reinterpret_cast<const f32x4*>(CS + MT * 16 + 16 * mt + 4 * g);
-          f32x4 y;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            y[r] = __builtin_fmaf(acc[mt][r], sc[r], sh[r]);
-            if (a.relu) y[r] = y[r] > 0.f ? y[r] : 0.f;
-          }
-          *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = y;
-        }
-      }
-    }
-  };
-
-  // The look-ahead loads are UNCONDITIONAL (past the wave's last tile they re-read the tile just loaded: cache hits): behind a
-  // branch the compiler's outstanding-request count takes the path without them and waits for the current tile with
-  // vmcnt(17) right behind the 18 new requests - every tile a full round trip again (the stage-3 chain's lesson).
-  f32x4 qa[K16], qb[K16];
-  int st = (int)blockIdx.x * NW + wave;
-  if (st < n_tiles) {
-    load(st, qa);
-    while (true) {
-      const int s1 = st + stride;
-      load(s1 < n_tiles ? s1 : st, qb);
-      tile_body(st, qa);
-      if (s1 >= n_tiles) break;
-      const int s2 = s1 + stride;
-      load(s2 < n_tiles ? s2 : s1, qa);
-      tile_body(s1, qb);
-      if (s2 >= n_tiles) break;
-      st = s2;
-    }
-  }
-  watch.report(a.nonfinite);
-}
-
-template <int K, int MODE>
-static void pwf_launch(const PwArgs& a, hipStream_t s) {
-  const size_t lds = ((size_t)5 * 16 * K + 2 * 5 * 16) * sizeof(float);
-  const int n_tiles = (a.P + 15) / 16;
-  int blocks = (n_tiles + 7) / 8;
-  const int cap = lds > 80 * 1024 ? 256 : 512;   // workgroups that fit the chip at once (one or two per CU)
-  if (blocks > cap) blocks = cap;
-  static std::atomic<unsigned long long> lds_ok{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&pwf_kernel<K, MODE>), lds_ok);
-  hipLaunchKernelGGL((pwf_kernel<K, MODE>), dim3(blocks), dim3(512), lds, s, a);
-}
-
 template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
 static void pw_launch(const PwArgs& a, hipStream_t s) {
   const size_t lds = (size_t)MT * 16 * K * sizeof(float);   // K/16 fragments of 256 floats + (K%16 == 8) 128 per M tile
@@ -550,16 +399,19 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
     if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_PLAIN>(a, s); return true; }
     if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_PLAIN, 256, true>(a, s); return true; }
     if (K == 72 && MT == 5) { pw_launch<72, 5, 2, PW_PLAIN>(a, s); return true; }
-    if (K == 192 && MT == 5 && (yfv2_variant() & 8) && a.bf6 && a.presplit) { pwf_launch<192, PW_PLAIN>(a, s); return true; }
     if (K == 192 && MT == 5) { pw_launch<192, 5, 1, PW_PLAIN, 512, true>(a, s); return true; }   // one pixel tile per wave: 121 pixels x 256 images are 1936 tiles for 2048 waves (two tiles: 15 -> 13.4 us)
   } else if (mode == PW_SHUFFLE) {
     if (K == 24 && MT == 2) { pw_launch<24, 2, 4, PW_SHUFFLE>(a, s); return true; }
     if (K == 48 && MT == 3) { pw_launch<48, 3, 4, PW_SHUFFLE>(a, s); return true; }
     if (K == 96 && MT == 6) { pw_launch<96, 6, 2, PW_SHUFFLE>(a, s); return true; }
   } else if (mode == PW_FPN) {
-    if (K == 288 && MT == 5 && (yfv2_variant() & 8) && a.bf6 && a.presplit) { pwf_launch<288, PW_FPN>(a, s); return true; }
-    if (K == 288 && MT == 5 && (yfv2_variant() & 4) && a.bf6 && a.presplit) { pw_launch<288, 5, 1, PW_FPN, 1024, true>(a, s); return true; }
-    if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }   // (four pixel tiles per wave: the same 31 us)
+    // the default (pre-split fp16x3) form as 1024-thread workgroups with ONE pixel tile per wave: 16 waves per CU instead of 8 hide
+    // more of the one-chunk-pair look-ahead's latency (32.3 -> 30.6 us same box; 115 registers).  Not faster: two tiles per wave
+    // at 1024 threads (28 spilled registers), four tiles per wave at 512 (the same 31 us), and a form with a tile's whole K in
+    // flight in two register sets (pwf_kernel, round 4: 32.0 us - the launch is not bound by that latency).  YFV2_VARIANT bit 0:
+    // the 512-thread form.
+    if (K == 288 && MT == 5 && !(yfv2_variant() & 1) && a.bf6 && a.presplit) { pw_launch<288, 5, 1, PW_FPN, 1024, true>(a, s); return true; }
+    if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }
   } else if (mode == PW_HEAD) {
     if (K == 72 && MT == 1) { pw_launch<72, 1, 4, PW_HEAD>(a, s); return true; }
     if (K == 72 && MT <= 6) { pw_launch<72, 6, 2, PW_HEAD>(a, s); return true; }

@@ -18,11 +18,11 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 #endif
 
-// Kernel-variant switches for same-box A/B measurements (YFV2_VARIANT = bit mask, read once per process; unset = the defaults):
-//   1  s1h_kernel at four waves per SIMD (launch bound 4: the compiler spills ten loop invariants)
-//   2  stem_h3_kernel at four waves per SIMD (five spilled registers)
-//   4  fpn.conv1x1_2 (pw_kernel<288>) as 1024-thread workgroups, one pixel tile per wave (16 waves per CU instead of 8)
-//   8  the two FPN reduces on pwf_kernel (a pixel tile's whole K in flight, two register sets) instead of pw_kernel's one-chunk-pair look-ahead
+// Kernel-variant switches for same-box A/B measurements (YFV2_VARIANT = bit mask, read once per process; unset = 0 = the defaults):
+//   1  fpn.conv1x1_2 (pw_kernel<288>) as 512-thread workgroups with two pixel tiles per wave (the form up to round 4)
+// (measured and removed in round 4, DESIGN.md 4.10: s1h / stem at four waves per SIMD by launch bound - the spills cost more than
+// the occupancy gives, 31 -> 44 us and 115 -> 131 us; non-temporal input loads in stem / s2h / s1h / s3h - the consumer of a
+// streamed tensor slows down, s2h 73 -> 98 us)
 #include <cstdlib>
 inline int yfv2_variant() {
   static const int v = [] { const char* e = std::getenv("YFV2_VARIANT"); return e ? std::atoi(e) : YFV2_VARIANT_DEFAULT; }();

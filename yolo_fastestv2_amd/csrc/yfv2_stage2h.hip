@@ -95,8 +95,7 @@ __device__ __forceinline__ void pw_h3(const yfv2_h8 (&w)[2][2], const f32x2 (&in
 // bias2 * 2^(sw2+4) [32] | 2^-(sw2+4) | pad | per-lane byte offsets: src [4][64], dst [4][64] (0x80000000 = no such pair)
 constexpr int S1H_W1 = 0, S1H_W2 = 1024, S1H_TAPS = 2048, S1H_CST = 3200, S1H_OFFS = 3272;
 
-template <int OCC>
-__global__ __launch_bounds__(64, OCC) void s1h_kernel(S1PxArgs a) {
+__global__ __launch_bounds__(64, 3) void s1h_kernel(S1PxArgs a) {
   const int H = a.H, W = a.W;
   const int nstrips = a.nstrips, nb = a.nb, R = a.R;
   const int wpi = nstrips * nb;
@@ -236,8 +235,7 @@ void yfv2_launch_s1h(const S1PxArgs& a0, hipStream_t s) {
                               // each, same box as 30-32 - neither the stores' place in the in-order vmcnt queue nor bytes in flight limit it)
   a.R = (a.H + a.nb - 1) / a.nb;
   a.nb = (a.H + a.R - 1) / a.R;
-  if (yfv2_variant() & 1) hipLaunchKernelGGL((s1h_kernel<4>), dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((s1h_kernel<3>), dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(s1h_kernel, dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
 }
 
 // ============================================================================

@@ -90,8 +90,8 @@ __device__ __forceinline__ void split_row(const f32x4 v, Row16& o) {
 
 }  // namespace
 
-template <bool PPOUT, int OCC = 3>
-__global__ __launch_bounds__(64, OCC) void stem_h3_kernel(StemArgs a) {
+template <bool PPOUT>
+__global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
   const int H = a.H, W = a.W, PH = H >> 2, PW = W >> 2;
   const int strips = (PW - 1 + 14) / 15;
   const int bands = PH / a.R;                      // a.R divides PH
@@ -409,7 +409,6 @@ void yfv2_launch_stem16(const StemArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((stem_h3u_kernel<false>), grid, dim3(64), 0, s, b);
     return;
   }
-  if (a.pp_out && (yfv2_variant() & 2)) hipLaunchKernelGGL((stem_h3_kernel<true, 4>), grid, dim3(64), 0, s, b);
-  else if (a.pp_out) hipLaunchKernelGGL((stem_h3_kernel<true>), grid, dim3(64), 0, s, b);
+  if (a.pp_out) hipLaunchKernelGGL((stem_h3_kernel<true>), grid, dim3(64), 0, s, b);
   else hipLaunchKernelGGL((stem_h3_kernel<false>), grid, dim3(64), 0, s, b);
 }

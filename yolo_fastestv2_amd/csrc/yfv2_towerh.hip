@@ -212,10 +212,22 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
     stage_load(ja.in, b, 1, pre);
   }
 
+  const int hmh = MH ? ja.mh : 0;                             // output channels of the merged matrix (MH > 0)
   for (; b < a.B; b += grid) {
-    f32x4 acc[KC][NT];
+    // MH == 0: acc[mt][nt] = output-channel tile mt x pixel tile nt of the 72 -> 72 pointwise conv (lane: 4 channels of 1 pixel).
+    // MH > 0 (the half ends in an output conv): pointwise conv + BN and the output conv are both linear and nothing sits between
+    // them (fpn.py:16-17,23-24; detector.py:25-31), so the host multiplied them into ONE matrix (WeightPacker::image_towerh:
+    // Wh diag(scale) Wp, bias Wh shift + b, in double) - the kernel applies that matrix to the depthwise result directly,
+    // TRANSPOSED (the data entries as A, rows = the tile's 16 pixels; the filter entries as B, columns = 16 output channels:
+    // both operands have the same lane layout, so this is the same registers with the arguments swapped): acc[m][nt] = pixel
+    // tile nt x output-channel tile m, lane (c = lane & 15, g) holds pixels 4g .. 4g+3 of ONE channel - a 16-byte run of the
+    // NCHW tensor.  (Until round 4 the 72 x 72 product ran first and its BN'd, re-split result fed the output conv in the
+    // epilogue: 25 + 30 filter tiles instead of 30 for obj + cls, 25 + 5 instead of 5 for reg, and 13-15 k cycles of a 67 k
+    // cycle job spent in that epilogue.)
+    constexpr int NA = MH == 0 ? KC : MH;
+    f32x4 acc[NA][NT];
 #pragma unroll
-    for (int mt = 0; mt < KC; ++mt)
+    for (int mt = 0; mt < NA; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     yfv2_u2 xprev[NT];                                                     // first terms of the even chunk, for the pair's main-product MFMA
@@ -289,6 +301,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
         if (ns >= KC) { ns -= KC; nb += grid; }
         stage_load(ja.in, nb < a.B ? nb : b, ns, pre);
       }
+      if constexpr (MH == 0) {
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
         const u32x4 wf = *reinterpret_cast<const u32x4*>(WP_ + ((mt * KC + s) * 64 + lane) * 4);
@@ -303,24 +316,43 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_main1(wf, xb[nt], acc[mt][nt]);
         }
       }
+      } else {
+#pragma unroll
+      for (int m = 0; m < MH; ++m) {
+        if (16 * m < hmh) {                                                 // (wave-uniform: a narrower output conv leaves zero tiles)
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_cross(xb[nt], wf, acc[m][nt]);
+          if (s & 1) {
+            const u32x4 w0 = *reinterpret_cast<const u32x4*>(WH + ((m * KC + s - 1) * 64 + lane) * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[m][nt] = mfma_main2((u32x4){xprev[nt][0], xprev[nt][1], 0u, 0u}, xb[nt], (yfv2_u2){w0[0], w0[1]}, wf, acc[m][nt]);
+          } else if (s == KC - 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_main1(xb[nt], wf, acc[m][nt]);
+          }
+        }
+      }
+      }
       if (!(s & 1)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) xprev[nt] = (yfv2_u2){xb[nt][0], xb[nt][1]};
       }
       YFV2_WSTAMP(4 + 3 * s);
     }
-    // pointwise BN (no ReLU: fpn.py:16-17,23-24); the scale carries 2^-(sw+4)
-#pragma unroll
-    for (int mt = 0; mt < KC; ++mt) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + 16 * mt + 4 * g);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + 16 * mt + 4 * g);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) watch.see(acc[0][nt][0]);   // a depthwise result beyond fp16's range: NaN in every channel of its pixel
     YFV2_WSTAMP(17);
     if constexpr (MH == 0) {
+      // pointwise BN (no ReLU: fpn.py:16-17,23-24); the scale carries 2^-(sw+4)
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + 16 * mt + 4 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) watch.see(acc[0][nt][0]);   // a depthwise result beyond fp16's range: NaN in every channel of its pixel
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if (!pv[nt]) continue;
@@ -330,44 +362,19 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
           if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
       }
     } else {
-      // chained output conv: tile s of the BN'd accumulators = B fragment of chunk s; split in place
-      u32x4 xs[KC][NT];
-#pragma unroll
-      for (int s = 0; s < KC; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xs[s][nt] = split4(acc[s][nt] * 16.0f);
-      const float us = CS[3 * 96];
-      // TRANSPOSED product: the data entries as A (rows = the tile's 16 pixels), the filter entries as B (columns = 16 output
-      // channels) - both operands have the same lane layout, so this is the same registers with the arguments swapped - and
-      // lane (c = lane & 15, g) ends up with pixels 4g..4g+3 of the tile for ONE channel: a 16-byte run of the NCHW tensor.
+      const float us = CS[3 * 96];                                          // 2^-(swh+4)
       const bool vec = (HW & 3) == 0;                                       // (alignment of every channel plane)
       // (both plane pointers in scalar registers BEFORE the lane-dependent choice: left to itself the compiler turns the choice
       // between two kernel-argument fields into ONE vector load from a chosen address - a full load latency in front of every
       // output tile's stores)
       float* hn0 = ja.nchw0; float* hn1 = ja.nchw1;
       asm volatile("" : "+s"(hn0), "+s"(hn1));
-      const int hmh = ja.mh, hsplit = ja.split;
-#pragma unroll 1
+      const int hsplit = ja.split;
+#pragma unroll
       for (int m = 0; m < MH; ++m) {
         if (16 * m >= hmh) break;
-        u32x4 wf[KC];
 #pragma unroll
-        for (int s = 0; s < KC; ++s) wf[s] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + s) * 64 + lane) * 4);
-        f32x4 hacc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) hacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KC; ++s)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_cross(xs[s][nt], wf[s], hacc[nt]);
-#pragma unroll
-        for (int s = 0; s + 1 < KC; s += 2)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main2(xs[s][nt], xs[s + 1][nt], (yfv2_u2){wf[s][0], wf[s][1]}, wf[s + 1], hacc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) hacc[nt] = mfma_main1(xs[KC - 1][nt], wf[KC - 1], hacc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) watch.see((hacc[nt][0] + hacc[nt][1]) + (hacc[nt][2] + hacc[nt][3]));   // transposed: a lane's four values are four PIXELS
+        for (int nt = 0; nt < NT; ++nt) watch.see((acc[m][nt][0] + acc[m][nt][1]) + (acc[m][nt][2] + acc[m][nt][3]));   // transposed: a lane's four values are four PIXELS
         const int co = 16 * m + p;
         if (co < hmh) {
           const float bias = CS[2 * 96 + co];
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
             const int px0 = 16 * (wv * NT + nt) + 4 * g;
             f32x4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(hacc[nt][r], us, bias);
+            for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(acc[m][nt][r], us, bias);
             if (vec) {
               if (px0 < HW) *reinterpret_cast<f32x4*>(plane + px0) = y;
             } else {
@@ -527,17 +534,19 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
     __syncthreads();                                              // exchange complete
     YFV2_WSTAMP(2);
 
-    // ---- pointwise: K = 72 in one go
+    // ---- pointwise: K = 72 in one go.  A half that ends in an output conv applies the host-merged matrix (output conv x BN x
+    // pointwise conv, see towerh_kernel) to these operand entries directly, transposed.
+    u32x4 xb[KC];
+#pragma unroll
+    for (int sc = 0; sc < KC; ++sc) {
+      const f32x4 v = 16 * sc + 4 * g < C ? *reinterpret_cast<const f32x4*>(X32 + opix * CP + 16 * sc + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      xb[sc] = split4(v);
+    }
+    if (MH == 0 || !ja.has_head) {
     f32x4 acc[KC];
 #pragma unroll
     for (int mt = 0; mt < KC; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-      u32x4 xb[KC];
-#pragma unroll
-      for (int sc = 0; sc < KC; ++sc) {
-        const f32x4 v = 16 * sc + 4 * g < C ? *reinterpret_cast<const f32x4*>(X32 + opix * CP + 16 * sc + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        xb[sc] = split4(v);
-      }
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
         u32x4 wf[KC];
@@ -558,7 +567,6 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
     }
     watch.see(acc[0][0]);
     YFV2_WSTAMP(3);
-    if (MH == 0 || !ja.has_head) {
       if (pv) {                                                   // (every depthwise read of IN is behind the exchange barrier)
         float* dst = out_lds ? IN + (2 * W + opix) * C : ja.out + ((size_t)b * HW + opix) * C;
 #pragma unroll
@@ -566,9 +574,7 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
           if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt];
       }
     } else {
-      u32x4 xs[KC];
-#pragma unroll
-      for (int sc = 0; sc < KC; ++sc) xs[sc] = split4(acc[sc] * 16.0f);
+      YFV2_WSTAMP(3);
       const float us = CS[3 * 96];
       const bool vec = (HW & 3) == 0;
       // (both plane pointers in scalar registers BEFORE the lane-dependent choice: left to itself the compiler turns the choice
@@ -585,10 +591,10 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
         for (int sc = 0; sc < KC; ++sc) wf[sc] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + sc) * 64 + lane) * 4);
         f32x4 hacc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sc = 0; sc < KC; ++sc) hacc = mfma_cross(xs[sc], wf[sc], hacc);
+        for (int sc = 0; sc < KC; ++sc) hacc = mfma_cross(xb[sc], wf[sc], hacc);
 #pragma unroll
-        for (int sc = 0; sc + 1 < KC; sc += 2) hacc = mfma_main2(xs[sc], xs[sc + 1], (yfv2_u2){wf[sc][0], wf[sc][1]}, wf[sc + 1], hacc);
-        hacc = mfma_main1(xs[KC - 1], wf[KC - 1], hacc);
+        for (int sc = 0; sc + 1 < KC; sc += 2) hacc = mfma_main2(xb[sc], xb[sc + 1], (yfv2_u2){wf[sc][0], wf[sc][1]}, wf[sc + 1], hacc);
+        hacc = mfma_main1(xb[KC - 1], wf[KC - 1], hacc);
         watch.see((hacc[0] + hacc[1]) + (hacc[2] + hacc[3]));      // transposed: a lane's four values are four PIXELS
         const int co = 16 * m + p;
         if (co < hmh) {
