@@ -1073,6 +1073,7 @@ struct PlanBuilder {
       }
     }
     s.s2px.in = h->a1.p; s.s2px.act = h->s2pp.p;
+    s.s2px.in_nhwc = stem_nhwc_ ? 1 : 0;
     s.s2px.IH = IH; s.s2px.IW = IW;
     s.s2px.in_stride = 24 * IH * IW; s.s2px.out_stride = 48 * OH * OW;
     s.s2px.in_records = 24 * IH * IW * 4; s.s2px.out_records = 48 * OH * OW * 4;
@@ -1517,6 +1518,7 @@ struct PlanBuilder {
   // towerh_kernel's single-pixel form (maps up to 11x11) runs the four tower halves of a map size in ONE launch (each
   // workgroup: cls a, cls b, reg a, reg b of its image, in the order the separate launches had): runs of four consecutive
   // such steps become one step.
+  bool stem_nhwc_ = false;
   void merge_tower_launches() {
     std::vector<Step> out;
     for (size_t i = 0; i < h->plan.size();) {
@@ -1575,8 +1577,13 @@ struct PlanBuilder {
     const bool fused = !(envf && envf[0] == '0');   // YFV2_FUSED=0: every layer its own launch (the general plan)
     const bool stage2_px = fused && h->s2pp.p && yfv2_s1px_supported(hh / 2, ww / 2) &&
                            yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0 && (pp_bufstride + 48LL * (hh / 2) * (ww / 2)) * 4 < (1LL << 31);
-    add_stem(h->a1, stage2_px);
-    h->stem_pp = stage2_px;
+    // the stem's output for s2h_kernel: [H/4][W/4][24] (a pixel's 96 bytes in one run: every lane group's 16-byte store lands in
+    // the same 1.5 KB of a wave's row) - 126 -> 120 us against the quad planes of round 4's first half on the same box, stage2.0
+    // unchanged (72.7 us either way); YFV2_VARIANT bit 1: quad planes.  The YFV2_BF6=0 plan keeps its pair planes.
+    const bool stem_nhwc = stage2_px && h->bf6 && !(yfv2_variant() & 2);
+    add_stem(h->a1, stage2_px && !stem_nhwc);
+    h->stem_pp = stage2_px && !stem_nhwc;
+    stem_nhwc_ = stem_nhwc;
     Buf* stage_bufs[3] = {h->s2, h->s3, h->s4};
     const int repeats[3] = {4, 8, 4};
     const Buf* x = &h->a1;

@@ -20,6 +20,7 @@ __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((fl
 
 // Kernel-variant switches for same-box A/B measurements (YFV2_VARIANT = bit mask, read once per process; unset = 0 = the defaults):
 //   1  fpn.conv1x1_2 (pw_kernel<288>) as 512-thread workgroups with two pixel tiles per wave (the form up to round 4)
+//   2  the stem writes quad planes [6][H/4][W/4][4] for s2h_kernel instead of [H/4][W/4][24] (round 4's first form)
 // (measured and removed in round 4, DESIGN.md 4.10: s1h / stem at four waves per SIMD by launch bound - the spills cost more than
 // the occupancy gives, 31 -> 44 us and 115 -> 131 us; non-temporal input loads in stem / s2h / s1h / s3h - the consumer of a
 // streamed tensor slows down, s2h 73 -> 98 us)
@@ -284,6 +285,7 @@ struct S2PxArgs {
   int st1_off[2][8];   // per role: byte offsets (plane + element) of output positions 16..23 (4-byte stores)
   const float* img16;  // s2h_kernel's image (yfv2_stage2h.hip, WeightPacker::image_s2h: both branches in one wave); null: the two role kernels
   int* nonfinite;      // range-guard word (Yfv2Watch), or null
+  int in_nhwc;         // s2h_kernel: the stem's output is [IH][IW][24] instead of quad planes
 };
 void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // a.img16 set: yfv2_launch_s2h (one kernel); else two kernels (proj role, main role)
 void yfv2_launch_s2h(const S2PxArgs& a, hipStream_t s);

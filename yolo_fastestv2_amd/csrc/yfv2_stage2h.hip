@@ -299,14 +299,17 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
   // input: the stem's QUAD planes [6][IH][IW][4] (round 4; yfv2_stem16.hip) - this lane's eight channel positions are plane g
   // (all lane groups: the stem's channel tile 0) and plane 4 + g (lane groups 0, 1: tile 1), two adjacent pixels of each
   int loff[2], soff[8];
-  loff[0] = xok ? (g * IH * IW + 2 * ox) * 16 : OOB;
-  loff[1] = (xok && g < 2) ? ((4 + g) * IH * IW + 2 * ox) * 16 : OOB;
+  // (a.in_nhwc: [IH][IW][24] - a pixel's 96 bytes in one run: the same 16-byte pieces at other offsets)
+  const int nhwc = a.in_nhwc;
+  loff[0] = xok ? (nhwc ? 2 * ox * 96 + 16 * g : (g * IH * IW + 2 * ox) * 16) : OOB;
+  loff[1] = (xok && g < 2) ? (nhwc ? 2 * ox * 96 + 64 + 16 * g : ((4 + g) * IH * IW + 2 * ox) * 16) : OOB;
+  const int coff = nhwc ? 96 : 16;                 // the lane's second pixel
   {
     const int* po = reinterpret_cast<const int*>(img + S2H_OFFS);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int v = po[(4 + k) * 64 + lane]; soff[k] = (st_lane && v != OOB) ? v + ox * 8 : OOB; }
   }
-  const int irowb = IW * 16, orowb = OW * 8;
+  const int irowb = nhwc ? IW * 96 : IW * 16, orowb = OW * 8;
 
   // one input row: X[2t + c] = the four channel positions 4t .. 4t+3 of column 2ox + c, times 2^4 later - four 16-byte loads
   auto load_row = [&](int iy, f32x4 (&X)[4]) {
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        X[2 * t + c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rok && loff[t] != OOB) ? loff[t] + iy * irowb : OOB, 16 * c, 0));   // (an out-of-range voffset stays out of range)
+        X[2 * t + c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rok && loff[t] != OOB) ? loff[t] + iy * irowb : OOB, c * coff, 0));   // (an out-of-range voffset stays out of range)
   };
   // the two branches' depthwise inputs of one input row: raw values x 2^4 (proj) and relu(pw1) x 2^(sw1+4) (main, 0 outside the image)
   auto columns = [&](const f32x4 (&X)[4], float lim, float (&xe)[8], float (&xo)[8], float (&te)[8], float (&to)[8]) {
