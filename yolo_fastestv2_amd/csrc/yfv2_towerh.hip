@@ -79,7 +79,13 @@ constexpr int TH_WH = TH_CS + 4 * 96;
 __host__ __device__ constexpr int th_lds_img(int MH) { return TH_WH + MH * TH_KC * 256; }   // = offset of TAPS
 constexpr int TH_Q = 27;   // parity-plane row pitch (16-byte slots)
 
-constexpr int TH_XOFF = 14;   // the odd-column plane of a row starts here (13 of the 27 slots of a row are used by each parity)
+constexpr int TH_XOFF = 13;   // the odd-column plane of a row starts here (13 of the 27 slots of a row are used by each parity).  13, not 14: the
+                              // staging stores (eight consecutive pixels per 8-lane store group: slots k, 13+k, k+1, 14+k, ..) then collide in one
+                              // bank pair instead of two
+// exchange-buffer slot of pixel q: bit 0 flipped in every other run of eight.  A 2x2-patch lane stores pixels two apart (eight
+// lanes of a ds_write_b128 group: slots q, q+2, .. q+14 - the same four bank quads twice); with the flip the second four land on
+// the odd quads.  A pixel tile's 16 consecutive slots stay a permutation of themselves: the pointwise reads are unaffected.
+__device__ __forceinline__ int th_xslot(int q) { return q ^ ((q >> 3) & 1); }
 
 template <int PS> struct ThGeom {
   static constexpr int YH = PS == 2 ? 13 : 16;                // plane rows: (H + 4) / PS rounded up (H <= 22 / H <= 11)
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
 #pragma unroll
   for (int k = 0; k < NPAR; ++k) {
     const int y = PS * py + k / PS, x = PS * pxx + k % PS;
-    xdst[k] = (pvalid && y < H && x < W) ? (qq * XP + y * W + x) * 4 : -1;
+    xdst[k] = (pvalid && y < H && x < W) ? (qq * XP + th_xslot(y * W + x)) * 4 : -1;
   }
   // ---- pointwise role: NT pixel tiles of 16
   int opix[NT];
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
   for (int nt = 0; nt < NT; ++nt) {
     const int q = 16 * (wv * NT + nt) + p;
     pv[nt] = q < HW;
-    opix[nt] = q;                                                           // < XP always: pixels past HW read the zeroed exchange tail
+    opix[nt] = q;                                                           // < XP always: pixels past HW read the zeroed exchange tail (th_xslot(q) stays inside q's aligned pair)
   }
 
   // (The four halves of a 22x22 level as a job list of ONE launch were measured: 145 us against 132 as four launches - a job is
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
       YFV2_WSTAMP(3 + 3 * s);
       u32x4 xb[NT];                                                         // (requested before the staging traffic below)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(XB + (g * XP + opix[nt]) * 4);
+      for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(XB + (g * XP + th_xslot(opix[nt])) * 4);
       // the next slice -> TIN, the one after into registers (of the next image after the last chunk)
       if (s + 1 < KC || b + grid < a.B) stage_store(s + 1 < KC ? s + 1 : 0, pre);
       {
