@@ -443,9 +443,9 @@ typedef float yfv2_f4 __attribute__((ext_vector_type(4)));
 // A wave = one image x 64 pixels x up to four 16-row tiles of output channels; lane (l, g): B operand = in[k0 + g][p0 + 16 e + l]
 // for the four pixel tiles e (four coalesced dword loads), A operand = Wm(16 t + l, k0 + g); D lane (l, g) reg r = out row
 // 16 t + 4 g + r, pixel p0 + 16 e + l.
-template <bool TRANS, bool ACCUM>
+template <bool TRANS, bool ACCUM, int MT>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(V in, V out, const float* __restrict__ w, const float* __restrict__ bias, int wld, int B) {
-  constexpr int MT = 4;
+  constexpr int KS = 4;                            // MFMA steps (4 input channels each) per round of loads
   const int HW = out.H * out.W, K = in.C, M = out.C;
   const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
   const int p0 = (blockIdx.x * 4 + wave) * 64, b = blockIdx.y, r0 = blockIdx.z * (16 * MT);
@@ -457,32 +457,50 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(V in, V out, const float* 
     for (int e = 0; e < 4; ++e) acc[t][e] = (yfv2_f4){0.f, 0.f, 0.f, 0.f};
   const float* inb = in.p + ((size_t)b * in.Ctot + in.coff) * HW;
   const size_t kstride = (size_t)in.cstride * HW;
-  // the operands of step k0 + 4 are requested before the sixteen MFMAs of step k0 run (one global round trip per step otherwise:
-  // the loop has 6 .. 72 steps and nothing else to hide it behind)
-  auto fetch = [&](int k0, float (&bv)[4], float (&av)[MT]) {
-    const int k = k0 + g;
-    const bool kok = k < K;
+  // A round = the operands of KS MFMA steps (16 input channels), requested before the MFMAs of the round before it run.  The
+  // first form fetched ONE step (4 channels) ahead: a layer was K / 4 dependent round trips to L2 with sixteen MFMAs each behind
+  // them - 6 .. 72 of them, the launch's whole duration (the 51 pointwise convs of an iteration: 4.7 ms of its 12.3).  The
+  // MFMAs run in the same order on the same operands: the results are bit-identical to that form.
+  auto fetch = [&](int k0, float (&bv)[KS][4], float (&av)[KS][MT]) {
+    // Every load is unconditional, from a clamped address, and what must not count is removed by an AND with a lane mask on the
+    // FILTER operand only (a channel past K: filter entry 0 times a real, finite activation; rows past M and pixels past HW are
+    // never stored).  A load behind a lane predicate - or a select the compiler turns back into one - is a branch, and the
+    // compiler then waits for every load where it stands: the first version of this round waited twice per pair of loads.
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int p = p0 + 16 * e + l; bv[e] = (kok && p < HW) ? inb[(size_t)k * kstride + p] : 0.f; }
+    for (int j = 0; j < KS; ++j) {
+      const int k = k0 + 4 * j + g;
+      const int kc = k < K ? k : K - 1;
+      const unsigned km = k < K ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { const int r = r0 + 16 * t + l; av[t] = (kok && r < M) ? (TRANS ? w[(size_t)k * wld + r] : w[(size_t)r * wld + k]) : 0.f; }
+      for (int e = 0; e < 4; ++e) { const int p = p0 + 16 * e + l; bv[j][e] = inb[(size_t)kc * kstride + (p < HW ? p : HW - 1)]; }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int r = r0 + 16 * t + l, rc = r < M ? r : M - 1;
+        const float v = TRANS ? w[(size_t)kc * wld + rc] : w[(size_t)rc * wld + kc];
+        av[j][t] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & km);
+      }
+    }
   };
-  auto mac = [&](const float (&bv)[4], const float (&av)[MT]) {
+  auto mac = [&](int k0, const float (&bv)[KS][4], const float (&av)[KS][MT]) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int j = 0; j < KS; ++j) {
+      if (k0 + 4 * j >= K) break;                  // (wave-uniform: a step of zeros adds nothing, but costs its MFMAs)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[e], acc[t][e], 0, 0, 0);
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t], bv[j][e], acc[t][e], 0, 0, 0);
+    }
   };
-  float b0[4], a0[MT], b1[4], a1[MT];
+  float b0[KS][4], a0[KS][MT], b1[KS][4], a1[KS][MT];
   fetch(0, b0, a0);
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    fetch(k0 + 4, b1, a1);
+  for (int k0 = 0; k0 < K; k0 += 8 * KS) {
+    fetch(k0 + 4 * KS, b1, a1);
     __builtin_amdgcn_sched_barrier(0);
-    mac(b0, a0);
-    if (k0 + 4 >= K) break;
-    fetch(k0 + 8, b0, a0);
+    mac(k0, b0, a0);
+    if (k0 + 4 * KS >= K) break;
+    fetch(k0 + 8 * KS, b0, a0);
     __builtin_amdgcn_sched_barrier(0);
-    mac(b1, a1);
+    mac(k0 + 4 * KS, b1, a1);
   }
   float* outb = out.p + ((size_t)b * out.Ctot + out.coff) * HW;
   const size_t rstride = (size_t)out.cstride * HW;
@@ -522,11 +540,15 @@ __global__ __launch_bounds__(64) void pw_wgrad_kernel(V x, V dy, double* __restr
 #pragma unroll
     for (int i = 0; i < T; ++i) {
       const int co = co0 + 16 * i + l, ci = ci0 + 16 * i + l;
+      const int coc = co < Cout ? co : Cout - 1, cic = ci < Cin ? ci : Cin - 1;   // (unconditional loads, see pw_gemm_kernel: rows past
+                                                                                 // Cout / Cin are never stored; a pixel past the segment
+                                                                                 // gets a zero dy against a real, finite x)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int p = q + 4 * g + e;
-        av[i][e] = (co < Cout && p < q1) ? gb[(size_t)co * gs + p] : 0.f;
-        bv[i][e] = (ci < Cin && p < q1) ? xb[(size_t)ci * xs + p] : 0.f;
+        const int p = q + 4 * g + e, pc = p < q1 ? p : q1 - 1;
+        const unsigned pm = p < q1 ? 0xffffffffu : 0u;
+        av[i][e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, gb[(size_t)coc * gs + pc]) & pm);
+        bv[i][e] = xb[(size_t)cic * xs + pc];
       }
     }
   };
@@ -716,11 +738,13 @@ struct Train {
   // pointwise conv launchers (round 4): forward / data gradient as one GEMM, weight gradient = GEMM into the double scratch + finish
   void pw_forward(const V& in, const V& out, const float* w, const float* bias, hipStream_t s) const {
     const int HW = out.H * out.W;
-    hipLaunchKernelGGL((pw_gemm_kernel<false, false>), dim3((HW + 255) / 256, B, (out.C + 63) / 64), dim3(256), 0, s, in, out, w, bias, in.C, B);
+    if (out.C <= 32) hipLaunchKernelGGL((pw_gemm_kernel<false, false, 2>), dim3((HW + 255) / 256, B, 1), dim3(256), 0, s, in, out, w, bias, in.C, B);   // (stage 2's 24 channels: two row tiles)
+    else hipLaunchKernelGGL((pw_gemm_kernel<false, false, 4>), dim3((HW + 255) / 256, B, (out.C + 63) / 64), dim3(256), 0, s, in, out, w, bias, in.C, B);
   }
   void pw_data_grad(const V& din, const V& dout, const float* w, int Bc, hipStream_t s) const {   // din += w^T dout
     const int HW = din.H * din.W;
-    hipLaunchKernelGGL((pw_gemm_kernel<true, true>), dim3((HW + 255) / 256, Bc, (din.C + 63) / 64), dim3(256), 0, s, dout, din, w, (const float*)nullptr, din.C, Bc);
+    if (din.C <= 32) hipLaunchKernelGGL((pw_gemm_kernel<true, true, 2>), dim3((HW + 255) / 256, Bc, 1), dim3(256), 0, s, dout, din, w, (const float*)nullptr, din.C, Bc);
+    else hipLaunchKernelGGL((pw_gemm_kernel<true, true, 4>), dim3((HW + 255) / 256, Bc, (din.C + 63) / 64), dim3(256), 0, s, dout, din, w, (const float*)nullptr, din.C, Bc);
   }
   void pw_weight_grad(const V& x, const V& dout, float* dw, int Bc, hipStream_t s) {
     const int HW = x.H * x.W, cob = (dout.C + 47) / 48, cib = (x.C + 47) / 48;
