@@ -244,9 +244,13 @@ YFV2_API int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_
  * the kernel-stats tables under profiles/ do. */
 YFV2_API int yfv2_stage_kernel(yfv2_handle h, int32_t i, char* name, int32_t name_cap);
 
-/* Measurement helper (synchronises): runs the forward `iters` times with a
- * hipEvent pair around every launch on `stream` and writes the mean duration
- * of each launch in milliseconds to ms[0..num_stages). */
+/* Measurement helper (synchronises once, at the end): one untimed pass, then
+ * `iters` passes of the forward queued back to back on `stream` with a hipEvent
+ * pair around every launch; the mean duration of each launch in milliseconds
+ * goes to ms[0..num_stages).  Between two passes the decode + NMS launch of
+ * yfv2_detect runs untimed (thresholds 0.3 / 0.4, results discarded) where the
+ * configuration has the fused form, so that a pass's first launch follows what it
+ * follows in a detect loop. */
 YFV2_API int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], int32_t iters,
                          float* ms, void* stream);
 
