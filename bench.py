@@ -2,7 +2,9 @@
 """bench.py - images/sec of the Yolo-FastestV2 hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*;
+     called PLAIN with --gpus N > 1, bench.py launches itself: it re-executes under `python -m torch.distributed.run --nnodes=1
+     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` and rank 0 prints the one JSON line.)
 
 A "step" is one pass of the whole hot path - forward (backbone + FPN + heads) ->
 anchor decode -> class-aware NMS - over one batch of 256 synthetic 352x352x3 fp32
@@ -16,15 +18,24 @@ Consecutive steps are independent batches: they rotate over three handles
 (own workspaces) on three HIP streams, so that one step's launches fill the
 under-filled tails of its neighbours' (all K steps complete inside the timed
 region); `single_stream_img_s` is the same K steps on one handle and one stream.
-The untimed warm-up is max(W, 80) steps (`warmup_steps_run`): a fresh process runs its
-first ~25 steps 8-10 % slower, until the device has left its idle power state.
+Order of a run: set-up (handles, one call per handle) -> SPIN-UP: the device is held under load for --spinup-seconds (2 s)
+of the same steps, because a fresh process runs its first steps 8-10 % slower until the device has left its idle power state
+(reported as `spinup`, not as warm-up) -> exactly W warm-up steps -> --blocks (5) back-to-back timed blocks of EXACTLY K steps,
+each bracketed by barrier + device synchronize.  `value` / `ms_per_step` are the MEDIAN block; every block's rate and the
+min / max ride along (`blocks`), so that a clock ramp or a noisy box is visible instead of guessed.  `box` records what the
+run ran at: the effective shader clock measured by the shader itself (s_memtime against the constant reference clock) under
+an all-CU vector load before and after the timed blocks and - by sleeping probe waves on a side stream - WHILE the timed kind
+of step loop and the per-kernel profile run, plus whatever rocm-smi / sysfs give on the box (performance level, power cap,
+partition modes).  `kernel_table` carries shader cycles next to milliseconds.
 The configs[2] variant the survey specifies (COCO weights, a 256-batch built from
 the shipped JPEGs, thresholds 0.3/0.4 and 0.01/0.4) is timed as well and reported
 in `coco_e2e` (extra fields, never `value`).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings):
-  value      whole-job images/s (all ranks' images / max-over-ranks time), steps pipelined over three streams
-  single_stream_img_s   the same steps strictly one after the other
+  value      whole-job images/s (all ranks' images / max-over-ranks time of the median block), consecutive steps (= batches
+             of 256) pipelined over three handles / HIP streams: up to three batches are in flight at any time
+  single_stream_img_s   the same steps strictly one batch at a time on one handle and one stream
+  fp32_mfma_plan   the same two figures with every contraction on the fp32 matrix instructions (YFV2_BF6=0) instead of fp16x3
   roofline   the kernel that owns the most forward time (sum over its launches, the
              top row of a rocprofv3 --stats table): algorithmic bytes (SURVEY.md 8(d):
              EXTERNAL reads + writes for a fused launch) and flops of its launches /
@@ -108,11 +119,16 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.3)
     ap.add_argument("--iou", type=float, default=0.4)
     ap.add_argument("--profile-iters", type=int, default=5)
-    ap.add_argument("--min-warmup", type=int, default=80, help="the untimed warm-up runs max(--warmup, this) steps: a fresh process needs ~60 ms of work to leave the device's idle power state")
+    ap.add_argument("--blocks", type=int, default=5, help="back-to-back timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--spinup-seconds", type=float, default=2.0, help="set-up: hold the device under load this long before the warm-up (a fresh process runs its first steps 8-10 %% slower until the device has left its idle power state)")
     ap.add_argument("--pipeline", type=int, default=3, help="handles / HIP streams consecutive steps rotate over (1 = one handle, one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-plan, COCO and training extras (counter passes)")
     ap.add_argument("--weights", choices=("random", "coco"), default="random")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="NOT a measurement: run the launch / sharding / gather logic of this script on CPU tensors with gloo and a stand-in "
+                         "engine (tests/test_abi_and_host.py: `bench.py --gpus 2 --launcher-selftest` must self-launch and print one line)")
     return ap.parse_args()
 
 
@@ -144,15 +160,154 @@ def timed(fn, steps, sync, barrier, finish=None):
     return time.perf_counter() - t0
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>` (exec: same pid, same stdout -
+    rank 0's JSON line is this process's output).  The port is one the kernel just handed out."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def smi_snapshot(index):
+    """Best effort: what the box's management interface says about the device (performance level, power cap, clocks, partition
+    modes).  Containers of this pool often expose little; whatever is readable is recorded, nothing is required."""
+    import glob
+    import subprocess
+    out = {}
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(index), "--showperflevel", "--showmaxpower", "--showpower", "--showclocks", "--showsclkrange",
+                            "--showcomputepartition", "--showmemorypartition", "--json"], capture_output=True, text=True, timeout=30)
+        j = json.loads(r.stdout[r.stdout.index("{"):]) if "{" in r.stdout else {}
+        for card, kv in j.items():
+            if isinstance(kv, dict):
+                out["rocm_smi"] = {k: v for k, v in kv.items() if any(t in k.lower() for t in ("perf", "power", "sclk", "mclk", "fclk", "partition", "socclk"))}
+                break
+    except Exception as e:                      # noqa: BLE001 - telemetry only
+        out["rocm_smi_error"] = repr(e)[:120]
+    sysfs = {}
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        for name in ("power_dpm_force_performance_level", "current_compute_partition", "current_memory_partition", "pp_dpm_sclk", "pp_dpm_mclk"):
+            try:
+                with open(os.path.join(card, name)) as fh:
+                    sysfs.setdefault(os.path.basename(os.path.dirname(card)), {})[name] = fh.read().strip()[:200]
+            except OSError:
+                pass
+        for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+            for name in ("power1_cap", "power1_cap_max", "power1_average", "power1_input", "freq1_input"):
+                try:
+                    with open(os.path.join(hw, name)) as fh:
+                        sysfs.setdefault(os.path.basename(os.path.dirname(card)), {})[name] = fh.read().strip()[:40]
+                except OSError:
+                    pass
+    if sysfs:
+        out["sysfs"] = sysfs
+    return out
+
+
+class _StandInEngine:
+    """--launcher-selftest only: the call shape of Engine.detect on CPU tensors; detections are a function of the rank and the
+    step, so that the gathered buffer can be checked word for word."""
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, 0
+
+    def detect(self, x, conf_thres, iou_thres, out=None, check=True):
+        d, i, c = out
+        self.calls += 1
+        d.fill_(float(self.rank) + 0.001 * self.calls); i.fill_(self.rank); c.fill_(self.calls % 300)
+        return d, i, c
+
+
+class _StandInPipe:
+    def __init__(self, rank, B, depth):
+        import contextlib
+        from yolo_fastestv2_amd.sharded import packed_det_buffers
+        self.depth, self.engines, self.streams = depth, [_StandInEngine(rank) for _ in range(depth)], [None] * depth
+        self.buffers = [packed_det_buffers(B, "cpu") for _ in range(depth)]
+        self._n = 0
+
+        @contextlib.contextmanager
+        def slot():
+            j = self._n % depth
+            self._n += 1
+            yield j, self.engines[j], self.buffers[j]
+        self.slot = slot
+
+
+def launcher_selftest(a, rank, world):
+    """The N > 1 control flow of main() - environment, process group, rotation over buffer sets, one asynchronous packed
+    all-gather per step, host-side completion, the timed blocks, max-over-ranks, ONE line from rank 0 - on CPU tensors over gloo.
+    Prints a line marked `selftest`; never a measurement."""
+    import torch.distributed as dist
+    import yolo_fastestv2_amd as yfv2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or "MASTER_PORT" in os.environ:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    use_dist = dist.is_initialized()
+    B = min(a.batch, 8)
+    pipe = _StandInPipe(rank, B, max(1, a.pipeline))
+    recv = [torch.empty(world * B * (300 * 7 + 1)) for _ in pipe.buffers] if use_dist else []
+    works = [None] * pipe.depth
+    x = torch.zeros(B, 3, 32, 32)
+
+    def step():
+        with pipe.slot() as (j, e, bufs):
+            if works[j] is not None:
+                works[j].wait_host(); works[j] = None
+            d, i, c = e.detect(x, a.conf, a.iou, out=bufs)
+            if use_dist:
+                works[j] = yfv2.gather_detections(d, i, c, force=True, async_op=True, out=recv[j])
+
+    def finish():
+        for j, w in enumerate(works):
+            if w is not None:
+                w.wait(unpack=False); works[j] = None
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+    for _ in range(a.warmup):
+        step()
+    finish()
+    dts = [timed(step, a.steps, lambda: None, barrier, finish) for _ in range(max(1, a.blocks))]
+    t = torch.tensor(dts, dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        from yolo_fastestv2_amd.sharded import rank_views
+        for j in range(pipe.depth):          # every rank holds every rank's last result of that slot, in rank order
+            for r, (d, i, c) in enumerate(rank_views(recv[j], world, B)):
+                assert int(i[0, 0]) == r and abs(float(d[0, 0, 0]) - r) < 0.5, (rank, j, r)
+    dt = float(t.median())
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (CPU stand-in engine over gloo; NOT a measurement)", "selftest": True,
+                          "value": round(world * B * a.steps / dt, 1), "unit": "stand-in images/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "blocks": len(dts), "scaling": "weak", "data": "stand-in",
+                          "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "plain"}), flush=True)
+    barrier()
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                      # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+        a.gpus = world                      # under a launcher the launcher's world size is the truth
+    if a.launcher_selftest:
+        return launcher_selftest(a, rank, world)
     import torch.distributed as dist
     import yolo_fastestv2_amd as yfv2
 
@@ -192,6 +347,7 @@ def main():
     x = torch.rand(a.batch, 3, 352, 352, device=dev, generator=g)  # resident in HBM before timing
     det_bufs = pipe.buffers[0]
     logit_bufs = [torch.empty(s, device=dev) for s in eng.logit_shapes(a.batch)]
+    side = torch.cuda.Stream(device=dev)      # the clock probe's stream
 
     # N > 1: a rank's padded detections (8.4 KB/image, one flat buffer) are all-gathered once per step on RCCL's own
     # stream, overlapped with the next step's kernels: two buffer sets, a set is reused only after its gather was waited for
@@ -204,7 +360,7 @@ def main():
             if works[j] is not None:
                 works[j].wait_host()      # issued len(sets) steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
                 works[j] = None
-            d, i, c = e.detect(x, a.conf, a.iou, out=bufs)
+            d, i, c = e.detect(x, a.conf, a.iou, out=bufs)     # (looks at the range guard first: Engine.detect check=True, a host memory read)
             if use_dist:
                 works[j] = yfv2.gather_detections(d, i, c, force=True, async_op=True, out=recv[j])
 
@@ -217,30 +373,81 @@ def main():
                 w.wait(unpack=False)
                 works[j] = None
 
+    def clock_busy(ms=25.0):
+        """effective shader clock with every CU issuing dependent FMAs (two one-wave workgroups per CU), main stream"""
+        eng.clock_probe_begin(2 * torch.cuda.get_device_properties(dev).multi_processor_count, ms, busy=True)
+        return eng.clock_probe_end()
+
+    def clock_during(fn, est_ms):
+        """run fn() (which enqueues and may synchronise) while 16 sleeping probe waves sit on the side stream for ~est_ms: the
+        clock the kernels of fn ran at.  The probe waves sleep between looks at the reference clock (no issue slots to speak of)."""
+        sync()
+        with torch.cuda.stream(side):
+            eng.clock_probe_begin(16, max(0.2, est_ms), busy=False)
+        r = fn()
+        with torch.cuda.stream(side):
+            c = eng.clock_probe_end()
+        sync()
+        return r, c
+
     for j in range(1, len(engs)):          # set-up, not a step: every extra handle's first call (lazy one-time initialisation)
         with torch.cuda.stream(streams[j]):
             engs[j].detect(x, a.conf, a.iou, out=sets[j])
     sync()
-    # set-up, not a step: bring the device out of its idle power state.  A fresh process runs its first ~25 steps 8-10 % slower
-    # than every later one (measured in round 3: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each
-    # following 20), which would put a --warmup 5 --steps 20 run entirely inside the ramp.  So the untimed warm-up is
-    # max(W, --min-warmup = 80) of the same steps (a fixed COUNT, the same on every rank: the steps hold a collective), then
-    # the K timed ones; the count actually run is reported as `warmup_steps_run`.
-    warm_steps = max(a.warmup, a.min_warmup)
-    for _ in range(warm_steps):
+    box = {"device": torch.cuda.get_device_name(dev), "cus": torch.cuda.get_device_properties(dev).multi_processor_count}
+    if rank == 0:
+        box.update(smi_snapshot(local))
+        box["sclk_cold"] = clock_busy()          # first look, before the device was held under load
+    # SPIN-UP (set-up, not a step, not the warm-up): hold the device under load for --spinup-seconds of the same steps on one
+    # handle (no collective: every rank decides by its own clock).  A fresh process runs its first steps 8-10 % slower than every
+    # later one (round 3: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each following 20) - the device
+    # leaving its idle power state - which would put a --warmup 5 --steps 20 run entirely inside the ramp.
+    t_spin, n_spin = time.perf_counter(), 0
+    while time.perf_counter() - t_spin < a.spinup_seconds:
+        for _ in range(20):
+            with pipe.slot() as (j, e, bufs):
+                e.detect(x, a.conf, a.iou, out=bufs)
+        n_spin += 20
+        sync()
+    spin_s = time.perf_counter() - t_spin
+    if rank == 0:
+        box["sclk_before_timed"] = clock_busy()
+    # exactly W warm-up steps (with the collective), then --blocks timed blocks of exactly K steps
+    for _ in range(a.warmup):
         step()
     finish()
     sync()
-    dt = timed(step, a.steps, sync, barrier, finish)
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dts = [timed(step, a.steps, sync, barrier, finish) for _ in range(max(1, a.blocks))]
+    t = torch.tensor(dts, device=dev, dtype=torch.float64)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # per block: the slowest rank
+    dts = sorted(float(v) for v in t.cpu())
+    dt = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])
     value = world * a.batch * a.steps / dt
+    blocks = {"n": len(dts), "steps_each": a.steps, "img_s": [round(world * a.batch * a.steps / v, 1) for v in dts],
+              "img_s_min": round(world * a.batch * a.steps / dts[-1], 1), "img_s_max": round(world * a.batch * a.steps / dts[0], 1),
+              "value_is": "median block"}
+    if rank == 0:
+        box["sclk_after_timed"] = clock_busy()
+        # the same kind of loop once more with the sleeping probe beside it: the clock the timed steps ran at
+    def k_steps():
+        for _ in range(a.steps):
+            step()
+        finish()
+    if rank == 0:
+        _, box["sclk_during_pipelined_steps"] = clock_during(k_steps, 0.85 * 1e3 * dt)
+    else:
+        k_steps()
     # the same K steps on one handle and one stream (no collective): what a caller that does not pipeline its batches gets
     for _ in range(2):
         step_single()
-    dt_s = timed(step_single, a.steps, sync, barrier)
+    dts_s = sorted(timed(step_single, a.steps, sync, barrier) for _ in range(max(1, a.blocks)))
+    dt_s = dts_s[len(dts_s) // 2]
+    if rank == 0:
+        def k_single():
+            for _ in range(a.steps):
+                step_single()
+        _, box["sclk_during_single_stream_steps"] = clock_during(k_single, 0.85 * 1e3 * dt_s)
 
     # ONE call per batch on ONE handle whose calls cut the batch into two slices on internal streams (YFV2_LANES=2, DESIGN.md 5)
     os.environ["YFV2_LANES"] = "2"
@@ -293,7 +500,10 @@ def main():
         # cannot be read from inside the process: they come from the newest profiles/*_traffic.json / *_pmc.json whose
         # source fingerprint (tools/srchash.py) equals this tree's - else null.
         stages = eng.stages()
-        ms = eng.profile_forward(x, iters=a.profile_iters)
+        # per-launch events, with the sleeping clock probe beside them: cycles = milliseconds x the clock those launches ran at
+        est_profile_ms = (a.profile_iters + 1) * 1e3 * dt_s / a.steps
+        ms, box["sclk_during_profile"] = clock_during(lambda: eng.profile_forward(x, iters=a.profile_iters), 0.9 * est_profile_ms)
+        sclk_prof = box["sclk_during_profile"]["sclk_mhz_mean"]
         src_hash = source_hash()
         prof_t, prof_p = newest_profile("_traffic.json", src_hash), newest_profile("_pmc.json", src_hash)
         table = {}
@@ -310,7 +520,7 @@ def main():
             moved, tf = k["ext"] / sec / 1e9, k["flops"] / sec / 1e12
             ai = k["flops"] / k["ext"]
             traffic = profile_lookup(prof_t, name, "total_bytes", k["launches"])
-            r = {"kernel": name, "launches": k["launches"], "ms": round(k["ms"], 4), "share": round(k["ms"] / tot_ms, 4),
+            r = {"kernel": name, "launches": k["launches"], "ms": round(k["ms"], 4), "kcycles": round(k["ms"] * sclk_prof, 1), "share": round(k["ms"] / tot_ms, 4),
                  "external_bytes": k["ext"], "moved_gbs": round(moved, 1), "hbm_frac_external": round(moved / HBM_PEAK_GBS, 4),
                  "hbm_frac_of_achievable": round(moved / HBM_ACHIEVABLE_GBS, 4),
                  "per_layer_gbs": round(k["bytes"] / sec / 1e9, 1),
@@ -334,7 +544,8 @@ def main():
                 "traffic": (drow["traffic_bytes"] / dom["launches"]) if drow["traffic_bytes"] else None,
                 "traffic_note": ("HBM bytes per launch by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction): profiles/%s, same source fingerprint as this run" % prof_t["_file"])
                                 if drow["traffic_bytes"] else "no profiles/*_traffic.json carries this tree's source fingerprint %s (PMC passes are separate runs: tools/gpu_traffic.sh)" % src_hash,
-                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "sum_ms_per_forward": round(dom["ms"], 4),
+                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "avg_launch_kcycles": round(dom["ms"] / dom["launches"] * sclk_prof, 1),
+                "sclk_mhz_during_profile": sclk_prof, "sum_ms_per_forward": round(dom["ms"], 4),
                 "share_of_forward": round(dom["ms"] / tot_ms, 4),
                 "algorithmic_bytes_per_launch": dom["ext"] / dom["launches"], "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                 "hbm_frac_external": drow["hbm_frac_external"], "hbm_frac_of_achievable": drow["hbm_frac_of_achievable"],
@@ -347,10 +558,43 @@ def main():
                                   "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                   "mfma_pipe_frac": round(PIPE_COST * tot_fl / (tot_ms * 1e-3) / 1e12 / PIPE_PEAK_TF, 4)}}
 
+        # ---- the literal-fp32 plan beside the headline: every contraction on v_mfma_f32_*_f32 (YFV2_BF6=0 at create time) - what the
+        # reference's own arithmetic (fp32 convolutions, model/detector.py:21-47) costs on this box, same weights, same input, same run
+        fp32 = None
+        if world == 1 and FP16X3 and not a.no_extras:
+            os.environ["YFV2_BF6"] = "0"
+            try:
+                pipe32 = yfv2.DetectPipeline(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch, depth=max(1, a.pipeline))
+            finally:
+                os.environ.pop("YFV2_BF6", None)
+            pipe32.load_state_dict(sd)
+
+            def step32():
+                with pipe32.slot() as (_, e, bufs):
+                    e.detect(x, a.conf, a.iou, out=bufs)
+
+            def single32():
+                pipe32.engines[0].detect(x, a.conf, a.iou, out=pipe32.buffers[0])
+            for _ in range(3 * pipe32.depth):
+                step32()
+            d32 = sorted(timed(step32, a.steps, sync, barrier) for _ in range(3))[1]
+            for _ in range(2):
+                single32()
+            d32s = sorted(timed(single32, a.steps, sync, barrier) for _ in range(3))[1]
+            for _ in range(2):
+                pipe32.engines[0].forward(x, out=logit_bufs)
+            d32f = timed(lambda: pipe32.engines[0].forward(x, out=logit_bufs), a.steps, sync, barrier)
+            fp32 = {"img_s": round(a.batch * a.steps / d32, 1), "ms_per_step": round(1e3 * d32 / a.steps, 4),
+                    "single_stream_img_s": round(a.batch * a.steps / d32s, 1), "single_stream_ms_per_step": round(1e3 * d32s / a.steps, 4),
+                    "forward_only_ms": round(1e3 * d32f / a.steps, 4), "headline_over_fp32_plan": round(d32 / dt, 3),
+                    "note": "YFV2_BF6=0: stem, stage 2, stage 4.0 and the towers on rounds 1-2's fp32-MFMA kernels, the chains and FPN reduces with fp32 MFMAs; "
+                            "same steps, same pipelining, median of three blocks"}
+            del pipe32
+
         # ---- BASELINE configs[2] as the survey specifies it: COCO weights, JPEG-derived batch, both threshold pairs ----
         coco = None
         gold = os.path.join(REPO, "tests", "golden")
-        if world == 1 and os.path.exists(os.path.join(gold, "weights_coco.npz")):
+        if world == 1 and not a.no_extras and os.path.exists(os.path.join(gold, "weights_coco.npz")):
             import numpy as np
             z = np.load(os.path.join(gold, "weights_coco.npz"))
             eng_c = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
@@ -420,7 +664,7 @@ def main():
         # ---- BASELINE configs[4]: one train.py iteration at batch 64 - train-mode forward, compute_loss,
         # backward to all 225 parameters, SGD - through the drop-in surface; an extra, never `value`
         train = None
-        if world == 1:
+        if world == 1 and not a.no_extras:
             import numpy as np
             cfg_t = {"anchor_num": 3, "classes": 80, "width": 352, "height": 352, "anchors": ANCHORS}
             model = yfv2.Detector(80, 3, True).to(dev)
@@ -450,28 +694,40 @@ def main():
 
         out = {
             "metric": "images/sec at 352x352 bs=256 per GPU (forward+decode+NMS)", "value": round(value, 1), "unit": "images/s",
+            "single_stream_img_s": round(a.batch * a.steps / dt_s, 1),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 tensors; contractions fp16x3 (two-term fp16 split operands on v_mfma_f32_16x16x32_f16, fp32 accumulate); depthwise/BN/ReLU/decode/NMS fp32 VALU"
+                     if FP16X3 else "f32 (fp32 MFMA contractions: YFV2_BF6=0 plan)",
+            "data": "synthetic",
             "arithmetic": "fp32 tensors, fp32 accumulation everywhere.  Depthwise convs, BatchNorm, ReLU, max-pool, decode: fp32 VALU.  Every "
                           "convolution with a channel contraction - stem (fp32 input), stage 2, stage3.0, the stage-3 chain, stage4.0, the stage-4 chain, "
                           "the FPN reduces, the towers and the output convs - is fp16x3: both operands split into two fp16 terms whose sum "
                           "reproduces them to 2^-24 (filters on the host, scaled by a power of two; activations scaled by 2^4 / 2^8), the three products "
                           "w1 x2 + w2 x1 + w1 x1 (each exact) accumulated in fp32 by v_mfma_f32_16x16x32_f16, the powers of two undone exactly; error vs "
                           "float64 within 2x of a plain fp32 convolution's (tests/test_stem16_host_model.py), valid for |activation| < 4094 (|pixel| < "
-                          "255.9).  The uint8 stem is fp16x2 (a pixel 0..255 is one exact fp16 term); the YFV2_BF6=0 plan runs the fp32 MFMA.  Every parity test (logits 1e-4, scores 1e-5, identical NMS survivors) runs on this arithmetic.",
+                          "255.9; guarded: yfv2_nonfinite).  The uint8 stem is fp16x2 (a pixel 0..255 is one exact fp16 term); the YFV2_BF6=0 plan runs the fp32 MFMA "
+                          "(timed beside the headline in fp32_mfma_plan).  Every parity test (logits 1e-4, scores 1e-5, identical NMS survivors) runs on this arithmetic.",
             "config": {"workload": "batch %d/GPU synthetic 352x352x3 fp32 (torch.rand), seeded random-init weights, "
                                    "Detector forward + anchor decode + class-aware NMS(conf %.2f, iou %.2f; 300 detections/image = NMS worst case)%s; "
+                                   "`value` keeps UP TO %d BATCHES OF %d IN FLIGHT (consecutive steps rotate over %d handles / HIP streams, every step complete inside its timed block); "
+                                   "the strict one-batch-at-a-time rate is single_stream_img_s.  "
                                    "BASELINE.json configs[1] (forward only) is the subset reported in forward_only_img_s, configs[2] "
                                    "(COCO weights, JPEG-derived batch) in coco_e2e"
-                                   % (a.batch, a.conf, a.iou, " + one RCCL all-gather of the padded detections per step, overlapped with the next step" if use_dist else ""),
-                       "global_batch": world * a.batch, "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
-            "warmup_steps_run": warm_steps,
-            "pipelining": "consecutive steps rotate over %d handles (own workspaces) on as many HIP streams; all K steps complete inside the timed region" % len(engs),
+                                   % (a.batch, a.conf, a.iou, " + one RCCL all-gather of the padded detections per step, overlapped with the next step" if use_dist else "",
+                                      len(engs), a.batch, len(engs)),
+                       "global_batch": world * a.batch, "batches_in_flight": len(engs), "single_stream_img_s": round(a.batch * a.steps / dt_s, 1),
+                       "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
+            "blocks": blocks,
+            "spinup": {"seconds": round(spin_s, 2), "steps": n_spin, "why": "set-up, before the W warm-up steps: the device is held under load until it has left its idle power state"},
+            "box": box,
+            "pipelining": "consecutive steps rotate over %d handles (own workspaces) on as many HIP streams; all K steps of a block complete inside its timed region" % len(engs),
             "forward_only_pipelined_img_s": round(world * a.batch * a.steps / dt_fp, 1), "forward_only_pipelined_ms": round(1e3 * dt_fp / a.steps, 4),
-            "single_stream_img_s": round(a.batch * a.steps / dt_s, 1), "single_stream_ms_per_step": round(1e3 * dt_s / a.steps, 4),
+            "single_stream_ms_per_step": round(1e3 * dt_s / a.steps, 4),
             "single_call_two_lanes_img_s": round(a.batch * a.steps / dt_l, 1), "single_call_two_lanes_ms_per_step": round(1e3 * dt_l / a.steps, 4),
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
             "forward_from_uint8_hwc_img_s": round(fwd_u8_img_s, 1), "forward_from_uint8_hwc_ms": round(1e3 * dt_u / a.steps, 4),
+            "fp32_mfma_plan": fp32,
             "roofline": roof, "cpu_baseline": cpu,
             "detections_per_image": {"mean": round(float(cnt_h.mean()), 1), "max": int(cnt_h.max())},
             "forward_launches": len(stages), "forward_sum_of_launch_ms": round(tot_ms, 4), "kernel_table": kernel_table,

@@ -23,7 +23,10 @@
  *     pointers; weights passed to yfv2_load_weights are HOST pointers.
  *     (YFV2_LANES=N in the environment of yfv2_create: a forward / detect of a large batch is cut into N slices that run on
  *     N streams owned by the handle - forked from and joined back into the caller's stream with events inside the call, same
- *     ordering contract, bit-identical results)
+ *     ordering contract, bit-identical results; DESIGN.md section 5.  Memory: the parent handle keeps its full workspace
+ *     for max_batch images - it serves batches below the slicing threshold, yfv2_profile_forward and the training entry
+ *     points - and every lane adds a workspace for max_batch / N images plus its own copy of the 1 MB weight blob:
+ *     about twice the activation memory of a handle without lanes, ~3 GB at max_batch 256.)
  *   - one handle per device, not thread-safe, and ONE STREAM AT A TIME: the handle's workspace (activations, logits
  *     and candidate rows of yfv2_detect, the class-filter scratch of yfv2_nms) is shared by all calls on it, so calls
  *     issued on different streams must be ordered by the caller (events); use one handle per concurrent stream.
@@ -39,7 +42,7 @@
 extern "C" {
 #endif
 
-#define YFV2_ABI_VERSION 4 /* 2: yfv2_stage_info reports external bytes as well; 3: yfv2_train_*, yfv2_sgd_step; 4: yfv2_nonfinite, lanes */
+#define YFV2_ABI_VERSION 5 /* 2: yfv2_stage_info reports external bytes as well; 3: yfv2_train_*, yfv2_sgd_step; 4: yfv2_nonfinite, lanes; 5: yfv2_nonfinite_peek, yfv2_clock_probe_* */
 #define YFV2_API __attribute__((visibility("default")))
 #define YFV2_MAX_DET 300 /* utils/utils.py:243 max_det */
 
@@ -50,7 +53,9 @@ typedef enum yfv2_status {
   YFV2_ERR_DEVICE = -3,  /* no usable gfx950 device / HIP runtime error */
   YFV2_ERR_WEIGHTS = -4, /* missing / mis-shaped tensor in yfv2_load_weights */
   YFV2_ERR_STATE = -5,   /* call order (e.g. forward before load_weights) */
-  YFV2_ERR_BATCH = -6    /* B < 1 or B > max_batch */
+  YFV2_ERR_BATCH = -6,   /* B < 1 or B > max_batch */
+  YFV2_ERR_RANGE = -7    /* reported by the HOST classes (include/yfv2.hpp detection(), the Python Engine): the range guard of the
+                            default plan tripped (yfv2_nonfinite) - the results of that call are invalid */
 } yfv2_status;
 
 typedef struct yfv2_ctx* yfv2_handle;
@@ -114,6 +119,12 @@ YFV2_API int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const
  * conv on the fp32 matrix instructions, has no such bound and never sets it.  The Python surface queries the word wherever it
  * synchronises anyway (handel_preds, non_max_suppression's callers, evaluation) and raises. */
 YFV2_API int yfv2_nonfinite(yfv2_handle h, int32_t* flag, void* stream);
+/* The same word WITHOUT waiting for anything and without clearing it: 1 if a kernel that has already completed tripped the
+ * guard.  The word lives in host-mapped memory, so this is a host memory read - free.  For callers that never synchronise
+ * with the host between calls (a detect loop that hands device tensors on, include/yfv2.hpp, Engine.detect): they look before
+ * every call and learn of a tripped guard one call late instead of never; yfv2_nonfinite (after the results were waited
+ * for) stays the exact query and the one that clears. */
+YFV2_API int yfv2_nonfinite_peek(yfv2_handle h, int32_t* flag);
 
 /* Same forward from the image layout the reference's callers hold BEFORE their pre-process step
  * (test.py:34-38, utils/datasets.py:106-111): uint8 (B, height, width, 3) - HWC, channel order as decoded
@@ -253,6 +264,19 @@ YFV2_API int yfv2_stage_kernel(yfv2_handle h, int32_t i, char* name, int32_t nam
  * follows in a detect loop. */
 YFV2_API int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], int32_t iters,
                          float* ms, void* stream);
+
+/* Measurement helper: the EFFECTIVE shader clock of the device, measured by the shader itself.  `workgroups` one-wave
+ * workgroups stay on the device for `milliseconds` and stamp s_memtime (shader cycles) against s_memrealtime (the constant
+ * reference clock, hipDeviceAttributeWallClockRate); the quotient is the clock the wave's engine ran at over the interval -
+ * DVFS, power cap and performance level included.  busy = 1: dependent FMAs between the stamps (launch >= one workgroup per
+ * CU: the clock under an all-CU vector load); busy = 0: the waves sleep between looks at the reference clock and take no issue
+ * slots worth naming - launched with a handful of workgroups on a SIDE stream while forwards run on the main stream, they
+ * report the clock those forwards' kernels actually ran at.  yfv2_clock_probe_begin only enqueues on `stream`;
+ * yfv2_clock_probe_end waits for `stream` and writes out[0..2] = min / mean / max MHz over the workgroups, out[3] = reference
+ * clock in MHz, out[4] = mean measured interval in ms, out[5] = number of distinct XCDs the workgroups ran on.  bench.py puts
+ * these figures next to every timing it reports (boxes of one pool differ). */
+YFV2_API int yfv2_clock_probe_begin(yfv2_handle h, int32_t workgroups, float milliseconds, int32_t busy, void* stream);
+YFV2_API int yfv2_clock_probe_end(yfv2_handle h, double out[6], void* stream);
 
 /* Debug/parity helper: copy one internal NHWC activation of the LAST forward
  * to host as (B,H,W,C).  which: 0 stem+pool, 1 stage2, 2 stage3 (C2), 3 stage4

@@ -125,6 +125,15 @@ class Detector {
     if (hipMemcpyAsync(&cnt, d_cnt_, sizeof(cnt), hipMemcpyDeviceToHost, stream_) != hipSuccess ||
         hipMemcpyAsync(rowsbuf, d_dets_, sizeof(rowsbuf), hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
       return fail(YFV2_ERR_DEVICE, "download failed");
+    /* the range guard of the default plan (yfv2.h yfv2_nonfinite): the stream was waited for just above, so the query costs a
+       host memory read.  A fine-tuned model whose activations leave +-4094 must come back as an ERROR here, not as boxes -
+       the reference's fp32 convolutions (model/backbone/shufflenetv2.py:19-32) have no such cliff. */
+    int32_t tripped = 0;
+    const int gr = yfv2_nonfinite(h_, &tripped, stream_);
+    if (gr != YFV2_OK) return fail(gr, yfv2_last_error(h_));
+    if (tripped)
+      return fail(YFV2_ERR_RANGE, "detection: an activation left the range of the default (fp16x3) plan - |activation| >= 4094; the result is "
+                                  "invalid.  Run this model with YFV2_BF6=0 in the environment (fp32 matrix instructions, no such bound)");
     for (int i = 0; i < cnt; ++i) {
       const float* r = rowsbuf + 6 * i;
       TargetBox b;

@@ -290,3 +290,53 @@ def test_data_parallel_backward_issues_one_rccl_all_reduce():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_cases", "train_dp.py")
     out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "train_dp ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_advice_r04_rebind_after_handle_recreation_pickled_optimizer_frozen_parameters():
+    """Three host-side defects ADVICE r04 found in the training glue, one scenario each:
+    (1) an eval call with a LARGER batch than the training batch makes Engine.ensure_batch() re-create the native handle (and
+        drop its training state); the next train-mode forward must bind again instead of failing with 'yfv2_train_bind has not
+        been called';
+    (2) after a step, optimizer.state_dict() must pickle and the optimizer must deep-copy (the kernel-argument table of ctypes
+        pointers is not part of the param groups), and a loaded state_dict carries no foreign key;
+    (3) a parameter with requires_grad == False gets no .grad and is not moved by the optimizer."""
+    import copy
+    import io
+    import yolo_fastestv2_amd as yfv2
+    dev = torch.device("cuda:0")
+    classes, B, T, seed, lr = make_golden.TRAIN_CASES[1]
+    w, x, t = make_golden.train_case_inputs(classes, B, T, seed)
+    anchors = [float(a) for a in np.load(os.path.join(GOLDEN, "cfg_coco.npz"))["anchors"]]
+    cfg = {"anchor_num": 3, "classes": classes, "width": 352, "height": 352, "anchors": anchors}
+    model = yfv2.Detector(classes, 3, True).to(dev)
+    model.load_state_dict(w)
+    frozen = "backbone.first_conv.0.weight"
+    dict(model.named_parameters())[frozen].requires_grad_(False)
+    before = dict(model.named_parameters())[frozen].detach().clone()
+    opt = yfv2.SGD(params=model.parameters(), lr=1e-3, momentum=0.949, weight_decay=0.0005)
+    xs, ts = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    model.train()
+    yfv2.compute_loss(model(xs), ts, cfg, dev)[3].backward()
+    assert dict(model.named_parameters())[frozen].grad is None
+    assert all(p.grad is not None for k, p in model.named_parameters() if k != frozen)
+    opt.step()
+    assert torch.equal(dict(model.named_parameters())[frozen].detach(), before)
+    # (2)
+    buf = io.BytesIO()
+    torch.save(opt.state_dict(), buf)
+    assert all(set(g) == {"lr", "momentum", "weight_decay", "params"} or "_yfv2_table" not in g for g in opt.state_dict()["param_groups"])
+    assert not any(k.startswith("_yfv2") for g in opt.state_dict()["param_groups"] for k in g)
+    opt2 = copy.deepcopy(opt)
+    assert len(opt2.state_dict()["state"]) == len(opt.state_dict()["state"])
+    opt.zero_grad()
+    # (1) eval with a larger batch than training: the handle is re-created
+    model.eval()
+    h_before = model.engine_for(xs).max_batch
+    big = torch.rand(max(2 * B, h_before + 1), 3, 352, 352, device=dev)
+    with torch.no_grad():
+        model(big)
+    model.train()
+    loss = yfv2.compute_loss(model(xs), ts, cfg, dev)[3]
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss.detach()).all()

@@ -11,10 +11,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # YFV2_LIB: opt-in override used only for same-box A/B of two builds (tools/gpu_quick.sh)
 LIB_PATH = os.environ.get("YFV2_LIB") or os.path.join(_HERE, "libyfv2.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DET = 300
 
-OK, ERR_ARG, ERR_CONFIG, ERR_DEVICE, ERR_WEIGHTS, ERR_STATE, ERR_BATCH = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_ARG, ERR_CONFIG, ERR_DEVICE, ERR_WEIGHTS, ERR_STATE, ERR_BATCH, ERR_RANGE = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class Config(C.Structure):
@@ -59,6 +59,9 @@ _PROTOTYPES = {
                                               C.c_void_p, C.c_void_p]),
     "yfv2_batch_statistics_overflow": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "yfv2_nonfinite": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "yfv2_nonfinite_peek": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "yfv2_clock_probe_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "yfv2_clock_probe_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "yfv2_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "yfv2_train_bind": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_int32, C.POINTER(TensorDesc), C.c_int32]),
     "yfv2_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),

@@ -90,7 +90,13 @@ struct yfv2_ctx {
   Buf cand;  // (rows, 8) compact candidate rows of yfv2_detect
   int32_t* d_classes = nullptr;  // class filter scratch (<= 256 entries), then one int32 of its own for the statistics overflow flag
   int32_t* d_stats_flag = nullptr;  // = d_classes + 256
-  int32_t* d_nonfinite = nullptr;   // = d_classes + 257 (a lane: its parent's word): the sticky range-guard word of the fp16x3 plan (yfv2_nonfinite)
+  // the sticky range-guard word of the fp16x3 plan (yfv2_nonfinite): ONE int32 in host-mapped, coherent memory.  The kernels
+  // store 1 into it through d_nonfinite (the rare path, a plain store); the host reads h_nonfinite - after waiting for a stream
+  // (yfv2_nonfinite: exact) or without waiting (yfv2_nonfinite_peek: what has landed so far).  A lane uses its parent's word.
+  int32_t* h_nonfinite = nullptr;
+  int32_t* d_nonfinite = nullptr;
+  unsigned long long* d_probe = nullptr;   // yfv2_clock_probe_*: [probe_wgs][4] stamps of the last probe launch
+  int probe_wgs = 0;
   // training-loss workspace (yfv2_loss): match slots for loss_cap labels, objectness target maps for max_batch images,
   // counters and float64 sums; grown on demand (a growth waits for the device)
   void* d_loss_ws = nullptr;
@@ -1912,7 +1918,7 @@ int create_lanes(yfv2_ctx* h) {
     const int rc = yfv2_create(&lane, &c);
     g_creating_lane = false;
     if (rc) return fail(h, rc, "lane " + std::to_string(i) + ": " + g_tls_error);
-    lane->d_nonfinite = h->d_nonfinite;
+    lane->d_nonfinite = h->d_nonfinite;   // the parent's word (its h_nonfinite stays null: only the parent owns and frees it)
     h->lanes.push_back(lane);
   }
   HIP_TRY(h, hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));
@@ -1932,25 +1938,34 @@ int run_lanes(yfv2_ctx* h, int B, hipStream_t s, F f) {
   const int n = (int)h->lanes.size();
   const int per = (B + n - 1) / n;
   h->last_split.clear();
-  HIP_TRY(h, hipEventRecord(h->lane_fork, s));
+  HIP_TRY(h, hipEventRecord(h->lane_fork, s));   // nothing is enqueued on a lane stream yet: a plain return is safe here
   int rc = YFV2_OK;
+  auto hip_ok = [&](hipError_t e, const char* what) {     // a HIP error inside the fork / join region must NOT return early:
+    if (e != hipSuccess && rc == YFV2_OK) rc = fail(h, YFV2_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    return e == hipSuccess;                               // work already queued on the lane streams still has to be joined
+  };
+  std::vector<char> forked((size_t)n, 0);
   // lanes 1.. first: their launches are queued behind the fork before lane 0's own launches occupy the caller's stream
   for (int i = 1; i < n && rc == YFV2_OK; ++i) {
     const int off = i * per, cnt = std::min(per, B - off);
     if (cnt <= 0) break;
-    HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[i - 1], h->lane_fork, 0));
-    rc = f(h->lanes[i], off, cnt, h->lane_stream[i - 1]);
-    if (rc) { h->err = h->lanes[i]->err; break; }
-    HIP_TRY(h, hipEventRecord(h->lane_join[i - 1], h->lane_stream[i - 1]));
+    if (!hip_ok(hipStreamWaitEvent(h->lane_stream[i - 1], h->lane_fork, 0), "hipStreamWaitEvent(lane fork)")) break;
+    forked[(size_t)i] = 1;
+    const int lrc = f(h->lanes[i], off, cnt, h->lane_stream[i - 1]);
+    if (lrc) { rc = lrc; h->err = h->lanes[i]->err; }
   }
   if (rc == YFV2_OK) {
     rc = f(h->lanes[0], 0, std::min(per, B), s);
     if (rc) h->err = h->lanes[0]->err;
   }
+  // the join, on every path: whatever reached a lane stream (a slice that failed half way included) is ordered in front of
+  // the caller's later use of the output and workspace buffers
   for (int i = 1; i < n; ++i) {
-    const int off = i * per, cnt = std::min(per, B - off);
-    if (cnt <= 0) break;
-    HIP_TRY(h, hipStreamWaitEvent(s, h->lane_join[i - 1], 0));   // also on the error path: whatever was enqueued is joined
+    if (!forked[(size_t)i]) continue;
+    if (hip_ok(hipEventRecord(h->lane_join[i - 1], h->lane_stream[i - 1]), "hipEventRecord(lane join)"))
+      hip_ok(hipStreamWaitEvent(s, h->lane_join[i - 1], 0), "hipStreamWaitEvent(lane join)");
+    else
+      (void)hipStreamSynchronize(h->lane_stream[i - 1]);   // no event to wait for: the host waits instead
   }
   if (rc == YFV2_OK)
     for (int i = 0; i < n; ++i) { const int cnt = std::min(per, B - i * per); if (cnt > 0) h->last_split.push_back(cnt); }
@@ -1997,8 +2012,18 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     rc = fail(h, YFV2_ERR_DEVICE, "hipMalloc(class filter) failed");
   if (rc == YFV2_OK) {
     h->d_stats_flag = h->d_classes + 256;
-    h->d_nonfinite = h->d_classes + 257;
     if (hipMemset(h->d_stats_flag, 0, 2 * sizeof(int32_t)) != hipSuccess) rc = fail(h, YFV2_ERR_DEVICE, "hipMemset(flags) failed");
+  }
+  if (rc == YFV2_OK && !h->in_lane) {
+    void* hp = nullptr; void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+      if (hp) (void)hipHostFree(hp);
+      rc = fail(h, YFV2_ERR_DEVICE, "hipHostMalloc(range-guard word) failed");
+    } else {
+      h->h_nonfinite = static_cast<int32_t*>(hp);
+      h->d_nonfinite = static_cast<int32_t*>(dp);
+      *reinterpret_cast<volatile int32_t*>(h->h_nonfinite) = 0;
+    }
   }
   if (rc != YFV2_OK) {
     g_tls_error = h->err;
@@ -2117,6 +2142,8 @@ void yfv2_destroy(yfv2_handle h) {
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
   free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);
+  if (h->h_nonfinite) (void)hipHostFree(h->h_nonfinite);
+  if (h->d_probe) (void)hipFree(h->d_probe);
   if (h->d_loss_ws) (void)hipFree(h->d_loss_ws);
   if (h->train) { yfv2_train_release(h->train); h->train = nullptr; }
   if (h->d_params) (void)hipFree(h->d_params);
@@ -2361,13 +2388,68 @@ int yfv2_batch_statistics_overflow(yfv2_handle h, int32_t* overflowed, void* str
 // the sticky range-guard word of the fp16x3 plan (yfv2_internal.h Yfv2Watch): waits for `stream`, reports and clears it
 int yfv2_nonfinite(yfv2_handle h, int32_t* flag, void* stream) {
   if (!h || !flag) return fail(h, YFV2_ERR_ARG, "yfv2_nonfinite: null argument");
+  if (!h->h_nonfinite) return fail(h, YFV2_ERR_STATE, "yfv2_nonfinite: this handle owns no guard word");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int32_t v = 0;
-  HIP_TRY(h, hipMemcpyAsync(&v, h->d_nonfinite, sizeof(v), hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipStreamSynchronize(s));
-  if (v) HIP_TRY(h, hipMemsetAsync(h->d_nonfinite, 0, sizeof(v), s));
+  HIP_TRY(h, hipStreamSynchronize(s));        // a kernel's stores to coherent host memory are visible once it has completed
+  volatile int32_t* w = h->h_nonfinite;
+  const int32_t v = *w;
+  if (v) *w = 0;
   *flag = v ? 1 : 0;
+  return YFV2_OK;
+}
+
+// ... and without waiting for anything: what has landed in the word so far (not cleared).  A caller that never synchronises
+// with the host (a detect loop that hands device tensors on) looks before every call and learns of a tripped guard one call late
+// instead of never.
+int yfv2_nonfinite_peek(yfv2_handle h, int32_t* flag) {
+  if (!h || !flag) return fail(h, YFV2_ERR_ARG, "yfv2_nonfinite_peek: null argument");
+  if (!h->h_nonfinite) return fail(h, YFV2_ERR_STATE, "yfv2_nonfinite_peek: this handle owns no guard word");
+  *flag = *reinterpret_cast<volatile int32_t*>(h->h_nonfinite) ? 1 : 0;
+  return YFV2_OK;
+}
+
+// effective shader clock, measured by the shader (yfv2_probe.hip): enqueue on `stream` ...
+int yfv2_clock_probe_begin(yfv2_handle h, int32_t workgroups, float milliseconds, int32_t busy, void* stream) {
+  if (!h || workgroups < 1 || workgroups > 4096 || !(milliseconds > 0.f) || milliseconds > 10000.f)
+    return fail(h, YFV2_ERR_ARG, "yfv2_clock_probe_begin: bad argument");
+  DeviceGuard guard(h->device);
+  if (!h->d_probe) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_probe), 4096 * 4 * sizeof(unsigned long long)));
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+  ClockProbeArgs a{};
+  a.out = h->d_probe; a.busy = busy ? 1 : 0;
+  a.ref_ticks = (unsigned long long)((double)milliseconds * (double)khz);
+  h->probe_wgs = workgroups;
+  if (!yfv2_launch_clock_probe(a, workgroups, static_cast<hipStream_t>(stream))) return fail(h, YFV2_ERR_DEVICE, "clock probe launch failed");
+  return YFV2_OK;
+}
+
+// ... and read it back (waits for `stream`): out[0..2] = min / mean / max over the probe's workgroups of
+// (shader cycles / reference ticks) x reference clock, in MHz; out[3] = the reference clock in MHz; out[4] = mean measured
+// interval in milliseconds; out[5] = number of distinct XCDs the workgroups ran on
+int yfv2_clock_probe_end(yfv2_handle h, double out[6], void* stream) {
+  if (!h || !out) return fail(h, YFV2_ERR_ARG, "yfv2_clock_probe_end: null argument");
+  if (!h->d_probe || h->probe_wgs < 1) return fail(h, YFV2_ERR_STATE, "yfv2_clock_probe_end without yfv2_clock_probe_begin");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<unsigned long long> st((size_t)h->probe_wgs * 4);
+  HIP_TRY(h, hipMemcpyAsync(st.data(), h->d_probe, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+  const double ref_mhz = khz * 1e-3;
+  double mn = 1e30, mx = 0., sum = 0., ms = 0.;
+  unsigned xcds = 0;
+  for (int i = 0; i < h->probe_wgs; ++i) {
+    const double cyc = (double)st[4 * i], ref = (double)st[4 * i + 1];
+    if (!(ref > 0.)) return fail(h, YFV2_ERR_DEVICE, "clock probe: a workgroup reported no reference ticks");
+    const double mhz = cyc / ref * ref_mhz;
+    mn = std::min(mn, mhz); mx = std::max(mx, mhz); sum += mhz; ms += ref / ref_mhz * 1e-3;
+    xcds |= 1u << (unsigned)(st[4 * i + 2] & 15);
+  }
+  out[0] = mn; out[1] = sum / h->probe_wgs; out[2] = mx; out[3] = ref_mhz; out[4] = ms / h->probe_wgs; out[5] = (double)__builtin_popcount(xcds);
+  h->probe_wgs = 0;
   return YFV2_OK;
 }
 
@@ -2482,18 +2564,30 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
   // follows the previous pass's last one, as in a running loop.  (Synchronising after every pass - the first form - put the stem
   // behind an idle device each time: 127 us by these events against 114 us in a rocprofv3 trace of the bench loop on the same box.)
   const size_t n = h->plan.size();
-  std::vector<hipEvent_t> ev(2 * n * (size_t)iters);
-  for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
+  // events and the post launch's output buffers are released on EVERY path out of this function (HIP_TRY returns early)
+  struct Scratch {
+    std::vector<hipEvent_t> ev;
+    float* dets = nullptr; int32_t* idx = nullptr; int32_t* cnt = nullptr;
+    ~Scratch() {
+      for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+      if (dets) (void)hipFree(dets);
+      if (idx) (void)hipFree(idx);
+      if (cnt) (void)hipFree(cnt);
+    }
+  } sc;
+  sc.ev.assign(2 * n * (size_t)iters, nullptr);
+  for (auto& e : sc.ev) HIP_TRY(h, hipEventCreate(&e));
+  std::vector<hipEvent_t>& ev = sc.ev;
   // Between two passes the post launch runs (untimed, on the logits just written, test.py's thresholds 0.3 / 0.4), as it does
   // between two forwards of a detect loop: a pass's first launch then meets the memory system in the state it meets there (behind
   // the last tower launch's 47 MB of logit stores instead, the stem took 121 us by these events against 109 us in the trace).
-  float* p_dets = nullptr; int32_t* p_idx = nullptr; int32_t* p_cnt = nullptr;
   const bool with_post = h->postfuse && yfv2_post_fusable(h->cfg.classes, h->rows);
   if (with_post) {
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&p_dets), (size_t)B * YFV2_MAX_DET * 6 * sizeof(float)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&p_idx), (size_t)B * YFV2_MAX_DET * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&p_cnt), (size_t)B * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sc.dets), (size_t)B * YFV2_MAX_DET * 6 * sizeof(float)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sc.idx), (size_t)B * YFV2_MAX_DET * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sc.cnt), (size_t)B * sizeof(int32_t)));
   }
+  float* const p_dets = sc.dets; int32_t* const p_idx = sc.idx; int32_t* const p_cnt = sc.cnt;
   auto post = [&]() {
     if (!with_post) return;
     const DecodeArgs d = decode_args(h, out6, B);
@@ -2509,9 +2603,7 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
   post();
   for (int it = 0; it < iters && rc == YFV2_OK; ++it) { rc = run_plan(h, x, false, B, out6, s, ev.data() + 2 * n * (size_t)it); post(); }
   if (rc == YFV2_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(h, YFV2_ERR_DEVICE, "yfv2_profile_forward: synchronize failed");
-  if (p_dets) (void)hipFree(p_dets);
-  if (p_idx) (void)hipFree(p_idx);
-  if (p_cnt) (void)hipFree(p_cnt);
+  if (rc != YFV2_OK) (void)hipStreamSynchronize(s);   // nothing may still be writing the post buffers when Scratch frees them
   std::vector<double> acc(n, 0.0);
   for (int it = 0; it < iters && rc == YFV2_OK; ++it)
     for (size_t i = 0; i < n; ++i) {
@@ -2519,7 +2611,6 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
       if (hipEventElapsedTime(&t, ev[2 * n * (size_t)it + 2 * i], ev[2 * n * (size_t)it + 2 * i + 1]) != hipSuccess) { rc = fail(h, YFV2_ERR_DEVICE, "yfv2_profile_forward: event query failed"); break; }
       acc[i] += t;
     }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   if (rc) return rc;
   for (size_t i = 0; i < n; ++i) ms[i] = (float)(acc[i] / iters);
   return YFV2_OK;

@@ -124,7 +124,10 @@ struct Yfv2Watch {
     m |= __builtin_amdgcn_ballot_w64((b << 1) >= 0xff000000u);
   }
   __device__ __forceinline__ void report(int* flag) const {
-    if (m != 0 && flag != nullptr) atomicOr(flag, 1);   // the rare path: every active lane of the wave, one word
+    // the rare path.  A plain store of the constant 1 (every writer stores the same value): the word lives in host-mapped,
+    // coherent memory (yfv2_create), where a store needs no PCIe atomic - the host can then LOOK at it without waiting for
+    // any stream (yfv2_nonfinite_peek)
+    if (m != 0 && flag != nullptr) *reinterpret_cast<volatile int*>(flag) = 1;
   }
 };
 #endif
@@ -406,6 +409,13 @@ void yfv2_launch_nms(const NmsArgs& a, hipStream_t s);
 void yfv2_launch_decode_nms(const DecodeArgs& d, const NmsArgs& a, hipStream_t s);   // yfv2_detect: decode + NMS in one launch
 bool yfv2_post_fusable(int classes, int rows);   // ... which exists for up to 96 classes and 2048 decode rows; beyond: two launches
 int yfv2_nms_max_rows();                         // decode rows per image nms_kernel handles (4096)
+// ---- measurement: effective shader clock (yfv2_probe.hip)
+struct ClockProbeArgs {
+  unsigned long long* out;       // [workgroups][4]: shader cycles, reference ticks, XCC id, (unused)
+  unsigned long long ref_ticks;  // how long to stay, in ticks of the constant reference clock (s_memrealtime)
+  int busy;                      // 1: dependent FMAs between the stamps, 0: s_sleep (runs beside other work without disturbing it)
+};
+bool yfv2_launch_clock_probe(const ClockProbeArgs& a, int workgroups, hipStream_t s);
 
 // ---- training path (yfv2_train.hip): its state hangs off the handle through an opaque slot owned by yfv2_api.hip
 struct yfv2_ctx;

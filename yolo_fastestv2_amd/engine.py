@@ -54,6 +54,7 @@ class Engine:
         check(L.yfv2_create(C.byref(h), C.byref(cfg)))
         self.close()
         self._h, self.max_batch = h, int(max_batch)
+        self._generation = getattr(self, "_generation", 0) + 1   # a NEW native handle: whatever was bound to the old one (yfv2_train_bind) is gone
         self.rows = int(L.yfv2_num_rows(self._h))
         if self._weights is not None:
             self._upload()
@@ -181,8 +182,14 @@ class Engine:
                                   _ptr(idx), _ptr(cnt), _stream(self.device)), self._h)
         return dets, idx, cnt
 
-    def detect(self, x, conf_thres, iou_thres, out=None):
+    def detect(self, x, conf_thres, iou_thres, out=None, check=True):
+        """forward + decode + NMS, enqueue only: the results are device tensors and nothing waits for the device.  check=True
+        (default) LOOKS at the range-guard word first (yfv2_nonfinite_peek: a host memory read, no synchronisation) and raises if a
+        call that has already completed on this handle tripped it - a loop that never synchronises with the host learns of
+        invalid results one call late instead of never; `check_finite()` after a synchronisation is the exact query."""
         self._need_anchors("detect")
+        if check and self.peek_nonfinite():
+            self.check_finite("detect (an earlier call on this handle)")
         x = self._check_x(x)
         B = x.shape[0]
         self.ensure_batch(B)
@@ -308,10 +315,27 @@ class Engine:
         check(_lib.lib().yfv2_nonfinite(self._h, C.byref(flag), _stream(self.device)), self._h)
         return bool(flag.value)
 
+    def peek_nonfinite(self):
+        """True if a kernel that has ALREADY COMPLETED on this handle tripped the range guard; waits for nothing, clears nothing."""
+        flag = C.c_int32(0)
+        check(_lib.lib().yfv2_nonfinite_peek(self._h, C.byref(flag)), self._h)
+        return bool(flag.value)
+
+    def clock_probe_begin(self, workgroups=256, milliseconds=50.0, busy=True):
+        """Enqueue the shader-clock probe on the CURRENT stream (include/yfv2.h yfv2_clock_probe_begin)."""
+        check(_lib.lib().yfv2_clock_probe_begin(self._h, int(workgroups), float(milliseconds), 1 if busy else 0, _stream(self.device)), self._h)
+
+    def clock_probe_end(self):
+        """Waits for the current stream; dict with the effective shader clock (MHz) min / mean / max over the probe's workgroups."""
+        out = (C.c_double * 6)()
+        check(_lib.lib().yfv2_clock_probe_end(self._h, out, _stream(self.device)), self._h)
+        return {"sclk_mhz_min": round(out[0], 1), "sclk_mhz_mean": round(out[1], 1), "sclk_mhz_max": round(out[2], 1),
+                "ref_clock_mhz": round(out[3], 3), "interval_ms": round(out[4], 3), "xcds_seen": int(out[5])}
+
     def check_finite(self, what="forward"):
         """Raise if the range guard tripped (call where the host waits for the device anyway)."""
         if self.nonfinite():
-            raise _lib.Yfv2Error(-7, "%s: an activation left the range of the default (fp16x3) plan - |activation| >= 4094 or a non-finite "
+            raise _lib.Yfv2Error(_lib.ERR_RANGE, "%s: an activation left the range of the default (fp16x3) plan - |activation| >= 4094 or a non-finite "
                                      "input; the result is invalid.  Create the handle with YFV2_BF6=0 in the environment (every conv on the "
                                      "fp32 matrix instructions, no such bound) for this model / input" % what)
 

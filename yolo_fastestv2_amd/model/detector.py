@@ -97,7 +97,10 @@ class _TrainForward(torch.autograd.Function):
         eng = module.engine_for(x, sync=False)
         names = module._train_names()
         state = {k: v for k, v in module.state_dict(keep_vars=True).items() if v.is_floating_point()}
-        key = (id(eng), str(x.device)) + tuple(v.data_ptr() for v in state.values())
+        # the binding lives in the NATIVE handle: Engine.ensure_batch() re-creates that handle (and drops its training state) when
+        # any call sees a larger batch than max_batch, while the Python Engine object and the parameter pointers stay what they
+        # were - so the handle's generation (Engine._create counts) is part of the key
+        key = (id(eng), getattr(eng, "_generation", 0), str(x.device)) + tuple(v.data_ptr() for v in state.values())
         bound = module.__dict__.get("_train_bound")
         if bound is None or bound["key"] != key:
             for k, v in state.items():
@@ -139,22 +142,25 @@ class _TrainForward(torch.autograd.Function):
         ctx.eng.train_backward([g if g is not None else torch.zeros(s, device=work.device) for g, s in zip(g6, ctx.eng.logit_shapes(g6[0].shape[0]))])
         if ctx.dp is not None:       # data parallel: one all-reduce over the whole gradient bucket (sharded.average_gradients_)
             average_gradients_(work, group=ctx.dp[0], force=ctx.dp[1])
+        # NOTE: this function assigns / accumulates the parameters' .grad ITSELF (views of one persistent bucket) and returns None
+        # for them: autograd's own accumulation - and with it torch.autograd.grad(), backward(inputs=...), tensor and
+        # post-accumulate-grad hooks on the parameters - is bypassed.  train.py's loop (loss.backward(); optimizer.step()) is
+        # what this path serves.  Parameters with requires_grad == False are left alone, as torch leaves them.
         params = dict(ctx.module.named_parameters())
+        live = [k for k in ctx.names if params[k].requires_grad]
+        frozen = len(live) != len(ctx.names)
         mine = {k: params[k].grad is not None and params[k].grad.data_ptr() == b["keep_views"][k].data_ptr() and params[k].grad.shape == b["keep_views"][k].shape
-                for k in ctx.names}
-        if all(mine.values()):
+                for k in live}
+        if not frozen and all(mine.values()):
             keep.add_(work)                          # accumulation over `subdivisions` batches (train.py:122), one kernel
         else:
-            foreign = {k: params[k].grad for k in ctx.names if params[k].grad is not None and not mine[k]}
-            if any(mine.values()):                   # a mixed state: keep what is there, parameter by parameter
-                for k in ctx.names:
-                    if mine[k]:
-                        b["keep_views"][k].add_(b["work_views"][k])
-                    else:
-                        b["keep_views"][k].copy_(b["work_views"][k])
-            else:
-                keep.copy_(work)
-            for k in ctx.names:
+            foreign = {k: params[k].grad for k in live if params[k].grad is not None and not mine[k]}
+            for k in live:                           # a mixed state: keep what is there, parameter by parameter
+                if mine[k]:
+                    b["keep_views"][k].add_(b["work_views"][k])
+                else:
+                    b["keep_views"][k].copy_(b["work_views"][k])
+            for k in live:
                 if not mine[k]:
                     if k in foreign:                 # somebody else's gradient tensor: add ours, as autograd would
                         foreign[k].add_(b["keep_views"][k])

@@ -91,6 +91,8 @@ class DetectPipeline:
             raise RuntimeError("this ticket's buffers were reused by a later submit (a slot is overwritten %d submits later)" % self.depth)
         if host:
             ticket.event.synchronize()
+            if self.engines[ticket.slot].peek_nonfinite():       # the batch is complete: what the range guard holds is exact
+                self.engines[ticket.slot].check_finite("DetectPipeline.result")
         else:
             torch.cuda.current_stream(self.device).wait_event(ticket.event)
         return ticket.out

@@ -14,6 +14,10 @@ class SGD(torch.optim.Optimizer):
         if lr < 0 or momentum < 0 or weight_decay < 0:
             raise ValueError("lr, momentum and weight_decay must be >= 0")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        # kernel-argument tables, one per parameter group, keyed by the group's position.  Kept OFF param_groups: state_dict()
+        # copies every non-'params' key of a group, and a ctypes array of pointers can be neither pickled (torch.save of the
+        # optimizer state) nor deep-copied
+        self._yfv2_tables = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -21,7 +25,7 @@ class SGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             todo = []
             for p in group["params"]:
                 if p.grad is None:
@@ -39,7 +43,7 @@ class SGD(torch.optim.Optimizer):
             # the table is rebuilt only when a pointer in it changed (gradients that are views of the Detector's persistent
             # bucket keep their addresses from step to step)
             key = tuple((p.data_ptr(), g.data_ptr(), b.data_ptr(), first) for p, g, b, first in todo)
-            cache = group.setdefault("_yfv2_table", {})
+            cache = self.__dict__.setdefault("_yfv2_tables", {}).setdefault(gi, {})
             if cache.get("key") != key:
                 items = (_lib.SgdItem * len(todo))()
                 for i, (p, g, b, first) in enumerate(todo):
