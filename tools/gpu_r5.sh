@@ -17,6 +17,8 @@ if [ "$MODE" = "quick" ]; then
   echo "== bench (quick)"
   timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; echo "bench rc=$?"; tail -1 $OUT/bench.log | cut -c1-3000
   timeout 300 python tools/scale_probe.py 1 256 > $OUT/scale_probe.txt 2>&1; tail -22 $OUT/scale_probe.txt | cut -c1-150
+  echo "== post: fused / two launches"
+  timeout 120 python tools/nms_probe.py 2>&1 | grep -v amdgpu.ids; YFV2_POSTFUSE=0 timeout 120 python tools/nms_probe.py 2>&1 | grep -v amdgpu.ids
   exit 0
 fi
 echo "== smoke"

@@ -195,7 +195,7 @@ class Engine:
         self.ensure_batch(B)
         dets, idx, cnt = out if out is not None else self.new_det_buffers(B)
         fn = _lib.lib().yfv2_detect_u8 if x.dtype == torch.uint8 else _lib.lib().yfv2_detect
-        check(fn(self._h, _ptr(x), B, float(conf_thres), float(iou_thres), _ptr(dets), _ptr(idx), _ptr(cnt), _stream(self.device)), self._h)
+        _lib.check(fn(self._h, _ptr(x), B, float(conf_thres), float(iou_thres), _ptr(dets), _ptr(idx), _ptr(cnt), _stream(self.device)), self._h)
         return dets, idx, cnt
 
     def resize(self, frames, out=None):
