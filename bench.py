@@ -500,10 +500,12 @@ def main():
         # cannot be read from inside the process: they come from the newest profiles/*_traffic.json / *_pmc.json whose
         # source fingerprint (tools/srchash.py) equals this tree's - else null.
         stages = eng.stages()
-        # per-launch events, with the sleeping clock probe beside them: cycles = milliseconds x the clock those launches ran at
-        est_profile_ms = (a.profile_iters + 1) * 1e3 * dt_s / a.steps
-        ms, box["sclk_during_profile"] = clock_during(lambda: eng.profile_forward(x, iters=a.profile_iters), 0.9 * est_profile_ms)
-        sclk_prof = box["sclk_during_profile"]["sclk_mhz_mean"]
+        # per-launch events on an otherwise EMPTY device.  (Round 5's first form kept the sleeping clock probe beside this pass: its 16
+        # one-wave workgroups hold a few registers on 16 CUs, the stage-3 chain needs a CU's whole register file - 8 waves x 256
+        # VGPRs - so 16 of its 256 workgroups waited for a second round and the launch read 119 us instead of 86.)  Cycles =
+        # milliseconds x the clock measured beside the single-stream step loop above, the same launches in the same order.
+        ms = eng.profile_forward(x, iters=a.profile_iters)
+        sclk_prof = box["sclk_during_single_stream_steps"]["sclk_mhz_mean"]
         src_hash = source_hash()
         prof_t, prof_p = newest_profile("_traffic.json", src_hash), newest_profile("_pmc.json", src_hash)
         table = {}
@@ -545,7 +547,7 @@ def main():
                 "traffic_note": ("HBM bytes per launch by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction): profiles/%s, same source fingerprint as this run" % prof_t["_file"])
                                 if drow["traffic_bytes"] else "no profiles/*_traffic.json carries this tree's source fingerprint %s (PMC passes are separate runs: tools/gpu_traffic.sh)" % src_hash,
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "avg_launch_kcycles": round(dom["ms"] / dom["launches"] * sclk_prof, 1),
-                "sclk_mhz_during_profile": sclk_prof, "sum_ms_per_forward": round(dom["ms"], 4),
+                "sclk_mhz_for_cycles": sclk_prof, "sum_ms_per_forward": round(dom["ms"], 4),
                 "share_of_forward": round(dom["ms"] / tot_ms, 4),
                 "algorithmic_bytes_per_launch": dom["ext"] / dom["launches"], "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                 "hbm_frac_external": drow["hbm_frac_external"], "hbm_frac_of_achievable": drow["hbm_frac_of_achievable"],
