@@ -177,6 +177,31 @@ def self_launch(a):
     os.execve(sys.executable, cmd, env)
 
 
+def sysfs_power_clock(pci=None):
+    """{card: {power_w, sclk_mhz}} from sysfs hwmon (a handful of file reads: cheap enough to take WHILE steps are queued on the
+    device).  The box exposes every GPU of the node; `pci` (the HIP device's bus id, when torch reports it) marks ours."""
+    import glob
+    out = {}
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        name = os.path.basename(os.path.dirname(card))
+        rec = {}
+        for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+            for key, fn, scale in (("power_w", "power1_input", 1e-6), ("power_w", "power1_average", 1e-6), ("sclk_mhz", "freq1_input", 1e-6)):
+                try:
+                    with open(os.path.join(hw, fn)) as fh:
+                        rec.setdefault(key, round(float(fh.read().strip()) * scale, 1))
+                except (OSError, ValueError):
+                    pass
+        if pci:
+            try:
+                rec["ours"] = pci.lower() in os.path.realpath(card).lower()
+            except OSError:
+                pass
+        if rec:
+            out[name] = rec
+    return out
+
+
 def smi_snapshot(index):
     """Best effort: what the box's management interface says about the device (performance level, power cap, clocks, partition
     modes).  Containers of this pool often expose little; whatever is readable is recorded, nothing is required."""
@@ -403,15 +428,22 @@ def main():
     # later one (round 3: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each following 20) - the device
     # leaving its idle power state - which would put a --warmup 5 --steps 20 run entirely inside the ramp.
     t_spin, n_spin = time.perf_counter(), 0
+    props = torch.cuda.get_device_properties(dev)
+    pci = None
+    if getattr(props, "pci_bus_id", None) is not None:
+        pci = "%04x:%02x:%02x" % (int(getattr(props, "pci_domain_id", 0)), int(props.pci_bus_id), int(getattr(props, "pci_device_id", 0)))
+        box["pci"] = pci
     while time.perf_counter() - t_spin < a.spinup_seconds:
         for _ in range(20):
             with pipe.slot() as (j, e, bufs):
                 e.detect(x, a.conf, a.iou, out=bufs)
         n_spin += 20
+        if rank == 0 and "sysfs_under_pipelined_load" not in box and time.perf_counter() - t_spin > 0.6 * a.spinup_seconds:
+            box["sysfs_under_pipelined_load"] = sysfs_power_clock(pci)     # the 20 steps just queued are still running
         sync()
     spin_s = time.perf_counter() - t_spin
-    if rank == 0:
-        box["sclk_before_timed"] = clock_busy()
+    # (no probe between the spin-up and the timed blocks: the all-CU FMA kernel drains the pipeline, and the first timed block then
+    # pays for refilling it - round 5's first form measured 368 k for block 1 against 385-392 k for blocks 2-5)
     # exactly W warm-up steps (with the collective), then --blocks timed blocks of exactly K steps
     for _ in range(a.warmup):
         step()
@@ -421,12 +453,13 @@ def main():
     t = torch.tensor(dts, device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)       # per block: the slowest rank
-    dts = sorted(float(v) for v in t.cpu())
+    chrono = [float(v) for v in t.cpu()]
+    dts = sorted(chrono)
     dt = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])
     value = world * a.batch * a.steps / dt
-    blocks = {"n": len(dts), "steps_each": a.steps, "img_s": [round(world * a.batch * a.steps / v, 1) for v in dts],
+    blocks = {"n": len(dts), "steps_each": a.steps, "img_s": [round(world * a.batch * a.steps / v, 1) for v in chrono],
               "img_s_min": round(world * a.batch * a.steps / dts[-1], 1), "img_s_max": round(world * a.batch * a.steps / dts[0], 1),
-              "value_is": "median block"}
+              "value_is": "median block", "img_s_order": "chronological"}
     if rank == 0:
         box["sclk_after_timed"] = clock_busy()
         # the same kind of loop once more with the sleeping probe beside it: the clock the timed steps ran at
