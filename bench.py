@@ -197,12 +197,13 @@ def sysfs_power_clock(pci=None):
                 rec["ours"] = pci.lower() in os.path.realpath(card).lower()
             except OSError:
                 pass
-        if rec:
+        if rec.get("power_w") is not None or rec.get("sclk_mhz") is not None:
             out[name] = rec
-    return out
+    mine = {k: v for k, v in out.items() if v.get("ours")}
+    return mine if mine else out          # ours when the bus id identifies it, else every GPU of the node that reports
 
 
-def smi_snapshot(index):
+def smi_snapshot(index, pci=None):
     """Best effort: what the box's management interface says about the device (performance level, power cap, clocks, partition
     modes).  Containers of this pool often expose little; whatever is readable is recorded, nothing is required."""
     import glob
@@ -220,6 +221,12 @@ def smi_snapshot(index):
         out["rocm_smi_error"] = repr(e)[:120]
     sysfs = {}
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if pci:
+            try:
+                if pci.lower() not in os.path.realpath(card).lower():
+                    continue                     # another GPU of the node
+            except OSError:
+                pass
         for name in ("power_dpm_force_performance_level", "current_compute_partition", "current_memory_partition", "pp_dpm_sclk", "pp_dpm_mclk"):
             try:
                 with open(os.path.join(card, name)) as fh:
@@ -419,20 +426,20 @@ def main():
         with torch.cuda.stream(streams[j]):
             engs[j].detect(x, a.conf, a.iou, out=sets[j])
     sync()
-    box = {"device": torch.cuda.get_device_name(dev), "cus": torch.cuda.get_device_properties(dev).multi_processor_count}
+    props = torch.cuda.get_device_properties(dev)
+    box = {"device": torch.cuda.get_device_name(dev), "cus": props.multi_processor_count}
+    pci = None
+    if getattr(props, "pci_bus_id", None) is not None:
+        pci = "%04x:%02x:%02x" % (int(getattr(props, "pci_domain_id", 0)), int(props.pci_bus_id), int(getattr(props, "pci_device_id", 0)))
+        box["pci"] = pci
     if rank == 0:
-        box.update(smi_snapshot(local))
+        box.update(smi_snapshot(local, pci))
         box["sclk_cold"] = clock_busy()          # first look, before the device was held under load
     # SPIN-UP (set-up, not a step, not the warm-up): hold the device under load for --spinup-seconds of the same steps on one
     # handle (no collective: every rank decides by its own clock).  A fresh process runs its first steps 8-10 % slower than every
     # later one (round 3: 0.754 ms per step for the first 20 from a cold start, 0.68-0.70 for each following 20) - the device
     # leaving its idle power state - which would put a --warmup 5 --steps 20 run entirely inside the ramp.
     t_spin, n_spin = time.perf_counter(), 0
-    props = torch.cuda.get_device_properties(dev)
-    pci = None
-    if getattr(props, "pci_bus_id", None) is not None:
-        pci = "%04x:%02x:%02x" % (int(getattr(props, "pci_domain_id", 0)), int(props.pci_bus_id), int(getattr(props, "pci_device_id", 0)))
-        box["pci"] = pci
     while time.perf_counter() - t_spin < a.spinup_seconds:
         for _ in range(20):
             with pipe.slot() as (j, e, bufs):
@@ -481,6 +488,11 @@ def main():
             for _ in range(a.steps):
                 step_single()
         _, box["sclk_during_single_stream_steps"] = clock_during(k_single, 0.85 * 1e3 * dt_s)
+        for _ in range(400):                 # ~0.3 s of the one-stream loop queued, then the hwmon reading while it runs
+            step_single()
+        time.sleep(0.15)
+        box["sysfs_under_single_stream_load"] = sysfs_power_clock(pci)
+        sync()
 
     # ONE call per batch on ONE handle whose calls cut the batch into two slices on internal streams (YFV2_LANES=2)
     os.environ["YFV2_LANES"] = "2"
