@@ -278,6 +278,11 @@ YFV2_API int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, floa
 YFV2_API int yfv2_clock_probe_begin(yfv2_handle h, int32_t workgroups, float milliseconds, int32_t busy, void* stream);
 YFV2_API int yfv2_clock_probe_end(yfv2_handle h, double out[6], void* stream);
 
+/* Measurement helper: one whole forward, then launch `step` of the plan (0 .. yfv2_num_stages) `iters` times back to back on
+ * `stream`; enqueue only.  A launch repeated for a few hundred milliseconds is long enough for the device's power sensor:
+ * tools/power_probe.py reads it meanwhile and prices every launch in joules (the pipelined headline is power-limited). */
+YFV2_API int yfv2_debug_repeat_step(yfv2_handle h, const float* x, int32_t B, float* const out6[6], int32_t step, int32_t iters, void* stream);
+
 /* Debug/parity helper: copy one internal NHWC activation of the LAST forward
  * to host as (B,H,W,C).  which: 0 stem+pool, 1 stage2, 2 stage3 (C2), 3 stage4
  * (C3), 4 S2 (fpn 22x22), 5 S3 (fpn 11x11).  Returns the element count. */

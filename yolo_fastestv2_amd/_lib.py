@@ -79,6 +79,7 @@ _PROTOTYPES = {
     "yfv2_stage_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     "yfv2_profile_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                        C.POINTER(C.c_float), C.c_void_p]),
+    "yfv2_debug_repeat_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "yfv2_debug_activation": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "yfv2_debug_train_relu_output": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
 }

@@ -1724,10 +1724,12 @@ size_t logit_elems(const yfv2_ctx* h, int i) {
   return (size_t)c * h->fh[sc] * h->fw[sc];
 }
 
-int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6], hipStream_t main_stream, hipEvent_t* ev /*nullable: 2 per step*/) {
+int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6], hipStream_t main_stream, hipEvent_t* ev /*nullable: 2 per step*/,
+             int only_step = -1 /* >= 0: this launch alone (yfv2_debug_repeat_step) */) {
   const float* params = h->d_params;
   const hipStream_t s = main_stream;
   for (size_t i = 0; i < h->plan.size(); ++i) {
+    if (only_step >= 0 && (int)i != only_step) continue;
     Step& st = h->plan[i];
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i], s));
     if (st.kind == STEP_STEM) {
@@ -2614,6 +2616,20 @@ int yfv2_profile_forward(yfv2_handle h, const float* x, int32_t B, float* const 
   if (rc) return rc;
   for (size_t i = 0; i < n; ++i) ms[i] = (float)(acc[i] / iters);
   return YFV2_OK;
+}
+
+// Measurement helper: one whole forward (so that every launch's inputs exist), then launch `step` of the plan `iters` times back to
+// back on `stream` (every launch reads its inputs and writes its outputs in place again: idempotent).  Enqueue only - the caller
+// times it, or reads the device's power sensor while it runs (tools/power_probe.py).
+int yfv2_debug_repeat_step(yfv2_handle h, const float* x, int32_t B, float* const out6[6], int32_t step, int32_t iters, void* stream) {
+  int rc = check_call(h, B, true);
+  if (rc) return rc;
+  if (!x || !out6 || iters < 0 || step < 0 || step >= (int32_t)h->plan.size()) return fail(h, YFV2_ERR_ARG, "yfv2_debug_repeat_step: bad argument");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = run_plan(h, x, false, B, out6, s, nullptr);
+  for (int it = 0; it < iters && rc == YFV2_OK; ++it) rc = run_plan(h, x, false, B, out6, s, nullptr, step);
+  return rc;
 }
 
 int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap) {
