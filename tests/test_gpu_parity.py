@@ -463,7 +463,10 @@ def test_end_to_end_batch256_detection_set_vs_oracle(yfv2, model, dev, cfg, imag
     assert n_diff <= (2 if conf_thres == 0.3 else N_DIFF_BOUND_001), "%d survivor differences at conf %.2f" % (n_diff, conf_thres)
 
 
-N_DIFF_BOUND_001 = 24
+# 2 x the worst ever measured: 5 differences out of 10 984 detections in every evidence run of rounds 3-5 (thirteen runs on
+# different boxes and builds, profiles/*_parity_counts.json: the device is deterministic, the count did not move once); all five
+# sit on a numerical margin.  (Rounds 3-4 allowed 24.)
+N_DIFF_BOUND_001 = 10
 
 
 def test_fused_post_pinned_in_the_bench_regime(yfv2, dev, record_parity):

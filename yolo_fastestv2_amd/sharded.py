@@ -65,9 +65,13 @@ class GatherWork:
     def wait_host(self):
         """Block the HOST until the collective has completed, without enqueueing anything on the caller's stream (a stream
         wait costs a ~10 us bubble on the compute stream; a collective issued two steps ago finished long before)."""
+        import time
         for w in self._works:
-            while not w.is_completed():
-                pass
+            spins = 0
+            while not w.is_completed():      # normally true on the first look: the collective was issued several steps ago
+                spins += 1
+                if spins > 64:               # still running: give the core away between looks instead of burning it
+                    time.sleep(20e-6)
         self._works = []
 
     def wait(self, unpack=True):
