@@ -5,7 +5,7 @@ TAG=${1:?tag}; MARK=${2:+_$2}; O=gpurun_out/$TAG; P=profiles/${TAG}${MARK}
 [ -d "$O" ] || { echo "no $O"; exit 1; }
 tail -1 $O/bench.log > ${P}_bench.json
 tail -30 $O/pytest_gpu.log > ${P}_pytest_gpu_tail.txt
-for f in kernel_stats.csv parity_counts.json pmc_sq_summary.txt scale_probe.txt src_hash.txt lanes_probe.txt post_phases.txt train_probe.txt stem_pattern.txt traffic.json pmc.json; do
+for f in kernel_stats.csv parity_counts.json pmc_sq_summary.txt scale_probe.txt src_hash.txt lanes_probe.txt post_phases.txt train_probe.txt stem_pattern.txt power_probe.txt traffic.json pmc.json; do
   [ -f $O/$f ] && cp $O/$f ${P}_$f
 done
 [ -f $O/smoke.log ] && cp $O/smoke.log ${P}_smoke.txt

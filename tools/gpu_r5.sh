@@ -51,5 +51,7 @@ echo "== post phases"
 (timeout 120 python tools/trace_post.py random 0.3; timeout 120 python tools/trace_post.py coco 0.3) 2>&1 | grep -v amdgpu.ids > $OUT/post_phases.txt; cat $OUT/post_phases.txt
 echo "== training iteration"
 timeout 200 python tools/train_probe.py 8 64 2>&1 | grep "B=" > $OUT/train_probe.txt; cat $OUT/train_probe.txt
+echo "== energy per launch"
+timeout 200 python tools/power_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/power_probe.txt; cat $OUT/power_probe.txt | cut -c1-170
 echo "== stem access pattern"
 timeout 60 tools/ubench/stem_pattern > $OUT/stem_pattern.txt 2>&1; tail -9 $OUT/stem_pattern.txt

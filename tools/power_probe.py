@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Energy per launch.  bench.py's pipelined headline runs at ~1300 W of the package's 1400 W cap with the shader clock pulled down
 to ~2.1 GHz: it is POWER-limited, so what a launch costs there is joules, not microseconds.  For every launch of the forward plan
-(and the post launch through detect): repeat it alone for ~0.4 s (yfv2_debug_repeat_step), read the device's hwmon power sensor and
+(and the post launch through detect): repeat it alone for ~1 s (yfv2_debug_repeat_step), read the device's hwmon power sensor and
 the in-kernel clock meanwhile, time it with events -> W, us, mJ per launch above the idle floor.
 usage: python tools/power_probe.py [B]      (on the GPU box)"""
 import glob
@@ -62,14 +62,14 @@ print("idle: %.0f W at %.0f MHz (hwmon %s)" % (idle[0], idle[1], hw))
 
 def measure(enqueue, per_iter_ms, label, streams=None):
     streams = streams or [torch.cuda.current_stream(dev)]
-    iters = max(50, int(450.0 / max(per_iter_ms, 0.005)))
+    iters = max(50, int(1000.0 / max(per_iter_ms, 0.005)))
     enqueue(20)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     enqueue(iters)                               # asynchronous: the device works through the queue while the host reads the sensor
     samples = []
     while not all(st.query() for st in streams):
-        if time.perf_counter() - t0 > 0.12:      # the sensor averages over a window: skip the ramp
+        if time.perf_counter() - t0 > 0.25:      # the sensor averages over a window: skip the ramp
             samples.append(sensor())
         time.sleep(0.02)
     us = (time.perf_counter() - t0) / iters * 1e6
