@@ -488,9 +488,9 @@ def main():
             for _ in range(a.steps):
                 step_single()
         _, box["sclk_during_single_stream_steps"] = clock_during(k_single, 0.85 * 1e3 * dt_s)
-        for _ in range(400):                 # ~0.3 s of the one-stream loop queued, then the hwmon reading while it runs
-            step_single()
-        time.sleep(0.15)
+        for _ in range(1000):                # ~0.7 s of the one-stream loop queued, then the hwmon reading while it runs
+            step_single()                    # (the sensor averages over a few hundred milliseconds)
+        time.sleep(0.3)
         box["sysfs_under_single_stream_load"] = sysfs_power_clock(pci)
         sync()
 
