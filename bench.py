@@ -488,10 +488,10 @@ def main():
             for _ in range(a.steps):
                 step_single()
         _, box["sclk_during_single_stream_steps"] = clock_during(k_single, 0.85 * 1e3 * dt_s)
-        for _ in range(1000):                # ~0.7 s of the one-stream loop queued, then the hwmon reading while it runs
-            step_single()                    # (the sensor averages over a few hundred milliseconds)
-        time.sleep(0.3)
-        box["sysfs_under_single_stream_load"] = sysfs_power_clock(pci)
+        for i in range(1000):                # ~0.7 s of the one-stream loop; the hwmon sensor (a few hundred milliseconds of averaging) is
+            step_single()                    # read while the device is 0.55 s into it and the host still enqueues
+            if i == 800:
+                box["sysfs_under_single_stream_load"] = sysfs_power_clock(pci)
         sync()
 
     # ONE call per batch on ONE handle whose calls cut the batch into two slices on internal streams (YFV2_LANES=2)
