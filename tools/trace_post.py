@@ -27,4 +27,5 @@ st = buf.view(torch.int64).tolist()
 names = ["decode", "filter", "sort", "geometry", "greedy", "output"]
 print("greedy: %d chunks of 64; thread 0: tests %d, scalar walk %d, barriers (= waiting for the slowest wave) %d ticks" % (st[9], st[10], st[11], st[12]))
 print("%s weights, conf %.2f: n = %d candidates, kept %d; ticks per phase: %s; total %d" % (
-    which, conf, st[7], st[8], "  ".join("%s %d" % (nm, st[i + 1] - st[i]) for i, nm in enumerate(names)), st[6] - st[0]))
+    which, conf, st[7], st[8], "  ".join("%s %s" % (nm, st[i + 1] - st[i] if st[i + 1] >= st[i] > 0 else "-") for i, nm in enumerate(names)),   # (an image without candidates leaves early: its later stamps are not written)
+    max(v for v in st[:7] if v > 0) - st[0]))
