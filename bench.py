@@ -177,12 +177,12 @@ def self_launch(a):
     os.execve(sys.executable, cmd, env)
 
 
-def sysfs_power_clock(pci=None):
+def sysfs_power_clock(pci=None, root="/sys/class/drm"):
     """{card: {power_w, sclk_mhz}} from sysfs hwmon (a handful of file reads: cheap enough to take WHILE steps are queued on the
     device).  The box exposes every GPU of the node; `pci` (the HIP device's bus id, when torch reports it) marks ours."""
     import glob
     out = {}
-    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+    for card in sorted(glob.glob(os.path.join(root, "card[0-9]*", "device"))):
         name = os.path.basename(os.path.dirname(card))
         rec = {}
         for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):

@@ -645,3 +645,29 @@ def test_bench_without_a_gpu_fails_loudly(tmp_path):
         pytest.skip("a GPU is present")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode != 0 and "needs an MI355X" in r.stderr
+
+
+def test_bench_reads_power_and_clock_of_its_own_device_from_sysfs(tmp_path):
+    """bench.py's `box.sysfs_under_*_load`: the GPU boxes expose every GPU of their node (and render nodes without sensors);
+    the reading must be the one of the device the run uses (matched by PCI bus id through the card's resolved path), in watts and
+    MHz, and must fall back to every reporting card when the bus id is unknown."""
+    sys.path.insert(0, REPO)
+    import bench
+    for i, (bus, uw, hz) in enumerate((("0000:26:00.0", 1286000000, 2366000000), ("0000:8e:00.0", 296000000, 2405000000))):
+        real = tmp_path / "devices" / "pci0000:00" / bus
+        hw = real / "hwmon" / ("hwmon%d" % (3 + i))
+        hw.mkdir(parents=True)
+        (hw / "power1_input").write_text("%d\n" % uw)
+        (hw / "freq1_input").write_text("%d\n" % hz)
+        card = tmp_path / "drm" / ("card%d" % (8 * i))
+        card.mkdir(parents=True)
+        os.symlink(str(real), str(card / "device"))
+    empty = tmp_path / "drm" / "card1"                       # a node without sensors
+    (empty / "device").mkdir(parents=True)
+    root = str(tmp_path / "drm")
+    mine = bench.sysfs_power_clock("0000:26:00", root=root)
+    assert mine == {"card0": {"power_w": 1286.0, "sclk_mhz": 2366.0, "ours": True}}
+    both = bench.sysfs_power_clock(None, root=root)
+    assert set(both) == {"card0", "card8"} and both["card8"]["power_w"] == 296.0
+    assert bench.sysfs_power_clock("0000:ff:00", root=root).keys() == both.keys()     # unknown bus id: everything that reports
+    assert bench.sysfs_power_clock("0000:26:00", root=str(tmp_path / "nothing")) == {}
