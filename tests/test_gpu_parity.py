@@ -926,6 +926,25 @@ def test_other_class_counts_in_their_own_interpreter(classes):
     assert "PARITY OK classes=%d" % classes in r.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,kind", [(6144, "fp32"), (4096, "uint8")], ids=["6144-fp32-9GiB-input", "4096-uint8"])
+def test_batches_beyond_4_gib_and_2_31_elements(B, kind):
+    """Maximum sizes: one call on 6144 images (input 9.1 GiB = 2.28e9 elements, stem output 4.6 GiB, stage-2 planes 4.6 GiB, decoded
+    tensor 3.8 GiB: every tensor that can pass 2^31 elements or 4 GiB does) and on 4096 uint8 images.  The reference has no
+    batch bound (utils/utils.py:251 loops over whatever it is given); a 288 GB device holds these.  Property checked
+    (tests/gpu_cases/large_batch.py): the batch is K copies of one 256-image block and every copy's logits, decoded rows and
+    detections are BIT-identical to the block's own batch-of-256 result - a per-image base address computed in 32 bits wraps
+    inside such a batch and fails it.  Own interpreter: a fault must not take the suite down, but it FAILS."""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_cases", "large_batch.py")
+    r = subprocess.run([sys.executable, script, str(B)] + (["uint8"] if kind == "uint8" else []), capture_output=True, text=True, timeout=400)
+    marks = [ln for ln in r.stdout.splitlines() if ln.startswith("[large_batch]")]
+    assert r.returncode == 0, ("exit code %d after %r" % (r.returncode, marks[-1] if marks else "no marker"), r.stdout[-1500:], r.stderr[-3000:])
+    assert "LARGE BATCH OK B=%d" % B in r.stdout
+
+
 def test_detect_pipeline_matches_one_handle_bit_for_bit(yfv2, dev, coco_weights, images_u8, cfg):
     """DetectPipeline (bench.py's `value` loop as a product class): seven different batches - fp32 and uint8, full and partial -
     rotating over three handles / streams give exactly what one handle gives batch by batch; a ticket whose slot was reused
