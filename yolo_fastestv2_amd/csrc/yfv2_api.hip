@@ -76,7 +76,8 @@ struct yfv2_ctx {
 
   // workspace (NHWC fp32), sized for cfg.max_batch
   Buf a1, s2[2], s3[2], s4[2], t1, t2, t3, f2, f3, ta, tb;
-  Buf s2pp;  // stage 2 in pair planes: two buffers back to back, [2][max_batch][24 pairs][H/8][W/8][2]
+  Buf s2pp;  // stage 2 in pair planes: an image's two buffers back to back, [max_batch][2][24 pairs][H/8][W/8][2] (every offset a kernel adds to an
+             // image base stays below 2 x 48 x H/8 x W/8 floats whatever max_batch is: no batch bound from 32-bit buffer offsets)
   // pair-plane bookkeeping at the END of stage 2 (for the stride-2 consumer and for yfv2_debug_activation)
   bool s2_px = false;
   bool stem_pp = false;     // the stem writes channel planes for stage2.0's streaming kernels: quad planes [6][H/4][W/4][4] (stem_h3 -> s2h_kernel), pair planes [12][H/4][W/4][2] on the YFV2_BF6=0 plan (stem_px -> s2px kernels)
@@ -1006,6 +1007,7 @@ struct PlanBuilder {
         fpp = wp.permuted_pw_inputs(fpp, cin, cin, pp_label);
         s.s2.pp_in = 1;
         s.s2.pp_bufstride = pp_bufstride;
+        s.s2.pp_imgstride = 2 * pp_bufstride;
         for (int q = 0; q < cin / 2; ++q) if (pp_buf[q]) s.s2.pp_mask |= 1u << q;
       } else if (in_label && ok) {
         f1 = wp.permuted_pw_inputs(f1, cin, cin, in_label);
@@ -1081,7 +1083,7 @@ struct PlanBuilder {
     s.s2px.in = h->a1.p; s.s2px.act = h->s2pp.p;
     s.s2px.in_nhwc = stem_nhwc_ ? 1 : 0;
     s.s2px.IH = IH; s.s2px.IW = IW;
-    s.s2px.in_stride = 24 * IH * IW; s.s2px.out_stride = 48 * OH * OW;
+    s.s2px.in_stride = 24 * IH * IW; s.s2px.out_stride = 2 * 48 * OH * OW;   // (an image owns both of its stage-2 buffers; this block fills buffer 0)
     s.s2px.in_records = 24 * IH * IW * 4; s.s2px.out_records = 48 * OH * OW * 4;
     if (ok) {
       s.img_off = wp.image_s2px_proj(fpd, fpp, pos[0]); s.img_off2 = wp.image_s2px_main(f1, fd, f2, pos[1]);
@@ -1126,7 +1128,7 @@ struct PlanBuilder {
     }
     s.s1px.act = h->s2pp.p;
     s.s1px.H = H; s.s1px.W = W;
-    s.s1px.img_stride = 48 * H * W;
+    s.s1px.img_stride = 2 * 48 * H * W;
     s.s1px.num_records = (int)((bufstride + 48LL * H * W) * 4);
     if (ok) { s.img_off = wp.image_s1px(f1, fd, f2, order); s.img_off2 = wp.image_s1h(f1, fd, f2, order, s.s1px.src_off, s.s1px.dst_off); }
     s.name = p + " s1 block, lane-per-pixel: pw1+bn+relu -> dw3x3+bn -> pw2+bn+relu on the 12 branch pairs (shuffle/pass/cat = bookkeeping)";
@@ -1578,11 +1580,11 @@ struct PlanBuilder {
   void build() {
     const int H = h->cfg.height, W = h->cfg.width;
     int hh = H / 4, ww = W / 4, cin = 24;
-    const long long pp_bufstride = (long long)h->cfg.max_batch * 48 * (H / 8) * (W / 8);
+    const long long pp_bufstride = 48LL * (H / 8) * (W / 8);   // floats from an image's copy in buffer 0 to its copy in buffer 1 (the image stride is twice that)
     const char* envf = std::getenv("YFV2_FUSED");
     const bool fused = !(envf && envf[0] == '0');   // YFV2_FUSED=0: every layer its own launch (the general plan)
     const bool stage2_px = fused && h->s2pp.p && yfv2_s1px_supported(hh / 2, ww / 2) &&
-                           yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0 && (pp_bufstride + 48LL * (hh / 2) * (ww / 2)) * 4 < (1LL << 31);
+                           yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0;
     // the stem's output for s2h_kernel: [H/4][W/4][24] (a pixel's 96 bytes in one run: every lane group's 16-byte store lands in
     // the same 1.5 KB of a wave's row) - 126 -> 120 us against the quad planes of round 4's first half on the same box, stage2.0
     // unchanged (72.7 us either way); YFV2_VARIANT bit 1: quad planes.  The YFV2_BF6=0 plan keeps its pair planes.
@@ -2640,11 +2642,12 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
     return n64;
   }
   if (h && which == 101 && h->s2_px && host_dst) {  // debug: both raw stage-2 pair-plane buffers, B images each
-    const size_t per = h->dbg_per_img[1], bufstride = (size_t)h->cfg.max_batch * per, nn = (size_t)B * per;
+    const size_t per = h->dbg_per_img[1], nn = (size_t)B * per;     // -> [buffer][image][..]; on the device an image's two copies are adjacent
     if (cap < (int64_t)(2 * nn)) return YFV2_ERR_ARG;
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host_dst, h->s2pp.p, nn * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(host_dst + nn, h->s2pp.p + bufstride, nn * sizeof(float), hipMemcpyDeviceToHost);
+    for (int k = 0; k < 2; ++k)
+      (void)hipMemcpy2D(host_dst + (size_t)k * nn, per * sizeof(float), h->s2pp.p + (size_t)k * per, 2 * per * sizeof(float), per * sizeof(float), (size_t)B,
+                        hipMemcpyDeviceToHost);
     return (int64_t)(2 * nn);
   }
   if (!h || which < 0 || which > 5 || !h->dbg[which] || B < 1 || B > h->cfg.max_batch) {
@@ -2693,11 +2696,11 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
     return n;
   }
   if (which == 1 && h->s2_px) {  // stage 2 lives in pair planes: gather the logical NHWC tensor on the host
-    const size_t per = h->dbg_per_img[1], hw = per / 48, bufstride = (size_t)h->cfg.max_batch * per;
-    std::vector<float> tmp(2 * (size_t)n);
+    const size_t per = h->dbg_per_img[1], hw = per / 48;
+    std::vector<float> tmp(2 * (size_t)n);     // [buffer][image][pair][pixel][2]; on the device an image's two copies are adjacent
     if (hipDeviceSynchronize() != hipSuccess ||
-        hipMemcpy(tmp.data(), h->s2pp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(tmp.data() + n, h->s2pp.p + bufstride, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        hipMemcpy2D(tmp.data(), per * sizeof(float), h->s2pp.p, 2 * per * sizeof(float), per * sizeof(float), (size_t)B, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy2D(tmp.data() + n, per * sizeof(float), h->s2pp.p + per, 2 * per * sizeof(float), per * sizeof(float), (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) {
       fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");
       return YFV2_ERR_DEVICE;
     }

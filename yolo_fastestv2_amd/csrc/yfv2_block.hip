@@ -897,8 +897,8 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
       const int npx = active ? (2 * rows + 1) * W : 0;    // pixels of the tile (rows 2*y0-1 .. 2*y0+2*rows-1): one contiguous run per plane
       const int g0 = (2 * y0 - 1) * W;                    // plane pixel index of the tile's first pixel; < 0 only in image row -1
       const bool okA = tid < npx && g0 + tid >= 0, okB = tid + THREADS < npx && g0 + tid + THREADS >= 0;
-      const float* pA = a.in + (size_t)b * CIN * H * W + (okA ? (size_t)(g0 + tid) * 2 : 0);
-      const float* pB = a.in + (size_t)b * CIN * H * W + (okB ? (size_t)(g0 + tid + THREADS) * 2 : 0);
+      const float* pA = a.in + (size_t)b * (size_t)a.pp_imgstride + (okA ? (size_t)(g0 + tid) * 2 : 0);
+      const float* pB = a.in + (size_t)b * (size_t)a.pp_imgstride + (okB ? (size_t)(g0 + tid + THREADS) * 2 : 0);
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
         const size_t po = (size_t)pl * H * W * 2 + (((a.pp_mask >> pl) & 1u) ? (size_t)a.pp_bufstride : 0);   // uniform

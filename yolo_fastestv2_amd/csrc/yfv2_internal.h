@@ -240,10 +240,12 @@ struct BlockS2Args {
   int B, H, W;       // input size
   int R;             // output rows per work item
   // pair-plane input (stage 2 in lane-per-pixel form, yfv2_stage2.hip): in = buffer 0 of the stage, pair p of
-  // image b lives at in + b*CIN*H*W + p*H*W*2 (+ pp_bufstride floats if bit p of pp_mask is set)
+  // image b lives at in + b*pp_imgstride + p*H*W*2 (+ pp_bufstride floats if bit p of pp_mask is set): an image's two buffers are
+  // adjacent (pp_bufstride = CIN*H*W, pp_imgstride twice that), so no offset grows with the batch
   int pp_in;
   unsigned pp_mask;
   long long pp_bufstride;
+  long long pp_imgstride;
   int bf6;           // pw1 as bf16x6 (pair-plane input form)
   long long* trace;  // debug: per-wave cycle stamps of workgroup 0 (block_s2w_kernel; or null)
   const float* img16;  // s3h_kernel's image (stage3.0 from pair planes in streaming form, yfv2_stage2h.hip; WeightPacker::image_s3h) or null
@@ -264,11 +266,11 @@ __host__ __device__ inline int yfv2_stage2_channel(int slot) {
   return b0 + 2 * b1 + 4 * b2 + 8 * h;
 }
 struct S1PxArgs {
-  float* act;          // buffer 0 of the stage: [max_batch][24 pairs][H][W][2]; buffer 1 follows at + bufstride
+  float* act;          // the stage: [max_batch][2 buffers][24 pairs][H][W][2] (src_off / dst_off carry the buffer: + 48*H*W floats for buffer 1)
   const float* img;    // w1q[10][64] | w2q[10][64] | (unused 24) | dw taps [9][24]  (yfv2_api.hip image_s1px)
   int B, H, W;
   int nstrips, nb, R;  // set by the launcher
-  int img_stride;      // floats per image (48*H*W)
+  int img_stride;      // floats per image (2*48*H*W: both buffers)
   int num_records;     // bytes addressable from an image base (covers its copy in buffer 1)
   int src_off[12];     // byte offsets (from the image base in buffer 0) of the 12 branch pairs: where they are read ...
   int dst_off[12];     // ... and where the block's output for the same pairs is written (the other buffer)

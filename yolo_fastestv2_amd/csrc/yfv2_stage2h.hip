@@ -493,8 +493,8 @@ __global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
   constexpr int OOB = (int)0x80000000;
   const float* W1 = lds; const float* WP = lds + S3H_WFL; const float* W2 = lds + 2 * S3H_WFL;
 
-  // input: stage 2's two pair-plane buffers of this image (a.in = buffer 0; buffer 1 follows at + pp_bufstride floats)
-  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * 48 * IH * IW), 0,
+  // input: stage 2's two pair-plane buffers of this image (adjacent: buffer 1 at + pp_bufstride floats, the next image at + pp_imgstride)
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * (size_t)a.pp_imgstride), 0,
                                                                    (int)((a.pp_bufstride + 48LL * IH * IW) * 4), 0x00020000);
   Yfv2Watch watch;
   float tm[27], tp[27];
