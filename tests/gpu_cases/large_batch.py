@@ -7,7 +7,7 @@ tests/test_gpu_parity.py.  The reference has no batch limit (its tensors are ATe
 Size-independent property (no oracle run on thousands of images): the batch is K copies of one 256-image block, and every copy's
 logits, decoded rows and detections must be BIT-identical to what the 256-image block gives as a batch of its own (batch-position
 invariance, tests/test_gpu_parity.py::test_batch_invariance_and_permutation, at a size where a 32-bit offset would wrap).
-usage: large_batch.py B [uint8]      (B a multiple of 256)"""
+usage: large_batch.py B [uint8|fp32 [H W]]      (B a multiple of 256; environment switches such as YFV2_BF6=0 select the other plans)"""
 import faulthandler
 import os
 import sys
@@ -29,16 +29,17 @@ def mark(msg):
 def main():
     B = int(sys.argv[1])
     u8 = len(sys.argv) > 2 and sys.argv[2] == "uint8"
+    H, W = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (352, 352)
     assert B % 256 == 0 and B >= 512
     K = B // 256
     dev = torch.device("cuda:0")
     sd = yfv2.random_state_dict(11)
     g = torch.Generator(device=dev).manual_seed(21)
-    blk = torch.rand(256, 3, 352, 352, device=dev, generator=g)
+    blk = torch.rand(256, 3, H, W, device=dev, generator=g)
     if u8:
         blk = (blk.permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
 
-    small = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=256)
+    small = yfv2.Engine(dev, H, W, 80, 3, anchors=ANCHORS, max_batch=256)
     small.load_state_dict(sd)
     ref_logits = [t.clone() for t in small.forward(blk)]
     ref_dec = small.decode(ref_logits).clone()
@@ -48,7 +49,7 @@ def main():
     assert int(ref_det[2].min()) > 0, "the block yields no detections: the comparison below would be empty"
     mark("block of 256 done (%d detections)" % int(ref_det[2].sum()))
 
-    big = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=B)
+    big = yfv2.Engine(dev, H, W, 80, 3, anchors=ANCHORS, max_batch=B)
     big.load_state_dict(sd)
     x = blk.repeat(K, 1, 1, 1)
     mark("input %s: %.2f GiB, %d elements" % (tuple(x.shape), x.numel() * x.element_size() / 2 ** 30, x.numel()))
@@ -83,7 +84,7 @@ def main():
                 assert torch.equal(torch.where(live, t[k], torch.zeros_like(r)), torch.where(live, r, torch.zeros_like(r))), \
                     "%s: copy %d differs" % (name, k)
     mark("detections ok")
-    print("LARGE BATCH OK B=%d%s" % (B, " uint8" if u8 else ""), flush=True)
+    print("LARGE BATCH OK B=%d%s %dx%d" % (B, " uint8" if u8 else "", H, W), flush=True)
 
 
 if __name__ == "__main__":

@@ -149,6 +149,47 @@ def test_forward_random_weights_odd_batches(yfv2, dev):
         _assert_logits_within_noise_floor(m(x.to(dev)), w, x, "B=%d" % B)
 
 
+def _quirky_state_dict(yfv2, seed):
+    """What fine-tuned / pruned checkpoints of the reference look like and random_state_dict never does: BatchNorm gains that went
+    to exactly zero (network slimming), running variances collapsed to ~0 (a dead input: scale = gamma / sqrt(0 + 1e-5) = 316 gamma),
+    whole filters zero, one filter row 1e4 times larger than its neighbours (the per-tensor power-of-two scale of the fp16x3 filter
+    split is set by it: the small rows' second terms approach fp16's absolute floor), large BatchNorm shifts."""
+    w = {k: v.clone() for k, v in yfv2.random_state_dict(seed).items()}
+    g = torch.Generator().manual_seed(100 + seed)
+    for k in sorted(w):
+        if k.endswith(".running_var"):
+            base = k[:-len(".running_var")]
+            c = w[k].numel()
+            dead = torch.rand(c, generator=g) < 0.08
+            w[base + ".weight"][dead] = 0.0                                    # pruned channels: the output is the BatchNorm shift alone
+            tiny = (torch.rand(c, generator=g) < 0.05) & ~dead
+            w[k][tiny] = 1e-9
+            w[base + ".weight"][tiny] *= 0.004                                 # ... with a gain that keeps the activation in range
+            w[base + ".bias"] += 0.5 * torch.randn(c, generator=g) * (torch.rand(c, generator=g) < 0.1)
+    for k in ("backbone.stage2.1.branch_main.0.weight", "backbone.stage3.4.branch_main.5.weight", "fpn.cls_head_2.block.3.weight"):
+        w[k][1] = 0.0                                                          # a dead filter row
+        w[k][2] *= 1e-4                                                        # a row far below the tensor's largest entry
+        w[k][3, :, 0, 0] *= torch.logspace(-4, 0, w[k].shape[1])               # and four decades of range inside one row
+    w["backbone.stage4.2.branch_main.3.weight"][5] = 0.0                       # a dead depthwise channel
+    w["fpn.conv1x1_2.0.weight"][:, ::7] = 0.0                                  # input channels nobody reads
+    return w
+
+
+def test_forward_pruned_and_collapsed_batchnorm_weights(yfv2, dev):
+    """Checkpoints the reference's own training produces but a seeded random init never does (zero gains, collapsed variances,
+    dead filters, rows four decades below the tensor's largest entry): the device stays within the noise floor of the
+    REFERENCE's fp32 arithmetic against float64 (3x: six images), and the range guard stays quiet."""
+    for seed in (0, 1):
+        w = _quirky_state_dict(yfv2, seed)
+        m = yfv2.Detector(80, 3, True).to(dev)
+        m.load_state_dict(w)
+        m.eval()
+        x = torch.rand(6, 3, 352, 352, generator=torch.Generator().manual_seed(40 + seed))
+        got = m(x.to(dev))
+        m.engine_for(x.to(dev)).check_finite("quirky weights, seed %d" % seed)
+        _assert_logits_within_noise_floor(got, w, x, "quirky weights, seed %d" % seed)
+
+
 def test_forward_more_images_than_compute_units(yfv2, dev):
     """Batch 300 on a 256-CU device: every one-workgroup-per-image kernel (the chains, stage3.0 / stage4.0, the towers) runs a
     second image on 44 of its workgroups, with the next image's first slice prefetched across the image boundary.  Images on
@@ -927,10 +968,12 @@ def test_other_class_counts_in_their_own_interpreter(classes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,kind", [(6144, "fp32"), (4096, "uint8")], ids=["6144-fp32-9GiB-input", "4096-uint8"])
-def test_batches_beyond_4_gib_and_2_31_elements(B, kind):
+@pytest.mark.parametrize("B,kind,hw", [(6144, "fp32", (352, 352)), (4096, "uint8", (352, 352)), (2304, "fp32", (512, 512))],
+                         ids=["6144-fp32-9GiB-input", "4096-uint8", "2304-fp32-512x512"])
+def test_batches_beyond_4_gib_and_2_31_elements(B, kind, hw):
     """Maximum sizes: one call on 6144 images (input 9.1 GiB = 2.28e9 elements, stem output 4.6 GiB, stage-2 planes 4.6 GiB, decoded
-    tensor 3.8 GiB: every tensor that can pass 2^31 elements or 4 GiB does) and on 4096 uint8 images.  The reference has no
+    tensor 3.8 GiB: every tensor that can pass 2^31 elements or 4 GiB does), on 4096 uint8 images and on 2304 images of 512x512 (the
+    general-size plan; round 5's probe also ran YFV2_BF6=0 / YFV2_FUSED=0 / YFV2_POSTFUSE=0, 640x384 and 288x384 uint8: tools/gpu_r5_probe2.sh).  The reference has no
     batch bound (utils/utils.py:251 loops over whatever it is given); a 288 GB device holds these.  Property checked
     (tests/gpu_cases/large_batch.py): the batch is K copies of one 256-image block and every copy's logits, decoded rows and
     detections are BIT-identical to the block's own batch-of-256 result - a per-image base address computed in 32 bits wraps
@@ -939,7 +982,7 @@ def test_batches_beyond_4_gib_and_2_31_elements(B, kind):
     import sys
 
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_cases", "large_batch.py")
-    r = subprocess.run([sys.executable, script, str(B)] + (["uint8"] if kind == "uint8" else []), capture_output=True, text=True, timeout=400)
+    r = subprocess.run([sys.executable, script, str(B), kind, str(hw[0]), str(hw[1])], capture_output=True, text=True, timeout=400)
     marks = [ln for ln in r.stdout.splitlines() if ln.startswith("[large_batch]")]
     assert r.returncode == 0, ("exit code %d after %r" % (r.returncode, marks[-1] if marks else "no marker"), r.stdout[-1500:], r.stderr[-3000:])
     assert "LARGE BATCH OK B=%d" % B in r.stdout

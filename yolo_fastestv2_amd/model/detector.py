@@ -153,6 +153,14 @@ class _TrainForward(torch.autograd.Function):
                 for k in live}
         if not frozen and all(mine.values()):
             keep.add_(work)                          # accumulation over `subdivisions` batches (train.py:122), one kernel
+        elif not frozen and all(params[k].grad is None for k in live):
+            # the state optimizer.zero_grad() leaves behind on this torch (set_to_none=True is the default: train.py:118 runs into
+            # it every iteration): ONE copy of the bucket, then every .grad becomes its view again - the parameter-by-parameter
+            # branch below spent 225 copy launches per iteration here (rocprofv3: 350 __amd_rocclr_copyBuffer per iteration,
+            # 1.2 ms of the 12.3 ms at batch 64)
+            keep.copy_(work)
+            for k in live:
+                params[k].grad = b["keep_views"][k]
         else:
             foreign = {k: params[k].grad for k in live if params[k].grad is not None and not mine[k]}
             for k in live:                           # a mixed state: keep what is there, parameter by parameter
