@@ -660,8 +660,8 @@ def test_other_input_size_320(yfv2, dev):
         assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)) and np.array_equal(idx[b].numpy(), o_idx[b])
 
 
-@pytest.mark.parametrize("env", [{"YFV2_FUSED": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_TPAIR": "0"}],
-                         ids=["layer-by-layer", "fp32-mfma-everywhere", "two-launch-post", "tower-halves-as-four-launches"])
+@pytest.mark.parametrize("env", [{"YFV2_FUSED": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_TPAIR": "0"}, {"YFV2_FRONT": "0"}],
+                         ids=["layer-by-layer", "fp32-mfma-everywhere", "two-launch-post", "tower-halves-as-four-launches", "stem-and-stage2.0-as-two-launches"])
 def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     """The three plan switches that remain: everything layer by layer - also what a shape outside a fused
     kernel's static bounds gets, block by block; every pointwise conv on the fp32 MFMA; decode and NMS as two launches.
@@ -686,9 +686,11 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     elif "YFV2_BF6" in env:
         assert not any("chain of 7" in n for n in names) and any("resident in LDS" in n for n in names), names
     elif "YFV2_TPAIR" in env:
-        assert len(names) == 16 and not any("side by side" in n for n in names), names   # cls a, cls b, reg a, reg b at 22x22
+        assert len(names) == 15 and not any("side by side" in n for n in names), names   # cls a, cls b, reg a, reg b at 22x22
+    elif "YFV2_FRONT" in env:
+        assert len(names) == 14 and sum("side by side" in n for n in names) == 2 and names[0].startswith("stem conv"), names
     else:
-        assert len(names) == 14 and sum("side by side" in n for n in names) == 2, names
+        assert len(names) == 13 and sum("side by side" in n for n in names) == 2 and names[0].startswith("stem + backbone.stage2.0 in one launch"), names
         eng.set_anchors([12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87])
         r1, i1 = yfv2.unpack_detections(*eng.detect(x.to(dev), 0.3, 0.4))                 # decode_kernel<compact> + nms_kernel<1>
         r2, i2 = yfv2.unpack_detections(*eng.nms(eng.decode(eng.forward(x.to(dev))), 0.3, 0.4))
@@ -1033,6 +1035,50 @@ def _engine_with_env(yfv2, dev, env, **kw):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("hw,B", [((352, 352), 9), ((320, 320), 3), ((288, 384), 2), ((64, 96), 3), ((32, 32), 4), ((352, 32), 2), ((96, 1024), 2),
+                                  ((512, 512), 2), ((416, 416), 2), ((352, 352), 300)])
+def test_front_kernel_is_bit_identical_to_stem_plus_stage2_0(yfv2, dev, hw, B):
+    """Round 5: the stem and stage2.0 as ONE launch (front_kernel: a lane owns two adjacent pooled columns, the stem's matrix-core
+    output layout IS the stride-2 block's input layout, the [H/4][W/4][24] tensor never leaves the registers) against the two
+    launches it replaces (YFV2_FRONT=0).  Every value passes through the same instructions on the same operands in the same
+    order, so stage 2 and the six logit maps must be BIT-identical - at sizes whose strips and bands are ragged (64x96, 32x32,
+    352x32, 96x1024), at the general sizes, and with more images than compute units.  The stem's own output, which the fused
+    launch never writes, is still there for the debug hook (re-run from the last input) and equal too; uint8 input takes the
+    two-launch route under either plan."""
+    H, W = hw
+    sd = yfv2.random_state_dict(17)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * 7 + W + B)).to(dev)
+    outs = []
+    for env in ({"YFV2_FRONT": "0"}, {}):
+        old = os.environ.get("YFV2_FRONT")
+        os.environ.update(env)
+        try:
+            e = yfv2.Engine(dev, H, W, 80, 3, max_batch=B)
+        finally:
+            if old is None:
+                os.environ.pop("YFV2_FRONT", None)
+            else:
+                os.environ["YFV2_FRONT"] = old
+        e.load_state_dict(sd)
+        names = [s["name"] for s in e.stages()]
+        if env:
+            px_plan = "lane-per-pixel" in names[1]      # maps too small for the streaming stage-2 kernels run layer-wise blocks: nothing to fuse there
+        assert names[0].startswith("stem + backbone.stage2.0 in one launch") == (not env and px_plan), names[:2]
+        logits = [t.clone() for t in e.forward(x)]
+        acts = [e.debug_activation(w, min(B, 9)) for w in (0, 1)]
+        xu = (x[:min(B, 4)].permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
+        lu = [t.clone() for t in e.forward(xu)]
+        e.check_finite("front / two-launch plan")
+        outs.append((logits, acts, lu))
+    (l0, a0, u0), (l1, a1, u1) = outs
+    for k, (p, q) in enumerate(zip(a0, a1)):
+        assert torch.equal(p, q), "%s: %d of %d elements differ" % (("stem output (debug hook)", "stage 2")[k], int((p != q).sum()), p.numel())
+    for key, p, q in zip(LOGIT_KEYS, l0, l1):
+        assert torch.equal(p, q), "%s differs between the one-launch and the two-launch front" % key
+    for key, p, q in zip(LOGIT_KEYS, u0, u1):
+        assert torch.equal(p, q), "uint8 input, %s" % key
 
 
 @pytest.mark.parametrize("lanes", [2, 3])

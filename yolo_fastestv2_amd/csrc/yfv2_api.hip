@@ -56,6 +56,8 @@ struct Step {
   std::vector<Step> jobs;       // STEP_TOWER on towerh_kernel: the tower halves this ONE launch runs one after the other (empty: the step is its own job)
   bool par = false;             // ... or (par) side by side: independent halves (cls a | reg a, cls b | reg b) as workgroup ranges of one launch
   int tw_tiles = 0;             // STEP_TOWER on towerh_kernel: output-conv tiles the images of the launch are packed for (0, 1 or 6)
+  std::string name_plain;       // STEP_S2PX with front: the step's name as a launch of its own
+  bool front = false;           // STEP_S2PX: the launch starts from the IMAGE (front_kernel: stem + stage2.0 in one wave); the stem's own step lives in yfv2_ctx::stem_aside
 };
 
 struct Buf { float* p = nullptr; size_t per_img = 0; };
@@ -80,6 +82,12 @@ struct yfv2_ctx {
              // image base stays below 2 x 48 x H/8 x W/8 floats whatever max_batch is: no batch bound from 32-bit buffer offsets)
   // pair-plane bookkeeping at the END of stage 2 (for the stride-2 consumer and for yfv2_debug_activation)
   bool s2_px = false;
+  // stem + stage2.0 as ONE launch (front_kernel, yfv2_stage2h.hip): plan[0] is then that launch and the stem's own step is kept HERE, for
+  // uint8 input (stem_h3u_kernel, then plan[0] as plain s2h_kernel) and for yfv2_debug_activation(0), which re-runs it on the last input
+  bool front_wanted = true;    // YFV2_FRONT=0 at create time: the two-launch form
+  bool front_fused = false;
+  Step stem_aside{};
+  const void* last_x = nullptr; int last_B = 0; bool last_u8 = false;
   bool stem_pp = false;     // the stem writes channel planes for stage2.0's streaming kernels: quad planes [6][H/4][W/4][4] (stem_h3 -> s2h_kernel), pair planes [12][H/4][W/4][2] on the YFV2_BF6=0 plan (stem_px -> s2px kernels)
   int s2_label[48] = {0};   // logical channel stored in slot 2*pair + element
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
@@ -1592,6 +1600,7 @@ struct PlanBuilder {
     add_stem(h->a1, stage2_px && !stem_nhwc);
     h->stem_pp = stage2_px && !stem_nhwc;
     stem_nhwc_ = stem_nhwc;
+    h->front_fused = stem_nhwc && h->front_wanted;   // YFV2_FRONT=0: the stem and stage2.0 as two launches (the form every other plan and the uint8 entry points use)
     Buf* stage_bufs[3] = {h->s2, h->s3, h->s4};
     const int repeats[3] = {4, 8, 4};
     const Buf* x = &h->a1;
@@ -1674,6 +1683,19 @@ struct PlanBuilder {
     tower("fpn.cls_head_2.block", h2, w2, h->f2, true, 0);
     tower("fpn.reg_head_2.block", h2, w2, h->f2, false, 0);
     merge_tower_launches();
+    if (h->front_fused && ok && h->plan.size() > 1 && h->plan[0].kind == STEP_STEM && h->plan[1].kind == STEP_S2PX && h->plan[1].img_off3) {
+      h->stem_aside = h->plan[0];
+      h->plan.erase(h->plan.begin());
+      Step& f = h->plan[0];
+      f.front = true;
+      f.name_plain = f.name;
+      f.name = "stem + backbone.stage2.0 in one launch: conv3x3s2+bn+relu+maxpool3x3s2 -> s2 block, lane-per-pixel (proj | main) -> pair planes (uint8 input: two launches)";
+      f.flops += h->stem_aside.flops;
+      f.bytes += h->stem_aside.bytes;                     // per-layer accounting: both layers' reads and writes
+      f.bytes_ext = 4.0 * (3.0 * H * W + 48.0 * (H / 8) * (W / 8));   // the image in, stage 2's 48 channels out
+    } else {
+      h->front_fused = false;
+    }
   }
 };
 
@@ -1689,7 +1711,7 @@ std::string step_kernel(const Step& st) {
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
-    case STEP_S2PX: return "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel)
+    case STEP_S2PX: return st.front ? "front_kernel" : "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel; uint8 input under front: stem_h3u_kernel + s2h_kernel)
     case STEP_S1CHAIN: return "block_s1chain6_kernel";
     case STEP_S1POOL: return "block_s1pool_kernel";
   }
@@ -1702,11 +1724,13 @@ std::string step_kernel(const Step& st) {
 //   YFV2_BF6=0       every pointwise conv on the fp32 MFMA; blocks whose fused kernel exists only in the bf16x6 form
 //                    (the stage-3 chain, stage4.0) then run layer by layer
 //   YFV2_POSTFUSE=0  yfv2_detect decodes and suppresses in two launches
+//   YFV2_FRONT=0     the stem and stage2.0 as two launches (stem_h3_kernel, s2h_kernel) instead of front_kernel's one
 //   YFV2_TPAIR=0     the tower halves of a level larger than 11x11 as four launches instead of two side-by-side pairs
 //                                                                                       - read by PlanBuilder::pair_level
 void read_plan_switches(yfv2_ctx* h) {
   if (const char* e = std::getenv("YFV2_BF6")) h->bf6 = !(e[0] == '0');
   if (const char* e = std::getenv("YFV2_POSTFUSE")) h->postfuse = !(e[0] == '0');
+  if (const char* e = std::getenv("YFV2_FRONT")) h->front_wanted = !(e[0] == '0');
 }
 
 int alloc_buf(yfv2_ctx* h, Buf* b, size_t per_img) {
@@ -1734,6 +1758,15 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
     if (only_step >= 0 && (int)i != only_step) continue;
     Step& st = h->plan[i];
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i], s));
+    auto stem_args = [&](const Step& ss) {
+      StemArgs a = ss.stem;
+      a.x = x; a.B = B; a.u8_in = x_u8 ? 1 : 0;
+      a.img = params + ss.img_off;
+      a.img_u8 = params + ss.img_off2;
+      a.img16 = h->bf6 ? params + ss.img_off3 : nullptr;
+      a.nonfinite = h->d_nonfinite;
+      return a;
+    };
     if (st.kind == STEP_STEM) {
       StemArgs a = st.stem;
       a.x = x; a.B = B; a.u8_in = x_u8 ? 1 : 0;
@@ -1824,7 +1857,16 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.img[1] = params + st.img_off2;
       a.img16 = h->bf6 ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: the two role kernels on the 4x4x1 fp32 MFMA
       a.nonfinite = h->d_nonfinite;
-      yfv2_launch_s2px(a, s);
+      if (st.front && !x_u8) {
+        FrontArgs f{};
+        f.x = x; f.H = h->cfg.height; f.W = h->cfg.width;
+        f.img_stem = params + h->stem_aside.img_off3;
+        f.s2 = a;
+        yfv2_launch_front(f, s);
+      } else {
+        if (st.front) yfv2_launch_stem(stem_args(h->stem_aside), s);   // uint8 input: stem_h3u_kernel, then stage2.0 on its own
+        yfv2_launch_s2px(a, s);
+      }
     } else if (st.kind == STEP_S1PX) {
       S1PxArgs a = st.s1px;
       a.B = B;
@@ -1841,6 +1883,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
     }
     if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i + 1], s));
   }
+  if (only_step < 0) { h->last_x = x; h->last_B = B; h->last_u8 = x_u8; }
   HIP_TRY(h, hipGetLastError());
   return YFV2_OK;
 }
@@ -2099,9 +2142,13 @@ int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* te
   // step + 1000 (k + 1): job k of a launch that runs several tower halves (towers_kernel's list, towerh_kernel's side-by-side pair)
   const int job = step >= 1000 ? step / 1000 - 1 : -1;
   if (step >= 1000) step %= 1000;
-  if (step < 0 || step >= (int32_t)ctx.plan.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: step out of range");
-  if (job >= (int)ctx.plan[step].jobs.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: job out of range");
-  const Step& st = job >= 0 ? ctx.plan[step].jobs[job] : ctx.plan[step];
+  // the images are those of the launches as packed: under front_kernel (one launch for the stem and stage2.0) the stem's step is
+  // put back in front and stage2.0 answers to its own name - step indices are those of the two-launch plan
+  std::vector<Step> view = ctx.plan;
+  if (ctx.front_fused) { view.insert(view.begin(), ctx.stem_aside); view[1].name = view[1].name_plain; }
+  if (step < 0 || step >= (int32_t)view.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: step out of range");
+  if (job >= (int)view[step].jobs.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: job out of range");
+  const Step& st = job >= 0 ? view[step].jobs[job] : view[step];
   if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", st.name.c_str());
   const int64_t avail = (int64_t)wp.blob.size() - (int64_t)st.img_off;
   const int64_t cnt = avail < cap ? avail : cap;
@@ -2669,6 +2716,17 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
     return n;
   }
   if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
+  if (which == 0 && h->front_fused && !h->last_u8) {
+    // front_kernel never writes the stem's output: run the stem's own launch on the last forward's input (which the caller must still hold)
+    if (!h->last_x || h->last_B < B) { fail(h, YFV2_ERR_STATE, "yfv2_debug_activation(0): no forward of at least this batch has run on the handle"); return YFV2_ERR_STATE; }
+    StemArgs a = h->stem_aside.stem;
+    a.x = h->last_x; a.B = B; a.u8_in = 0;
+    a.img = h->d_params + h->stem_aside.img_off; a.img_u8 = h->d_params + h->stem_aside.img_off2;
+    a.img16 = h->bf6 ? h->d_params + h->stem_aside.img_off3 : nullptr;
+    a.nonfinite = h->d_nonfinite;
+    if (hipDeviceSynchronize() != hipSuccess) { fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: synchronize failed"); return YFV2_ERR_DEVICE; }
+    yfv2_launch_stem(a, nullptr);
+  }
   if (which == 0 && h->stem_pp && h->bf6) {  // stem output in quad planes [6][PH*PW][4] (stem_h3 / stem_h3u kernels) -> NHWC
     const size_t per = h->dbg_per_img[0], hw = per / 24;
     std::vector<float> tmp((size_t)n);

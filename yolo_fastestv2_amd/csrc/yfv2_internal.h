@@ -292,6 +292,14 @@ struct S2PxArgs {
   int* nonfinite;      // range-guard word (Yfv2Watch), or null
   int in_nhwc;         // s2h_kernel: the stem's output is [IH][IW][24] instead of quad planes
 };
+// stem + stage2.0 in one wave (front_kernel, yfv2_stage2h.hip): the fp32 input image straight to stage 2's pair planes
+struct FrontArgs {
+  const void* x;         // fp32 (B,3,H,W)
+  int H, W;
+  const float* img_stem; // WeightPacker::image_stem16
+  S2PxArgs s2;           // as for s2h_kernel (IH x IW = H/4 x W/4; in / in_nhwc unused)
+};
+void yfv2_launch_front(const FrontArgs& a, hipStream_t s);
 void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // a.img16 set: yfv2_launch_s2h (one kernel); else two kernels (proj role, main role)
 void yfv2_launch_s2h(const S2PxArgs& a, hipStream_t s);
 bool yfv2_s1px_supported(int H, int W);

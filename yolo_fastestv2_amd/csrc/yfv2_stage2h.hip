@@ -421,6 +421,347 @@ void yfv2_launch_s2h(const S2PxArgs& a0, hipStream_t s) {
 }
 
 // ============================================================================
+// stem + stage2.0 in ONE wave (round 5): conv3x3 s2 3 -> 24 + BN + ReLU + maxpool3x3 s2 (yfv2_stem16.hip's arithmetic) feeding
+// the stride-2 block above without the [H/4][W/4][24] tensor between them ever leaving the registers
+// ============================================================================
+// Why: plain streaming costs 130 pJ per byte above idle on these boxes (tools/traffic_energy_probe.py), the two
+// launches move 856 MB of which 380 are the stem's output written and read back: ~50 mJ of a 850 mJ pipelined step that runs at
+// the package's power cap, and 117 + 72 us on one stream for what a single pass over 381 MB in + 95 MB out could do.
+// How: the matrix core's D layout of the stem - lane (p, g): channels 16 t + 4 g .. + 3 of ITS pooled pixel - is, record for
+// record, what s2h_kernel loads per lane: X[2 t + c] = channel positions 4 t .. 4 t + 3 of pooled column 2 ox + c.  So a lane of
+// this kernel owns TWO adjacent pooled columns A = 2 ox, B = 2 ox + 1 (input columns 8 ox .. 8 ox + 7: two aligned 16-byte loads
+// per input row and channel), runs the stem's implicit GEMM for both (four pixel tiles per conv row instead of two: even / odd
+// conv columns of A and of B), pools, and hands the result to the stride-2 block's code above as if it had been loaded.  What a
+// lane needs from a neighbour: the input column left of A (= the left lane's B, one DPP row shift of its converted pair, as in
+// the stem) and the odd conv column left of A for the horizontal max (one DPP row shift of the left lane's accumulator).  Lane 0
+// of an inner strip has no left lane: its column A is wrong, its column B is right - and B is all lane 1 needs from it (the
+// depthwise's dx = 0 tap); lane 0 stores nothing (the halo lane of s2h_kernel).  Pooled rows are produced in exactly the order
+// the block consumes them (2 y0 - 1, 2 y0, ..): none is ever held beside another.  Every value goes through the same
+// instructions on the same operands in the same order as in stem_h3_kernel + s2h_kernel: the results are bit-identical
+// (tests/test_gpu_parity.py compares the two plans).  State: both kernels' (filters, taps, carried rows) plus two sets of eight
+// 16-byte input buffers - the kernel runs ONE wave per SIMD (launch bound) and hides its load latency behind its own arithmetic
+// (~5.4 k issue cycles per output row against ~1.3 k for the loads of the next one).
+namespace {
+struct FCol { unsigned p01[2], p23[2], m[2]; };   // a 16-byte run of one input row, both fp16 terms: (v0, v1), (v2, v3); m: high half = the column left of v0
+__device__ __forceinline__ unsigned f_dpp_shr1_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ float f_dpp_shr1_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)); }
+__device__ __forceinline__ int f_f2i(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ float f_i2f(int v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ void f_split2(float a, float b, unsigned& h1, unsigned& h2) {   // the stem's split: x 2^8 first (yfv2_stem16.hip)
+  const f32x2 v = (f32x2){a, b} * 256.0f;
+  const yfv2_h2 t1 = __builtin_convertvector(v, yfv2_h2);
+  const f32x2 r = v - __builtin_convertvector(t1, f32x2);
+  const yfv2_h2 t2 = __builtin_convertvector(r, yfv2_h2);
+  h1 = __builtin_bit_cast(unsigned, t1);
+  h2 = __builtin_bit_cast(unsigned, t2);
+}
+__device__ __forceinline__ unsigned f_hi_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // {a.hi, b.hi}
+__device__ __forceinline__ unsigned f_hi_lo(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }   // {a.hi, b.lo}
+__device__ __forceinline__ void f_split(const f32x4 v, FCol& o) {
+  f_split2(v[0], v[1], o.p01[0], o.p01[1]);
+  f_split2(v[2], v[3], o.p23[0], o.p23[1]);
+}
+// one pooled column's two conv columns (tile E: even, tile O: odd) of one conv row: rows x0 (carried), x1, x2 - stem_h3_kernel's K slots
+__device__ __forceinline__ void f_conv_col(const FCol& x0, const FCol& x1, const FCol& x2, const yfv2_h8 (&wa)[2][2], const f32x4 sh0, const f32x4 sh1,
+                                           f32x4 (&ae)[2], f32x4 (&ao)[2]) {
+  yfv2_h8 be[2], bo[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const u32x4 e = {x0.p01[k], x1.p01[k], f_hi_hi(x0.m[k], x1.m[k]), f_hi_lo(x2.m[k], x2.p01[k])};
+    const u32x4 o = {x0.p23[k], x1.p23[k], f_hi_hi(x0.p01[k], x1.p01[k]), f_hi_lo(x2.p01[k], x2.p23[k])};
+    be[k] = __builtin_bit_cast(yfv2_h8, e);
+    bo[k] = __builtin_bit_cast(yfv2_h8, o);
+  }
+  ae[0] = sh0; ae[1] = sh1; ao[0] = sh0; ao[1] = sh1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], be[1], ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], bo[1], ao[t], 0, 0, 0); }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], be[0], ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], bo[0], ao[t], 0, 0, 0); }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], be[0], ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], bo[0], ao[t], 0, 0, 0); }
+}
+}  // namespace
+
+template <int V>   // experiment bits: 1 = every conv row's buffers are refilled right behind the conv row that used them; 2 = no loads at all (the arithmetic alone)
+__global__ __launch_bounds__(64, 1) void front_kernel(FrontArgs fa) {
+  const S2PxArgs& a = fa.s2;
+  const int IH = a.IH, IW = a.IW, OH = IH >> 1, OW = IW >> 1;      // IH x IW = the pooled map the stem produces (H/4 x W/4)
+  const int H = fa.H, W = fa.W;
+  const int nstrips = a.nstrips, nb = a.nb, R = a.R;
+  const int wpi = nstrips * nb;
+  const int nwg = gridDim.x;
+  const int wid = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+  const int b = __builtin_amdgcn_readfirstlane(wid / wpi), wi = __builtin_amdgcn_readfirstlane(wid - b * wpi);
+  const int strip = wi % nstrips, band = wi / nstrips;
+  const int lane = threadIdx.x, l = lane & 15, g = lane >> 4;
+  const int ox = 15 * strip + l;
+  const bool xok = ox < OW;
+  const bool st_lane = xok && (l > 0 || strip == 0);
+  const int y0 = band * R, y1 = min(OH, y0 + R);
+  constexpr int OOB = (int)0x80000000;
+
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)fa.x + (size_t)b * 3 * H * W * 4), 0, 3 * H * W * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.act + (size_t)b * a.out_stride), 0, a.out_records, 0x00020000);
+  // ---- stage2.0's state (s2h_kernel)
+  const float* img = a.img16;
+  yfv2_h8 w1[2][2], wp[2][2], w2[2][2];
+  {
+    const u32x4* q = reinterpret_cast<const u32x4*>(img);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        w1[t][k] = __builtin_bit_cast(yfv2_h8, q[(S2H_W1 / 4) + (t * 2 + k) * 64 + lane]);
+        wp[t][k] = __builtin_bit_cast(yfv2_h8, q[(S2H_WP / 4) + (t * 2 + k) * 64 + lane]);
+        w2[t][k] = __builtin_bit_cast(yfv2_h8, q[(S2H_W2 / 4) + (t * 2 + k) * 64 + lane]);
+      }
+  }
+  Yfv2Watch watch;
+  float tm[18], tp[18];
+#pragma unroll
+  for (int q = 0; q < 18; ++q) { tm[q] = img[S2H_TM + q * 64 + lane]; tp[q] = img[S2H_TP + q * 64 + lane]; }
+  const f32x4 sh1[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 16 + 4 * g)};
+  const f32x4 bip[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 32 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 48 + 4 * g)};
+  const f32x4 bi2[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 64 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 80 + 4 * g)};
+  const float unscale_p = img[S2H_CST + 96], unscale_2 = img[S2H_CST + 97];
+  int soff[8];
+  {
+    const int* po = reinterpret_cast<const int*>(img + S2H_OFFS);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int v = po[(4 + k) * 64 + lane]; soff[k] = (st_lane && v != OOB) ? v + ox * 8 : OOB; }
+  }
+  const int orowb = OW * 8;
+  // ---- the stem's state (stem_h3_kernel): filter [tile 2][term 2][64 lanes][4 dwords], shift x 2^(sw+8) [32], 2^-(sw+8)
+  yfv2_h8 wa[2][2];
+  {
+    const u32x4* wimg = reinterpret_cast<const u32x4*>(fa.img_stem);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) wa[t][k] = __builtin_bit_cast(yfv2_h8, wimg[(t * 2 + k) * 64 + lane]);
+  }
+  const float* cst = fa.img_stem + 2 * 2 * 64 * 4;
+  const f32x4 ssh0 = *reinterpret_cast<const f32x4*>(cst + 4 * g), ssh1 = *reinterpret_cast<const f32x4*>(cst + 16 + 4 * g);
+  const float sunscale = cst[32];
+  const int rowb = W * 4;
+  const int chan_off = (xok && g < 3 && !(V & 2)) ? g * H * rowb + 8 * ox * 4 : OOB;     // lane groups 0..2: input channel g, columns 8 ox .. 8 ox + 7
+  const int src0 = (0 * 16 + l) * 4, src1 = (1 * 16 + l) * 4, src2 = (2 * 16 + l) * 4;   // ds_bpermute byte addresses of lanes (l, 0..2)
+  const int hlast = H - 1;
+
+  // input rows 4 r .. 4 r + 3 (the two conv rows of pooled row r), columns A | B: eight 16-byte loads
+  struct InSet { f32x4 a[4], b[4]; };
+  auto issue_half = [&](int r, InSet& s, int hf) {
+#pragma unroll
+    for (int i = 2 * hf; i < 2 * hf + 2; ++i) {
+      const int row = min(4 * r + i, hlast);
+      const int off = chan_off != OOB ? chan_off + row * rowb : OOB;
+      s.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      s.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+    }
+  };
+  auto issue = [&](int r, InSet& s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(4 * r + i, hlast);          // (a row past the image: a re-read that stays in range, never used)
+      const int off = chan_off != OOB ? chan_off + row * rowb : OOB;
+      s.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      s.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+    }
+  };
+  // one conv row of both pooled columns from the carried rows (cA, cB) and the fresh rows r1 (2c), r2 (2c + 1) -> horizontally
+  // pooled raw values (BN shift inside, pre-ReLU, x 2^(sw+8)); cA, cB <- the split row 2c + 1
+  auto conv_row2 = [&](FCol& cA, FCol& cB, f32x4 r1A, f32x4 r2A, f32x4 r1B, f32x4 r2B, f32x4 (&hA)[2], f32x4 (&hB)[2]) {
+    {   // lane group 3: tap (2, 2) of the three channels = columns + 1 | + 3 of row 2c + 1, out of the registers of lanes (l, 0..2)
+      const int a1 = f_f2i(r2A[1]), a3 = f_f2i(r2A[3]), b1 = f_f2i(r2B[1]), b3 = f_f2i(r2B[3]);
+      const int e0 = __builtin_amdgcn_ds_bpermute(src0, a1), e1 = __builtin_amdgcn_ds_bpermute(src1, a1), e2 = __builtin_amdgcn_ds_bpermute(src2, a1);
+      const int q0 = __builtin_amdgcn_ds_bpermute(src0, a3), q1 = __builtin_amdgcn_ds_bpermute(src1, a3), q2 = __builtin_amdgcn_ds_bpermute(src2, a3);
+      const int f0 = __builtin_amdgcn_ds_bpermute(src0, b1), f1 = __builtin_amdgcn_ds_bpermute(src1, b1), f2 = __builtin_amdgcn_ds_bpermute(src2, b1);
+      const int u0 = __builtin_amdgcn_ds_bpermute(src0, b3), u1 = __builtin_amdgcn_ds_bpermute(src1, b3), u2 = __builtin_amdgcn_ds_bpermute(src2, b3);
+      if (g == 3) {
+        r1A = (f32x4){f_i2f(e0), f_i2f(e1), f_i2f(q0), f_i2f(q1)};
+        r2A = (f32x4){f_i2f(e2), 0.f, f_i2f(q2), 0.f};
+        r1B = (f32x4){f_i2f(f0), f_i2f(f1), f_i2f(u0), f_i2f(u1)};
+        r2B = (f32x4){f_i2f(f2), 0.f, f_i2f(u2), 0.f};
+      }
+    }
+    FCol x1A, x2A, x1B, x2B;
+    f_split(r1A, x1A); f_split(r2A, x2A); f_split(r1B, x1B); f_split(r2B, x2B);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      x1A.m[k] = f_dpp_shr1_u(x1B.p23[k]); x2A.m[k] = f_dpp_shr1_u(x2B.p23[k]);   // the column left of A: the left lane's B
+      x1B.m[k] = x1A.p23[k]; x2B.m[k] = x2A.p23[k];                               // the column left of B: this lane's A
+    }
+    f32x4 aeA[2], aoA[2], aeB[2], aoB[2];
+    f_conv_col(cA, x1A, x2A, wa, ssh0, ssh1, aeA, aoA);
+    f_conv_col(cB, x1B, x2B, wa, ssh0, ssh1, aeB, aoB);
+    cA = x2A; cB = x2B;
+    watch.see(aeA[0][0]); watch.see(aoA[0][0]); watch.see(aeB[0][0]); watch.see(aoB[0][0]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // 0 from the DPP at the image's left edge stands for the -inf padding: ReLU follows the pooling
+        hA[t][e] = __builtin_fmaxf(__builtin_fmaxf(f_dpp_shr1_f(aoB[t][e]), aeA[t][e]), aoA[t][e]);
+        hB[t][e] = __builtin_fmaxf(__builtin_fmaxf(aoA[t][e], aeB[t][e]), aoB[t][e]);
+      }
+  };
+  FCol cA, cB;
+  f32x4 upA[2], upB[2];
+  // pooled row from its input set -> X[2 t + c] as s2h_kernel's load_row delivers it
+  auto pooled = [&](InSet& s, f32x4 (&X)[4], int rnext) {
+    f32x4 h0A[2], h0B[2], h1A[2], h1B[2];
+    conv_row2(cA, cB, s.a[0], s.a[1], s.b[0], s.b[1], h0A, h0B);
+    if constexpr (V & 1) { __builtin_amdgcn_sched_barrier(0); issue_half(rnext, s, 0); __builtin_amdgcn_sched_barrier(0); }
+    conv_row2(cA, cB, s.a[2], s.a[3], s.b[2], s.b[3], h1A, h1B);
+    if constexpr (V & 1) { __builtin_amdgcn_sched_barrier(0); issue_half(rnext, s, 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float mA = __builtin_fmaxf(__builtin_fmaxf(upA[t][e], h0A[t][e]), h1A[t][e]);
+        const float mB = __builtin_fmaxf(__builtin_fmaxf(upB[t][e], h0B[t][e]), h1B[t][e]);
+        X[2 * t][e] = __builtin_fmaxf(mA, 0.f) * sunscale;
+        X[2 * t + 1][e] = __builtin_fmaxf(mB, 0.f) * sunscale;
+      }
+      upA[t] = h1A[t]; upB[t] = h1B[t];
+    }
+    if (g >= 2 || !xok) { X[2] = (f32x4){0.f, 0.f, 0.f, 0.f}; X[3] = X[2]; }   // channel tile 1 holds channels 16..23 in lane groups 0, 1
+    if (!xok) { X[0] = X[2]; X[1] = X[2]; }
+  };
+
+  // ---- stage2.0's row machinery (s2h_kernel)
+  auto columns = [&](const f32x4 (&X)[4], float lim, float (&xe)[8], float (&xo)[8], float (&te)[8], float (&to)[8]) {
+    f32x2 ine[4], ino[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 ve = X[2 * t] * 16.0f, vo = X[2 * t + 1] * 16.0f;
+      ine[2 * t] = (f32x2){ve[0], ve[1]}; ine[2 * t + 1] = (f32x2){ve[2], ve[3]};
+      ino[2 * t] = (f32x2){vo[0], vo[1]}; ino[2 * t + 1] = (f32x2){vo[2], vo[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xe[4 * t + e] = ve[e]; xo[4 * t + e] = vo[e]; }
+    }
+    f32x4 ae[2], ao[2];
+    pw_h3(w1, ine, sh1, ae, watch);
+    pw_h3(w1, ino, sh1, ao, watch);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      te[c] = __builtin_amdgcn_fmed3f(ae[c >> 2][c & 3], 0.f, lim);
+      to[c] = __builtin_amdgcn_fmed3f(ao[c >> 2][c & 3], 0.f, lim);
+    }
+  };
+#define YFV2_TQ(T, c, t) T[((c) * 9 + (t)) >> 2]
+#define YFV2_TK(c, t) (((c) * 9 + (t)) & 3)
+  auto acc_row = [&](auto dyc, const float (&T)[18], const float (&v0)[8], const float (&v1)[8], float (&S)[8], float (&Q)[8]) {
+    constexpr int DY = decltype(dyc)::value;
+    [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
+      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(T, Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(T, Cs, 0), v1[Cs]),
+                         quad_fmac1<YFV2_TK(Cs, 2)>(S[Cs], YFV2_TQ(T, Cs, 2), v1[Cs]))
+                : (void)quad_fmac3<YFV2_TK(Cs, DY * 3 + 1), YFV2_TK(Cs, DY * 3), YFV2_TK(Cs, DY * 3 + 2)>(
+                      S[Cs], Q[Cs], YFV2_TQ(T, Cs, DY * 3 + 1), YFV2_TQ(T, Cs, DY * 3), YFV2_TQ(T, Cs, DY * 3 + 2), v0[Cs], v1[Cs])), ...);
+    }(std::make_integer_sequence<int, 8>{});
+  };
+
+  InSet s0, s1;
+  f32x4 P[4];
+  float cxe[8], cxo[8], cte[8], cto[8];            // the odd pooled row above the current output row (dy = 0): raw and pw1'd
+  const float limx = xok ? __builtin_inff() : 0.f;
+  {
+    const int r0 = 2 * y0 - 1;                      // the first pooled row this band needs
+    if (r0 > 0) {
+      // the conv row above pooled row r0 (2 r0 - 1: input rows 4 r0 - 3 .. 4 r0 - 1) gives the carried maxima and the carried split row
+      issue(r0 - 1, s1);                            // rows 4 r0 - 4 .. 4 r0 - 1 (the first of them is not needed)
+      issue(r0, s0);
+      f_split(s1.a[1], cA); f_split(s1.b[1], cB);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { cA.m[k] = f_dpp_shr1_u(cB.p23[k]); cB.m[k] = cA.p23[k]; }
+      conv_row2(cA, cB, s1.a[2], s1.a[3], s1.b[2], s1.b[3], upA, upB);
+      issue(r0 + 1, s1);
+      __builtin_amdgcn_sched_barrier(0);
+      pooled(s0, P, r0 + 2);
+      columns(P, limx, cxe, cxo, cte, cto);
+      if constexpr (!(V & 1)) issue(r0 + 2, s0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // band 0: pooled row -1 is the block's zero padding; the stem starts above the image (zero carried row, zero maxima: the
+      // post-ReLU equivalent of the max-pool's padding)
+      issue(0, s1);
+      f_split((f32x4){0.f, 0.f, 0.f, 0.f}, cA); cB = cA;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { cA.m[k] = 0u; cB.m[k] = 0u; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { upA[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; upB[t] = upA[t]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) P[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      columns(P, 0.f, cxe, cxo, cte, cto);
+      issue(1, s0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // here: s1 holds the inputs of pooled row 2 y0 (even), s0 those of 2 y0 + 1 (odd)
+  for (int j = 0; j < R; ++j) {
+    const int oy = y0 + j;
+    float Sm[8], Qm[8], Sp[8], Qp[8], xe[8], xo[8], te[8], to[8];
+    acc_row(std::integral_constant<int, 0>{}, tm, cte, cto, Sm, Qm);
+    acc_row(std::integral_constant<int, 0>{}, tp, cxe, cxo, Sp, Qp);
+    pooled(s1, P, 2 * oy + 2);                      // even pooled row 2 oy: dy = 1
+    columns(P, limx, xe, xo, te, to);
+    acc_row(std::integral_constant<int, 1>{}, tm, te, to, Sm, Qm);
+    acc_row(std::integral_constant<int, 1>{}, tp, xe, xo, Sp, Qp);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(V & 1)) issue(2 * oy + 2, s1);  // next step's even row
+    __builtin_amdgcn_sched_barrier(0);
+    pooled(s0, P, 2 * oy + 3);                      // odd pooled row 2 oy + 1: dy = 2, and the next output row's dy = 0
+    columns(P, limx, cxe, cxo, cte, cto);
+    acc_row(std::integral_constant<int, 2>{}, tm, cte, cto, Sm, Qm);
+    acc_row(std::integral_constant<int, 2>{}, tp, cxe, cxo, Sp, Qp);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(V & 1)) issue(2 * oy + 3, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 dm[4], dp[4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      dpp_src_ready(Qm[c]); dpp_src_ready(Qp[c]);
+      dm[c >> 1][c & 1] = Sm[c] + row_shr1(Qm[c]);
+      dp[c >> 1][c & 1] = Sp[c] + row_shr1(Qp[c]);
+    }
+    f32x4 am[2], ap[2];
+    pw_h3(wp, dp, bip, ap, watch);
+    pw_h3(w2, dm, bi2, am, watch);
+    const bool rowok = oy < y1;                    // wave-uniform
+    f32x4 op[2], om[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { op[t][e] = __builtin_fmaxf(ap[t][e], 0.f) * unscale_p; om[t][e] = __builtin_fmaxf(am[t][e], 0.f) * unscale_2; }
+    const int ro = oy * orowb;
+    auto st = [&](int k, float v0, float v1) {
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v0, v1}), rout, (rowok && soff[k] != OOB) ? soff[k] + ro : OOB, 0, 0);
+    };
+    st(0, op[0][0], op[0][1]); st(1, op[0][2], op[0][3]);
+    st(2, om[0][0], om[0][1]); st(3, om[0][2], om[0][3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st(4 + e, op[1][e], om[1][e]);
+  }
+  watch.report(a.nonfinite);
+#undef YFV2_TQ
+#undef YFV2_TK
+}
+
+void yfv2_launch_front(const FrontArgs& a0, hipStream_t s) {
+  FrontArgs a = a0;
+  const int OW = a.s2.IW / 2, OH = a.s2.IH / 2;
+  a.s2.nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+  a.s2.nb = OH >= 16 ? 4 : 1;
+  a.s2.R = (OH + a.s2.nb - 1) / a.s2.nb;
+  a.s2.nb = (OH + a.s2.R - 1) / a.s2.R;
+  const dim3 grid(a.s2.B * a.s2.nstrips * a.s2.nb);
+  const int v = (yfv2_variant() >> 3) & 3;        // YFV2_VARIANT bits 8 / 16: the experiment forms
+  if (v == 1) hipLaunchKernelGGL(front_kernel<1>, grid, dim3(64), 0, s, a);
+  else if (v == 2) hipLaunchKernelGGL(front_kernel<2>, grid, dim3(64), 0, s, a);
+  else if (v == 3) hipLaunchKernelGGL(front_kernel<3>, grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(front_kernel<0>, grid, dim3(64), 0, s, a);
+}
+
+// ============================================================================
 // stage3.0: the stride-2 block 48 -> 96 (44x44 -> 22x22) in the same streaming form
 // ============================================================================
 // Reads stage 2's pair planes (two buffers, slot bookkeeping folded into the filter columns / tap channels on the host,
