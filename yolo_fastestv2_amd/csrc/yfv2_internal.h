@@ -239,6 +239,8 @@ struct BlockS2Args {
   const float* img;  // LDS image: W1 | W2 | Wproj | main dw taps | proj dw taps | 10 BN vectors [10][KS]
   int B, H, W;       // input size
   int R;             // output rows per work item
+  int s4_main_bands; // s4h_kernel, maps up to 16 columns wide: > 0 = one workgroup per image, waves 0 .. n-1 run the MAIN branch on n bands of rows,
+                     // wave 3 the PROJ branch on all rows (the main branch is five times the proj branch's instructions); 0 = two units x two roles
   // pair-plane input (stage 2 in lane-per-pixel form, yfv2_stage2.hip): in = buffer 0 of the stage, pair p of
   // image b lives at in + b*pp_imgstride + p*H*W*2 (+ pp_bufstride floats if bit p of pp_mask is set): an image's two buffers are
   // adjacent (pp_bufstride = CIN*H*W, pp_imgstride twice that), so no offset grows with the batch

@@ -1281,17 +1281,195 @@ __global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
 #undef YFV2_TK
 }
 
+// s3h2_kernel (round 5): the same wave program at TWO waves per SIMD.  s3h_kernel's 316 registers are 54 depthwise taps + 36 BatchNorm
+// constants + state; with the taps and constants read from the workgroup's LDS copy at the point of use (as front2_kernel does) the
+// wave fits 256 registers, two workgroups share a CU and an image is cut into eight (strip, band) units instead of four: the launch
+// is a latency chain (36 us for ONE image, 45 for 256) that a second wave per SIMD overlaps.  Bit-identical to s3h_kernel.
+constexpr int S3H2_TAPS = 3 * S3H_WFL, S3H2_TSTRIDE = 60, S3H2_CST = S3H2_TAPS + 64 * S3H2_TSTRIDE, S3H2_FLOATS = S3H2_CST + 160;
+__global__ __launch_bounds__(256, 2) void s3h2_kernel(BlockS2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int IH = a.H, IW = a.W, OH = IH >> 1, OW = IW >> 1;
+  const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
+  const int R = a.R, nb = (OH + R - 1) / R;
+  const int units = nstrips * nb, wpi = (units + 3) >> 2;     // workgroups per image
+  const int b = blockIdx.x / wpi, wi = blockIdx.x - b * wpi;
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 15, g = lane >> 4;
+  const int uid = wi * 4 + (tid >> 6);
+  const float* img = a.img16;
+  {   // the three filters -> LDS (straight 16-byte copy, every load issued before the first store)
+    const f32x4* src = reinterpret_cast<const f32x4*>(img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    f32x4 tmp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tmp[k] = src[tid + k * 256];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst[tid + k * 256] = tmp[k];
+    float tv[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) { const int e = tid + 256 * j; tv[j] = e < 54 * 64 ? img[S3H_TM + e] : 0.f; }   // e = q * 64 + lane over tm [27] then tp [27]
+    const float cv = tid < 146 ? img[S3H_CST + tid] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) { const int e = tid + 256 * j; if (e < 54 * 64) lds[S3H2_TAPS + (e & 63) * S3H2_TSTRIDE + (e >> 6)] = tv[j]; }
+    if (tid < 146) lds[S3H2_CST + tid] = cv;
+  }
+  __syncthreads();
+  if (uid >= units) return;
+  const int strip = uid % nstrips, band = uid / nstrips;
+  const int ox = 15 * strip + l;
+  const bool xok = ox < OW;
+  const bool st_lane = xok && (l > 0 || strip == 0);
+  const int y0 = band * R, y1 = min(OH, y0 + R);
+  constexpr int OOB = (int)0x80000000;
+  const float* W1 = lds; const float* WP = lds + S3H_WFL; const float* W2 = lds + 2 * S3H_WFL;
+
+  // input: stage 2's two pair-plane buffers of this image (adjacent: buffer 1 at + pp_bufstride floats, the next image at + pp_imgstride)
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * (size_t)a.pp_imgstride), 0,
+                                                                   (int)((a.pp_bufstride + 48LL * IH * IW) * 4), 0x00020000);
+  Yfv2Watch watch;
+  auto ld_taps = [&](float (&tm)[27], float (&tp)[27]) {   // [lane][54] at a pitch of 60 floats (16-byte reads, the 16 lanes of a read group on 16 bank quads)
+    asm volatile("" ::: "memory");
+    const f32x4* q = reinterpret_cast<const f32x4*>(lds + S3H2_TAPS + lane * S3H2_TSTRIDE);
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const f32x4 v = q[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int i = 4 * j + e; if (i < 27) tm[i] = v[e]; else if (i < 54) tp[i - 27] = v[e]; }
+    }
+  };
+  auto ld_c3 = [&](int off, f32x4 (&c)[3]) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 3; ++t) c[t] = *reinterpret_cast<const f32x4*>(lds + S3H2_CST + off + 16 * t + 4 * g);
+  };
+  const float unscale_p = img[S3H_CST + 144], unscale_2 = img[S3H_CST + 145];
+  int loff[6];
+  {
+    const int* po = reinterpret_cast<const int*>(img + S3H_OFFS);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) loff[k] = xok ? po[k * 64 + lane] + 2 * ox * 8 : OOB;
+  }
+  const int irowb = IW * 8;
+  float* __restrict__ outp = a.out + ((size_t)b * OH * OW + (st_lane ? ox : 0)) * 96 + 4 * g;
+
+  auto load_row = [&](int iy, f32x4 (&X)[6]) {
+    const bool rok = iy >= 0 && iy < IH;           // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      X[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rok && loff[k] != OOB) ? loff[k] + iy * irowb : OOB, 0, 0));
+  };
+  auto columns = [&](const f32x4 (&X)[6], float lim, float (&xe)[12], float (&xo)[12], float (&te)[12], float (&to)[12]) {
+    f32x2 ine[6], ino[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const f32x4 v = X[k] * 16.0f;
+      ine[k] = (f32x2){v[0], v[1]}; ino[k] = (f32x2){v[2], v[3]};
+      xe[2 * k] = v[0]; xe[2 * k + 1] = v[1]; xo[2 * k] = v[2]; xo[2 * k + 1] = v[3];
+    }
+    f32x4 ae[3], ao[3];
+    {
+      f32x4 sh1[3]; ld_c3(0, sh1);
+      pw_h3_48(W1, lane, ine, sh1, ae, watch);
+      pw_h3_48(W1, lane, ino, sh1, ao, watch);
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      te[c] = __builtin_amdgcn_fmed3f(ae[c >> 2][c & 3], 0.f, lim);
+      to[c] = __builtin_amdgcn_fmed3f(ao[c >> 2][c & 3], 0.f, lim);
+    }
+  };
+#define YFV2_TQ(T, c, t) T[((c) * 9 + (t)) >> 2]
+#define YFV2_TK(c, t) (((c) * 9 + (t)) & 3)
+  auto acc_row = [&](auto dyc, const float (&T)[27], const float (&v0)[12], const float (&v1)[12], float (&S)[12], float (&Q)[12]) {
+    constexpr int DY = decltype(dyc)::value;
+    [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
+      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(T, Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(T, Cs, 0), v1[Cs]),
+                         quad_fmac1<YFV2_TK(Cs, 2)>(S[Cs], YFV2_TQ(T, Cs, 2), v1[Cs]))
+                : (void)quad_fmac3<YFV2_TK(Cs, DY * 3 + 1), YFV2_TK(Cs, DY * 3), YFV2_TK(Cs, DY * 3 + 2)>(
+                      S[Cs], Q[Cs], YFV2_TQ(T, Cs, DY * 3 + 1), YFV2_TQ(T, Cs, DY * 3), YFV2_TQ(T, Cs, DY * 3 + 2), v0[Cs], v1[Cs])), ...);
+    }(std::make_integer_sequence<int, 12>{});
+  };
+
+  f32x4 X[6], Y[6];
+  float cxe[12], cxo[12], cte[12], cto[12];
+  {
+    const int iy = 2 * y0 - 1;
+    load_row(iy, X);
+    load_row(iy + 1, Y);
+    columns(X, (xok && iy >= 0) ? __builtin_inff() : 0.f, cxe, cxo, cte, cto);
+    load_row(iy + 2, X);
+  }
+  const float limx = xok ? __builtin_inff() : 0.f;
+  for (int j = 0; j < R; ++j) {
+    const int oy = y0 + j;
+    float Sm[12], Qm[12], Sp[12], Qp[12], xe[12], xo[12], te[12], to[12];
+    {
+      float tm[27], tp[27]; ld_taps(tm, tp);
+      acc_row(std::integral_constant<int, 0>{}, tm, cte, cto, Sm, Qm);
+      acc_row(std::integral_constant<int, 0>{}, tp, cxe, cxo, Sp, Qp);
+    }
+    columns(Y, limx, xe, xo, te, to);
+    {
+      float tm[27], tp[27]; ld_taps(tm, tp);
+      acc_row(std::integral_constant<int, 1>{}, tm, te, to, Sm, Qm);
+      acc_row(std::integral_constant<int, 1>{}, tp, xe, xo, Sp, Qp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 2, Y);
+    __builtin_amdgcn_sched_barrier(0);
+    columns(X, limx, cxe, cxo, cte, cto);
+    {
+      float tm[27], tp[27]; ld_taps(tm, tp);
+      acc_row(std::integral_constant<int, 2>{}, tm, cte, cto, Sm, Qm);
+      acc_row(std::integral_constant<int, 2>{}, tp, cxe, cxo, Sp, Qp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(2 * oy + 3, X);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 dm[6], dp[6];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      dpp_src_ready(Qm[c]); dpp_src_ready(Qp[c]);
+      dm[c >> 1][c & 1] = Sm[c] + row_shr1(Qm[c]);
+      dp[c >> 1][c & 1] = Sp[c] + row_shr1(Qp[c]);
+    }
+    f32x4 am[3], ap[3];
+    { f32x4 bip[3]; ld_c3(48, bip); pw_h3_48(WP, lane, dp, bip, ap, watch); }
+    { f32x4 bi2[3]; ld_c3(96, bi2); pw_h3_48(W2, lane, dm, bi2, am, watch); }
+    if (st_lane && oy < y1) {
+      float* o = outp + (size_t)oy * OW * 96;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        f32x4 vp, vm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vp[e] = __builtin_fmaxf(ap[t][e], 0.f) * unscale_p; vm[e] = __builtin_fmaxf(am[t][e], 0.f) * unscale_2; }
+        *reinterpret_cast<f32x4*>(o + 16 * t) = vp;          // proj: channels 0..47
+        *reinterpret_cast<f32x4*>(o + 48 + 16 * t) = vm;     // main: channels 48..95
+      }
+    }
+  }
+  watch.report(a.nonfinite);
+#undef YFV2_TQ
+#undef YFV2_TK
+}
+
 bool yfv2_s3h_supported(int H, int W) { return H >= 4 && W >= 4 && !(H & 1) && !(W & 1) && W / 2 <= 16 * 15; }
 
 void yfv2_launch_s3h(const BlockS2Args& a0, hipStream_t s) {
   BlockS2Args a = a0;
   const int OH = a.H / 2, OW = a.W / 2;
   const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
-  int nb = (4 + nstrips - 1) / nstrips;             // about four (strip, band) waves per image: one workgroup
+  const bool two = !(yfv2_variant() & 32);          // YFV2_VARIANT bit 32: s3h_kernel (one wave per SIMD, four units per image)
+  int nb = ((two ? 8 : 4) + nstrips - 1) / nstrips; // about four (strip, band) waves per image: one workgroup (s3h2_kernel: eight, two workgroups)
   if (nb > OH) nb = OH;
   a.R = (OH + nb - 1) / nb;
   nb = (OH + a.R - 1) / a.R;
   const int units = nstrips * nb;
+  if (two) {
+    static std::atomic<unsigned long long> lds_ok{0};
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&s3h2_kernel), lds_ok);
+    hipLaunchKernelGGL(s3h2_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), S3H2_FLOATS * sizeof(float), s, a);
+    return;
+  }
   hipLaunchKernelGGL(s3h_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), 3 * S3H_WFL * sizeof(float), s, a);
 }
 
@@ -1477,6 +1655,17 @@ __global__ __launch_bounds__(256, 1) void s4h_kernel(BlockS2Args a) {
     }
   }
   __syncthreads();
+  if (a.s4_main_bands > 0) {
+    // Round 5.  The launch is as long as its longest wave: per output row the main branch issues 3331 instructions (pw1 of two input
+    // rows of two columns, depthwise, pw2), the proj branch 672 - with two bands x two roles the two proj waves were done after a
+    // fifth of the launch and the two main waves walked six rows each: 36 us for ONE image.  Now three main waves walk four rows
+    // each and one proj wave walks all eleven (7.4 k instructions against 13.3 k + the band's extra pw1 row).  Same arithmetic per
+    // output row whatever the band: bit-identical.
+    const int mb = a.s4_main_bands;
+    if (wave < mb) s4h_body<true>(a, lds, (int)blockIdx.x, 0, wave, (OH + mb - 1) / mb, tid & 63);
+    else if (wave == 3) s4h_body<false>(a, lds, (int)blockIdx.x, 0, 0, OH, tid & 63);
+    return;
+  }
   const int uid = wi * 2 + (wave >> 1);
   if (uid >= units) return;
   const int strip = uid % nstrips, band = uid / nstrips;
@@ -1497,5 +1686,7 @@ void yfv2_launch_s4h(const BlockS2Args& a0, hipStream_t s) {
   const int units = nstrips * nb;
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&s4h_kernel), lds_ok);
+  a.s4_main_bands = (nstrips == 1 && OH >= 6 && !(yfv2_variant() & 64)) ? 3 : 0;   // YFV2_VARIANT bit 64: two bands x two roles (round 4's form)
+  if (a.s4_main_bands) { hipLaunchKernelGGL(s4h_kernel, dim3(a.B), dim3(256), 3 * S4H_WFL * sizeof(float), s, a); return; }
   hipLaunchKernelGGL(s4h_kernel, dim3(a.B * ((units + 1) / 2)), dim3(256), 3 * S4H_WFL * sizeof(float), s, a);
 }
