@@ -1709,9 +1709,9 @@ std::string step_kernel(const Step& st) {
       if (st.img_off3 && !st.jobs.empty() && !st.par) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
       if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");   // default plan
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
-    case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
+    case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : ((yfv2_variant() & 32) ? "s3h_kernel" : "s3h2_kernel")) : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
-    case STEP_S2PX: return st.front ? "front2_kernel" : "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel; uint8 input under front: stem_h3u_kernel + s2h_kernel)
+    case STEP_S2PX: return st.front ? ((yfv2_variant() & 4) ? "front_kernel" : "front2_kernel") : "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel; uint8 input under front: stem_h3u_kernel + s2h_kernel)
     case STEP_S1CHAIN: return "block_s1chain6_kernel";
     case STEP_S1POOL: return "block_s1pool_kernel";
   }
