@@ -21,6 +21,10 @@ __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((fl
 // Kernel-variant switches for same-box A/B measurements (YFV2_VARIANT = bit mask, read once per process; unset = 0 = the defaults):
 //   1  fpn.conv1x1_2 (pw_kernel<288>) as 512-thread workgroups with two pixel tiles per wave (the form up to round 4)
 //   2  the stem writes quad planes [6][H/4][W/4][4] for s2h_kernel instead of [H/4][W/4][24] (round 4's first form)
+//   4  front_kernel (stem + stage2.0 in one wave, everything in registers, one wave per SIMD) instead of front2_kernel
+//   8 / 16  experiment forms of the front kernels: conv-row-wise refill of front_kernel's two input sets / no loads at all
+//   32 s3h_kernel (stage3.0 at one wave per SIMD, four units per image) instead of s3h2_kernel
+//   64 stage4.0 as two (strip, band) units x two roles per image (round 4's form) instead of three main waves + one proj wave
 // (measured and removed in round 4, DESIGN.md 4.10: s1h / stem at four waves per SIMD by launch bound - the spills cost more than
 // the occupancy gives, 31 -> 44 us and 115 -> 131 us; non-temporal input loads in stem / s2h / s1h / s3h - the consumer of a
 // streamed tensor slows down, s2h 73 -> 98 us)
