@@ -1857,9 +1857,9 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.img[1] = params + st.img_off2;
       a.img16 = h->bf6 ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: the two role kernels on the 4x4x1 fp32 MFMA
       a.nonfinite = h->d_nonfinite;
-      if (st.front && !x_u8) {
+      if (st.front && (!x_u8 || !(yfv2_variant() & (4 | 128)))) {   // (uint8 input: front2_kernel only; YFV2_VARIANT bit 128: the two-launch route for it)
         FrontArgs f{};
-        f.x = x; f.H = h->cfg.height; f.W = h->cfg.width;
+        f.x = x; f.H = h->cfg.height; f.W = h->cfg.width; f.u8_in = x_u8 ? 1 : 0;
         f.img_stem = params + h->stem_aside.img_off3;
         f.s2 = a;
         yfv2_launch_front(f, s);
@@ -2716,11 +2716,11 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
     return n;
   }
   if (cap < n) { fail(h, YFV2_ERR_ARG, "yfv2_debug_activation: destination too small"); return YFV2_ERR_ARG; }
-  if (which == 0 && h->front_fused && !h->last_u8) {
+  if (which == 0 && h->front_fused) {
     // front_kernel never writes the stem's output: run the stem's own launch on the last forward's input (which the caller must still hold)
     if (!h->last_x || h->last_B < B) { fail(h, YFV2_ERR_STATE, "yfv2_debug_activation(0): no forward of at least this batch has run on the handle"); return YFV2_ERR_STATE; }
     StemArgs a = h->stem_aside.stem;
-    a.x = h->last_x; a.B = B; a.u8_in = 0;
+    a.x = h->last_x; a.B = B; a.u8_in = h->last_u8 ? 1 : 0;
     a.img = h->d_params + h->stem_aside.img_off; a.img_u8 = h->d_params + h->stem_aside.img_off2;
     a.img16 = h->bf6 ? h->d_params + h->stem_aside.img_off3 : nullptr;
     a.nonfinite = h->d_nonfinite;

@@ -300,8 +300,9 @@ struct S2PxArgs {
 };
 // stem + stage2.0 in one wave (front_kernel, yfv2_stage2h.hip): the fp32 input image straight to stage 2's pair planes
 struct FrontArgs {
-  const void* x;         // fp32 (B,3,H,W)
+  const void* x;         // fp32 (B,3,H,W), or (u8_in, front2_kernel only) uint8 (B,H,W,3)
   int H, W;
+  int u8_in;
   const float* img_stem; // WeightPacker::image_stem16
   S2PxArgs s2;           // as for s2h_kernel (IH x IW = H/4 x W/4; in / in_nhwc unused)
 };

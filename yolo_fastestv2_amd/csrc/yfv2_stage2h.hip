@@ -754,7 +754,36 @@ __global__ __launch_bounds__(64, 1) void front_kernel(FrontArgs fa) {
 // compiler from hoisting the loop-invariant reads back into registers); the input look-ahead is ONE set of eight 16-byte buffers
 // refilled conv row by conv row right behind their use.  Same instructions on the same operands in the same order: bit-identical.
 constexpr int F2_WA = 0, F2_S2 = 1024, F2_TAPS = F2_S2 + 3072, F2_CST = F2_TAPS + 36 * 64, F2_SCST = F2_CST + 104, F2_FLOATS = F2_SCST + 40;
-template <int V>
+// U8: the input is uint8 (B,H,W,3) (yfv2_forward_u8 / yfv2_detect_u8) and the stem part is stem_h3u_kernel's (yfv2_stem16.hip): a pixel
+// is exactly ONE fp16 term (two products per MAC), HWC puts the three channels of a lane's four columns into one aligned 12-byte
+// load - a lane's two pooled columns are 24 consecutive bytes - lane group g picks its channel's bytes with v_perm_b32, lane group 3
+// picks tap (2,2)'s values out of its own load (no ds_bpermute), the 1 / 255 rides in the final unscale.  Bit-identical to
+// stem_h3u_kernel + s2h_kernel.
+typedef unsigned yfv2_u3x __attribute__((ext_vector_type(3)));
+namespace {
+struct FCol8 { unsigned p01, p23, m; };
+__device__ __forceinline__ unsigned f_u8pair(unsigned hi, unsigned lo, unsigned sel) {
+  const unsigned v = __builtin_amdgcn_perm(hi, lo, sel) | 0x64006400u;
+  const yfv2_h2 h = __builtin_bit_cast(yfv2_h2, v) - (yfv2_h2){(_Float16)1024.0f, (_Float16)1024.0f};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void f_split_u8(const yfv2_u3x d, unsigned sel_a, unsigned sel_b, FCol8& o) {
+  o.p01 = f_u8pair(d[1], d[0], sel_a);
+  o.p23 = f_u8pair(d[2], d[1], sel_b);
+}
+__device__ __forceinline__ void f_conv_col8(const FCol8& x0, const FCol8& x1, const FCol8& x2, const yfv2_h8 (&wa)[2][2], const f32x4 sh0, const f32x4 sh1,
+                                            f32x4 (&ae)[2], f32x4 (&ao)[2]) {
+  const u32x4 e = {x0.p01, x1.p01, f_hi_hi(x0.m, x1.m), f_hi_lo(x2.m, x2.p01)};
+  const u32x4 o = {x0.p23, x1.p23, f_hi_hi(x0.p01, x1.p01), f_hi_lo(x2.p01, x2.p23)};
+  const yfv2_h8 be = __builtin_bit_cast(yfv2_h8, e), bo = __builtin_bit_cast(yfv2_h8, o);
+  ae[0] = sh0; ae[1] = sh1; ao[0] = sh0; ao[1] = sh1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], be, ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], bo, ao[t], 0, 0, 0); }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], be, ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], bo, ao[t], 0, 0, 0); }
+}
+}  // namespace
+template <int V, bool U8 = false>
 __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const S2PxArgs& a = fa.s2;
@@ -766,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
     float tp9[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) { const int e = tid + 256 * j, q = e >> 6, ln = e & 63; tp9[j] = a.img16[S2H_TM + q * 64 + ln]; }   // e = q * 64 + lane over tm then tp (tp follows tm: 18 * 64 floats)
-    const float c0 = tid < 104 ? a.img16[S2H_CST + tid] : 0.f, c1 = tid < 33 ? fa.img_stem[1024 + tid] : 0.f;
+    const float c0 = tid < 104 ? a.img16[S2H_CST + tid] : 0.f, c1 = tid < 33 ? fa.img_stem[1024 + (U8 ? 36 : 0) + tid] : 0.f;   // (the uint8 constants follow the fp32 ones)
     reinterpret_cast<f32x4*>(lds + F2_WA)[tid] = t0;
     reinterpret_cast<f32x4*>(lds + F2_S2)[tid] = t1; reinterpret_cast<f32x4*>(lds + F2_S2)[256 + tid] = t2; reinterpret_cast<f32x4*>(lds + F2_S2)[512 + tid] = t3;
 #pragma unroll
@@ -792,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
   const int y0 = band * R, y1 = min(OH, y0 + R);
   constexpr int OOB = (int)0x80000000;
 
-  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)fa.x + (size_t)b * 3 * H * W * 4), 0, 3 * H * W * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)fa.x + (size_t)b * 3 * H * W * (U8 ? 1 : 4)), 0, 3 * H * W * (U8 ? 1 : 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.act + (size_t)b * a.out_stride), 0, a.out_records, 0x00020000);
   // ---- stage2.0's state (s2h_kernel)
   const float* img = a.img16;
@@ -828,36 +857,75 @@ __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
   }
   const int orowb = OW * 8;
   // ---- the stem's state (stem_h3_kernel): filter [tile 2][term 2][64 lanes][4 dwords], shift x 2^(sw+8) [32], 2^-(sw+8)
-  const float* cst = fa.img_stem + 2 * 2 * 64 * 4;
+  const float* cst = fa.img_stem + 2 * 2 * 64 * 4 + (U8 ? 36 : 0);
   const float sunscale = cst[32];
-  const int rowb = W * 4;
-  const int chan_off = (xok && g < 3 && !(V & 2)) ? g * H * rowb + 8 * ox * 4 : OOB;     // lane groups 0..2: input channel g, columns 8 ox .. 8 ox + 7
+  const int rowb = U8 ? W * 3 : W * 4;
+  // fp32: lane groups 0..2 = input channel g, columns 8 ox .. 8 ox + 7; uint8: every lane group loads the same 24 bytes (columns 8 ox .. + 7, three channels each)
+  const int chan_off = U8 ? ((xok && !(V & 2)) ? 24 * ox : OOB) : ((xok && g < 3 && !(V & 2)) ? g * H * rowb + 8 * ox * 4 : OOB);
+  // uint8 byte selectors (stem_h3u_kernel): lane group g < 3: channel g of columns 0..3; lane group 3: X1 = (ch0, ch1) of columns 1 | 3, X2 = (ch2, 0)
+  constexpr unsigned Z = 0x0c;
+  const unsigned sel1a = g < 3 ? (unsigned)g | (Z << 8) | ((unsigned)(g + 3) << 16) | (Z << 24) : 3u | (Z << 8) | (4u << 16) | (Z << 24);
+  const unsigned sel1b = g < 3 ? (unsigned)(g + 2) | (Z << 8) | ((unsigned)(g + 5) << 16) | (Z << 24) : 5u | (Z << 8) | (6u << 16) | (Z << 24);
+  const unsigned sel2a = g < 3 ? sel1a : 5u | (Z << 8) | (Z << 16) | (Z << 24);
+  const unsigned sel2b = g < 3 ? sel1b : 7u | (Z << 8) | (Z << 16) | (Z << 24);
   const int src0 = (0 * 16 + l) * 4, src1 = (1 * 16 + l) * 4, src2 = (2 * 16 + l) * 4;   // ds_bpermute byte addresses of lanes (l, 0..2)
   const int hlast = H - 1;
 
   // input rows 4 r .. 4 r + 3 (the two conv rows of pooled row r), columns A | B: eight 16-byte loads
-  struct InSet { f32x4 a[4], b[4]; };
+  struct InSet { f32x4 a[4], b[4]; };                 // (uint8: the first three dwords of each hold the 12-byte load)
+  auto load_ab = [&](int off, f32x4& va, f32x4& vb) {
+    if constexpr (U8) {
+      const yfv2_u3x ua = __builtin_bit_cast(yfv2_u3x, __builtin_amdgcn_raw_buffer_load_b96(rx, off, 0, 0));
+      const yfv2_u3x ub = __builtin_bit_cast(yfv2_u3x, __builtin_amdgcn_raw_buffer_load_b96(rx, off, 12, 0));
+      va = __builtin_bit_cast(f32x4, (u32x4){ua[0], ua[1], ua[2], 0u}); vb = __builtin_bit_cast(f32x4, (u32x4){ub[0], ub[1], ub[2], 0u});
+    } else {
+      va = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      vb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+    }
+  };
   auto issue_half = [&](int r, InSet& s, int hf) {
 #pragma unroll
     for (int i = 2 * hf; i < 2 * hf + 2; ++i) {
       const int row = min(4 * r + i, hlast);
-      const int off = chan_off != OOB ? chan_off + row * rowb : OOB;
-      s.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-      s.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+      load_ab(chan_off != OOB ? chan_off + row * rowb : OOB, s.a[i], s.b[i]);
     }
   };
   auto issue = [&](int r, InSet& s) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = min(4 * r + i, hlast);          // (a row past the image: a re-read that stays in range, never used)
-      const int off = chan_off != OOB ? chan_off + row * rowb : OOB;
-      s.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-      s.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+      load_ab(chan_off != OOB ? chan_off + row * rowb : OOB, s.a[i], s.b[i]);
     }
   };
   // one conv row of both pooled columns from the carried rows (cA, cB) and the fresh rows r1 (2c), r2 (2c + 1) -> horizontally
   // pooled raw values (BN shift inside, pre-ReLU, x 2^(sw+8)); cA, cB <- the split row 2c + 1
   auto conv_row2 = [&](FCol& cA, FCol& cB, f32x4 r1A, f32x4 r2A, f32x4 r1B, f32x4 r2B, f32x4 (&hA)[2], f32x4 (&hB)[2]) {
+    if constexpr (U8) {
+      // (the carried columns live in the first term's slots of cA / cB: p01[0], p23[0], m[0])
+      const u32x4 q1A = __builtin_bit_cast(u32x4, r1A), q2A = __builtin_bit_cast(u32x4, r2A), q1B = __builtin_bit_cast(u32x4, r1B), q2B = __builtin_bit_cast(u32x4, r2B);
+      const yfv2_u3x d1A = {q1A[0], q1A[1], q1A[2]}, d2A = {q2A[0], q2A[1], q2A[2]}, d1B = {q1B[0], q1B[1], q1B[2]}, d2B = {q2B[0], q2B[1], q2B[2]};
+      FCol8 x0A = {cA.p01[0], cA.p23[0], cA.m[0]}, x0B = {cB.p01[0], cB.p23[0], cB.m[0]}, x1A, x2A, x1B, x2B;
+      f_split_u8(g == 3 ? d2A : d1A, sel1a, sel1b, x1A); f_split_u8(d2A, sel2a, sel2b, x2A);
+      f_split_u8(g == 3 ? d2B : d1B, sel1a, sel1b, x1B); f_split_u8(d2B, sel2a, sel2b, x2B);
+      x1A.m = f_dpp_shr1_u(x1B.p23); x2A.m = f_dpp_shr1_u(x2B.p23);
+      x1B.m = x1A.p23; x2B.m = x2A.p23;
+      f32x4 aeA[2], aoA[2], aeB[2], aoB[2];
+      {
+        yfv2_h8 wa[2][2]; f32x4 ssh[2];
+        ld_filter(F2_WA, wa); ld_c2(F2_SCST, ssh);
+        f_conv_col8(x0A, x1A, x2A, wa, ssh[0], ssh[1], aeA, aoA);
+        f_conv_col8(x0B, x1B, x2B, wa, ssh[0], ssh[1], aeB, aoB);
+      }
+      cA.p01[0] = x2A.p01; cA.p23[0] = x2A.p23; cA.m[0] = x2A.m; cB.p01[0] = x2B.p01; cB.p23[0] = x2B.p23; cB.m[0] = x2B.m;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hA[t][e] = __builtin_fmaxf(__builtin_fmaxf(f_dpp_shr1_f(aoB[t][e]), aeA[t][e]), aoA[t][e]);
+          hB[t][e] = __builtin_fmaxf(__builtin_fmaxf(aoA[t][e], aeB[t][e]), aoB[t][e]);
+        }
+      return;
+    }
     {   // lane group 3: tap (2, 2) of the three channels = columns + 1 | + 3 of row 2c + 1, out of the registers of lanes (l, 0..2)
       const int a1 = f_f2i(r2A[1]), a3 = f_f2i(r2A[3]), b1 = f_f2i(r2B[1]), b3 = f_f2i(r2B[3]);
       const int e0 = __builtin_amdgcn_ds_bpermute(src0, a1), e1 = __builtin_amdgcn_ds_bpermute(src1, a1), e2 = __builtin_amdgcn_ds_bpermute(src2, a1);
@@ -964,9 +1032,18 @@ __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
     if (r0 > 0) {
       // the conv row above pooled row r0 (2 r0 - 1: input rows 4 r0 - 3 .. 4 r0 - 1) gives the carried maxima and the carried split row
       issue(r0 - 1, s0);                            // rows 4 r0 - 4 .. 4 r0 - 1 (the first of them is not needed)
-      f_split(s0.a[1], cA); f_split(s0.b[1], cB);
+      if constexpr (U8) {                           // a carried row is an X2 (stem_h3u_kernel)
+        const u32x4 qa = __builtin_bit_cast(u32x4, s0.a[1]), qb = __builtin_bit_cast(u32x4, s0.b[1]);
+        FCol8 ta, tb;
+        f_split_u8((yfv2_u3x){qa[0], qa[1], qa[2]}, sel2a, sel2b, ta); f_split_u8((yfv2_u3x){qb[0], qb[1], qb[2]}, sel2a, sel2b, tb);
+        ta.m = f_dpp_shr1_u(tb.p23); tb.m = ta.p23;
+        cA.p01[0] = ta.p01; cA.p23[0] = ta.p23; cA.m[0] = ta.m; cB.p01[0] = tb.p01; cB.p23[0] = tb.p23; cB.m[0] = tb.m;
+        cA.p01[1] = cA.p23[1] = cA.m[1] = 0u; cB.p01[1] = cB.p23[1] = cB.m[1] = 0u;
+      } else {
+        f_split(s0.a[1], cA); f_split(s0.b[1], cB);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) { cA.m[k] = f_dpp_shr1_u(cB.p23[k]); cB.m[k] = cA.p23[k]; }
+        for (int k = 0; k < 2; ++k) { cA.m[k] = f_dpp_shr1_u(cB.p23[k]); cB.m[k] = cA.p23[k]; }
+      }
       conv_row2(cA, cB, s0.a[2], s0.a[3], s0.b[2], s0.b[3], upA, upB);
       __builtin_amdgcn_sched_barrier(0);
       issue(r0, s0);
@@ -1085,7 +1162,8 @@ void yfv2_launch_front(const FrontArgs& a0, hipStream_t s) {
   const int v = (yfv2_variant() >> 3) & 3;        // YFV2_VARIANT bits 8 / 16: the experiment forms
   if (!(yfv2_variant() & 4)) {                    // bit 4: front_kernel (one wave per SIMD, everything in registers)
     const unsigned units = a.s2.B * a.s2.nstrips * a.s2.nb;
-    if (v & 2) hipLaunchKernelGGL(front2_kernel<2>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
+    if (a.u8_in) hipLaunchKernelGGL((front2_kernel<0, true>), dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
+    else if (v & 2) hipLaunchKernelGGL(front2_kernel<2>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
     else hipLaunchKernelGGL(front2_kernel<0>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
     return;
   }
