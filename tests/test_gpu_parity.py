@@ -1045,8 +1045,9 @@ def test_front_kernel_is_bit_identical_to_stem_plus_stage2_0(yfv2, dev, hw, B):
     launches it replaces (YFV2_FRONT=0).  Every value passes through the same instructions on the same operands in the same
     order, so stage 2 and the six logit maps must be BIT-identical - at sizes whose strips and bands are ragged (64x96, 32x32,
     352x32, 96x1024), at the general sizes, and with more images than compute units.  The stem's own output, which the fused
-    launch never writes, is still there for the debug hook (re-run from the last input) and equal too; uint8 input takes the
-    two-launch route under either plan."""
+    launch never writes, is still there for the debug hook (re-run from the last input) and equal too.  uint8 (B,H,W,3) input runs
+    the same fusion on stem_h3u_kernel's arithmetic (front2_kernel<.., U8>: a lane's two pooled columns are 24 consecutive bytes)
+    and is compared the same way: logits and stage 2 bit-identical to stem_h3u_kernel + s2h_kernel."""
     H, W = hw
     sd = yfv2.random_state_dict(17)
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * 7 + W + B)).to(dev)
@@ -1068,8 +1069,8 @@ def test_front_kernel_is_bit_identical_to_stem_plus_stage2_0(yfv2, dev, hw, B):
         assert names[0].startswith("stem + backbone.stage2.0 in one launch") == (not env and px_plan), names[:2]
         logits = [t.clone() for t in e.forward(x)]
         acts = [e.debug_activation(w, min(B, 9)) for w in (0, 1)]
-        xu = (x[:min(B, 4)].permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
-        lu = [t.clone() for t in e.forward(xu)]
+        xu = (x[:min(B, 9)].permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
+        lu = [t.clone() for t in e.forward(xu)] + [e.debug_activation(w, xu.shape[0]) for w in (0, 1)]
         e.check_finite("front / two-launch plan")
         outs.append((logits, acts, lu))
     (l0, a0, u0), (l1, a1, u1) = outs
@@ -1077,7 +1078,7 @@ def test_front_kernel_is_bit_identical_to_stem_plus_stage2_0(yfv2, dev, hw, B):
         assert torch.equal(p, q), "%s: %d of %d elements differ" % (("stem output (debug hook)", "stage 2")[k], int((p != q).sum()), p.numel())
     for key, p, q in zip(LOGIT_KEYS, l0, l1):
         assert torch.equal(p, q), "%s differs between the one-launch and the two-launch front" % key
-    for key, p, q in zip(LOGIT_KEYS, u0, u1):
+    for key, p, q in zip(list(LOGIT_KEYS) + ["stem output (debug hook)", "stage 2"], u0, u1):
         assert torch.equal(p, q), "uint8 input, %s" % key
 
 
