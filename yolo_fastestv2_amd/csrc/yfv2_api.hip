@@ -1689,7 +1689,7 @@ struct PlanBuilder {
       Step& f = h->plan[0];
       f.front = true;
       f.name_plain = f.name;
-      f.name = "stem + backbone.stage2.0 in one launch: conv3x3s2+bn+relu+maxpool3x3s2 -> s2 block, lane-per-pixel (proj | main) -> pair planes (uint8 input: two launches)";
+      f.name = "stem + backbone.stage2.0 in one launch: conv3x3s2+bn+relu+maxpool3x3s2 -> s2 block, lane-per-pixel (proj | main) -> pair planes";
       f.flops += h->stem_aside.flops;
       f.bytes += h->stem_aside.bytes;                     // per-layer accounting: both layers' reads and writes
       f.bytes_ext = 4.0 * (3.0 * H * W + 48.0 * (H / 8) * (W / 8));   // the image in, stage 2's 48 channels out

@@ -25,6 +25,7 @@ __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((fl
 //   8 / 16  experiment forms of the front kernels: conv-row-wise refill of front_kernel's two input sets / no loads at all
 //   32 s3h_kernel (stage3.0 at one wave per SIMD, four units per image) instead of s3h2_kernel
 //   64 stage4.0 as two (strip, band) units x two roles per image (round 4's form) instead of three main waves + one proj wave
+//   128 uint8 input: stem_h3u_kernel + s2h_kernel instead of front2_kernel<.., U8>
 // (measured and removed in round 4, DESIGN.md 4.10: s1h / stem at four waves per SIMD by launch bound - the spills cost more than
 // the occupancy gives, 31 -> 44 us and 115 -> 131 us; non-temporal input loads in stem / s2h / s1h / s3h - the consumer of a
 // streamed tensor slows down, s2h 73 -> 98 us)
