@@ -100,10 +100,14 @@ def profile_lookup(prof, kernel, field, launches, mean=False):
         return None
     vals = []
     for part in kernel.split(" + "):
-        hit = [v[field] for k, v in prof["kernels"].items() if part in k and field in v]
-        if len(hit) != 1:
+        hit = [(v.get("n", 0), v[field]) for k, v in prof["kernels"].items() if part in k and field in v]
+        if len(hit) > 1:      # several instantiations of one template in the profile (front2_kernel<0, false> / <0, true>: the fp32 and
+            hit.sort(reverse=True)   # the uint8 form): the one the timed loop ran is the one with by far the most launches
+            if hit[0][0] < 20 * max(1, hit[1][0]):
+                return None
+        if not hit:
             return None
-        vals.append(hit[0])
+        vals.append(hit[0][1])
     if mean:
         return round(sum(vals) / len(vals), 2)
     return sum(vals) * launches      # per-launch means -> bytes per forward (a '+' step launches each of its kernels once)
