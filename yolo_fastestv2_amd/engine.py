@@ -367,7 +367,9 @@ class Engine:
         return list(ms)
 
     def debug_activation(self, which, B):
-        """NHWC activation of the last forward: 0 stem+pool, 1 stage2, 2 C2, 3 C3, 4 S2, 5 S3."""
+        """NHWC activation of the last forward: 0 stem+pool, 1 stage2, 2 C2, 3 C3, 4 S2, 5 S3.
+        (0: the default plan runs the stem and stage2.0 as ONE launch that never writes the stem's output - the hook then re-runs the
+        stem's own launch on the LAST forward's input, which the caller must still hold.)"""
         L = _lib.lib()
         n = L.yfv2_debug_activation(self._h, which, B, None, 0)
         if n < 0:
