@@ -481,6 +481,23 @@ def test_bench_quotes_counters_only_from_a_profile_of_the_same_tree(tmp_path, mo
     assert bench.profile_lookup(got, "tower2_kernel<0", "total_bytes", 2) is None                                  # ambiguous prefix: refuse
     assert bench.profile_lookup(got, "stem_px_kernel", "mfma_busy_pct", 1, mean=True) == 55.5
     assert bench.profile_lookup(None, "stem_px_kernel", "total_bytes", 1) is None
+    # two instantiations of one template in a counter profile (the fp32 and the uint8 form of the fused front): the one the timed
+    # loop ran has by far the most launches; two comparable counts stay ambiguous
+    two = {"kernels": {"void front2_kernel<0, false>(FrontArgs)": {"n": 1193, "mfma_busy_pct": 24.6}, "void front2_kernel<0, true>(FrontArgs)": {"n": 4, "mfma_busy_pct": 25.0}}}
+    assert bench.profile_lookup(two, "front2_kernel", "mfma_busy_pct", 1, mean=True) == 24.6
+    two["kernels"]["void front2_kernel<0, true>(FrontArgs)"]["n"] = 900
+    assert bench.profile_lookup(two, "front2_kernel", "mfma_busy_pct", 1, mean=True) is None
+
+
+def test_committed_counter_profiles_belong_to_this_tree():
+    """The evidence rule, applied to the repository itself: profiles/ must hold an HBM-traffic profile and an SQ-counter profile taken on
+    THIS source tree (tools/srchash.py fingerprint), or bench.py's roofline.traffic / mfma_busy would print null on the driver's run."""
+    import bench
+    h = bench.source_hash()
+    for suffix in ("_traffic.json", "_pmc.json"):
+        got = bench.newest_profile(suffix, h)
+        assert got is not None, "no profiles/*%s carries this tree's fingerprint %s: re-run tools/gpu_r5.sh and commit its summaries" % (suffix, h)
+        assert any("front2_kernel" in k for k in got["kernels"]), got["_file"]
 
 
 def test_data_parallel_training_averages_the_gradient_bucket_world_size_2_gloo(tmp_path):
