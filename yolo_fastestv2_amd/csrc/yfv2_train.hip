@@ -520,14 +520,28 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(V in, V out, const float* 
 }
 
 // weight gradient: scratch[co * Cin + ci] += sum over one image's pixel segment of dy[b][co][p] x[b][ci][p] (double atomics: the
-// fp32 accumulation runs over at most `seg` pixels).  A wave = (image, segment, up to 3 x 3 tiles of 16 co x 16 ci); per 16 pixels
-// lane (l, g) holds pixels q + 4 g .. + 3 of channel row l of every tile: MFMA step e contracts pixel q + 4 g + e.
-__global__ __launch_bounds__(64) void pw_wgrad_kernel(V x, V dy, double* __restrict__ scratch, int seg, int ci_blocks) {
+// fp32 accumulation runs over at most `seg` pixels).  A wave = up to 3 x 3 tiles of 16 co x 16 ci x `upw` consecutive (image, segment)
+// UNITS (round 5): each unit's fp32 sums are added to DOUBLE registers and the wave issues ONE set of atomics for all of them - a
+// layer's ~2000 waves used to send ~2000 atomics to every filter entry (rocprofv3: 33 us per layer for ~5 us of matrix-core work; a
+// sweep of the wave count alone gave 11.1 -> 10.6 ms per iteration at the price of four times longer fp32 sums - this form keeps
+// the sums at `seg` pixels).  Per 16 pixels lane (l, g) holds pixels q + 4 g .. + 3 of channel row l of every tile: MFMA step e
+// contracts pixel q + 4 g + e.
+__global__ __launch_bounds__(64) void pw_wgrad_kernel(V x, V dy, double* __restrict__ scratch, int seg, int ci_blocks, int nseg, int units, int upw) {
   constexpr int T = 3;
   const int HW = x.H * x.W, Cin = x.C, Cout = dy.C;
   const int lane = threadIdx.x, l = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y, q0 = blockIdx.x * seg, q1 = min(HW, q0 + seg);
   const int co0 = (blockIdx.z / ci_blocks) * (16 * T), ci0 = (blockIdx.z % ci_blocks) * (16 * T);
+  const size_t xs = (size_t)x.cstride * HW, gs = (size_t)dy.cstride * HW;
+  double dacc[T][T][4];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dacc[i][j][rr] = 0.0;
+#pragma unroll 1
+  for (int u = blockIdx.x * upw; u < min(units, (int)(blockIdx.x + 1) * upw); ++u) {
+  const int b = u / nseg, q0 = (u - b * nseg) * seg, q1 = min(HW, q0 + seg);
   yfv2_f4 acc[T][T];
 #pragma unroll
   for (int i = 0; i < T; ++i)
@@ -535,7 +549,6 @@ __global__ __launch_bounds__(64) void pw_wgrad_kernel(V x, V dy, double* __restr
     for (int j = 0; j < T; ++j) acc[i][j] = (yfv2_f4){0.f, 0.f, 0.f, 0.f};
   const float* xb = x.p + ((size_t)b * x.Ctot + x.coff) * HW;
   const float* gb = dy.p + ((size_t)b * dy.Ctot + dy.coff) * HW;
-  const size_t xs = (size_t)x.cstride * HW, gs = (size_t)dy.cstride * HW;
   auto fetch = [&](int q, float (&av)[T][4], float (&bv)[T][4]) {
 #pragma unroll
     for (int i = 0; i < T; ++i) {
@@ -576,9 +589,16 @@ __global__ __launch_bounds__(64) void pw_wgrad_kernel(V x, V dy, double* __restr
 #pragma unroll
     for (int j = 0; j < T; ++j)
 #pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dacc[i][j][rr] += (double)acc[i][j][rr];
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int co = co0 + 16 * i + 4 * g + rr, ci = ci0 + 16 * j + l;
-        if (co < Cout && ci < Cin) atomicAdd(&scratch[(size_t)co * Cin + ci], (double)acc[i][j][rr]);
+        if (co < Cout && ci < Cin) atomicAdd(&scratch[(size_t)co * Cin + ci], dacc[i][j][rr]);
       }
 }
 // Every layer's weight gradient is summed in double in its own range of one scratch (zeroed per backward) and added to the bound
@@ -751,7 +771,11 @@ struct Train {
     int seg = 256;                                     // pixels per wave: enough waves for the machine, fp32 partial sums over few terms
     while (seg > 64 && (long long)((HW + seg - 1) / seg) * Bc * cob * cib < 2048) seg >>= 1;
     double* scr = wgrad_scratch(dw, dout.C * x.C);
-    if (scr) hipLaunchKernelGGL(pw_wgrad_kernel, dim3((HW + seg - 1) / seg, Bc, cob * cib), dim3(64), 0, s, x, dout, scr, seg, cib);
+    const int nseg = (HW + seg - 1) / seg, units = nseg * Bc;
+    int upw = (int)(((long long)units * cob * cib) / 512);     // about 512 waves per layer (a launch below ~256 waves leaves CUs idle)
+    if (upw < 1) upw = 1;
+    if (upw > 16) upw = 16;
+    if (scr) hipLaunchKernelGGL(pw_wgrad_kernel, dim3((units + upw - 1) / upw, 1, cob * cib), dim3(64), 0, s, x, dout, scr, seg, cib, nseg, units, upw);
   }
 
   // conv (no bias) + BatchNorm (batch statistics) [+ ReLU]: in view -> zout view (a channel slice of some tensor)
