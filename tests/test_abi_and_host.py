@@ -427,9 +427,12 @@ def test_plan_and_weight_packing_on_the_host_for_every_admitted_config():
     # stage4.0, which exist only as bf16x6 kernels, then run layer by layer) are planned and packed by the same code
     import os
     assert _dryrun(80, 352, 352)[1] == 13      # ten backbone + FPN launches (the stem and stage2.0 are ONE: front_kernel), one launch for the four 11x11 tower halves, two at 22x22 (cls | reg side by side)
+    blob_fused = _dryrun(80, 352, 352)[2]
     os.environ["YFV2_FRONT"] = "0"
     try:
-        assert _dryrun(80, 352, 352)[1] == 14  # the stem and stage2.0 as two launches (round 4's form; what uint8 input runs)
+        rc, steps, blob, _ = _dryrun(80, 352, 352)
+        assert rc == 0 and steps == 14          # the stem and stage2.0 as two launches (round 4's form)
+        assert blob == blob_fused               # front2_kernel reads the two launches' own packed images: the fusion packs nothing new
     finally:
         del os.environ["YFV2_FRONT"]
     os.environ["YFV2_TPAIR"] = "0"
