@@ -523,6 +523,14 @@ struct WeightPacker {
             im.push_back(ch >= 72 ? 0.f : t < 25 ? blob[fd.w + (size_t)t * 72 + ch] : 16.0f * (t == 25 ? blob[fd.scale + ch] : blob[fd.shift + ch]));   // x 2^4: exact
           }
     for (int i = 0; i < 16; ++i) im.push_back(0.f);   // the scalar-cache warm-up reads whole 64-byte lines
+    // towerp_kernel's table (round 6): the same numbers per channel PAIR, one 256-byte record per (chunk, pair) = what a wave's
+    // depthwise unit pulls into 54 SGPRs: floats 2 t + e = tap t of channel 16 s + 2 pair + e, 50 + e = BN scale x 16, 52 + e = BN shift x 16
+    for (int s = 0; s < 5; ++s)
+      for (int pr = 0; pr < 8; ++pr)
+        for (int i = 0; i < 64; ++i) {
+          const int t = i >> 1, ch = 16 * s + 2 * pr + (i & 1);
+          im.push_back((ch >= 72 || t > 26) ? 0.f : t < 25 ? blob[fd.w + (size_t)t * 72 + ch] : 16.0f * (t == 25 ? blob[fd.scale + ch] : blob[fd.shift + ch]));
+        }
     return put(im);
   }
   // ---- stage 2 in lane-per-pixel form (yfv2_stage2.hip)
@@ -1707,7 +1715,8 @@ std::string step_kernel(const Step& st) {
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
       if (st.img_off3 && !st.jobs.empty() && !st.par) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
-      if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");   // default plan
+      if (st.img_off3 && (st.tw.H > 11 || st.tw.W > 11) && !((st.tw.H | st.tw.W) & 1) && !(yfv2_variant() & 256)) return "towerp_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan
+      if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : ((yfv2_variant() & 32) ? "s3h_kernel" : "s3h2_kernel")) : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)

@@ -378,6 +378,7 @@ struct TowerJobs {   // up to four tower halves of one map size in ONE launch
   int par;   // 0: a job LIST - every workgroup runs the jobs one after the other on its image (towers_kernel, maps up to 11x11);
              // 1: INDEPENDENT jobs side by side - workgroups [k gpj, (k + 1) gpj) run job k (towerh_kernel)
   int gpj;   // par: workgroups per job (set by the launcher)
+  unsigned char lane_patch[128];   // towerp_kernel: the 2x2 patch of lane l in depthwise round r at [64 r + l] (255: none); set by the launcher
 };
 bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s);
 // ---- evaluation statistics (get_batch_statistics): which detections are true positives

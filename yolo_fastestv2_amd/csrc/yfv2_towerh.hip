@@ -33,6 +33,12 @@
 // the pointwise phase, the next image's first slice during the last chunk.
 #include "yfv2_internal.h"
 #include <atomic>
+#include <algorithm>
+#include <array>
+#include <cstddef>
+#include <map>
+#include <mutex>
+#include <vector>
 
 typedef _Float16 yfv2_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 yfv2_h8 __attribute__((ext_vector_type(8)));
@@ -300,6 +306,7 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
       u32x4 xb[NT];                                                         // (requested before the staging traffic below)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(XB + (g * XP + th_xslot(opix[nt])) * 4);
+      if (s == 0) YFV2_WSTAMP(22);
       // the next slice -> TIN, the one after into registers (of the next image after the last chunk)
       if (s + 1 < KC || b + grid < a.B) stage_store(s + 1 < KC ? s + 1 : 0, pre);
       {
@@ -629,6 +636,405 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
   watch.report(kj[0].nonfinite);
 }
 
+// ============================================================================
+// towerp_kernel (round 6): the 2x2-patch maps (up to 22x22) with the depthwise on CHANNEL-PAIR units
+// ============================================================================
+// What the per-wave stamps and the disassembly of towerh_kernel<.., 2, 4> showed (profiles/r06_tower_stamps.txt): a job is 55-58 k
+// cycles, the same 3.7 k per chunk in the depthwise phase and 2.5-3.4 k in the pointwise phase at ONE image as at 256 - on-CU latency,
+// not memory: (1) the depthwise took its taps from the scalar cache row by row INSIDE the window loop; scalar loads and LDS reads
+// share one counter and return out of order, so every `s_waitcnt` in that loop was lgkmcnt(0): the row just requested was waited
+// for on the spot, six exposed LDS round trips per wave and chunk for 1.6 k cycles of packed FMAs per SIMD; (2) the pointwise phase
+// read each filter fragment right in front of the four MFMAs that use it (ten exposed round trips), and with the chunk loop rolled
+// the even / odd / last forms were run-time branches between MFMA groups, accumulator copies and `s_nop 7` included.  Here:
+//   * depthwise unit = (channel PAIR, 64 patches): 25 tap pairs + the BN pair = 54 SGPRs, requested ONCE per chunk before the
+//     chunk's first barrier - no scalar load is in flight while the window is read, the compiler counts the LDS reads down one by
+//     one.  A wave owns one pair of the 16-channel chunk and runs both 64-patch rounds (last chunk, 4 live pairs: pair wv & 3,
+//     round wv >> 2).  The staged slice is eight pair planes [pair][row 26][col 26] of 8-byte slots (zero halo of 2): a lane's 6x6
+//     window is 18 ds_read_b128 (two adjacent columns x two channels each) instead of 36, all in flight at once (72 registers);
+//     the 16-lane service groups of ds_read_b128 are conflict-free through a host-computed lane -> patch table (TowerJobs::lane_patch:
+//     every group's patches have distinct 16-byte slot residues mod 16).  v_pk_fma_f32 on (channel, channel + 1) with the SGPR
+//     tap pair: the same products in the same order as towerh_kernel - BIT-identical results.
+//   * pointwise: the chunk loop is unrolled by pairs (even, odd) + the last, every form straight-line: all filter fragments of
+//     the chunk requested up front (the depthwise's window registers are free by then), then the MFMAs back to back.
+// Everything else (exchange layout, fp16x3 products, merged output matrix, epilogues) as in towerh_kernel above.
+constexpr int TP_P = 26, TP_ROWS = 26, TP_PLANE = TP_ROWS * TP_P;     // pair plane: rows x pitch, 8-byte slots (5408 bytes = 32 mod 64: the two
+                                                                       // planes a staged 16-byte piece is split into fall into different bank halves)
+constexpr int TP_TIN_FL = 8 * TP_PLANE * 2;                            // floats
+constexpr int TP_DUMP_FL = 2 * TP_PLANE + 64;                          // where staged pieces of pixels that do not exist go (both halves of a piece)
+constexpr int TP_XS = 2 * 512 + 16;                                    // exchange buffer: [pair 8][pixel 512]{first fp16 terms of the pair's two channels, second terms}
+                                                                       // (8 bytes), pair stride 4160 bytes = 64 mod 128: the pointwise phase's two lane groups of a
+                                                                       // ds_read_b64 (channel groups g, g + 1 = pairs 2 apart) fall into different bank halves
+constexpr int TP_XB_FL = 8 * TP_XS;
+constexpr int TP_TAPS2 = TH_KC * 4 * 27 * 4 + 16;                      // offset of the pair tap table behind th_lds_img(MH): [s 5][pair 8][64]:
+                                                                       // floats 2t + e = tap t of channel 16s + 2 pair + e, 50 + e = BN scale x 16, 52 + e = BN shift x 16
+__host__ __device__ constexpr int tp_lds_floats(int MH) { return th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + TP_DUMP_FL; }
+typedef float yfv2_f8 __attribute__((ext_vector_type(8)));
+typedef float yfv2_f16v __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(4))) const yfv2_f16v yfv2_cf16;
+typedef __attribute__((address_space(4))) const yfv2_f8 yfv2_cf8;
+
+template <int MH>
+__global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
+  struct { int B, H, W; long long* trace; } a;
+  a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
+  constexpr int KC = TH_KC, C = TH_C, NT = 4, P = TP_P;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* WP_ = lds;
+  float* CS = lds + TH_CS;
+  float* WH = lds + TH_WH;
+  float* XB = lds + th_lds_img(MH);
+  float* TIN = XB + TP_XB_FL;
+  const int H = a.H, W = a.W, HW = H * W;
+  const float invW = 1.0f / (float)W;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gpj = jobs.par ? jobs.gpj : (int)gridDim.x;
+  const int bid = blockIdx.x;
+  const int jidx = __builtin_amdgcn_readfirstlane(jobs.par ? (bid >= gpj) + (bid >= 2 * gpj) + (bid >= 3 * gpj) : 0);
+  const int grid = gpj;
+  YFV2_WSTAMP(0);
+
+  // ---- staging map (as towerh_kernel: eight consecutive lanes = eight consecutive pixels of one quad); a piece = (pixel, quad) is
+  // stored as two 8-byte halves into the planes of pairs 2 quad and 2 quad + 1
+  int s_dst[NT];
+  const int my_c4 = (tid >> 3) & 3;
+  const int px0 = (tid & 7) + 8 * (tid >> 5);                  // piece j = pixel px0 + 128 j
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int px = px0 + 128 * j;
+    const bool ok = px < HW;
+    const int y = ok ? yfv2_fdiv(px, invW) : 0, x = ok ? px - y * W : 0;
+    s_dst[j] = ok ? (2 * my_c4 * TP_PLANE + (y + 2) * P + (x + 2)) * 2 : TP_TIN_FL + 4 * (tid & 15);
+  }
+  auto stage_load = [&](const float* in, int bb, int sl, f32x4 (&pre)[NT]) {
+    const int ch = 16 * sl + 4 * my_c4;
+    const float* img = in + (size_t)bb * HW * C + (ch < C ? ch : 0);
+    int pxo = px0;
+    asm volatile("" : "+v"(pxo));                              // (the four source offsets are recomputed here: three registers fewer across the job)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) pre[j] = *reinterpret_cast<const f32x4*>(img + (pxo + 128 * j < HW ? pxo + 128 * j : 0) * C);
+  };
+  auto stage_store = [&](int sl, const f32x4 (&pre)[NT]) {
+    const bool live = 16 * sl + 4 * my_c4 < C;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const f32x4 v = live ? pre[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x2*>(TIN + s_dst[j]) = (f32x2){v[0], v[1]};
+      *reinterpret_cast<f32x2*>(TIN + s_dst[j] + 2 * TP_PLANE) = (f32x2){v[2], v[3]};
+    }
+  };
+
+  // ---- depthwise role: the lane's patch in either round (host table: conflict-free 16-lane groups), ONE register per round
+  // (py << 8 | px, or -1); window corner and exchange slots are recomputed from it where they are used (~30 VALU per round
+  // against 400 of packed FMAs) - held in registers across the job they cost 10 of the 256 this kernel has
+  int patch[2];
+  {
+    const int PWn = (W + 1) / 2;
+    const __attribute__((address_space(4))) unsigned char* tbl =
+        (const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TowerJobs, lane_patch);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int pid = tbl[64 * r + lane];
+      const int pidc = pid != 255 ? pid : 0;
+      const int py = yfv2_fdiv(pidc, 1.0f / (float)PWn), pxx = pidc - py * PWn;
+      patch[r] = pid != 255 ? (py << 8 | pxx) : -1;
+    }
+  }
+  // ---- pointwise role: NT pixel tiles of 16
+  int opix[NT];
+  bool pv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int q = 16 * (wv * NT + nt) + p;
+    pv[nt] = q < HW;
+    opix[nt] = q;
+  }
+
+  const __attribute__((address_space(4))) TowerArgs& ja = ((const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[jidx];
+  const float* taps2 = ja.img16 + th_lds_img(MH) + TP_TAPS2;
+  int b = bid - jidx * gpj;
+  Yfv2Watch watch;
+  f32x4 pre[NT];
+  stage_load(ja.in, b < a.B ? b : 0, 0, pre);
+
+  // ---- the filter fragments this wave carries into LDS (prologue: set 0; chunk s: set s + 1)
+  constexpr int NFW = MH == 0 ? KC : MH;                        // fragment tiles per chunk = waves that carry one
+  constexpr int FBOFF = MH == 0 ? 0 : TH_WH;
+  const int fdump = th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + 4 * (lane & 15);
+  auto frag_off = [&](int sc) { return FBOFF + (((wv < NFW ? wv : 0) * KC + sc) * 64 + lane) * 4; };
+  f32x4 fpre;
+  // ---- prologue: fragment set 0 and the constants -> LDS, exchange and planes zeroed (the halo stays zero for the whole job)
+  {
+    // this wave's five tap records -> scalar cache: one request per 64-byte line, issued back to back NOW (nothing waits for them:
+    // the results are dropped).  Left to the first use, each of a chunk's four loads is a miss to L2 / HBM - and in the job's
+    // set-up, where scalar registers are short, the compiler serialises them: 2.8 k cycles in front of the first chunk
+    const float* tq = taps2 + wv * 64;
+    const float* tq4 = taps2 + (4 * 8 + (wv & 3)) * 64;
+#define YFV2_L(p, o) "s_load_dword s40, %" #p ", " #o "\n\t"
+#define YFV2_R(p, o) YFV2_L(p, o + 0) YFV2_L(p, o + 64) YFV2_L(p, o + 128) YFV2_L(p, o + 192)
+    asm volatile(YFV2_R(0, 0) YFV2_R(0, 2048) YFV2_R(0, 4096) YFV2_R(0, 6144) YFV2_R(1, 0) :: "s"(tq), "s"(tq4) : "s40", "memory");
+#undef YFV2_R
+#undef YFV2_L
+    // The filter image is streamed: a chunk's pointwise phase reads only that chunk's fragments (NF tiles x 1 KB, + the previous
+    // chunk's in odd chunks), so fragment set s + 1 is written into LDS during chunk s's pointwise phase from a register loaded a
+    // chunk earlier (wave m < NF carries tile m's fragment, one 16-byte piece per lane).  Only set 0 and the 1.5 KB of constants
+    // are fetched here: 7.5 KB instead of 27 / 58 KB (the merged-matrix forms never read the 72 x 72 filter at all) in the burst
+    // in which every CU of the chip fills at ~11 bytes per cycle.
+    constexpr int NZ = (TP_XB_FL + TP_TIN_FL + TP_DUMP_FL) / 4;
+    for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(ja.img16 + (wv < NFW ? frag_off(0) : TH_CS + (wv == NFW ? 0 : 256) + 4 * (wv > NFW + 1 || (wv == NFW + 1 && lane >= 32) ? 0 : lane)));
+    fpre = *reinterpret_cast<const f32x4*>(ja.img16 + frag_off(1));
+    // (every lane stores: what is not part of the image goes where nothing reads - a store behind a lane predicate leaves the
+    // compiler a path on which the load is still pending, and it then guards the registers with vmcnt(0) behind the NEXT requests)
+    *reinterpret_cast<f32x4*>(lds + (wv < NFW ? frag_off(0) : (wv > NFW + 1 || (wv == NFW + 1 && lane >= 32)) ? fdump : TH_CS + (wv == NFW ? 0 : 256) + 4 * lane)) = f0;
+  }
+  __syncthreads();
+  YFV2_WSTAMP(1);
+  if (b < a.B) {
+    stage_store(0, pre);
+    stage_load(ja.in, b, 1, pre);
+  }
+
+  const int hmh = MH ? ja.mh : 0;
+  const int mlive = (hmh + 15) >> 4;                           // output-channel tiles of the merged matrix (wave-uniform)
+  // this wave's depthwise unit of the coming chunk: the pair's 25 taps + BN constants in 56 SGPRs
+  yfv2_f16v t0, t1, t2;
+  yfv2_f8 t3;
+  auto load_taps = [&](int s) __attribute__((always_inline)) {
+    const int pair = s == KC - 1 ? (wv & 3) : wv;
+    const yfv2_cf16* tp = (const yfv2_cf16*)(taps2 + (s * 8 + pair) * 64);
+    t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+    t3 = *(const yfv2_cf8*)(tp + 3);
+    __builtin_amdgcn_sched_barrier(0);                         // (requested HERE: invariant loads move freely otherwise)
+  };
+  load_taps(0);
+  for (; b < a.B; b += grid) {
+    constexpr int NA = MH == 0 ? KC : MH;
+    f32x4 acc[NA][NT];
+#pragma unroll
+    for (int mt = 0; mt < NA; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    yfv2_u2 xprev[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xprev[nt] = (yfv2_u2){0u, 0u};
+
+    auto chunk = [&]<bool ODD, bool LAST>(int s, int stamp0) __attribute__((always_inline)) {
+      // ---- this wave's depthwise unit: the pair's 25 taps + BN constants -> SGPRs (requested before the barrier)
+      const int pair = LAST ? (wv & 3) : wv;
+      auto tap = [&](int t) -> f32x2 {
+        const int i = 2 * t;
+        return i < 16 ? (f32x2){t0[i & 15], t0[(i & 15) + 1]} : i < 32 ? (f32x2){t1[i & 15], t1[(i & 15) + 1]}
+             : i < 48 ? (f32x2){t2[i & 15], t2[(i & 15) + 1]} : (f32x2){t3[i & 7], t3[(i & 7) + 1]};
+      };
+      __syncthreads();                                                      // slice s complete in TIN; exchange free
+      YFV2_WSTAMP(stamp0);
+      auto round = [&](int pq) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(pq));                                        // (opaque: what is derived from it below is not hoisted out of the job)
+        const bool pvalid = pq >= 0;
+        const int py = pvalid ? pq >> 8 : 0, pxx = pvalid ? pq & 255 : 0;
+        const float* wp = TIN + pair * (TP_PLANE * 2) + ((2 * py) * P + 2 * pxx) * 2;
+        // three window rows in flight (36 registers), row r + 3 requested behind row r's FMAs
+        constexpr int WIN = 3;
+        f32x4 w[6][3];
+        auto read_row = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) w[r][j] = *reinterpret_cast<const f32x4*>(wp + (r * P + 2 * j) * 2);
+        };
+#pragma unroll
+        for (int r = 0; r < WIN; ++r) read_row(r);
+        f32x2 d[2][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k >> 1][k & 1] = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+              const int ky = r - dy;
+              if (ky < 0 || ky >= 5) continue;
+#pragma unroll
+              for (int dx = 0; dx < 2; ++dx) {
+                const int c = dx + kx;
+                const f32x2 v = (c & 1) ? (f32x2){w[r][c >> 1][2], w[r][c >> 1][3]} : (f32x2){w[r][c >> 1][0], w[r][c >> 1][1]};
+                d[dy][dx] = __builtin_elementwise_fma(v, tap(ky * 5 + kx), d[dy][dx]);
+              }
+            }
+          // keeps the four accumulation chains interleaved, row by row in source order (left alone the scheduler runs the chains one
+          // after the other: 25 dependent packed FMAs with a wait state between each two) and the window reads behind it (left alone
+          // all 18 are hoisted to the top: 72 registers).  Per output the order is tap row, then tap column - towerh_kernel's, bit for bit
+          asm volatile("" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) :: "memory");
+          if (r + WIN < 6) read_row(r + WIN);
+        }
+        const f32x2 sc = tap(25), sh = tap(26);
+        // BN + ReLU, ONE split into two fp16 terms; a patch row = two adjacent pixels = one 16-byte record {h1, h2, h1, h2} of the
+        // pair's exchange run (H and W are even here: both rows of a patch exist, the record is aligned).  A patch that does not
+        // exist stores where nothing reads (a store behind a lane predicate makes the compiler sink the pixel's 25 FMAs into the
+        // branch: one serial chain)
+        const int xdump = TP_XB_FL + TP_TIN_FL + 4 * (lane & 15);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          u32x4 rec;
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            f32x2 u = __builtin_elementwise_fma(d[dy][dx], sc, sh);
+            u[0] = u[0] > 0.f ? u[0] : 0.f; u[1] = u[1] > 0.f ? u[1] : 0.f;           // (the BN constants carry the 2^4)
+            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+            const h2_t h1 = __builtin_convertvector(u, h2_t);
+            const f32x2 rr = u - __builtin_convertvector(h1, f32x2);                   // exact
+            const h2_t h2 = __builtin_convertvector(rr, h2_t);
+            rec[2 * dx] = __builtin_bit_cast(unsigned, h1);
+            rec[2 * dx + 1] = __builtin_bit_cast(unsigned, h2);
+          }
+          const int q = (2 * py + dy) * W + 2 * pxx;
+          *reinterpret_cast<u32x4*>(XB + (pvalid ? pair * TP_XS + 2 * q : xdump)) = rec;
+        }
+      };
+      if constexpr (!LAST) {
+        round(patch[0]);
+        __builtin_amdgcn_sched_barrier(0);                                  // (round 1's reads stay behind round 0's FMAs)
+        if (s == 0) YFV2_WSTAMP(19);
+        round(patch[1]);
+        if (s == 0) YFV2_WSTAMP(20);
+      } else {
+        round(wv < 4 ? patch[0] : patch[1]);
+      }
+      __syncthreads();                                                      // exchange complete; TIN free
+      YFV2_WSTAMP(stamp0 + 1);
+
+      // ---- pointwise: everything the chunk needs from LDS requested up front, then the MFMAs back to back
+      u32x4 xb[NT];                                                         // {first terms of channels 4g .. 4g+3, second terms}: pairs 2g and 2g + 1
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(XB + (2 * g) * TP_XS + 2 * opix[nt]);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(XB + (2 * g + 1) * TP_XS + 2 * opix[nt]);
+        xb[nt] = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+      }
+      constexpr int NF = MH == 0 ? KC : MH;
+      const float* FB = MH == 0 ? WP_ : WH;
+      u32x4 wf[NF], w0[NF];
+#pragma unroll
+      for (int m = 0; m < NF; ++m) {   // (all tiles, also where a job's output conv is narrower - the image holds zero tiles there: reads behind the
+                                       // wave-uniform `m < mlive` end up one per branch, each waited for on the spot)
+        wf[m] = *reinterpret_cast<const u32x4*>(FB + ((m * KC + s) * 64 + lane) * 4);
+        if constexpr (ODD) w0[m] = *reinterpret_cast<const u32x4*>(FB + ((m * KC + s - 1) * 64 + lane) * 4);
+      }
+      // the next chunk's filter fragments -> LDS (requested a chunk ago), the set after that into the register
+      *reinterpret_cast<f32x4*>(lds + (wv < NFW ? frag_off(s + 1 < KC ? s + 1 : 0) : fdump)) = fpre;
+      fpre = *reinterpret_cast<const f32x4*>(ja.img16 + frag_off(s + 2 < KC ? s + 2 : s + 2 - KC));
+      // the next slice -> TIN, the one after into registers (of the next image after the last chunk)
+      if (s + 1 < KC || b + grid < a.B) stage_store(s + 1 < KC ? s + 1 : 0, pre);
+      {
+        int ns = s + 2, nb = b;
+        if (ns >= KC) { ns -= KC; nb += grid; }
+        stage_load(ja.in, nb < a.B ? nb : b, ns, pre);
+      }
+      if (s == 0) YFV2_WSTAMP(23);
+#pragma unroll
+      for (int m = 0; m < NF; ++m) {
+        if (MH == 0 || m < mlive) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = MH == 0 ? mfma_cross(wf[m], xb[nt], acc[m][nt]) : mfma_cross(xb[nt], wf[m], acc[m][nt]);
+        }
+      }
+      if constexpr (ODD) {
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+          if (MH == 0 || m < mlive) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[m][nt] = MH == 0 ? mfma_main2(w0[m], wf[m], xprev[nt], xb[nt], acc[m][nt])
+                                   : mfma_main2((u32x4){xprev[nt][0], xprev[nt][1], 0u, 0u}, xb[nt], (yfv2_u2){w0[m][0], w0[m][1]}, wf[m], acc[m][nt]);
+          }
+        }
+      } else if constexpr (LAST) {
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+          if (MH == 0 || m < mlive) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = MH == 0 ? mfma_main1(wf[m], xb[nt], acc[m][nt]) : mfma_main1(xb[nt], wf[m], acc[m][nt]);
+          }
+        }
+      }
+      if constexpr (!ODD) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xprev[nt] = (yfv2_u2){xb[nt][0], xb[nt][1]};
+      }
+      // the NEXT chunk's taps (of the next image's first chunk behind the last): requested here, behind this phase's last LDS wait -
+      // scalar loads and LDS reads share one counter, a scalar load in flight turns every LDS wait into "wait for everything" -
+      // and landed (a scalar-cache miss is an L2 round trip) by the time the matrix pipe has drained and the barrier opens
+      if (s == 0) YFV2_WSTAMP(21);
+      load_taps(LAST ? 0 : s + 1);
+      YFV2_WSTAMP(stamp0 + 2);
+    };
+#pragma unroll 1
+    for (int sp = 0; sp < 2; ++sp) {
+      chunk.template operator()<false, false>(2 * sp, 2 + 6 * sp);
+      chunk.template operator()<true, false>(2 * sp + 1, 5 + 6 * sp);
+    }
+    chunk.template operator()<false, true>(KC - 1, 14);
+    YFV2_WSTAMP(17);
+
+    if constexpr (MH == 0) {
+#pragma unroll
+      for (int mt = 0; mt < KC; ++mt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + 16 * mt + 4 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(CS + 1 * 96 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) watch.see(acc[0][nt][0]);
+      int po = p;
+      asm volatile("" : "+v"(po));                               // (the four row addresses are formed HERE: hoisted out of the job they are spilled,
+                                                                 // and a scratch reload between the stores waits for every store before it)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = 16 * (wv * NT + nt) + po;
+        if (q >= HW) continue;
+        float* dst = ja.out + ((size_t)b * HW + q) * C;
+#pragma unroll
+        for (int mt = 0; mt < KC; ++mt)
+          if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
+      }
+    } else {
+      const float us = CS[3 * 96];
+      const bool vec = (HW & 3) == 0;
+      float* hn0 = ja.nchw0; float* hn1 = ja.nchw1;
+      asm volatile("" : "+s"(hn0), "+s"(hn1));
+      const int hsplit = ja.split;
+#pragma unroll
+      for (int m = 0; m < MH; ++m) {
+        if (m >= mlive) break;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) watch.see((acc[m][nt][0] + acc[m][nt][1]) + (acc[m][nt][2] + acc[m][nt][3]));
+        const int co = 16 * m + p;
+        if (co < hmh) {
+          const float bias = CS[2 * 96 + co];
+          float* plane = co < hsplit ? hn0 + ((size_t)b * hsplit + co) * HW : hn1 + ((size_t)b * (hmh - hsplit) + (co - hsplit)) * HW;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int px0 = 16 * (wv * NT + nt) + 4 * g;
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(acc[m][nt][r], us, bias);
+            if (vec) {
+              if (px0 < HW) *reinterpret_cast<f32x4*>(plane + px0) = y;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (px0 + r < HW) plane[px0 + r] = y[r];
+            }
+          }
+        }
+      }
+    }
+    YFV2_WSTAMP(18);
+  }
+  watch.report(ja.nonfinite);
+}
+
 template <int MH>
 static void launch_towers(const TowerJobs& jobs, hipStream_t s) {
   const int B = jobs.j[0].B;
@@ -646,6 +1052,90 @@ static void launch_towerh(TowerJobs jobs, hipStream_t s) {
   const int B = jobs.j[0].B;
   jobs.gpj = B < 256 ? B : 256;
   hipLaunchKernelGGL((towerh_kernel<MH, PS, NT>), dim3(jobs.gpj * (jobs.par ? jobs.n : 1)), dim3(512), lds, s, jobs);
+}
+
+// towerp_kernel's lane -> patch table.  ds_read_b128 is serviced in four groups of 16 lanes, one LDS cycle per group when the 16
+// slots are distinct mod 16 (64 banks x 4 bytes).  A patch (py, px) reads slots py * TP_P + px + const: patches are dealt to the
+// eight groups of the two rounds so that no group holds two patches of one residue class (a class has at most ceil(patches / 16)
+// + 1 members; with more than eight the extra one costs its group one cycle).
+static void towerp_lane_patches(int H, int W, unsigned char (&tbl)[128]) {
+  static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                 {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  const int PWn = (W + 1) / 2, PHn = (H + 1) / 2, NP = PWn * PHn;
+  // step 1 (reads): patches -> the eight 16-lane groups of the two rounds, one patch per residue class and group
+  int member[8][16], fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool has[8][16] = {};
+  std::vector<int> late;
+  for (int pid = 0; pid < NP; ++pid) {
+    const int res = ((pid / PWn) * TP_P + pid % PWn) & 15;
+    int gi = 0;
+    while (gi < 8 && (has[gi][res] || fill[gi] >= 16)) ++gi;
+    if (gi == 8) { late.push_back(pid); continue; }
+    has[gi][res] = true;
+    member[gi][fill[gi]++] = pid;
+  }
+  for (int pid : late)
+    for (int gi = 0; gi < 8; ++gi)
+      if (fill[gi] < 16) { member[gi][fill[gi]++] = pid; break; }
+  // step 2 (the exchange stores, ds_write_b128: eight groups of eight CONTIGUOUS lanes, 32 banks): inside a round, which lane of
+  // its group a patch sits on is free - swap until the eight lanes 8k .. 8k+7 store to distinct 16-byte slots mod 8 (slot of a
+  // patch row = ((2 py + dy) W + 2 px) / 2: the same residue pattern for dy = 0 and 1), as far as a fixed-seed local search gets
+  for (int i = 0; i < 128; ++i) tbl[i] = 255;
+  unsigned rs = 12345u;
+  auto rnd = [&](unsigned n) { rs = rs * 1664525u + 1013904223u; return (rs >> 8) % n; };
+  for (int r = 0; r < 2; ++r) {
+    int at[64];
+    for (int l = 0; l < 64; ++l) at[l] = -1;
+    for (int gi = 0; gi < 4; ++gi)
+      for (int i = 0; i < fill[4 * r + gi]; ++i) at[grp[gi][i]] = member[4 * r + gi][i];
+    auto wres = [&](int pid) { return ((2 * (pid / PWn)) * (W / 2) + pid % PWn) & 7; };
+    auto cost = [&]() {
+      int c = 0;
+      for (int k = 0; k < 8; ++k) {
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx = 1;
+        for (int l = 8 * k; l < 8 * k + 8; ++l)
+          if (at[l] >= 0) mx = std::max(mx, ++cnt[wres(at[l])]);
+        c += mx - 1;
+      }
+      return c;
+    };
+    int cur = cost();
+    for (int it = 0; it < 40000 && cur > 0; ++it) {
+      const int gi = (int)rnd(4), l1 = grp[gi][rnd(16)], l2 = grp[gi][rnd(16)];
+      if (l1 == l2) continue;
+      std::swap(at[l1], at[l2]);
+      const int c = cost();
+      if (c <= cur) cur = c;
+      else std::swap(at[l1], at[l2]);
+    }
+    for (int l = 0; l < 64; ++l)
+      if (at[l] >= 0) tbl[64 * r + l] = (unsigned char)at[l];
+  }
+}
+
+template <int MH>
+static void launch_towerp(TowerJobs jobs, hipStream_t s) {
+  const size_t lds = sizeof(float) * (size_t)tp_lds_floats(MH);
+  static std::atomic<unsigned long long> lds_ok{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerp_kernel<MH>), lds_ok);
+  const int B = jobs.j[0].B;
+  jobs.gpj = B < 256 ? B : 256;
+  {
+    static std::mutex mu;
+    static std::map<int, std::array<unsigned char, 128>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const int key = jobs.j[0].H * 64 + jobs.j[0].W;
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+      unsigned char t[128];
+      towerp_lane_patches(jobs.j[0].H, jobs.j[0].W, t);
+      std::array<unsigned char, 128> arr;
+      std::copy(t, t + 128, arr.begin());
+      it = cache.emplace(key, arr).first;
+    }
+    std::copy(it->second.begin(), it->second.end(), jobs.lane_patch);
+  }
+  hipLaunchKernelGGL((towerp_kernel<MH>), dim3(jobs.gpj * (jobs.par ? jobs.n : 1)), dim3(512), lds, s, jobs);
 }
 
 // 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
@@ -673,10 +1163,14 @@ bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
     if (mh_tiles == 0) launch_towerh<0, 1, 1>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 1, 1>(jobs, s);
     else launch_towerh<6, 1, 1>(jobs, s);
-  } else {
+  } else if ((yfv2_variant() & 256) || (a.H & 1) || (a.W & 1)) {   // odd maps (13x13 at 416x416), or YFV2_VARIANT bit 256 (A/B): towerh_kernel<.., 2, 4>
     if (mh_tiles == 0) launch_towerh<0, 2, 4>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 2, 4>(jobs, s);
     else launch_towerh<6, 2, 4>(jobs, s);
+  } else {
+    if (mh_tiles == 0) launch_towerp<0>(jobs, s);
+    else if (mh_tiles == 1) launch_towerp<1>(jobs, s);
+    else launch_towerp<6>(jobs, s);
   }
   return true;
 }
