@@ -1715,7 +1715,7 @@ std::string step_kernel(const Step& st) {
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
       if (st.img_off3 && !st.jobs.empty() && !st.par) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
-      if (st.img_off3 && (st.tw.H > 11 || st.tw.W > 11) && !((st.tw.H | st.tw.W) & 1) && !(yfv2_variant() & 256)) return "towerp_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan
+      if (st.img_off3 && (st.tw.H > 11 || st.tw.W > 11) && !((st.tw.H | st.tw.W) & 1) && !(yfv2_variant() & 256)) return "towerp_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, even maps up to 22x22
       if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : ((yfv2_variant() & 32) ? "s3h_kernel" : "s3h2_kernel")) : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");

@@ -678,6 +678,9 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   struct { int B, H, W; long long* trace; } a;
   a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
   constexpr int KC = TH_KC, C = TH_C, NT = 4, P = TP_P;
+  constexpr int FORM = MH == 0 ? 0 : 1;                        // 0: the 72 -> 72 pointwise conv (accumulators = output-channel tiles x pixel tiles);
+                                                               // 1: the merged matrix, transposed (a lane holds four pixels of one output channel)
+  constexpr int NF = FORM == 0 ? KC : MH;                      // filter / accumulator tiles
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* WP_ = lds;
   float* CS = lds + TH_CS;
@@ -742,51 +745,50 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   }
   // ---- pointwise role: NT pixel tiles of 16
   int opix[NT];
-  bool pv[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int q = 16 * (wv * NT + nt) + p;
-    pv[nt] = q < HW;
-    opix[nt] = q;
-  }
+  for (int nt = 0; nt < NT; ++nt) opix[nt] = 16 * (wv * NT + nt) + p;
 
-  const __attribute__((address_space(4))) TowerArgs& ja = ((const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[jidx];
+  typedef const __attribute__((address_space(4))) TowerArgs JobArgs;
+  JobArgs& ja = ((JobArgs*)__builtin_amdgcn_kernarg_segment_ptr())[jidx];
   const float* taps2 = ja.img16 + th_lds_img(MH) + TP_TAPS2;
   int b = bid - jidx * gpj;
   Yfv2Watch watch;
   f32x4 pre[NT];
   stage_load(ja.in, b < a.B ? b : 0, 0, pre);
 
-  // ---- the filter fragments this wave carries into LDS (prologue: set 0; chunk s: set s + 1)
-  constexpr int NFW = MH == 0 ? KC : MH;                        // fragment tiles per chunk = waves that carry one
-  constexpr int FBOFF = MH == 0 ? 0 : TH_WH;
+  // ---- the filter fragments a wave carries into LDS: chunk s's pointwise phase reads only that chunk's fragments (NF tiles x 1 KB, + the
+  // previous chunk's in odd chunks), so set s + 1 is written during chunk s's pointwise phase from a register loaded a chunk earlier (wave
+  // m < NF carries tile m's fragment, one 16-byte piece per lane).  form 0: the 72 x 72 filter WP (5 tiles), form 1: the merged matrix WH
   const int fdump = th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + 4 * (lane & 15);
-  auto frag_off = [&](int sc) { return FBOFF + (((wv < NFW ? wv : 0) * KC + sc) * 64 + lane) * 4; };
+  auto frag_off = [&](int sc) { return (FORM == 0 ? 0 : TH_WH) + (((wv < NF ? wv : 0) * KC + sc) * 64 + lane) * 4; };
+  auto frag_dst = [&](int sc) { return wv < NF ? frag_off(sc) : fdump; };
   f32x4 fpre;
   // ---- prologue: fragment set 0 and the constants -> LDS, exchange and planes zeroed (the halo stays zero for the whole job)
   {
-    // this wave's five tap records -> scalar cache: one request per 64-byte line, issued back to back NOW (nothing waits for them:
+    // this wave's tap records -> scalar cache: one request per 64-byte line, issued back to back NOW (nothing waits for them:
     // the results are dropped).  Left to the first use, each of a chunk's four loads is a miss to L2 / HBM - and in the job's
     // set-up, where scalar registers are short, the compiler serialises them: 2.8 k cycles in front of the first chunk
-    const float* tq = taps2 + wv * 64;
-    const float* tq4 = taps2 + (4 * 8 + (wv & 3)) * 64;
 #define YFV2_L(p, o) "s_load_dword s40, %" #p ", " #o "\n\t"
 #define YFV2_R(p, o) YFV2_L(p, o + 0) YFV2_L(p, o + 64) YFV2_L(p, o + 128) YFV2_L(p, o + 192)
-    asm volatile(YFV2_R(0, 0) YFV2_R(0, 2048) YFV2_R(0, 4096) YFV2_R(0, 6144) YFV2_R(1, 0) :: "s"(tq), "s"(tq4) : "s40", "memory");
+    {
+      const float* tq = taps2 + wv * 64;
+      const float* tq4 = taps2 + (4 * 8 + (wv & 3)) * 64;
+      asm volatile(YFV2_R(0, 0) YFV2_R(0, 2048) YFV2_R(0, 4096) YFV2_R(0, 6144) YFV2_R(1, 0) :: "s"(tq), "s"(tq4) : "s40", "memory");
+    }
 #undef YFV2_R
 #undef YFV2_L
-    // The filter image is streamed: a chunk's pointwise phase reads only that chunk's fragments (NF tiles x 1 KB, + the previous
-    // chunk's in odd chunks), so fragment set s + 1 is written into LDS during chunk s's pointwise phase from a register loaded a
-    // chunk earlier (wave m < NF carries tile m's fragment, one 16-byte piece per lane).  Only set 0 and the 1.5 KB of constants
-    // are fetched here: 7.5 KB instead of 27 / 58 KB (the merged-matrix forms never read the 72 x 72 filter at all) in the burst
-    // in which every CU of the chip fills at ~11 bytes per cycle.
+    // Only set 0 and the 1.5 KB of constants are fetched here: 7.5 KB instead of 27 / 58 KB (the merged-matrix forms never read the
+    // 72 x 72 filter at all) in the burst in which every CU of the chip fills at ~11 bytes per cycle.
     constexpr int NZ = (TP_XB_FL + TP_TIN_FL + TP_DUMP_FL) / 4;
     for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4 f0 = *reinterpret_cast<const f32x4*>(ja.img16 + (wv < NFW ? frag_off(0) : TH_CS + (wv == NFW ? 0 : 256) + 4 * (wv > NFW + 1 || (wv == NFW + 1 && lane >= 32) ? 0 : lane)));
+    // waves NF, NF + 1: the 96 16-byte pieces of the constants (lanes 0..63, 0..31)
+    const bool cs_w = wv == NF || (wv == NF + 1 && lane < 32);
+    const int cs_i = cs_w ? (wv == NF ? lane : 64 + lane) : 0;
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(ja.img16 + (wv < NF ? frag_off(0) : TH_CS + 4 * cs_i));
     fpre = *reinterpret_cast<const f32x4*>(ja.img16 + frag_off(1));
     // (every lane stores: what is not part of the image goes where nothing reads - a store behind a lane predicate leaves the
     // compiler a path on which the load is still pending, and it then guards the registers with vmcnt(0) behind the NEXT requests)
-    *reinterpret_cast<f32x4*>(lds + (wv < NFW ? frag_off(0) : (wv > NFW + 1 || (wv == NFW + 1 && lane >= 32)) ? fdump : TH_CS + (wv == NFW ? 0 : 256) + 4 * lane)) = f0;
+    *reinterpret_cast<f32x4*>(lds + (wv < NF ? frag_off(0) : cs_w ? TH_CS + 4 * cs_i : fdump)) = f0;
   }
   __syncthreads();
   YFV2_WSTAMP(1);
@@ -808,19 +810,21 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
     __builtin_amdgcn_sched_barrier(0);                         // (requested HERE: invariant loads move freely otherwise)
   };
   load_taps(0);
+  // (a fused job is launched with one workgroup per image and tower: no image loop - out of a loop the compiler hoists the address
+  // arithmetic of every unrolled chunk copy, ~40 registers spilled in the set-up and reloaded in every phase)
   for (; b < a.B; b += grid) {
-    constexpr int NA = MH == 0 ? KC : MH;
-    f32x4 acc[NA][NT];
+    f32x4 acc[NF][NT];                                         // form 0: output-channel tile x pixel tile (lane: 4 channels of 1 pixel);
+                                                               // form 1: pixel tile x output-channel tile, transposed (lane: 4 pixels of 1 channel)
 #pragma unroll
-    for (int mt = 0; mt < NA; ++mt)
+    for (int mt = 0; mt < NF; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     yfv2_u2 xprev[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xprev[nt] = (yfv2_u2){0u, 0u};
 
+    // One chunk: [barrier] depthwise of slice s (both rounds of this wave's channel pair) [barrier] pointwise of slice s
     auto chunk = [&]<bool ODD, bool LAST>(int s, int stamp0) __attribute__((always_inline)) {
-      // ---- this wave's depthwise unit: the pair's 25 taps + BN constants -> SGPRs (requested before the barrier)
       const int pair = LAST ? (wv & 3) : wv;
       auto tap = [&](int t) -> f32x2 {
         const int i = 2 * t;
@@ -894,9 +898,7 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       if constexpr (!LAST) {
         round(patch[0]);
         __builtin_amdgcn_sched_barrier(0);                                  // (round 1's reads stay behind round 0's FMAs)
-        if (s == 0) YFV2_WSTAMP(19);
         round(patch[1]);
-        if (s == 0) YFV2_WSTAMP(20);
       } else {
         round(wv < 4 ? patch[0] : patch[1]);
       }
@@ -911,17 +913,14 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
         const u32x2 hi = *reinterpret_cast<const u32x2*>(XB + (2 * g + 1) * TP_XS + 2 * opix[nt]);
         xb[nt] = (u32x4){lo[0], hi[0], lo[1], hi[1]};
       }
-      constexpr int NF = MH == 0 ? KC : MH;
-      const float* FB = MH == 0 ? WP_ : WH;
-      u32x4 wf[NF], w0[NF];
-#pragma unroll
-      for (int m = 0; m < NF; ++m) {   // (all tiles, also where a job's output conv is narrower - the image holds zero tiles there: reads behind the
-                                       // wave-uniform `m < mlive` end up one per branch, each waited for on the spot)
-        wf[m] = *reinterpret_cast<const u32x4*>(FB + ((m * KC + s) * 64 + lane) * 4);
-        if constexpr (ODD) w0[m] = *reinterpret_cast<const u32x4*>(FB + ((m * KC + s - 1) * 64 + lane) * 4);
-      }
+      const float* FB = FORM == 0 ? WP_ : WH;
+      // filter fragments: tile m + 1's requested in front of tile m's MFMAs (two tiles = 16 registers in flight, not all 2 x NF: 201 / 227
+      // registers instead of 252 / 255).  All tiles, also where a job's output conv is narrower - the image holds zero tiles there
+      auto frag = [&](int m, int sc) { return *reinterpret_cast<const u32x4*>(FB + ((m * KC + sc) * 64 + lane) * 4); };
+      u32x4 wfn = frag(0, s), w0n;
+      if constexpr (ODD) w0n = frag(0, s - 1);
       // the next chunk's filter fragments -> LDS (requested a chunk ago), the set after that into the register
-      *reinterpret_cast<f32x4*>(lds + (wv < NFW ? frag_off(s + 1 < KC ? s + 1 : 0) : fdump)) = fpre;
+      *reinterpret_cast<f32x4*>(lds + frag_dst(s + 1 < KC ? s + 1 : 0)) = fpre;
       fpre = *reinterpret_cast<const f32x4*>(ja.img16 + frag_off(s + 2 < KC ? s + 2 : s + 2 - KC));
       // the next slice -> TIN, the one after into registers (of the next image after the last chunk)
       if (s + 1 < KC || b + grid < a.B) stage_store(s + 1 < KC ? s + 1 : 0, pre);
@@ -930,30 +929,34 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
         if (ns >= KC) { ns -= KC; nb += grid; }
         stage_load(ja.in, nb < a.B ? nb : b, ns, pre);
       }
-      if (s == 0) YFV2_WSTAMP(23);
 #pragma unroll
       for (int m = 0; m < NF; ++m) {
-        if (MH == 0 || m < mlive) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = MH == 0 ? mfma_cross(wf[m], xb[nt], acc[m][nt]) : mfma_cross(xb[nt], wf[m], acc[m][nt]);
+        const u32x4 wf = wfn, w0 = w0n;
+        __builtin_amdgcn_sched_barrier(0);                                  // (tile by tile: in straight-line code every fragment read is hoisted to the top otherwise)
+        if (m + 1 < NF) {
+          wfn = frag(m + 1, s);
+          if constexpr (ODD) w0n = frag(m + 1, s - 1);
         }
-      }
-      if constexpr (ODD) {
+        if constexpr (FORM == 0) {
 #pragma unroll
-        for (int m = 0; m < NF; ++m) {
-          if (MH == 0 || m < mlive) {
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_cross(wf, xb[nt], acc[m][nt]);
+          if constexpr (ODD) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_main2(w0, wf, xprev[nt], xb[nt], acc[m][nt]);
+          } else if constexpr (LAST) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_main1(wf, xb[nt], acc[m][nt]);
+          }
+        } else if (m < mlive) {                                           // (wave-uniform: a narrower output conv leaves zero tiles)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_cross(xb[nt], wf, acc[m][nt]);
+          if constexpr (ODD) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[m][nt] = MH == 0 ? mfma_main2(w0[m], wf[m], xprev[nt], xb[nt], acc[m][nt])
-                                   : mfma_main2((u32x4){xprev[nt][0], xprev[nt][1], 0u, 0u}, xb[nt], (yfv2_u2){w0[m][0], w0[m][1]}, wf[m], acc[m][nt]);
-          }
-        }
-      } else if constexpr (LAST) {
+              acc[m][nt] = mfma_main2((u32x4){xprev[nt][0], xprev[nt][1], 0u, 0u}, xb[nt], (yfv2_u2){w0[0], w0[1]}, wf, acc[m][nt]);
+          } else if constexpr (LAST) {
 #pragma unroll
-        for (int m = 0; m < NF; ++m) {
-          if (MH == 0 || m < mlive) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = MH == 0 ? mfma_main1(wf[m], xb[nt], acc[m][nt]) : mfma_main1(xb[nt], wf[m], acc[m][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_main1(xb[nt], wf, acc[m][nt]);
           }
         }
       }
@@ -961,13 +964,13 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) xprev[nt] = (yfv2_u2){xb[nt][0], xb[nt][1]};
       }
-      // the NEXT chunk's taps (of the next image's first chunk behind the last): requested here, behind this phase's last LDS wait -
-      // scalar loads and LDS reads share one counter, a scalar load in flight turns every LDS wait into "wait for everything" -
+      // the NEXT chunk's taps (of the next image's first chunk behind the last): requested here, behind this phase's last LDS
+      // wait - scalar loads and LDS reads share one counter, a scalar load in flight turns every LDS wait into "wait for everything" -
       // and landed (a scalar-cache miss is an L2 round trip) by the time the matrix pipe has drained and the barrier opens
-      if (s == 0) YFV2_WSTAMP(21);
       load_taps(LAST ? 0 : s + 1);
       YFV2_WSTAMP(stamp0 + 2);
     };
+
 #pragma unroll 1
     for (int sp = 0; sp < 2; ++sp) {
       chunk.template operator()<false, false>(2 * sp, 2 + 6 * sp);
@@ -976,7 +979,12 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
     chunk.template operator()<false, true>(KC - 1, 14);
     YFV2_WSTAMP(17);
 
-    if constexpr (MH == 0) {
+    // (the store addresses are formed HERE, from opaque copies: hoisted out of the job they are spilled, and a scratch reload between the
+    // stores waits for every store before it)
+    int pe = p, ge = g;
+    asm volatile("" : "+v"(pe), "+v"(ge));
+    if constexpr (FORM == 0) {
+      // pointwise BN (no ReLU: fpn.py:16-17,23-24); the scale carries 2^-(sw+4)
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(CS + 0 * 96 + 16 * mt + 4 * g);
@@ -985,22 +993,22 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_elementwise_fma(acc[mt][nt], sc, sh);
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) watch.see(acc[0][nt][0]);
-      int po = p;
-      asm volatile("" : "+v"(po));                               // (the four row addresses are formed HERE: hoisted out of the job they are spilled,
-                                                                 // and a scratch reload between the stores waits for every store before it)
+      for (int nt = 0; nt < NT; ++nt) watch.see(acc[0][nt][0]);   // a depthwise result beyond fp16's range: NaN in every channel of its pixel
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int q = 16 * (wv * NT + nt) + po;
+        const int q = 16 * (wv * NT + nt) + pe;
         if (q >= HW) continue;
         float* dst = ja.out + ((size_t)b * HW + q) * C;
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt)
-          if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt][nt];
+          if (16 * mt + 4 * ge < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * ge) = acc[mt][nt];
       }
     } else {
-      const float us = CS[3 * 96];
-      const bool vec = (HW & 3) == 0;
+      const float us = CS[3 * 96];                                          // 2^-(swh+4)
+      const bool vec = (HW & 3) == 0;                                       // (alignment of every channel plane)
+      // (both plane pointers in scalar registers BEFORE the lane-dependent choice: left to itself the compiler turns the choice
+      // between two kernel-argument fields into ONE vector load from a chosen address - a full load latency in front of every
+      // output tile's stores)
       float* hn0 = ja.nchw0; float* hn1 = ja.nchw1;
       asm volatile("" : "+s"(hn0), "+s"(hn1));
       const int hsplit = ja.split;
@@ -1008,14 +1016,14 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       for (int m = 0; m < MH; ++m) {
         if (m >= mlive) break;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) watch.see((acc[m][nt][0] + acc[m][nt][1]) + (acc[m][nt][2] + acc[m][nt][3]));
-        const int co = 16 * m + p;
+        for (int nt = 0; nt < NT; ++nt) watch.see((acc[m][nt][0] + acc[m][nt][1]) + (acc[m][nt][2] + acc[m][nt][3]));   // transposed: a lane's four values are four PIXELS
+        const int co = 16 * m + pe;
         if (co < hmh) {
           const float bias = CS[2 * 96 + co];
           float* plane = co < hsplit ? hn0 + ((size_t)b * hsplit + co) * HW : hn1 + ((size_t)b * (hmh - hsplit) + (co - hsplit)) * HW;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const int px0 = 16 * (wv * NT + nt) + 4 * g;
+            const int px0 = 16 * (wv * NT + nt) + 4 * ge;
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(acc[m][nt][r], us, bias);
