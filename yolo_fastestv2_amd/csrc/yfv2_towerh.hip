@@ -479,17 +479,11 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
       for (int j = 0; j < NPF; ++j) { const int i = tid + j * 512; pre[j] = img[i < HW * NQ ? i : 0]; }
     }
     const bool first_image = b == (int)blockIdx.x;
-    // the two lane units of this wave
-    bool uon[2], ulane[2];
-    int uy[2], uc[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int L = 64 * (wv + 8 * k) + lane;
-      uon[k] = 64 * (wv + 8 * k) < H * C;
-      ulane[k] = L < H * C;
-      const int Lc = ulane[k] ? L : 0;
-      uy[k] = yfv2_fdiv(Lc, 1.0f / (float)C); uc[k] = Lc - uy[k] * C;
-    }
+    // this lane's depthwise unit: (output row, channel PAIR) - H x 36 units <= 396 lanes, ONE round (round 6; until then (row, channel):
+    // 792 units on 512 lanes, the second round 45 % empty, every FMA a plain one)
+    const int UL = 64 * wv + lane;
+    const bool uon = 64 * wv < H * (C / 2), ulane = UL < H * (C / 2);
+    const int uy = yfv2_fdiv(ulane ? UL : 0, 1.0f / (float)(C / 2)), uc = 2 * ((ulane ? UL : 0) - uy * (C / 2));
     __syncthreads();                                              // the previous job / image is done with LDS
     if (!in_lds) {
 #pragma unroll
@@ -507,41 +501,48 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
       for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
     }
 
-    // ---- depthwise: lane units (row, channel); a unit's five input rows are requested at once (one LDS round trip)
+    // ---- depthwise: a lane = (output row, channel pair): packed FMAs on (c, c + 1) against the tap pair (the table holds a quad's
+    // taps side by side: the pair is one 8-byte read), row by row with the next input row and tap row in flight.  Per output the
+    // products are added in the order tap row, tap column - as before, bit for bit
+    if (uon) {                                                    // wave-uniform
+      const int y = uy, c = uc;
+      const float* tl = tapsf + ((c >> 2) * 27) * 4 + (c & 3);
+      auto ld_taps = [&](int r, f32x2 (&t)[5]) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (!uon[k]) continue;                                      // wave-uniform
-      const bool on = ulane[k];
-      const int y = uy[k], c = uc[k];
-      float twk[27];
-      {
-        const float* tl = tapsf + ((c >> 2) * 27) * 4 + (c & 3);
-#pragma unroll
-        for (int t = 0; t < 27; ++t) twk[t] = tl[4 * t];
-      }
-      float v[5][MAXW];
-#pragma unroll
-      for (int r = 0; r < 5; ++r) {
+        for (int kx = 0; kx < 5; ++kx) t[kx] = *reinterpret_cast<const f32x2*>(tl + 4 * (r * 5 + kx));
+      };
+      auto ld_row = [&](int r, f32x2 (&v)[MAXW]) {
         const float* rp = IN + (y + r) * W * C + c;               // row y + r - 2 of the image: the halo rows are zero, every read is inside the buffer
 #pragma unroll
-        for (int x = 0; x < MAXW; ++x) { const float t = rp[x * C]; v[r][x] = x < W ? t : 0.f; }
-      }
-      float acc[MAXW];
+        for (int x = 0; x < MAXW; ++x) { const f32x2 t = *reinterpret_cast<const f32x2*>(rp + x * C); v[x] = x < W ? t : (f32x2){0.f, 0.f}; }
+      };
+      f32x2 acc[MAXW];
 #pragma unroll
-      for (int x = 0; x < MAXW; ++x) acc[x] = 0.f;
+      for (int x = 0; x < MAXW; ++x) acc[x] = (f32x2){0.f, 0.f};
+      f32x2 v[2][MAXW], tw[2][5];
+      ld_row(0, v[0]); ld_taps(0, tw[0]);
 #pragma unroll
-      for (int r = 0; r < 5; ++r)
+      for (int r = 0; r < 5; ++r) {
+        if (r + 1 < 5) { ld_row(r + 1, v[(r + 1) & 1]); ld_taps(r + 1, tw[(r + 1) & 1]); }
 #pragma unroll
         for (int x = 0; x < MAXW; ++x)
 #pragma unroll
           for (int kx = 0; kx < 5; ++kx) {
             const int xi = x + kx - 2;
-            if (xi >= 0 && xi < MAXW) acc[x] = __builtin_fmaf(v[r][xi], twk[r * 5 + kx], acc[x]);
+            if (xi >= 0 && xi < MAXW) acc[x] = __builtin_elementwise_fma(v[r & 1][xi], tw[r & 1][kx], acc[x]);
           }
-      if (on) {
+        // (two rows in flight: left alone the scheduler requests all five rows and tap rows first - 164 registers)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]) :: "memory");
+      }
+      const f32x2 bsc = *reinterpret_cast<const f32x2*>(tl + 4 * 25), bsh = *reinterpret_cast<const f32x2*>(tl + 4 * 26);
+      if (ulane) {
 #pragma unroll
         for (int x = 0; x < MAXW; ++x)
-          if (x < W) { const float uu = __builtin_fmaf(acc[x], twk[25], twk[26]); X32[(y * W + x) * CP + c] = uu > 0.f ? uu : 0.f; }   // (the BN constants carry the 2^4)
+          if (x < W) {
+            f32x2 uu = __builtin_elementwise_fma(acc[x], bsc, bsh);                                            // (the BN constants carry the 2^4)
+            uu[0] = uu[0] > 0.f ? uu[0] : 0.f; uu[1] = uu[1] > 0.f ? uu[1] : 0.f;
+            *reinterpret_cast<f32x2*>(X32 + (y * W + x) * CP + c) = uu;
+          }
       }
     }
     __syncthreads();                                              // exchange complete
