@@ -16,12 +16,9 @@
  *     hipStream_t passed as void*; NULL = the default stream).  No hidden
  *     device synchronisation, except in yfv2_profile_forward and
  *     yfv2_debug_activation, which are measurement/debug helpers and say so.
- *     (Opt-in, YFV2_SIDE=1 in the environment of yfv2_create: the coarse-level towers run on two streams the handle
- *     owns, forked from and joined back into the caller's stream with events inside the call - the caller still
- *     orders against ONE stream.  Off by default: measured no gain)
  *   - all pointers named x / out6 / boxes / dets / idx / count are DEVICE
  *     pointers; weights passed to yfv2_load_weights are HOST pointers.
- *     (YFV2_LANES=N in the environment of yfv2_create: a forward / detect of a large batch is cut into N slices that run on
+ *     (yfv2_plan.lanes = N at yfv2_create_ex: a forward / detect of a large batch is cut into N slices that run on
  *     N streams owned by the handle - forked from and joined back into the caller's stream with events inside the call, same
  *     ordering contract, bit-identical results; DESIGN.md section 5.  Memory: the parent handle keeps its full workspace
  *     for max_batch images - it serves batches below the slicing threshold, yfv2_profile_forward and the training entry
@@ -42,7 +39,7 @@
 extern "C" {
 #endif
 
-#define YFV2_ABI_VERSION 5 /* 2: yfv2_stage_info reports external bytes as well; 3: yfv2_train_*, yfv2_sgd_step; 4: yfv2_nonfinite, lanes; 5: yfv2_nonfinite_peek, yfv2_clock_probe_* */
+#define YFV2_ABI_VERSION 6 /* 2: yfv2_stage_info reports external bytes as well; 3: yfv2_train_*, yfv2_sgd_step; 4: yfv2_nonfinite, lanes; 5: yfv2_nonfinite_peek, yfv2_clock_probe_*; 6: yfv2_plan / yfv2_create_ex (the library reads no environment variable) */
 #define YFV2_API __attribute__((visibility("default")))
 #define YFV2_MAX_DET 300 /* utils/utils.py:243 max_det */
 
@@ -80,10 +77,31 @@ typedef struct yfv2_tensor_desc {
   int64_t numel;
 } yfv2_tensor_desc;
 
+/* Plan switches of a handle: WHICH kernels compute the path, never WHAT it computes (every plan is held to the same parity
+ * tests, tests/test_gpu_parity.py::test_fallback_plans_match_oracle).  All zero = the default plan.  The library reads no
+ * environment variable: this struct, passed to yfv2_create_ex, is the only way a plan is chosen (the Python layer and the
+ * tools map YFV2_BF6=0 / YFV2_FUSED=0 / YFV2_POSTFUSE=0 / YFV2_FRONT=0 / YFV2_TPAIR=0 / YFV2_LANES=N / YFV2_TRACE=1 of THEIR
+ * environment onto it, yolo_fastestv2_amd/_lib.py plan_from_env). */
+typedef struct yfv2_plan {
+  int32_t struct_size;        /* sizeof(yfv2_plan) of the caller's header (the struct may grow at its end) */
+  int32_t fp32_matrix;        /* 1: every channel contraction on the fp32 matrix instructions (the reference's own arithmetic: no
+                                 range limit, about half the speed) instead of fp16x3 on the f16 matrix cores */
+  int32_t layer_by_layer;     /* 1: one launch per reference layer (77 launches), NHWC throughout: the general plan every fused
+                                 kernel was first validated against */
+  int32_t post_two_launches;  /* 1: yfv2_detect's decode and NMS as two launches (the only form beyond 96 classes / 2048 rows) */
+  int32_t front_two_launches; /* 1: the stem and stage2.0 as two launches */
+  int32_t towers_unpaired;    /* 1: the tower halves of the 22x22-class level as four launches instead of two */
+  int32_t lanes;              /* N > 1: one call on a large batch is cut into N slices on N streams the handle owns; 0 / 1: off */
+  int32_t trace;              /* 1: debug - per-wave cycle stamps of the stamped kernels (yfv2_debug_activation(100)) ... */
+  int32_t trace_step;         /* ... of launch `trace_step` of the plan only (-1: of every stamped launch) */
+} yfv2_plan;
+
 /* ---- lifetime -------------------------------------------------------------- */
 
-/* replaces: model/detector.py:8-19 Detector.__init__ (+ .to(device)) */
+/* replaces: model/detector.py:8-19 Detector.__init__ (+ .to(device)).  yfv2_create(out, cfg) = yfv2_create_ex(out, cfg, NULL):
+ * the default plan. */
 YFV2_API int yfv2_create(yfv2_handle* out, const yfv2_config* cfg);
+YFV2_API int yfv2_create_ex(yfv2_handle* out, const yfv2_config* cfg, const yfv2_plan* plan);
 YFV2_API void yfv2_destroy(yfv2_handle h);
 YFV2_API const char* yfv2_last_error(yfv2_handle h);
 YFV2_API int yfv2_abi_version(void);
@@ -101,9 +119,9 @@ YFV2_API int yfv2_set_anchors(yfv2_handle h, const double anchors[12]);
 /* ---- the hot path ---------------------------------------------------------- */
 
 /* replaces: model/detector.py:21-47 Detector.forward (export_onnx=False).
- * x: (B,3,H,W) fp32 NCHW in [0,1] (test.py:38; any |x| < 255.9 is computed to fp32 accuracy, beyond that the default
+ * x: (B,3,H,W) fp32 NCHW in [0,1], 16-byte aligned (YFV2_ERR_ARG otherwise; the uint8 entry points: 4-byte aligned) (test.py:38; any |x| < 255.9 is computed to fp32 accuracy, beyond that the default
  * plan's stem - two-term fp16 operands on the matrix cores, yfv2_stem16.hip - leaves fp16's range: DETECTED, see
- * yfv2_nonfinite below; YFV2_BF6=0 at create time and the uint8 entry point yfv2_forward_u8 have no such bound).  out6: six NCHW fp32 logit tensors in the
+ * yfv2_nonfinite below; a handle created with yfv2_plan.fp32_matrix = 1 and the uint8 entry point yfv2_forward_u8 have no such bound).  out6: six NCHW fp32 logit tensors in the
  * reference's return order (reg_2, obj_2, cls_2, reg_3, obj_3, cls_3) with
  * shapes (B,4A,H/16,W/16) (B,A,..) (B,classes,..) and the same at H/32. */
 YFV2_API int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const out6[6], void* stream);
@@ -115,7 +133,7 @@ YFV2_API int yfv2_forward(yfv2_handle h, const float* x, int32_t B, float* const
  * the NaN into a silent 0; the reference's fp32 conv has no such cliff.  So every kernel of that plan tests its matrix-core
  * accumulators BEFORE the ReLU and sets a sticky word in the handle when one is not a number (also true for non-finite
  * values in x itself).  yfv2_nonfinite waits for `stream`, writes 1 to *flag if any forward / detect since the last query
- * tripped the guard (0 otherwise) and clears the word.  A handle created with YFV2_BF6=0 in the environment computes every
+ * tripped the guard (0 otherwise) and clears the word.  A handle created with yfv2_plan.fp32_matrix = 1 computes every
  * conv on the fp32 matrix instructions, has no such bound and never sets it.  The Python surface queries the word wherever it
  * synchronises anyway (handel_preds, non_max_suppression's callers, evaluation) and raises. */
 YFV2_API int yfv2_nonfinite(yfv2_handle h, int32_t* flag, void* stream);
@@ -285,7 +303,10 @@ YFV2_API int yfv2_debug_repeat_step(yfv2_handle h, const float* x, int32_t B, fl
 
 /* Debug/parity helper: copy one internal NHWC activation of the LAST forward
  * to host as (B,H,W,C).  which: 0 stem+pool, 1 stage2, 2 stage3 (C2), 3 stage4
- * (C3), 4 S2 (fpn 22x22), 5 S3 (fpn 11x11).  Returns the element count. */
+ * (C3), 4 S2 (fpn 22x22), 5 S3 (fpn 11x11).  Returns the element count.
+ * which = 0 on the default plan: the stem's output never exists in memory (it is fused into stage2.0's launch), so the hook RE-RUNS
+ * the stem's own launch on the input pointer of the last forward / detect - the caller must still hold that buffer, unchanged
+ * (YFV2_ERR_STATE if no forward of at least B images has run on the handle since it was created). */
 YFV2_API int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* host_dst, int64_t cap);
 
 /* Debug/parity helper for the training path: the output of one ReLU'd conv+BatchNorm of the LAST yfv2_train_forward, dense
@@ -300,10 +321,19 @@ YFV2_API int64_t yfv2_debug_train_relu_output(yfv2_handle h, const char* conv_na
  * reports the number of launches and the packed blob size.  Lets the CPU test suite exercise the host logic for every
  * (classes, height, width) the configuration check admits.  Never launches or computes anything. */
 YFV2_API int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* n_steps, int64_t* blob_floats);
+/* the same for a plan other than the default (NULL = the default plan) */
+YFV2_API int yfv2_debug_plan_dryrun_ex(const yfv2_config* cfg, const yfv2_plan* plan, const yfv2_tensor_desc* tensors, int32_t n, int32_t* n_steps,
+                                       int64_t* blob_floats);
 /* Host-only test hook: the packed LDS image of launch `step` of that plan (up to `cap` floats from the image's start) and
- * the launch's name; returns the number of floats copied or a negative error code. */
+ * the launch's name; returns the number of floats copied or a negative error code.
+ * INDEX SPACE: images are packed per reference block, so this hook numbers the steps of the IMAGE VIEW: where the default plan runs
+ * the stem and stage2.0 as one launch (front2_kernel) the view still has two steps - 0 = the stem's image, 1 = stage2.0's, launch k of
+ * the plan (yfv2_num_stages / yfv2_stage_info / yfv2_profile_forward / yfv2_debug_repeat_step index the LAUNCHES) = view step k + 1.
+ * step = -1 returns the number of view steps (dst may be NULL).  step + 1000 (j + 1) = job j of a launch that runs several tower halves. */
 YFV2_API int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t step, char* name,
                                        int32_t name_cap, float* dst, int64_t cap);
+YFV2_API int64_t yfv2_debug_plan_image_ex(const yfv2_config* cfg, const yfv2_plan* plan, const yfv2_tensor_desc* tensors, int32_t n, int32_t step,
+                                          char* name, int32_t name_cap, float* dst, int64_t cap);   /* ... of a plan other than the default */
 /* Host-only test hook: the channel order in which that plan stores stage 3's output C2 (label[k] = logical channel at
  * NHWC position k, 96 entries); returns 1 if the plan permutes (chain kernel), 0 for plain NHWC, negative on error. */
 YFV2_API int yfv2_debug_plan_c2_label(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* label);

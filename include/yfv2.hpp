@@ -37,12 +37,13 @@ struct TargetBox {   // sample/ncnn/src/yolo-fastestv2.h TargetBox
 
 class Detector {
  public:
-  Detector(int classes, const double (&anchors)[12], int width = 352, int height = 352, int device = 0) : width_(width), height_(height) {
+  Detector(int classes, const double (&anchors)[12], int width = 352, int height = 352, int device = 0, const yfv2_plan* plan = nullptr)
+      : width_(width), height_(height) {
     yfv2_config cfg{};
     cfg.classes = classes; cfg.anchor_num = 3; cfg.height = height; cfg.width = width;
     for (int i = 0; i < 12; ++i) cfg.anchors[i] = anchors[i];
     cfg.max_batch = 1; cfg.device = device;
-    rc_ = yfv2_create(&h_, &cfg);
+    rc_ = yfv2_create_ex(&h_, &cfg, plan);   // plan: NULL = the default (fp16x3) plan; {.fp32_matrix = 1} = fp32 matrix instructions, no range limit
     if (rc_ != YFV2_OK) { err_ = yfv2_last_error(nullptr); return; }
     const size_t img = (size_t)width * height * 3;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&d_img_, img) != hipSuccess || hipMalloc(&d_dets_, 300 * 6 * sizeof(float)) != hipSuccess ||
@@ -133,7 +134,7 @@ class Detector {
     if (gr != YFV2_OK) return fail(gr, yfv2_last_error(h_));
     if (tripped)
       return fail(YFV2_ERR_RANGE, "detection: an activation left the range of the default (fp16x3) plan - |activation| >= 4094; the result is "
-                                  "invalid.  Run this model with YFV2_BF6=0 in the environment (fp32 matrix instructions, no such bound)");
+                                  "invalid.  Run this model on a handle created with yfv2_plan.fp32_matrix = 1 (the former YFV2_BF6=0: fp32 matrix instructions, no such bound)");
     for (int i = 0; i < cnt; ++i) {
       const float* r = rowsbuf + 6 * i;
       TargetBox b;

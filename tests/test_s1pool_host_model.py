@@ -28,11 +28,12 @@ def _plan_image(w):
     cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = 80, 3, 352, 352, 1, 0
     L = _lib.lib()
     ns, nb = C.c_int32(0), C.c_int64(0)
-    assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0
+    plan = _lib.make_plan(_lib.plan_from_env())     # (the library reads no environment: the Python layer maps YFV2_BF6=0 onto yfv2_plan.fp32_matrix)
+    assert L.yfv2_debug_plan_dryrun_ex(C.byref(cfg), C.byref(plan), arr, len(host), C.byref(ns), C.byref(nb)) == 0
     name = C.create_string_buffer(256)
     buf = np.zeros(NB * 3 * (sum(SIZES[True]) + REST_FL), np.float32)
     for st in range(ns.value):
-        n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st, name, 256, buf.ctypes.data_as(C.c_void_p), buf.size)
+        n = L.yfv2_debug_plan_image_ex(C.byref(cfg), C.byref(plan), arr, len(host), st, name, 256, buf.ctypes.data_as(C.c_void_p), buf.size)
         if n > 0 and "whole activation resident in LDS" in name.value.decode():
             return buf[:n].copy()          # (n = what fitted of the blob from the image's start on, not the image's length)
     return None

@@ -32,10 +32,11 @@ def _images(w, classes):
     cap = 2 * (WP_FL + 6 * TILE_FL + 2000 + 480) + CS_FL + TAPS_FL + 64
     buf = np.zeros(cap, np.float32)
     nm = C.create_string_buffer(256)
-    for st in range(ns.value + 1):     # (the image hook counts the stem and stage2.0 as two steps even where they are one launch)
+    n_view = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), -1, None, 0, None, 0)    # steps of the image view (yfv2.h: the stem and stage2.0
+    assert ns.value <= n_view <= ns.value + 1                                                # are two steps there even where they are one launch)
+    for st in range(n_view):
         n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st, nm, 256, buf.ctypes.data_as(C.c_void_p), cap)
-        if n < 0:
-            break
+        assert n >= 0, st
         out[nm.value.decode()] = buf[:max(n, 0)].copy()
         for job in range(4):                                                    # launches that run several tower halves: each half's own image
             n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st + 1000 * (job + 1), nm, 256, buf.ctypes.data_as(C.c_void_p), cap)

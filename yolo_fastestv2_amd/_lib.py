@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # YFV2_LIB: opt-in override used only for same-box A/B of two builds (tools/gpu_quick.sh)
 LIB_PATH = os.environ.get("YFV2_LIB") or os.path.join(_HERE, "libyfv2.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_DET = 300
 
 OK, ERR_ARG, ERR_CONFIG, ERR_DEVICE, ERR_WEIGHTS, ERR_STATE, ERR_BATCH, ERR_RANGE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -20,6 +20,44 @@ OK, ERR_ARG, ERR_CONFIG, ERR_DEVICE, ERR_WEIGHTS, ERR_STATE, ERR_BATCH, ERR_RANG
 class Config(C.Structure):
     _fields_ = [("classes", C.c_int32), ("anchor_num", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
                 ("anchors", C.c_double * 12), ("max_batch", C.c_int32), ("device", C.c_int32)]
+
+
+class Plan(C.Structure):
+    """yfv2_plan (include/yfv2.h): WHICH kernels compute the path.  All zero = the default plan."""
+    _fields_ = [("struct_size", C.c_int32), ("fp32_matrix", C.c_int32), ("layer_by_layer", C.c_int32), ("post_two_launches", C.c_int32),
+                ("front_two_launches", C.c_int32), ("towers_unpaired", C.c_int32), ("lanes", C.c_int32), ("trace", C.c_int32), ("trace_step", C.c_int32)]
+
+
+PLAN_FIELDS = ("fp32_matrix", "layer_by_layer", "post_two_launches", "front_two_launches", "towers_unpaired", "lanes", "trace", "trace_step")
+
+
+def make_plan(plan=None):
+    """dict (or None) -> Plan.  Unknown keys are an error: a misspelt switch must not silently select the default plan."""
+    p = Plan()
+    p.struct_size = C.sizeof(Plan)
+    p.trace_step = -1
+    for k, v in (plan or {}).items():
+        if k not in PLAN_FIELDS:
+            raise ValueError("unknown plan switch %r (known: %s)" % (k, ", ".join(PLAN_FIELDS)))
+        setattr(p, k, int(v))
+    return p
+
+
+def plan_from_env(env=None):
+    """The plan the measurement tools and the fallback-plan tests ask for through THEIR environment (the library itself reads none):
+    YFV2_BF6=0 -> fp32_matrix, YFV2_FUSED=0 -> layer_by_layer, YFV2_POSTFUSE=0 -> post_two_launches, YFV2_FRONT=0 -> front_two_launches,
+    YFV2_TPAIR=0 -> towers_unpaired, YFV2_LANES=N -> lanes, YFV2_TRACE=1 [YFV2_TRACE_STEP=k] -> trace [trace_step]."""
+    env = os.environ if env is None else env
+    off = lambda k: 1 if env.get(k, "1")[:1] == "0" else 0
+    plan = {"fp32_matrix": off("YFV2_BF6"), "layer_by_layer": off("YFV2_FUSED"), "post_two_launches": off("YFV2_POSTFUSE"),
+            "front_two_launches": off("YFV2_FRONT"), "towers_unpaired": off("YFV2_TPAIR")}
+    if env.get("YFV2_LANES"):
+        plan["lanes"] = int(env["YFV2_LANES"])
+    if env.get("YFV2_TRACE", "")[:1] == "1":
+        plan["trace"] = 1
+        if env.get("YFV2_TRACE_STEP"):
+            plan["trace_step"] = int(env["YFV2_TRACE_STEP"])
+    return plan
 
 
 class TensorDesc(C.Structure):
@@ -40,6 +78,7 @@ _PROTOTYPES = {
     # name: (restype, argtypes)
     "yfv2_abi_version": (C.c_int, []),
     "yfv2_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config)]),
+    "yfv2_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config), C.POINTER(Plan)]),
     "yfv2_destroy": (None, [C.c_void_p]),
     "yfv2_last_error": (C.c_char_p, [C.c_void_p]),
     "yfv2_load_weights": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_int32]),
@@ -70,7 +109,9 @@ _PROTOTYPES = {
     "yfv2_sgd_step_multi": (C.c_int, [C.c_void_p, C.POINTER(SgdItem), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "yfv2_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "yfv2_debug_plan_dryrun": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "yfv2_debug_plan_dryrun_ex": (C.c_int, [C.c_void_p, C.POINTER(Plan), C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "yfv2_debug_plan_image": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "yfv2_debug_plan_image_ex": (C.c_int64, [C.c_void_p, C.POINTER(Plan), C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64]),
     "yfv2_debug_plan_c2_label": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "yfv2_num_rows": (C.c_int32, [C.c_void_p]),
     "yfv2_num_stages": (C.c_int32, [C.c_void_p]),

@@ -87,12 +87,13 @@ struct yfv2_ctx {
   bool front_wanted = true;    // YFV2_FRONT=0 at create time: the two-launch form
   bool front_fused = false;
   Step stem_aside{};
-  const void* last_x = nullptr; int last_B = 0; bool last_u8 = false;
-  bool stem_pp = false;     // the stem writes channel planes for stage2.0's streaming kernels: quad planes [6][H/4][W/4][4] (stem_h3 -> s2h_kernel), pair planes [12][H/4][W/4][2] on the YFV2_BF6=0 plan (stem_px -> s2px kernels)
+  const void* last_x = nullptr; int last_B = 0; bool last_u8 = false;   // the input of the last forward run on THIS handle's workspace (a raw caller pointer: yfv2_debug_activation(0) re-reads it)
+  bool stem_pp = false;     // the stem writes pair planes [12][H/4][W/4][2] for stage2.0 (the fp32-matrix plan: stem_px -> s2px kernels)
   int s2_label[48] = {0};   // logical channel stored in slot 2*pair + element
   int s2_buf[24] = {0};     // which of the two buffers holds pair p
   bool bf6 = true;          // pointwise convs on the bf16 matrix cores where a kernel has that form (YFV2_BF6=0 at create time: fp32 MFMA)
-  bool postfuse = true;     // yfv2_detect: decode + NMS as one launch (YFV2_POSTFUSE=0 at create time: two launches)
+  yfv2_plan plan_sw{};      // the caller's plan switches (yfv2_create_ex); the library reads no environment
+  bool postfuse = true;     // yfv2_detect: decode + NMS as one launch (yfv2_plan.post_two_launches: two launches)
   bool c2_permuted = false; // stage 3's output (C2) is stored in the chain kernel's order:
   int c2_label[96] = {0};   //   physical channel position k holds logical channel c2_label[k]
   Buf logits[6];
@@ -1003,9 +1004,9 @@ struct PlanBuilder {
                 const int* pp_buf = nullptr, long long pp_bufstride = 0, const int* in_label = nullptr) {
     Folded f;
     const int oh = H / 2, ow = W / 2, co = 2 * cin;
-    const char* env = std::getenv("YFV2_FUSED");
+    const bool layer_plan = h->plan_sw.layer_by_layer != 0;
     const int rfused = (cin == 24 || cin == 48 || (cin == 96 && !pp_label && h->bf6)) ? yfv2_block_s2_rows(cin, H, W) : 0;   // 96: block_s2w_kernel (its pw1 is bf16x6 only)
-    if (!(env && env[0] == '0') && rfused > 0) {
+    if (!layer_plan && rfused > 0) {
       Folded f1, fd, f2, fpd, fpp;
       ok &= wp.dw(p + ".branch_proj.0", p + ".branch_proj.1", cin, 3, &fpd);
       ok &= wp.pw(p + ".branch_proj.2", p + ".branch_proj.3", cin, cin, &fpp);
@@ -1097,7 +1098,6 @@ struct PlanBuilder {
       }
     }
     s.s2px.in = h->a1.p; s.s2px.act = h->s2pp.p;
-    s.s2px.in_nhwc = stem_nhwc_ ? 1 : 0;
     s.s2px.IH = IH; s.s2px.IW = IW;
     s.s2px.in_stride = 24 * IH * IW; s.s2px.out_stride = 2 * 48 * OH * OW;   // (an image owns both of its stage-2 buffers; this block fills buffer 0)
     s.s2px.in_records = 24 * IH * IW * 4; s.s2px.out_records = 48 * OH * OW * 4;
@@ -1432,10 +1432,7 @@ struct PlanBuilder {
   // ends instead of waiting for the slowest image of the launch (YFV2_TPAIR=0: four launches).  Needs the chained output convs
   // on both towers (anchors + classes <= 96) and a second intermediate buffer (tb: unused on this path otherwise).
   bool pair_level(int H, int W) const {
-    const char* env = std::getenv("YFV2_TPAIR");
-    if (env && env[0] == '0') return false;
-    const char* envf = std::getenv("YFV2_FUSED");
-    if (envf && envf[0] == '0') return false;
+    if (h->plan_sw.towers_unpaired || h->plan_sw.layer_by_layer) return false;
     return yfv2_tower2_supported(H, W) && yfv2_towerh_supported(H, W) && !yfv2_towerh_multi(H, W) && h->cfg.anchor_num + h->cfg.classes <= 96;
   }
 
@@ -1487,8 +1484,7 @@ struct PlanBuilder {
     Folded f;
     const int px = H * W;
     {
-      const char* env = std::getenv("YFV2_FUSED");
-      if (!(env && env[0] == '0') && yfv2_tower2_supported(H, W)) {
+      if (!h->plan_sw.layer_by_layer && yfv2_tower2_supported(H, W)) {
         Folded fd1, fp1, fd2, fp2, fh;
         ok &= wp.dw(p + ".0", p + ".1", 72, 5, &fd1);
         ok &= wp.pw(p + ".3", p + ".4", 72, 72, &fp1);
@@ -1542,7 +1538,6 @@ struct PlanBuilder {
   // towerh_kernel's single-pixel form (maps up to 11x11) runs the four tower halves of a map size in ONE launch (each
   // workgroup: cls a, cls b, reg a, reg b of its image, in the order the separate launches had): runs of four consecutive
   // such steps become one step.
-  bool stem_nhwc_ = false;
   void merge_tower_launches() {
     std::vector<Step> out;
     for (size_t i = 0; i < h->plan.size();) {
@@ -1597,17 +1592,15 @@ struct PlanBuilder {
     const int H = h->cfg.height, W = h->cfg.width;
     int hh = H / 4, ww = W / 4, cin = 24;
     const long long pp_bufstride = 48LL * (H / 8) * (W / 8);   // floats from an image's copy in buffer 0 to its copy in buffer 1 (the image stride is twice that)
-    const char* envf = std::getenv("YFV2_FUSED");
-    const bool fused = !(envf && envf[0] == '0');   // YFV2_FUSED=0: every layer its own launch (the general plan)
+    const bool fused = !h->plan_sw.layer_by_layer;   // yfv2_plan.layer_by_layer: every layer its own launch (the general plan)
     const bool stage2_px = fused && h->s2pp.p && yfv2_s1px_supported(hh / 2, ww / 2) &&
                            yfv2_block_s2_rows(48, hh / 2, ww / 2) > 0;
     // the stem's output for s2h_kernel: [H/4][W/4][24] (a pixel's 96 bytes in one run: every lane group's 16-byte store lands in
     // the same 1.5 KB of a wave's row) - 126 -> 120 us against the quad planes of round 4's first half on the same box, stage2.0
-    // unchanged (72.7 us either way); YFV2_VARIANT bit 1: quad planes.  The YFV2_BF6=0 plan keeps its pair planes.
-    const bool stem_nhwc = stage2_px && h->bf6 && !(yfv2_variant() & 2);
+    // unchanged (72.7 us either way).  The fp32-matrix plan keeps its pair planes.
+    const bool stem_nhwc = stage2_px && h->bf6;
     add_stem(h->a1, stage2_px && !stem_nhwc);
     h->stem_pp = stage2_px && !stem_nhwc;
-    stem_nhwc_ = stem_nhwc;
     h->front_fused = stem_nhwc && h->front_wanted;   // YFV2_FRONT=0: the stem and stage2.0 as two launches (the form every other plan and the uint8 entry points use)
     Buf* stage_bufs[3] = {h->s2, h->s3, h->s4};
     const int repeats[3] = {4, 8, 4};
@@ -1715,12 +1708,12 @@ std::string step_kernel(const Step& st) {
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
       if (st.img_off3 && !st.jobs.empty() && !st.par) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
-      if (st.img_off3 && (st.tw.H > 11 || st.tw.W > 11) && !((st.tw.H | st.tw.W) & 1) && !(yfv2_variant() & 256)) return "towerp_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, even maps up to 22x22
+      if (st.img_off3 && (st.tw.H > 11 || st.tw.W > 11) && !((st.tw.H | st.tw.W) & 1)) return "towerp_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, even maps up to 22x22
       if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
-    case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : ((yfv2_variant() & 32) ? "s3h_kernel" : "s3h2_kernel")) : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
+    case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h2_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");
     case STEP_S1PX: return "s1h_kernel";   // default plan (YFV2_BF6=0: s1px_kernel)
-    case STEP_S2PX: return st.front ? ((yfv2_variant() & 4) ? "front_kernel" : "front2_kernel") : "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel; uint8 input under front: stem_h3u_kernel + s2h_kernel)
+    case STEP_S2PX: return st.front ? "front2_kernel" : "s2h_kernel";   // default plan (YFV2_BF6=0: s2px_proj_kernel + s2px_main_kernel; uint8 input under front: stem_h3u_kernel + s2h_kernel)
     case STEP_S1CHAIN: return "block_s1chain6_kernel";
     case STEP_S1POOL: return "block_s1pool_kernel";
   }
@@ -1736,10 +1729,16 @@ std::string step_kernel(const Step& st) {
 //   YFV2_FRONT=0     the stem and stage2.0 as two launches (stem_h3_kernel, s2h_kernel) instead of front_kernel's one
 //   YFV2_TPAIR=0     the tower halves of a level larger than 11x11 as four launches instead of two side-by-side pairs
 //                                                                                       - read by PlanBuilder::pair_level
-void read_plan_switches(yfv2_ctx* h) {
-  if (const char* e = std::getenv("YFV2_BF6")) h->bf6 = !(e[0] == '0');
-  if (const char* e = std::getenv("YFV2_POSTFUSE")) h->postfuse = !(e[0] == '0');
-  if (const char* e = std::getenv("YFV2_FRONT")) h->front_wanted = !(e[0] == '0');
+void read_plan_switches(yfv2_ctx* h, const yfv2_plan* plan) {
+  h->plan_sw = yfv2_plan{};
+  if (plan) {   // (a caller built against an older, shorter struct: the fields it does not have stay 0)
+    const size_t n = plan->struct_size > 0 && (size_t)plan->struct_size < sizeof(yfv2_plan) ? (size_t)plan->struct_size : sizeof(yfv2_plan);
+    std::memcpy(&h->plan_sw, plan, n);
+  }
+  h->plan_sw.struct_size = (int32_t)sizeof(yfv2_plan);
+  h->bf6 = !h->plan_sw.fp32_matrix;
+  h->postfuse = !h->plan_sw.post_two_launches;
+  h->front_wanted = !h->plan_sw.front_two_launches;
 }
 
 int alloc_buf(yfv2_ctx* h, Buf* b, size_t per_img) {
@@ -1761,6 +1760,10 @@ size_t logit_elems(const yfv2_ctx* h, int i) {
 
 int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6], hipStream_t main_stream, hipEvent_t* ev /*nullable: 2 per step*/,
              int only_step = -1 /* >= 0: this launch alone (yfv2_debug_repeat_step) */) {
+  // the front kernels read the image with 16-byte (fp32) / 12-byte-at-4-byte-alignment (uint8) buffer loads: a base address that
+  // is not so aligned would be read at the wrong offsets without any fault (include/yfv2.h yfv2_forward)
+  if (reinterpret_cast<uintptr_t>(x) & (x_u8 ? 3u : 15u))
+    return fail(h, YFV2_ERR_ARG, x_u8 ? "input images: the uint8 tensor must be 4-byte aligned" : "input images: the fp32 tensor must be 16-byte aligned");
   const float* params = h->d_params;
   const hipStream_t s = main_stream;
   for (size_t i = 0; i < h->plan.size(); ++i) {
@@ -1866,7 +1869,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       a.img[1] = params + st.img_off2;
       a.img16 = h->bf6 ? params + st.img_off3 : nullptr;   // YFV2_BF6=0: the two role kernels on the 4x4x1 fp32 MFMA
       a.nonfinite = h->d_nonfinite;
-      if (st.front && (!x_u8 || !(yfv2_variant() & (4 | 128)))) {   // (uint8 input: front2_kernel only; YFV2_VARIANT bit 128: the two-launch route for it)
+      if (st.front) {
         FrontArgs f{};
         f.x = x; f.H = h->cfg.height; f.W = h->cfg.width; f.u8_in = x_u8 ? 1 : 0;
         f.img_stem = params + h->stem_aside.img_off3;
@@ -1960,8 +1963,7 @@ int setup_ctx(yfv2_ctx* h, const yfv2_config* cfg, int rows, Alloc alloc) {
 constexpr int LANES_DEFAULT = 1, LANES_MAX = 8, LANE_MIN_IMAGES = 32;   // per slice: below that a slice is pure latency (tools/scale_probe.py)
 
 int create_lanes(yfv2_ctx* h) {
-  int n = LANES_DEFAULT;
-  if (const char* e = std::getenv("YFV2_LANES")) n = std::atoi(e);
+  int n = h->plan_sw.lanes > 1 ? h->plan_sw.lanes : LANES_DEFAULT;
   if (h->d_trace || h->in_lane) n = 1;             // cycle stamps are taken on the parent's own launches
   n = n < 1 ? 1 : (n > LANES_MAX ? LANES_MAX : n);
   if (n == 1 || h->cfg.max_batch < n * LANE_MIN_IMAGES) return YFV2_OK;
@@ -1970,8 +1972,10 @@ int create_lanes(yfv2_ctx* h) {
   c.max_batch = (h->cfg.max_batch + n - 1) / n;
   for (int i = 0; i < n; ++i) {
     yfv2_ctx* lane = nullptr;
+    yfv2_plan lp = h->plan_sw;            // a lane runs the parent's plan, without lanes or stamps of its own
+    lp.lanes = 0; lp.trace = 0;
     g_creating_lane = true;
-    const int rc = yfv2_create(&lane, &c);
+    const int rc = yfv2_create_ex(&lane, &c, &lp);
     g_creating_lane = false;
     if (rc) return fail(h, rc, "lane " + std::to_string(i) + ": " + g_tls_error);
     lane->d_nonfinite = h->d_nonfinite;   // the parent's word (its h_nonfinite stays null: only the parent owns and frees it)
@@ -1994,6 +1998,8 @@ int run_lanes(yfv2_ctx* h, int B, hipStream_t s, F f) {
   const int n = (int)h->lanes.size();
   const int per = (B + n - 1) / n;
   h->last_split.clear();
+  h->last_x = nullptr; h->last_B = 0;   // (this call's input is recorded slice by slice on the lanes; yfv2_debug_activation follows last_split - the
+                                        // parent's own record would be a stale pointer)
   HIP_TRY(h, hipEventRecord(h->lane_fork, s));   // nothing is enqueued on a lane stream yet: a plain return is safe here
   int rc = YFV2_OK;
   auto hip_ok = [&](hipError_t e, const char* what) {     // a HIP error inside the fork / join region must NOT return early:
@@ -2045,7 +2051,9 @@ int yfv2_abi_version(void) { return YFV2_ABI_VERSION; }
 
 const char* yfv2_last_error(yfv2_handle h) { return h ? h->err.c_str() : g_tls_error.c_str(); }
 
-int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
+int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) { return yfv2_create_ex(out, cfg, nullptr); }
+
+int yfv2_create_ex(yfv2_handle* out, const yfv2_config* cfg, const yfv2_plan* plan) {
   if (!out || !cfg) return fail(nullptr, YFV2_ERR_ARG, "yfv2_create: null argument");
   *out = nullptr;
   int rows = 0;
@@ -2086,9 +2094,12 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
     yfv2_destroy(h);
     return rc;
   }
-  read_plan_switches(h);
-  if (const char* tr = std::getenv("YFV2_TRACE"))
-    if (tr[0] == '1') { if (const char* ts = std::getenv("YFV2_TRACE_STEP")) h->trace_step = std::atoi(ts); (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long)); (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long)); }
+  read_plan_switches(h, plan);
+  if (h->plan_sw.trace) {
+    h->trace_step = h->plan_sw.trace_step;
+    (void)hipMalloc(reinterpret_cast<void**>(&h->d_trace), 8192 * sizeof(long long));
+    (void)hipMemset(h->d_trace, 0, 8192 * sizeof(long long));
+  }
   if (int rc2 = create_lanes(h)) { g_tls_error = h->err; yfv2_destroy(h); return rc2; }
   *out = h;
   return YFV2_OK;
@@ -2098,6 +2109,10 @@ int yfv2_create(yfv2_handle* out, const yfv2_config* cfg) {
 // yfv2_create + yfv2_load_weights do, but without a device - the workspace gets made-up addresses that are only ever
 // used for pointer arithmetic.  Reports the number of launches and the size of the packed parameter blob.
 int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t* n_steps, int64_t* blob_floats) {
+  return yfv2_debug_plan_dryrun_ex(cfg, nullptr, tensors, n, n_steps, blob_floats);
+}
+
+int yfv2_debug_plan_dryrun_ex(const yfv2_config* cfg, const yfv2_plan* plan, const yfv2_tensor_desc* tensors, int32_t n, int32_t* n_steps, int64_t* blob_floats) {
   if (!cfg || !tensors || n <= 0) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_dryrun: bad argument");
   int rows = 0;
   if (int rc = check_config(cfg, &rows)) return rc;
@@ -2110,7 +2125,7 @@ int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tenso
     return (int)YFV2_OK;
   };
   setup_ctx(&ctx, cfg, rows, fake);
-  read_plan_switches(&ctx);
+  read_plan_switches(&ctx, plan);
   WeightPacker wp;
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
@@ -2129,7 +2144,12 @@ int yfv2_debug_plan_dryrun(const yfv2_config* cfg, const yfv2_tensor_desc* tenso
 // numpy model of a kernel's dataflow.  Returns the number of floats copied or a negative error code.
 int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* tensors, int32_t n, int32_t step, char* name, int32_t name_cap,
                               float* dst, int64_t cap) {
-  if (!cfg || !tensors || n <= 0 || !dst || cap <= 0) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: bad argument");
+  return yfv2_debug_plan_image_ex(cfg, nullptr, tensors, n, step, name, name_cap, dst, cap);
+}
+
+int64_t yfv2_debug_plan_image_ex(const yfv2_config* cfg, const yfv2_plan* plan, const yfv2_tensor_desc* tensors, int32_t n, int32_t step, char* name,
+                                 int32_t name_cap, float* dst, int64_t cap) {
+  if (!cfg || !tensors || n <= 0 || (step != -1 && (!dst || cap <= 0))) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: bad argument");
   int rows = 0;
   if (int rc = check_config(cfg, &rows)) return rc;
   yfv2_ctx ctx;
@@ -2141,7 +2161,7 @@ int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* te
     return (int)YFV2_OK;
   };
   setup_ctx(&ctx, cfg, rows, fake);
-  read_plan_switches(&ctx);
+  read_plan_switches(&ctx, plan);
   WeightPacker wp;
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
@@ -2155,6 +2175,7 @@ int64_t yfv2_debug_plan_image(const yfv2_config* cfg, const yfv2_tensor_desc* te
   // put back in front and stage2.0 answers to its own name - step indices are those of the two-launch plan
   std::vector<Step> view = ctx.plan;
   if (ctx.front_fused) { view.insert(view.begin(), ctx.stem_aside); view[1].name = view[1].name_plain; }
+  if (step == -1) return (int64_t)view.size();   // the number of steps of THIS index space (launch plan + 1 where the front is one launch)
   if (step < 0 || step >= (int32_t)view.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: step out of range");
   if (job >= (int)view[step].jobs.size()) return fail(nullptr, YFV2_ERR_ARG, "yfv2_debug_plan_image: job out of range");
   const Step& st = job >= 0 ? view[step].jobs[job] : view[step];
@@ -2180,7 +2201,7 @@ int yfv2_debug_plan_c2_label(const yfv2_config* cfg, const yfv2_tensor_desc* ten
     return (int)YFV2_OK;
   };
   setup_ctx(&ctx, cfg, rows, fake);
-  read_plan_switches(&ctx);
+  read_plan_switches(&ctx, nullptr);
   WeightPacker wp;
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) wp.byname[tensors[i].name] = &tensors[i];
@@ -2735,19 +2756,6 @@ int64_t yfv2_debug_activation(yfv2_handle h, int32_t which, int32_t B, float* ho
     a.nonfinite = h->d_nonfinite;
     if (hipDeviceSynchronize() != hipSuccess) { fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: synchronize failed"); return YFV2_ERR_DEVICE; }
     yfv2_launch_stem(a, nullptr);
-  }
-  if (which == 0 && h->stem_pp && h->bf6) {  // stem output in quad planes [6][PH*PW][4] (stem_h3 / stem_h3u kernels) -> NHWC
-    const size_t per = h->dbg_per_img[0], hw = per / 24;
-    std::vector<float> tmp((size_t)n);
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(tmp.data(), h->dbg[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
-      fail(h, YFV2_ERR_DEVICE, "yfv2_debug_activation: copy failed");
-      return YFV2_ERR_DEVICE;
-    }
-    for (int b = 0; b < B; ++b)
-      for (int q = 0; q < 6; ++q)
-        for (size_t px = 0; px < hw; ++px)
-          for (int e = 0; e < 4; ++e) host_dst[((size_t)b * hw + px) * 24 + 4 * q + e] = tmp[(size_t)b * per + ((size_t)q * hw + px) * 4 + e];
-    return n;
   }
   if (which == 0 && h->stem_pp) {  // stem output in pair planes [12][PH*PW][2] (stem_px_kernel, YFV2_BF6=0) -> NHWC
     const size_t per = h->dbg_per_img[0], hw = per / 24;

@@ -1553,8 +1553,6 @@ static size_t s2w_lds_floats(int R, int W) {
 // rows per work item of the 96-channel kernel: the largest band that fits LDS and the staging registers and keeps pw1
 // at one tile per wave (<= 128 pixels) when any band does; 0 = not supported
 static int s2w_rows(int H, int W) {
-  const char* env = std::getenv("YFV2_S2W");
-  if (env && env[0] == '0') return 0;
   if ((H & 1) || (W & 1)) return 0;
   const int OH = H / 2;
   int best = 0, best128 = 0;

@@ -408,9 +408,9 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
     // the default (pre-split fp16x3) form as 1024-thread workgroups with ONE pixel tile per wave: 16 waves per CU instead of 8 hide
     // more of the one-chunk-pair look-ahead's latency (32.3 -> 30.6 us same box; 115 registers).  Not faster: two tiles per wave
     // at 1024 threads (28 spilled registers), four tiles per wave at 512 (the same 31 us), and a form with a tile's whole K in
-    // flight in two register sets (pwf_kernel, round 4: 32.0 us - the launch is not bound by that latency).  YFV2_VARIANT bit 0:
-    // the 512-thread form.
-    if (K == 288 && MT == 5 && !(yfv2_variant() & 1) && a.bf6 && a.presplit) { pw_launch<288, 5, 1, PW_FPN, 1024, true>(a, s); return true; }
+    // flight in two register sets (pwf_kernel, round 4: 32.0 us - the launch is not bound by that latency).  The fp32-matrix plan
+    // runs the 512-thread form below.
+    if (K == 288 && MT == 5 && a.bf6 && a.presplit) { pw_launch<288, 5, 1, PW_FPN, 1024, true>(a, s); return true; }
     if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }
   } else if (mode == PW_HEAD) {
     if (K == 72 && MT == 1) { pw_launch<72, 1, 4, PW_HEAD>(a, s); return true; }

@@ -4,8 +4,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define YFV2_VARIANT_DEFAULT 0
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));   // three floats at any dword address (global_load/store_dwordx3)
@@ -17,23 +15,6 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 #ifdef __HIPCC__
 __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 #endif
-
-// Kernel-variant switches for same-box A/B measurements (YFV2_VARIANT = bit mask, read once per process; unset = 0 = the defaults):
-//   1  fpn.conv1x1_2 (pw_kernel<288>) as 512-thread workgroups with two pixel tiles per wave (the form up to round 4)
-//   2  the stem writes quad planes [6][H/4][W/4][4] for s2h_kernel instead of [H/4][W/4][24] (round 4's first form)
-//   4  front_kernel (stem + stage2.0 in one wave, everything in registers, one wave per SIMD) instead of front2_kernel
-//   8 / 16  experiment forms of the front kernels: conv-row-wise refill of front_kernel's two input sets / no loads at all
-//   32 s3h_kernel (stage3.0 at one wave per SIMD, four units per image) instead of s3h2_kernel
-//   64 stage4.0 as two (strip, band) units x two roles per image (round 4's form) instead of three main waves + one proj wave
-//   128 uint8 input: stem_h3u_kernel + s2h_kernel instead of front2_kernel<.., U8>
-// (measured and removed in round 4, DESIGN.md 4.10: s1h / stem at four waves per SIMD by launch bound - the spills cost more than
-// the occupancy gives, 31 -> 44 us and 115 -> 131 us; non-temporal input loads in stem / s2h / s1h / s3h - the consumer of a
-// streamed tensor slows down, s2h 73 -> 98 us)
-#include <cstdlib>
-inline int yfv2_variant() {
-  static const int v = [] { const char* e = std::getenv("YFV2_VARIANT"); return e ? std::atoi(e) : YFV2_VARIANT_DEFAULT; }();
-  return v;
-}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-(function, device) attribute: raise it to the 160 KiB cap the first
 // time a function is launched on each device (`done` = the call site's bit mask of devices already served).
@@ -137,21 +118,6 @@ struct Yfv2Watch {
 };
 #endif
 
-// A 16-byte BUFFER store whose soffset is an SGPR needs wait states before a VALU instruction overwrites its data registers.
-// Round 4, measured (two handles on two streams, uint8 input: element 0 of the store of lanes 12..15 of every lane group came
-// back holding the NEXT value of that register, in 4-5 of 12 runs; never with one kernel on the machine at a time): hipcc put
-//     buffer_store_dwordx4 v[2:5], v63, s[12:15], s19 offen ; v_max3_f32 v2, v1, v10, 0
-// back to back at the end of stem_h3u_kernel.  LLVM's hazard recognizer covers "VMEM store of more than 64 bits, then a VALU
-// write of its data" only when soffset is NOT a register (GCNHazardRecognizer::createsVALUHazard); with a register soffset it
-// assumes the hardware is safe, and under back-pressure from a second kernel's memory traffic it is not.  Every such store is
-// followed by yfv2_after_wide_buffer_store(): four wait states nothing may be scheduled into.
-#ifdef __HIPCC__
-__device__ __forceinline__ void yfv2_after_wide_buffer_store() {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 3" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-#endif
 
 // ---- stem: conv3x3 s2 (3->24) + BN + ReLU + maxpool3x3 s2, NCHW in -> NHWC out
 struct StemArgs {
@@ -297,7 +263,6 @@ struct S2PxArgs {
   int st1_off[2][8];   // per role: byte offsets (plane + element) of output positions 16..23 (4-byte stores)
   const float* img16;  // s2h_kernel's image (yfv2_stage2h.hip, WeightPacker::image_s2h: both branches in one wave); null: the two role kernels
   int* nonfinite;      // range-guard word (Yfv2Watch), or null
-  int in_nhwc;         // s2h_kernel: the stem's output is [IH][IW][24] instead of quad planes
 };
 // stem + stage2.0 in one wave (front_kernel, yfv2_stage2h.hip): the fp32 input image straight to stage 2's pair planes
 struct FrontArgs {
@@ -305,7 +270,7 @@ struct FrontArgs {
   int H, W;
   int u8_in;
   const float* img_stem; // WeightPacker::image_stem16
-  S2PxArgs s2;           // as for s2h_kernel (IH x IW = H/4 x W/4; in / in_nhwc unused)
+  S2PxArgs s2;           // as for s2h_kernel (IH x IW = H/4 x W/4; in unused)
 };
 void yfv2_launch_front(const FrontArgs& a, hipStream_t s);
 void yfv2_launch_s2px(const S2PxArgs& a, hipStream_t s);   // a.img16 set: yfv2_launch_s2h (one kernel); else two kernels (proj role, main role)

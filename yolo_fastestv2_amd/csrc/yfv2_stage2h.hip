@@ -296,20 +296,18 @@ __global__ __launch_bounds__(64, 2) void s2h_kernel(S2PxArgs a) {
   const f32x4 bip[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 32 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 48 + 4 * g)};
   const f32x4 bi2[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 64 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 80 + 4 * g)};
   const float unscale_p = img[S2H_CST + 96], unscale_2 = img[S2H_CST + 97];
-  // input: the stem's QUAD planes [6][IH][IW][4] (round 4; yfv2_stem16.hip) - this lane's eight channel positions are plane g
-  // (all lane groups: the stem's channel tile 0) and plane 4 + g (lane groups 0, 1: tile 1), two adjacent pixels of each
+  // input: the stem's [IH][IW][24] (a pixel's 96 bytes in one run; yfv2_stem16.hip) - this lane's eight channel positions are the
+  // 16-byte pieces g (all lane groups: the stem's channel tile 0) and 4 + g (lane groups 0, 1: tile 1) of two adjacent pixels
   int loff[2], soff[8];
-  // (a.in_nhwc: [IH][IW][24] - a pixel's 96 bytes in one run: the same 16-byte pieces at other offsets)
-  const int nhwc = a.in_nhwc;
-  loff[0] = xok ? (nhwc ? 2 * ox * 96 + 16 * g : (g * IH * IW + 2 * ox) * 16) : OOB;
-  loff[1] = (xok && g < 2) ? (nhwc ? 2 * ox * 96 + 64 + 16 * g : ((4 + g) * IH * IW + 2 * ox) * 16) : OOB;
-  const int coff = nhwc ? 96 : 16;                 // the lane's second pixel
+  loff[0] = xok ? 2 * ox * 96 + 16 * g : OOB;
+  loff[1] = (xok && g < 2) ? 2 * ox * 96 + 64 + 16 * g : OOB;
+  constexpr int coff = 96;                         // the lane's second pixel
   {
     const int* po = reinterpret_cast<const int*>(img + S2H_OFFS);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int v = po[(4 + k) * 64 + lane]; soff[k] = (st_lane && v != OOB) ? v + ox * 8 : OOB; }
   }
-  const int irowb = nhwc ? IW * 96 : IW * 16, orowb = OW * 8;
+  const int irowb = IW * 96, orowb = OW * 8;
 
   // one input row: X[2t + c] = the four channel positions 4t .. 4t+3 of column 2ox + c, times 2^4 later - four 16-byte loads
   auto load_row = [&](int iy, f32x4 (&X)[4]) {
@@ -438,9 +436,7 @@ void yfv2_launch_s2h(const S2PxArgs& a0, hipStream_t s) {
 // depthwise's dx = 0 tap); lane 0 stores nothing (the halo lane of s2h_kernel).  Pooled rows are produced in exactly the order
 // the block consumes them (2 y0 - 1, 2 y0, ..): none is ever held beside another.  Every value goes through the same
 // instructions on the same operands in the same order as in stem_h3_kernel + s2h_kernel: the results are bit-identical
-// (tests/test_gpu_parity.py compares the two plans).  State: both kernels' (filters, taps, carried rows) plus two sets of eight
-// 16-byte input buffers - the kernel runs ONE wave per SIMD (launch bound) and hides its load latency behind its own arithmetic
-// (~5.4 k issue cycles per output row against ~1.3 k for the loads of the next one).
+// (tests/test_gpu_parity.py compares the two plans).
 namespace {
 struct FCol { unsigned p01[2], p23[2], m[2]; };   // a 16-byte run of one input row, both fp16 terms: (v0, v1), (v2, v3); m: high half = the column left of v0
 __device__ __forceinline__ unsigned f_dpp_shr1_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
@@ -482,274 +478,11 @@ __device__ __forceinline__ void f_conv_col(const FCol& x0, const FCol& x1, const
 }
 }  // namespace
 
-template <int V>   // experiment bits: 1 = every conv row's buffers are refilled right behind the conv row that used them; 2 = no loads at all (the arithmetic alone)
-__global__ __launch_bounds__(64, 1) void front_kernel(FrontArgs fa) {
-  const S2PxArgs& a = fa.s2;
-  const int IH = a.IH, IW = a.IW, OH = IH >> 1, OW = IW >> 1;      // IH x IW = the pooled map the stem produces (H/4 x W/4)
-  const int H = fa.H, W = fa.W;
-  const int nstrips = a.nstrips, nb = a.nb, R = a.R;
-  const int wpi = nstrips * nb;
-  const int nwg = gridDim.x;
-  const int wid = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
-  const int b = __builtin_amdgcn_readfirstlane(wid / wpi), wi = __builtin_amdgcn_readfirstlane(wid - b * wpi);
-  const int strip = wi % nstrips, band = wi / nstrips;
-  const int lane = threadIdx.x, l = lane & 15, g = lane >> 4;
-  const int ox = 15 * strip + l;
-  const bool xok = ox < OW;
-  const bool st_lane = xok && (l > 0 || strip == 0);
-  const int y0 = band * R, y1 = min(OH, y0 + R);
-  constexpr int OOB = (int)0x80000000;
 
-  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)fa.x + (size_t)b * 3 * H * W * 4), 0, 3 * H * W * 4, 0x00020000);
-  __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.act + (size_t)b * a.out_stride), 0, a.out_records, 0x00020000);
-  // ---- stage2.0's state (s2h_kernel)
-  const float* img = a.img16;
-  yfv2_h8 w1[2][2], wp[2][2], w2[2][2];
-  {
-    const u32x4* q = reinterpret_cast<const u32x4*>(img);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        w1[t][k] = __builtin_bit_cast(yfv2_h8, q[(S2H_W1 / 4) + (t * 2 + k) * 64 + lane]);
-        wp[t][k] = __builtin_bit_cast(yfv2_h8, q[(S2H_WP / 4) + (t * 2 + k) * 64 + lane]);
-        w2[t][k] = __builtin_bit_cast(yfv2_h8, q[(S2H_W2 / 4) + (t * 2 + k) * 64 + lane]);
-      }
-  }
-  Yfv2Watch watch;
-  float tm[18], tp[18];
-#pragma unroll
-  for (int q = 0; q < 18; ++q) { tm[q] = img[S2H_TM + q * 64 + lane]; tp[q] = img[S2H_TP + q * 64 + lane]; }
-  const f32x4 sh1[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 16 + 4 * g)};
-  const f32x4 bip[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 32 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 48 + 4 * g)};
-  const f32x4 bi2[2] = {*reinterpret_cast<const f32x4*>(img + S2H_CST + 64 + 4 * g), *reinterpret_cast<const f32x4*>(img + S2H_CST + 80 + 4 * g)};
-  const float unscale_p = img[S2H_CST + 96], unscale_2 = img[S2H_CST + 97];
-  int soff[8];
-  {
-    const int* po = reinterpret_cast<const int*>(img + S2H_OFFS);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { const int v = po[(4 + k) * 64 + lane]; soff[k] = (st_lane && v != OOB) ? v + ox * 8 : OOB; }
-  }
-  const int orowb = OW * 8;
-  // ---- the stem's state (stem_h3_kernel): filter [tile 2][term 2][64 lanes][4 dwords], shift x 2^(sw+8) [32], 2^-(sw+8)
-  yfv2_h8 wa[2][2];
-  {
-    const u32x4* wimg = reinterpret_cast<const u32x4*>(fa.img_stem);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) wa[t][k] = __builtin_bit_cast(yfv2_h8, wimg[(t * 2 + k) * 64 + lane]);
-  }
-  const float* cst = fa.img_stem + 2 * 2 * 64 * 4;
-  const f32x4 ssh0 = *reinterpret_cast<const f32x4*>(cst + 4 * g), ssh1 = *reinterpret_cast<const f32x4*>(cst + 16 + 4 * g);
-  const float sunscale = cst[32];
-  const int rowb = W * 4;
-  const int chan_off = (xok && g < 3 && !(V & 2)) ? g * H * rowb + 8 * ox * 4 : OOB;     // lane groups 0..2: input channel g, columns 8 ox .. 8 ox + 7
-  const int src0 = (0 * 16 + l) * 4, src1 = (1 * 16 + l) * 4, src2 = (2 * 16 + l) * 4;   // ds_bpermute byte addresses of lanes (l, 0..2)
-  const int hlast = H - 1;
-
-  // input rows 4 r .. 4 r + 3 (the two conv rows of pooled row r), columns A | B: eight 16-byte loads
-  struct InSet { f32x4 a[4], b[4]; };
-  auto issue_half = [&](int r, InSet& s, int hf) {
-#pragma unroll
-    for (int i = 2 * hf; i < 2 * hf + 2; ++i) {
-      const int row = min(4 * r + i, hlast);
-      const int off = chan_off != OOB ? chan_off + row * rowb : OOB;
-      s.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-      s.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
-    }
-  };
-  auto issue = [&](int r, InSet& s) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = min(4 * r + i, hlast);          // (a row past the image: a re-read that stays in range, never used)
-      const int off = chan_off != OOB ? chan_off + row * rowb : OOB;
-      s.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-      s.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
-    }
-  };
-  // one conv row of both pooled columns from the carried rows (cA, cB) and the fresh rows r1 (2c), r2 (2c + 1) -> horizontally
-  // pooled raw values (BN shift inside, pre-ReLU, x 2^(sw+8)); cA, cB <- the split row 2c + 1
-  auto conv_row2 = [&](FCol& cA, FCol& cB, f32x4 r1A, f32x4 r2A, f32x4 r1B, f32x4 r2B, f32x4 (&hA)[2], f32x4 (&hB)[2]) {
-    {   // lane group 3: tap (2, 2) of the three channels = columns + 1 | + 3 of row 2c + 1, out of the registers of lanes (l, 0..2)
-      const int a1 = f_f2i(r2A[1]), a3 = f_f2i(r2A[3]), b1 = f_f2i(r2B[1]), b3 = f_f2i(r2B[3]);
-      const int e0 = __builtin_amdgcn_ds_bpermute(src0, a1), e1 = __builtin_amdgcn_ds_bpermute(src1, a1), e2 = __builtin_amdgcn_ds_bpermute(src2, a1);
-      const int q0 = __builtin_amdgcn_ds_bpermute(src0, a3), q1 = __builtin_amdgcn_ds_bpermute(src1, a3), q2 = __builtin_amdgcn_ds_bpermute(src2, a3);
-      const int f0 = __builtin_amdgcn_ds_bpermute(src0, b1), f1 = __builtin_amdgcn_ds_bpermute(src1, b1), f2 = __builtin_amdgcn_ds_bpermute(src2, b1);
-      const int u0 = __builtin_amdgcn_ds_bpermute(src0, b3), u1 = __builtin_amdgcn_ds_bpermute(src1, b3), u2 = __builtin_amdgcn_ds_bpermute(src2, b3);
-      if (g == 3) {
-        r1A = (f32x4){f_i2f(e0), f_i2f(e1), f_i2f(q0), f_i2f(q1)};
-        r2A = (f32x4){f_i2f(e2), 0.f, f_i2f(q2), 0.f};
-        r1B = (f32x4){f_i2f(f0), f_i2f(f1), f_i2f(u0), f_i2f(u1)};
-        r2B = (f32x4){f_i2f(f2), 0.f, f_i2f(u2), 0.f};
-      }
-    }
-    FCol x1A, x2A, x1B, x2B;
-    f_split(r1A, x1A); f_split(r2A, x2A); f_split(r1B, x1B); f_split(r2B, x2B);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      x1A.m[k] = f_dpp_shr1_u(x1B.p23[k]); x2A.m[k] = f_dpp_shr1_u(x2B.p23[k]);   // the column left of A: the left lane's B
-      x1B.m[k] = x1A.p23[k]; x2B.m[k] = x2A.p23[k];                               // the column left of B: this lane's A
-    }
-    f32x4 aeA[2], aoA[2], aeB[2], aoB[2];
-    f_conv_col(cA, x1A, x2A, wa, ssh0, ssh1, aeA, aoA);
-    f_conv_col(cB, x1B, x2B, wa, ssh0, ssh1, aeB, aoB);
-    cA = x2A; cB = x2B;
-    watch.see(aeA[0][0]); watch.see(aoA[0][0]); watch.see(aeB[0][0]); watch.see(aoB[0][0]);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {   // 0 from the DPP at the image's left edge stands for the -inf padding: ReLU follows the pooling
-        hA[t][e] = __builtin_fmaxf(__builtin_fmaxf(f_dpp_shr1_f(aoB[t][e]), aeA[t][e]), aoA[t][e]);
-        hB[t][e] = __builtin_fmaxf(__builtin_fmaxf(aoA[t][e], aeB[t][e]), aoB[t][e]);
-      }
-  };
-  FCol cA, cB;
-  f32x4 upA[2], upB[2];
-  // pooled row from its input set -> X[2 t + c] as s2h_kernel's load_row delivers it
-  auto pooled = [&](InSet& s, f32x4 (&X)[4], int rnext) {
-    f32x4 h0A[2], h0B[2], h1A[2], h1B[2];
-    conv_row2(cA, cB, s.a[0], s.a[1], s.b[0], s.b[1], h0A, h0B);
-    if constexpr (V & 1) { __builtin_amdgcn_sched_barrier(0); issue_half(rnext, s, 0); __builtin_amdgcn_sched_barrier(0); }
-    conv_row2(cA, cB, s.a[2], s.a[3], s.b[2], s.b[3], h1A, h1B);
-    if constexpr (V & 1) { __builtin_amdgcn_sched_barrier(0); issue_half(rnext, s, 1); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float mA = __builtin_fmaxf(__builtin_fmaxf(upA[t][e], h0A[t][e]), h1A[t][e]);
-        const float mB = __builtin_fmaxf(__builtin_fmaxf(upB[t][e], h0B[t][e]), h1B[t][e]);
-        X[2 * t][e] = __builtin_fmaxf(mA, 0.f) * sunscale;
-        X[2 * t + 1][e] = __builtin_fmaxf(mB, 0.f) * sunscale;
-      }
-      upA[t] = h1A[t]; upB[t] = h1B[t];
-    }
-    if (g >= 2 || !xok) { X[2] = (f32x4){0.f, 0.f, 0.f, 0.f}; X[3] = X[2]; }   // channel tile 1 holds channels 16..23 in lane groups 0, 1
-    if (!xok) { X[0] = X[2]; X[1] = X[2]; }
-  };
-
-  // ---- stage2.0's row machinery (s2h_kernel)
-  auto columns = [&](const f32x4 (&X)[4], float lim, float (&xe)[8], float (&xo)[8], float (&te)[8], float (&to)[8]) {
-    f32x2 ine[4], ino[4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const f32x4 ve = X[2 * t] * 16.0f, vo = X[2 * t + 1] * 16.0f;
-      ine[2 * t] = (f32x2){ve[0], ve[1]}; ine[2 * t + 1] = (f32x2){ve[2], ve[3]};
-      ino[2 * t] = (f32x2){vo[0], vo[1]}; ino[2 * t + 1] = (f32x2){vo[2], vo[3]};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { xe[4 * t + e] = ve[e]; xo[4 * t + e] = vo[e]; }
-    }
-    f32x4 ae[2], ao[2];
-    pw_h3(w1, ine, sh1, ae, watch);
-    pw_h3(w1, ino, sh1, ao, watch);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      te[c] = __builtin_amdgcn_fmed3f(ae[c >> 2][c & 3], 0.f, lim);
-      to[c] = __builtin_amdgcn_fmed3f(ao[c >> 2][c & 3], 0.f, lim);
-    }
-  };
-#define YFV2_TQ(T, c, t) T[((c) * 9 + (t)) >> 2]
-#define YFV2_TK(c, t) (((c) * 9 + (t)) & 3)
-  auto acc_row = [&](auto dyc, const float (&T)[18], const float (&v0)[8], const float (&v1)[8], float (&S)[8], float (&Q)[8]) {
-    constexpr int DY = decltype(dyc)::value;
-    [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
-      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(T, Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(T, Cs, 0), v1[Cs]),
-                         quad_fmac1<YFV2_TK(Cs, 2)>(S[Cs], YFV2_TQ(T, Cs, 2), v1[Cs]))
-                : (void)quad_fmac3<YFV2_TK(Cs, DY * 3 + 1), YFV2_TK(Cs, DY * 3), YFV2_TK(Cs, DY * 3 + 2)>(
-                      S[Cs], Q[Cs], YFV2_TQ(T, Cs, DY * 3 + 1), YFV2_TQ(T, Cs, DY * 3), YFV2_TQ(T, Cs, DY * 3 + 2), v0[Cs], v1[Cs])), ...);
-    }(std::make_integer_sequence<int, 8>{});
-  };
-
-  InSet s0, s1;
-  f32x4 P[4];
-  float cxe[8], cxo[8], cte[8], cto[8];            // the odd pooled row above the current output row (dy = 0): raw and pw1'd
-  const float limx = xok ? __builtin_inff() : 0.f;
-  {
-    const int r0 = 2 * y0 - 1;                      // the first pooled row this band needs
-    if (r0 > 0) {
-      // the conv row above pooled row r0 (2 r0 - 1: input rows 4 r0 - 3 .. 4 r0 - 1) gives the carried maxima and the carried split row
-      issue(r0 - 1, s1);                            // rows 4 r0 - 4 .. 4 r0 - 1 (the first of them is not needed)
-      issue(r0, s0);
-      f_split(s1.a[1], cA); f_split(s1.b[1], cB);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) { cA.m[k] = f_dpp_shr1_u(cB.p23[k]); cB.m[k] = cA.p23[k]; }
-      conv_row2(cA, cB, s1.a[2], s1.a[3], s1.b[2], s1.b[3], upA, upB);
-      issue(r0 + 1, s1);
-      __builtin_amdgcn_sched_barrier(0);
-      pooled(s0, P, r0 + 2);
-      columns(P, limx, cxe, cxo, cte, cto);
-      if constexpr (!(V & 1)) issue(r0 + 2, s0);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      // band 0: pooled row -1 is the block's zero padding; the stem starts above the image (zero carried row, zero maxima: the
-      // post-ReLU equivalent of the max-pool's padding)
-      issue(0, s1);
-      f_split((f32x4){0.f, 0.f, 0.f, 0.f}, cA); cB = cA;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) { cA.m[k] = 0u; cB.m[k] = 0u; }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) { upA[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; upB[t] = upA[t]; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) P[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      columns(P, 0.f, cxe, cxo, cte, cto);
-      issue(1, s0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // here: s1 holds the inputs of pooled row 2 y0 (even), s0 those of 2 y0 + 1 (odd)
-  for (int j = 0; j < R; ++j) {
-    const int oy = y0 + j;
-    float Sm[8], Qm[8], Sp[8], Qp[8], xe[8], xo[8], te[8], to[8];
-    acc_row(std::integral_constant<int, 0>{}, tm, cte, cto, Sm, Qm);
-    acc_row(std::integral_constant<int, 0>{}, tp, cxe, cxo, Sp, Qp);
-    pooled(s1, P, 2 * oy + 2);                      // even pooled row 2 oy: dy = 1
-    columns(P, limx, xe, xo, te, to);
-    acc_row(std::integral_constant<int, 1>{}, tm, te, to, Sm, Qm);
-    acc_row(std::integral_constant<int, 1>{}, tp, xe, xo, Sp, Qp);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(V & 1)) issue(2 * oy + 2, s1);  // next step's even row
-    __builtin_amdgcn_sched_barrier(0);
-    pooled(s0, P, 2 * oy + 3);                      // odd pooled row 2 oy + 1: dy = 2, and the next output row's dy = 0
-    columns(P, limx, cxe, cxo, cte, cto);
-    acc_row(std::integral_constant<int, 2>{}, tm, cte, cto, Sm, Qm);
-    acc_row(std::integral_constant<int, 2>{}, tp, cxe, cxo, Sp, Qp);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(V & 1)) issue(2 * oy + 3, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x2 dm[4], dp[4];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      dpp_src_ready(Qm[c]); dpp_src_ready(Qp[c]);
-      dm[c >> 1][c & 1] = Sm[c] + row_shr1(Qm[c]);
-      dp[c >> 1][c & 1] = Sp[c] + row_shr1(Qp[c]);
-    }
-    f32x4 am[2], ap[2];
-    pw_h3(wp, dp, bip, ap, watch);
-    pw_h3(w2, dm, bi2, am, watch);
-    const bool rowok = oy < y1;                    // wave-uniform
-    f32x4 op[2], om[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { op[t][e] = __builtin_fmaxf(ap[t][e], 0.f) * unscale_p; om[t][e] = __builtin_fmaxf(am[t][e], 0.f) * unscale_2; }
-    const int ro = oy * orowb;
-    auto st = [&](int k, float v0, float v1) {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v0, v1}), rout, (rowok && soff[k] != OOB) ? soff[k] + ro : OOB, 0, 0);
-    };
-    st(0, op[0][0], op[0][1]); st(1, op[0][2], op[0][3]);
-    st(2, om[0][0], om[0][1]); st(3, om[0][2], om[0][3]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) st(4 + e, op[1][e], om[1][e]);
-  }
-  watch.report(a.nonfinite);
-#undef YFV2_TQ
-#undef YFV2_TK
-}
-
-// front2_kernel: the same wave program at TWO waves per SIMD.  front_kernel holds ~400 registers (both kernels' filters, depthwise
-// taps and BatchNorm constants, two sets of input buffers) and runs one wave per SIMD, where nothing covers its dependency and LDS
-// stalls and the matrix core's results have to be fetched from the accumulation registers one by one: 139 us of arithmetic for
-// 97 us of memory traffic.  Here a workgroup of four waves shares ONE copy of the filters, taps and constants in LDS (26 KB) and
+// front2_kernel: that wave program at TWO waves per SIMD.  Its first form (front_kernel, round 5, removed in round 6) held ~400
+// registers (both kernels' filters, depthwise taps and BatchNorm constants, two sets of input buffers) and ran one wave per SIMD,
+// where nothing covered its dependency and LDS stalls and the matrix core's results had to be fetched from the accumulation
+// registers one by one: 157 us.  Here a workgroup of four waves shares ONE copy of the filters, taps and constants in LDS (26 KB) and
 // every wave reads what it needs right where it needs it (a compiler-level memory barrier in front of each read keeps the
 // compiler from hoisting the loop-invariant reads back into registers); the input look-ahead is ONE set of eight 16-byte buffers
 // refilled conv row by conv row right behind their use.  Same instructions on the same operands in the same order: bit-identical.
@@ -783,7 +516,7 @@ __device__ __forceinline__ void f_conv_col8(const FCol8& x0, const FCol8& x1, co
   for (int t = 0; t < 2; ++t) { ae[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], be, ae[t], 0, 0, 0); ao[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], bo, ao[t], 0, 0, 0); }
 }
 }  // namespace
-template <int V, bool U8 = false>
+template <bool U8>
 __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const S2PxArgs& a = fa.s2;
@@ -826,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
   // ---- stage2.0's state (s2h_kernel)
   const float* img = a.img16;
   Yfv2Watch watch;
-  // what front_kernel holds in registers, read from the workgroup's LDS copy at the point of use
+  // filters, taps and constants: read from the workgroup's LDS copy at the point of use
   auto ld_filter = [&](int off, yfv2_h8 (&w)[2][2]) {   // [tile 2][term 2][64 lanes][4 dwords]
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -861,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void front2_kernel(FrontArgs fa) {
   const float sunscale = cst[32];
   const int rowb = U8 ? W * 3 : W * 4;
   // fp32: lane groups 0..2 = input channel g, columns 8 ox .. 8 ox + 7; uint8: every lane group loads the same 24 bytes (columns 8 ox .. + 7, three channels each)
-  const int chan_off = U8 ? ((xok && !(V & 2)) ? 24 * ox : OOB) : ((xok && g < 3 && !(V & 2)) ? g * H * rowb + 8 * ox * 4 : OOB);
+  const int chan_off = U8 ? (xok ? 24 * ox : OOB) : ((xok && g < 3) ? g * H * rowb + 8 * ox * 4 : OOB);
   // uint8 byte selectors (stem_h3u_kernel): lane group g < 3: channel g of columns 0..3; lane group 3: X1 = (ch0, ch1) of columns 1 | 3, X2 = (ch2, 0)
   constexpr unsigned Z = 0x0c;
   const unsigned sel1a = g < 3 ? (unsigned)g | (Z << 8) | ((unsigned)(g + 3) << 16) | (Z << 24) : 3u | (Z << 8) | (4u << 16) | (Z << 24);
@@ -1134,43 +867,29 @@ void yfv2_launch_front(const FrontArgs& a0, hipStream_t s) {
   FrontArgs a = a0;
   const int OW = a.s2.IW / 2, OH = a.s2.IH / 2;
   a.s2.nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
-  if (!(yfv2_variant() & 4)) {
-    // Bands per image.  A band of R output rows costs R + ~0.75 row times (its first pooled row and the conv row above it are computed
-    // again), so fewer bands are less work - but the launch is bound by instruction issue and wants two waves on every SIMD for
-    // most of its duration: 1.5 x (two 4-wave workgroups per CU) workgroups or more.  256 images: 4 bands (768 workgroups; 5 bands
-    // measured the same 130 us, 768 workgroups being three per CU either way); 512 images: 2; one image: 16 bands (47 -> 19.5 us).
-    static std::atomic<int> cus_of[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
-    int cus = cus_of[dev].load(std::memory_order_relaxed);
-    if (cus <= 0) { if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; cus_of[dev].store(cus, std::memory_order_relaxed); }
-    const long long want = 3LL * cus;
-    int best_nb = 1;
-    for (int nb = 1; nb <= OH && nb <= 16; ++nb) {
-      const int R = (OH + nb - 1) / nb, nbe = (OH + R - 1) / R;
-      if (R < 2 && OH >= 2) break;
-      best_nb = nbe;
-      if (((long long)a.s2.B * a.s2.nstrips * nbe + 3) / 4 >= want) break;
-    }
-    a.s2.nb = best_nb;
-  } else {
-    a.s2.nb = OH >= 16 ? 4 : 1;
+  // Bands per image.  A band of R output rows costs R + ~0.75 row times (its first pooled row and the conv row above it are computed
+  // again), so fewer bands are less work - but the launch is bound by instruction issue and wants two waves on every SIMD for
+  // most of its duration: 1.5 x (two 4-wave workgroups per CU) workgroups or more.  256 images: 4 bands (768 workgroups; 5 bands
+  // measured the same 130 us, 768 workgroups being three per CU either way); 512 images: 2; one image: 16 bands (47 -> 19.5 us).
+  static std::atomic<int> cus_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
+  if (cus <= 0) { if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; cus_of[dev].store(cus, std::memory_order_relaxed); }
+  const long long want = 3LL * cus;
+  int best_nb = 1;
+  for (int nb = 1; nb <= OH && nb <= 16; ++nb) {
+    const int R = (OH + nb - 1) / nb, nbe = (OH + R - 1) / R;
+    if (R < 2 && OH >= 2) break;
+    best_nb = nbe;
+    if (((long long)a.s2.B * a.s2.nstrips * nbe + 3) / 4 >= want) break;
   }
+  a.s2.nb = best_nb;
   a.s2.R = (OH + a.s2.nb - 1) / a.s2.nb;
   a.s2.nb = (OH + a.s2.R - 1) / a.s2.R;
-  const dim3 grid(a.s2.B * a.s2.nstrips * a.s2.nb);
-  const int v = (yfv2_variant() >> 3) & 3;        // YFV2_VARIANT bits 8 / 16: the experiment forms
-  if (!(yfv2_variant() & 4)) {                    // bit 4: front_kernel (one wave per SIMD, everything in registers)
-    const unsigned units = a.s2.B * a.s2.nstrips * a.s2.nb;
-    if (a.u8_in) hipLaunchKernelGGL((front2_kernel<0, true>), dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
-    else if (v & 2) hipLaunchKernelGGL(front2_kernel<2>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
-    else hipLaunchKernelGGL(front2_kernel<0>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
-    return;
-  }
-  if (v == 1) hipLaunchKernelGGL(front_kernel<1>, grid, dim3(64), 0, s, a);
-  else if (v == 2) hipLaunchKernelGGL(front_kernel<2>, grid, dim3(64), 0, s, a);
-  else if (v == 3) hipLaunchKernelGGL(front_kernel<3>, grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(front_kernel<0>, grid, dim3(64), 0, s, a);
+  const unsigned units = a.s2.B * a.s2.nstrips * a.s2.nb;
+  if (a.u8_in) hipLaunchKernelGGL(front2_kernel<true>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
+  else hipLaunchKernelGGL(front2_kernel<false>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
 }
 
 // ============================================================================
@@ -1217,152 +936,11 @@ __device__ __forceinline__ void pw_h3_48(const float* W, int lane, const f32x2 (
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 1) void s3h_kernel(BlockS2Args a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int IH = a.H, IW = a.W, OH = IH >> 1, OW = IW >> 1;
-  const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
-  const int R = a.R, nb = (OH + R - 1) / R;
-  const int units = nstrips * nb, wpi = (units + 3) >> 2;     // workgroups per image
-  const int b = blockIdx.x / wpi, wi = blockIdx.x - b * wpi;
-  const int tid = threadIdx.x, lane = tid & 63, l = lane & 15, g = lane >> 4;
-  const int uid = wi * 4 + (tid >> 6);
-  const float* img = a.img16;
-  {   // the three filters -> LDS (straight 16-byte copy, every load issued before the first store)
-    const f32x4* src = reinterpret_cast<const f32x4*>(img);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    f32x4 tmp[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) tmp[k] = src[tid + k * 256];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dst[tid + k * 256] = tmp[k];
-  }
-  __syncthreads();
-  if (uid >= units) return;
-  const int strip = uid % nstrips, band = uid / nstrips;
-  const int ox = 15 * strip + l;
-  const bool xok = ox < OW;
-  const bool st_lane = xok && (l > 0 || strip == 0);
-  const int y0 = band * R, y1 = min(OH, y0 + R);
-  constexpr int OOB = (int)0x80000000;
-  const float* W1 = lds; const float* WP = lds + S3H_WFL; const float* W2 = lds + 2 * S3H_WFL;
-
-  // input: stage 2's two pair-plane buffers of this image (adjacent: buffer 1 at + pp_bufstride floats, the next image at + pp_imgstride)
-  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * (size_t)a.pp_imgstride), 0,
-                                                                   (int)((a.pp_bufstride + 48LL * IH * IW) * 4), 0x00020000);
-  Yfv2Watch watch;
-  float tm[27], tp[27];
-#pragma unroll
-  for (int q = 0; q < 27; ++q) { tm[q] = img[S3H_TM + q * 64 + lane]; tp[q] = img[S3H_TP + q * 64 + lane]; }
-  f32x4 sh1[3], bip[3], bi2[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    sh1[t] = *reinterpret_cast<const f32x4*>(img + S3H_CST + 16 * t + 4 * g);
-    bip[t] = *reinterpret_cast<const f32x4*>(img + S3H_CST + 48 + 16 * t + 4 * g);
-    bi2[t] = *reinterpret_cast<const f32x4*>(img + S3H_CST + 96 + 16 * t + 4 * g);
-  }
-  const float unscale_p = img[S3H_CST + 144], unscale_2 = img[S3H_CST + 145];
-  int loff[6];
-  {
-    const int* po = reinterpret_cast<const int*>(img + S3H_OFFS);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) loff[k] = xok ? po[k * 64 + lane] + 2 * ox * 8 : OOB;
-  }
-  const int irowb = IW * 8;
-  float* __restrict__ outp = a.out + ((size_t)b * OH * OW + (st_lane ? ox : 0)) * 96 + 4 * g;
-
-  auto load_row = [&](int iy, f32x4 (&X)[6]) {
-    const bool rok = iy >= 0 && iy < IH;           // wave-uniform
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-      X[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (rok && loff[k] != OOB) ? loff[k] + iy * irowb : OOB, 0, 0));
-  };
-  auto columns = [&](const f32x4 (&X)[6], float lim, float (&xe)[12], float (&xo)[12], float (&te)[12], float (&to)[12]) {
-    f32x2 ine[6], ino[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const f32x4 v = X[k] * 16.0f;
-      ine[k] = (f32x2){v[0], v[1]}; ino[k] = (f32x2){v[2], v[3]};
-      xe[2 * k] = v[0]; xe[2 * k + 1] = v[1]; xo[2 * k] = v[2]; xo[2 * k + 1] = v[3];
-    }
-    f32x4 ae[3], ao[3];
-    pw_h3_48(W1, lane, ine, sh1, ae, watch);
-    pw_h3_48(W1, lane, ino, sh1, ao, watch);
-#pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      te[c] = __builtin_amdgcn_fmed3f(ae[c >> 2][c & 3], 0.f, lim);
-      to[c] = __builtin_amdgcn_fmed3f(ao[c >> 2][c & 3], 0.f, lim);
-    }
-  };
-#define YFV2_TQ(T, c, t) T[((c) * 9 + (t)) >> 2]
-#define YFV2_TK(c, t) (((c) * 9 + (t)) & 3)
-  auto acc_row = [&](auto dyc, const float (&T)[27], const float (&v0)[12], const float (&v1)[12], float (&S)[12], float (&Q)[12]) {
-    constexpr int DY = decltype(dyc)::value;
-    [&]<int... Cs>(std::integer_sequence<int, Cs...>) {
-      ((DY == 0 ? (void)(S[Cs] = quad_mul<YFV2_TK(Cs, 1)>(YFV2_TQ(T, Cs, 1), v0[Cs]), Q[Cs] = quad_mul<YFV2_TK(Cs, 0)>(YFV2_TQ(T, Cs, 0), v1[Cs]),
-                         quad_fmac1<YFV2_TK(Cs, 2)>(S[Cs], YFV2_TQ(T, Cs, 2), v1[Cs]))
-                : (void)quad_fmac3<YFV2_TK(Cs, DY * 3 + 1), YFV2_TK(Cs, DY * 3), YFV2_TK(Cs, DY * 3 + 2)>(
-                      S[Cs], Q[Cs], YFV2_TQ(T, Cs, DY * 3 + 1), YFV2_TQ(T, Cs, DY * 3), YFV2_TQ(T, Cs, DY * 3 + 2), v0[Cs], v1[Cs])), ...);
-    }(std::make_integer_sequence<int, 12>{});
-  };
-
-  f32x4 X[6], Y[6];
-  float cxe[12], cxo[12], cte[12], cto[12];
-  {
-    const int iy = 2 * y0 - 1;
-    load_row(iy, X);
-    load_row(iy + 1, Y);
-    columns(X, (xok && iy >= 0) ? __builtin_inff() : 0.f, cxe, cxo, cte, cto);
-    load_row(iy + 2, X);
-  }
-  const float limx = xok ? __builtin_inff() : 0.f;
-  for (int j = 0; j < R; ++j) {
-    const int oy = y0 + j;
-    float Sm[12], Qm[12], Sp[12], Qp[12], xe[12], xo[12], te[12], to[12];
-    acc_row(std::integral_constant<int, 0>{}, tm, cte, cto, Sm, Qm);
-    acc_row(std::integral_constant<int, 0>{}, tp, cxe, cxo, Sp, Qp);
-    columns(Y, limx, xe, xo, te, to);
-    acc_row(std::integral_constant<int, 1>{}, tm, te, to, Sm, Qm);
-    acc_row(std::integral_constant<int, 1>{}, tp, xe, xo, Sp, Qp);
-    __builtin_amdgcn_sched_barrier(0);
-    load_row(2 * oy + 2, Y);
-    __builtin_amdgcn_sched_barrier(0);
-    columns(X, limx, cxe, cxo, cte, cto);
-    acc_row(std::integral_constant<int, 2>{}, tm, cte, cto, Sm, Qm);
-    acc_row(std::integral_constant<int, 2>{}, tp, cxe, cxo, Sp, Qp);
-    __builtin_amdgcn_sched_barrier(0);
-    load_row(2 * oy + 3, X);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x2 dm[6], dp[6];
-#pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      dpp_src_ready(Qm[c]); dpp_src_ready(Qp[c]);
-      dm[c >> 1][c & 1] = Sm[c] + row_shr1(Qm[c]);
-      dp[c >> 1][c & 1] = Sp[c] + row_shr1(Qp[c]);
-    }
-    f32x4 am[3], ap[3];
-    pw_h3_48(WP, lane, dp, bip, ap, watch);
-    pw_h3_48(W2, lane, dm, bi2, am, watch);
-    if (st_lane && oy < y1) {
-      float* o = outp + (size_t)oy * OW * 96;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        f32x4 vp, vm;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { vp[e] = __builtin_fmaxf(ap[t][e], 0.f) * unscale_p; vm[e] = __builtin_fmaxf(am[t][e], 0.f) * unscale_2; }
-        *reinterpret_cast<f32x4*>(o + 16 * t) = vp;          // proj: channels 0..47
-        *reinterpret_cast<f32x4*>(o + 48 + 16 * t) = vm;     // main: channels 48..95
-      }
-    }
-  }
-  watch.report(a.nonfinite);
-#undef YFV2_TQ
-#undef YFV2_TK
-}
-
-// s3h2_kernel (round 5): the same wave program at TWO waves per SIMD.  s3h_kernel's 316 registers are 54 depthwise taps + 36 BatchNorm
-// constants + state; with the taps and constants read from the workgroup's LDS copy at the point of use (as front2_kernel does) the
-// wave fits 256 registers, two workgroups share a CU and an image is cut into eight (strip, band) units instead of four: the launch
-// is a latency chain (36 us for ONE image, 45 for 256) that a second wave per SIMD overlaps.  Bit-identical to s3h_kernel.
+// s3h2_kernel (round 5): the wave program described above at TWO waves per SIMD.  Its first form (s3h_kernel, rounds 3-5, removed in
+// round 6) held 54 depthwise taps + 36 BatchNorm constants + state in 316 registers; with the taps and constants read from the
+// workgroup's LDS copy at the point of use (as front2_kernel does) the wave fits 256 registers, two workgroups share a CU and an
+// image is cut into eight (strip, band) units instead of four: the launch is a latency chain (36 us for ONE image, 45 for 256)
+// that a second wave per SIMD overlaps.  Bit-identical to that first form (round 5's same-box check, profiles/r05_experiments.txt).
 constexpr int S3H2_TAPS = 3 * S3H_WFL, S3H2_TSTRIDE = 60, S3H2_CST = S3H2_TAPS + 64 * S3H2_TSTRIDE, S3H2_FLOATS = S3H2_CST + 160;
 __global__ __launch_bounds__(256, 2) void s3h2_kernel(BlockS2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1536,19 +1114,14 @@ void yfv2_launch_s3h(const BlockS2Args& a0, hipStream_t s) {
   BlockS2Args a = a0;
   const int OH = a.H / 2, OW = a.W / 2;
   const int nstrips = OW <= 16 ? 1 : (OW - 1 + 14) / 15;
-  const bool two = !(yfv2_variant() & 32);          // YFV2_VARIANT bit 32: s3h_kernel (one wave per SIMD, four units per image)
-  int nb = ((two ? 8 : 4) + nstrips - 1) / nstrips; // about four (strip, band) waves per image: one workgroup (s3h2_kernel: eight, two workgroups)
+  int nb = (8 + nstrips - 1) / nstrips;             // about eight (strip, band) waves per image: two workgroups
   if (nb > OH) nb = OH;
   a.R = (OH + nb - 1) / nb;
   nb = (OH + a.R - 1) / a.R;
   const int units = nstrips * nb;
-  if (two) {
-    static std::atomic<unsigned long long> lds_ok{0};
-    yfv2_allow_full_lds(reinterpret_cast<const void*>(&s3h2_kernel), lds_ok);
-    hipLaunchKernelGGL(s3h2_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), S3H2_FLOATS * sizeof(float), s, a);
-    return;
-  }
-  hipLaunchKernelGGL(s3h_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), 3 * S3H_WFL * sizeof(float), s, a);
+  static std::atomic<unsigned long long> lds_ok{0};
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&s3h2_kernel), lds_ok);
+  hipLaunchKernelGGL(s3h2_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), S3H2_FLOATS * sizeof(float), s, a);
 }
 
 // ============================================================================
@@ -1764,7 +1337,7 @@ void yfv2_launch_s4h(const BlockS2Args& a0, hipStream_t s) {
   const int units = nstrips * nb;
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&s4h_kernel), lds_ok);
-  a.s4_main_bands = (nstrips == 1 && OH >= 6 && !(yfv2_variant() & 64)) ? 3 : 0;   // YFV2_VARIANT bit 64: two bands x two roles (round 4's form)
+  a.s4_main_bands = (nstrips == 1 && OH >= 6) ? 3 : 0;   // (wider or very low maps: two bands x two roles per workgroup, round 4's form)
   if (a.s4_main_bands) { hipLaunchKernelGGL(s4h_kernel, dim3(a.B), dim3(256), 3 * S4H_WFL * sizeof(float), s, a); return; }
   hipLaunchKernelGGL(s4h_kernel, dim3(a.B * ((units + 1) / 2)), dim3(256), 3 * S4H_WFL * sizeof(float), s, a);
 }

@@ -90,7 +90,6 @@ __device__ __forceinline__ void split_row(const f32x4 v, Row16& o) {
 
 }  // namespace
 
-template <bool PPOUT>
 __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
   const int H = a.H, W = a.W, PH = H >> 2, PW = W >> 2;
   const int strips = (PW - 1 + 14) / 15;
@@ -199,12 +198,10 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
     load2(1, ro0);
     split_row((f32x4){0.f, 0.f, 0.f, 0.f}, carry);
   }
-  // PPOUT (round 4): QUAD planes [6][PH][PW][4] - channel tile t of lane group g = channels 16 t + 4 g .. +3 = plane 4 t + g, ONE
-  // 16-byte store per tile.  (Rounds 1-3 wrote 8-byte pair-plane records, two stores per tile: tools/ubench/stem_pattern.hip -
-  // this kernel's loads and stores without its arithmetic - takes 139 us with those and 123 with these; stage2.0's loads,
-  // two pixels of a plane per lane, cost the same from either layout.)
-  float* __restrict__ ob = PPOUT ? a.out + (size_t)b * 24 * PH * PW + ((size_t)py0 * PW + (st_ok ? px : 0)) * 4
-                                 : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
+  // output [PH][PW][24]: a pixel's 96 bytes in one run, ONE 16-byte store per channel tile and lane group.  (Rounds 1-3 wrote 8-byte
+  // pair-plane records, round 4's first half quad planes [6][PH][PW][4]: tools/ubench/stem_pattern.hip - this kernel's loads and
+  // stores without its arithmetic - 139 / 123 / 118 us; stage2.0's loads cost the same from either layout.)
+  float* __restrict__ ob = a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
   const int ylast = (H >> 1) - 1;
   auto step = [&](int t, const f32x4 (&ce)[2], const f32x4 (&co)[2], f32x4 (&ne)[2], f32x4 (&no)[2]) {
     const int y = 2 * (py0 + t);
@@ -223,15 +220,9 @@ __global__ __launch_bounds__(64, 3) void stem_h3_kernel(StemArgs a) {
         o[e] = __builtin_fmaxf(m, 0.f) * unscale;  // ReLU, then the exact power of two back
       }
       up[tt] = h1[tt];
-      if (st_ok && (tt == 0 || g < 2)) {           // channel tile 1 holds channels 16..23 in lane groups 0, 1
-        if constexpr (PPOUT) {
-          *reinterpret_cast<f32x4*>(ob + (size_t)(4 * tt + g) * PH * PW * 4) = o;
-        } else {
-          *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;
-        }
-      }
+      if (st_ok && (tt == 0 || g < 2)) *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;   // channel tile 1 holds channels 16..23 in lane groups 0, 1
     }
-    ob += PPOUT ? (size_t)PW * 4 : (size_t)PW * 24;
+    ob += (size_t)PW * 24;
   };
   int t = 0;
 #pragma unroll 1
@@ -266,7 +257,6 @@ __device__ __forceinline__ void split_row_u8(const yfv2_u3 d, unsigned sel_a, un
 }
 }  // namespace
 
-template <bool PPOUT>
 __global__ __launch_bounds__(64, 4) void stem_h3u_kernel(StemArgs a) {
   const int H = a.H, W = a.W, PH = H >> 2, PW = W >> 2;
   const int strips = (PW - 1 + 14) / 15;
@@ -351,14 +341,7 @@ __global__ __launch_bounds__(64, 4) void stem_h3u_kernel(StemArgs a) {
     load2(1, ro0);
     carry.p01 = carry.p23 = carry.m = 0u;
   }
-  // plane output through a buffer resource: a 32-bit lane offset (plane pair of the lane group; lanes that do not store
-  // carry the out-of-range offset, the store is dropped) + a wave-uniform offset (plane, row) instead of two 64-bit pointers
-  float* __restrict__ ob = PPOUT ? nullptr : a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
-  __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * 24 * PH * PW), 0, 24 * PH * PW * 4, 0x00020000);
-  const int plane = PH * PW * 16;                   // bytes of one quad plane (four channels; see stem_h3_kernel)
-  const int ovoff0 = st_ok ? (py0 * PW + px) * 16 + g * plane : OOB;
-  const int ovoff1 = g < 2 ? ovoff0 : OOB;         // channel tile 1 holds channels 16..23 in lane groups 0, 1
-  int osoff = 0;
+  float* __restrict__ ob = a.out + (((size_t)b * PH + py0) * PW + (st_ok ? px : 0)) * 24;
   const int ylast = (H >> 1) - 1;
   auto step = [&](int t, const yfv2_u3 (&ce)[2], const yfv2_u3 (&co)[2], yfv2_u3 (&ne)[2], yfv2_u3 (&no)[2]) {
     const int y = 2 * (py0 + t);
@@ -377,15 +360,9 @@ __global__ __launch_bounds__(64, 4) void stem_h3u_kernel(StemArgs a) {
         o[e] = __builtin_fmaxf(m, 0.f) * unscale;
       }
       up[tt] = h1[tt];
-      if constexpr (PPOUT) {                         // channels 16 tt + 4 g .. +3 = quad plane 4 tt + g
-        const int vo = tt ? ovoff1 : ovoff0;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, vo, osoff + 4 * tt * plane, 0);
-        yfv2_after_wide_buffer_store();   // (the next tile's values are formed in the same registers: yfv2_internal.h)
-      } else if (st_ok && (tt == 0 || g < 2)) {
-        *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;
-      }
+      if (st_ok && (tt == 0 || g < 2)) *reinterpret_cast<f32x4*>(ob + 16 * tt + 4 * g) = o;
     }
-    if constexpr (PPOUT) osoff += PW * 16; else ob += (size_t)PW * 24;
+    ob += (size_t)PW * 24;
   };
   int t = 0;
 #pragma unroll 1
@@ -404,11 +381,6 @@ void yfv2_launch_stem16(const StemArgs& a, hipStream_t s) {
   b.R = PH / nb;
   const int strips = (PW - 1 + 14) / 15;
   const dim3 grid(a.B * strips * nb);
-  if (a.u8_in) {
-    if (a.pp_out) hipLaunchKernelGGL((stem_h3u_kernel<true>), grid, dim3(64), 0, s, b);
-    else hipLaunchKernelGGL((stem_h3u_kernel<false>), grid, dim3(64), 0, s, b);
-    return;
-  }
-  if (a.pp_out) hipLaunchKernelGGL((stem_h3_kernel<true>), grid, dim3(64), 0, s, b);
-  else hipLaunchKernelGGL((stem_h3_kernel<false>), grid, dim3(64), 0, s, b);
+  if (a.u8_in) hipLaunchKernelGGL(stem_h3u_kernel, grid, dim3(64), 0, s, b);
+  else hipLaunchKernelGGL(stem_h3_kernel, grid, dim3(64), 0, s, b);
 }

@@ -1172,7 +1172,7 @@ bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
     if (mh_tiles == 0) launch_towerh<0, 1, 1>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 1, 1>(jobs, s);
     else launch_towerh<6, 1, 1>(jobs, s);
-  } else if ((yfv2_variant() & 256) || (a.H & 1) || (a.W & 1)) {   // odd maps (13x13 at 416x416), or YFV2_VARIANT bit 256 (A/B): towerh_kernel<.., 2, 4>
+  } else if ((a.H & 1) || (a.W & 1)) {   // odd maps (13x13 at 416x416): towerh_kernel<.., 2, 4> (towerp_kernel's 16-byte patch-row records want even sizes)
     if (mh_tiles == 0) launch_towerh<0, 2, 4>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 2, 4>(jobs, s);
     else launch_towerh<6, 2, 4>(jobs, s);

@@ -23,7 +23,10 @@ class Engine:
     """Owns a yfv2 handle.  ``max_batch`` grows on demand (the handle is re-created
     and the weights re-uploaded)."""
 
-    def __init__(self, device, height=352, width=352, classes=80, anchor_num=3, anchors=None, max_batch=1):
+    def __init__(self, device, height=352, width=352, classes=80, anchor_num=3, anchors=None, max_batch=1, plan=None):
+        """plan: dict of yfv2_plan switches ({"fp32_matrix": 1}, {"layer_by_layer": 1}, {"lanes": 2} ...; include/yfv2.h), None = what the
+        process environment asks for (YFV2_BF6=0 etc., _lib.plan_from_env: how the tools and the fallback-plan tests pick a plan) - with
+        nothing set that is the default plan.  The native library itself reads no environment variable."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("yolo_fastestv2_amd runs on an MI355X only (got device %s); there is no CPU path" % device)
@@ -38,6 +41,7 @@ class Engine:
         self.max_batch = 0
         self._h = None
         self._weights = None  # host copies (name -> contiguous fp32 cpu tensor), kept for re-creation
+        self.plan = dict(_lib.plan_from_env() if plan is None else plan)
         self._create(max_batch)
 
     # ---- lifetime -------------------------------------------------------------------------
@@ -51,7 +55,7 @@ class Engine:
         cfg.max_batch = int(max_batch)
         cfg.device = self.device.index
         h = C.c_void_p()
-        check(L.yfv2_create(C.byref(h), C.byref(cfg)))
+        check(L.yfv2_create_ex(C.byref(h), C.byref(cfg), C.byref(_lib.make_plan(self.plan))))
         self.close()
         self._h, self.max_batch = h, int(max_batch)
         self._generation = getattr(self, "_generation", 0) + 1   # a NEW native handle: whatever was bound to the old one (yfv2_train_bind) is gone
@@ -336,8 +340,9 @@ class Engine:
         """Raise if the range guard tripped (call where the host waits for the device anyway)."""
         if self.nonfinite():
             raise _lib.Yfv2Error(_lib.ERR_RANGE, "%s: an activation left the range of the default (fp16x3) plan - |activation| >= 4094 or a non-finite "
-                                     "input; the result is invalid.  Create the handle with YFV2_BF6=0 in the environment (every conv on the "
-                                     "fp32 matrix instructions, no such bound) for this model / input" % what)
+                                     "input; the result is invalid.  Create the handle on the fp32-matrix plan - Engine(..., plan={'fp32_matrix': 1}), "
+                                     "yfv2_plan.fp32_matrix = 1, or YFV2_BF6=0 in the environment of the Python layer (every conv on the fp32 matrix "
+                                     "instructions, no such bound) - for this model / input" % what)
 
     # ---- introspection --------------------------------------------------------------------
     def stages(self):

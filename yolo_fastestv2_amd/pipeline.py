@@ -32,12 +32,12 @@ class Ticket:
 
 
 class DetectPipeline:
-    def __init__(self, device, height, width, classes, anchor_num, anchors=None, max_batch=1, depth=3):
+    def __init__(self, device, height, width, classes, anchor_num, anchors=None, max_batch=1, depth=3, plan=None):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.device = torch.device(device)
         self.depth = int(depth)
-        self.engines = [Engine(self.device, height, width, classes, anchor_num, anchors=anchors, max_batch=max_batch) for _ in range(self.depth)]
+        self.engines = [Engine(self.device, height, width, classes, anchor_num, anchors=anchors, max_batch=max_batch, plan=plan) for _ in range(self.depth)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.buffers = [e.new_det_buffers(max_batch) for e in self.engines]
         self.max_batch = int(max_batch)
@@ -71,6 +71,18 @@ class DetectPipeline:
         if B > self.max_batch:
             raise ValueError("batch %d exceeds max_batch %d" % (B, self.max_batch))
         cur = torch.cuda.current_stream(self.device)
+        # The slot's previous batch may have tripped the range guard.  Looked at BEFORE the rotation advances: the error then names that
+        # batch's ticket, which stays valid (its buffers are not overwritten - nothing is enqueued for the new batch), and the caller
+        # can submit again.  (Inside the slot the same look would clear the word with the rotation already advanced: the flagged
+        # ticket would read "reused by a later submit" and could no longer be told from a good one.)
+        jn = self._serial % self.depth
+        if self.engines[jn].peek_nonfinite():
+            try:
+                with torch.cuda.stream(self.streams[jn]):
+                    self.engines[jn].check_finite("DetectPipeline.submit: the batch of ticket #%s (slot %d), the last one run on this slot" % (self._last[jn], jn))
+            except Exception as e:
+                e.slot, e.serial = jn, self._last[jn]
+                raise
         with self.slot() as (j, eng, (dets, idx, cnt)):
             # write-after-read: streams that result() ordered behind this slot's previous batch may still be reading its
             # detection buffers - the slot's stream waits for the marks they left before it overwrites them
@@ -80,7 +92,7 @@ class DetectPipeline:
             if wait_for_input:
                 self.streams[j].wait_stream(cur)
                 x.record_stream(self.streams[j])
-            out = eng.detect(x, conf_thres, iou_thres, out=(dets[:B], idx[:B], cnt[:B]))
+            out = eng.detect(x, conf_thres, iou_thres, out=(dets[:B], idx[:B], cnt[:B]), check=False)
             ev = torch.cuda.Event()
             ev.record(self.streams[j])
         return Ticket(j, ev, out, self._serial)

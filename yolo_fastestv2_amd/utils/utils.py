@@ -60,8 +60,25 @@ def handel_preds(preds, cfg, device):
     dev = eng.decode([p.detach().float() for p in preds])
     out = dev.cpu()
     eng.check_finite("handel_preds (the forward that produced these logits)")   # the host has just waited for the device: free
-    out._yfv2_dev = (dev, eng, out._version)
+    out._yfv2_dev = (dev, eng, out._version, _host_checksum(out))
     return out
+
+
+_CACHE_MAX_BYTES = 8 << 20
+
+
+def _host_checksum(t):
+    """What non_max_suppression compares before it trusts the device copy handel_preds left on its CPU result: the reference's callers
+    may edit that tensor in place - through torch (bumps `_version`) or through `t.numpy()` (does not).  Two wrap-around integer sums
+    over the raw bits (every 32-bit word; every 64-bit pair of words): any edit of a single element changes both, and an edit that
+    keeps both is not something a caller produces by accident.  Tensors beyond 8 MB (more than 12 images of 1815 x 85) are not
+    cached at all: summing 158 MB on the host costs as much as uploading them."""
+    if t.numel() * t.element_size() > _CACHE_MAX_BYTES or not t.is_contiguous() or t.dtype != torch.float32:
+        return None
+    w = t.view(-1).view(torch.int32)
+    s32 = int(w.sum(dtype=torch.int64))
+    s64 = int(w[: w.numel() & ~1].view(torch.int64).sum()) if w.numel() >= 2 else 0
+    return (t.data_ptr(), t.numel(), s32, s64)
 
 
 def non_max_suppression(prediction, conf_thres=0.3, iou_thres=0.45, classes=None):
@@ -75,8 +92,8 @@ def nms_with_indices(prediction, conf_thres=0.3, iou_thres=0.45, classes=None):
     """non_max_suppression that also returns, per image, the index of every
     survivor in the decode row order (SURVEY.md 8(b) 'survivor indices')."""
     cached = getattr(prediction, "_yfv2_dev", None)
-    if cached is not None and cached[2] == prediction._version:
-        dev, eng = cached[0], cached[1]
+    if cached is not None and cached[2] == prediction._version and cached[3] is not None and cached[3] == _host_checksum(prediction):
+        dev, eng = cached[0], cached[1]           # the very tensor handel_preds returned, unedited (in-place torch ops AND numpy-side writes are seen)
     else:
         if not torch.cuda.is_available():
             raise RuntimeError("non_max_suppression: no MI355X visible (there is no CPU path)")
@@ -198,7 +215,7 @@ def evaluation(val_dataloader, cfg, model, device, conf_thres=0.01, nms_thresh=0
         raise RuntimeError("evaluation: an image has more than 1024 targets (yfv2_batch_statistics limit)")
     if any(bad):
         raise RuntimeError("evaluation: an activation left the range of the default (fp16x3) plan (include/yfv2.h yfv2_nonfinite); "
-                           "run with YFV2_BF6=0 in the environment")
+                           "run on the fp32-matrix plan (YFV2_BF6=0 in the environment of the Python layer / yfv2_plan.fp32_matrix = 1)")
     if not kept:
         print("---- No detections over whole validation set ----")
         return None
