@@ -71,6 +71,8 @@ MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (= fp32 vector peak): the 
 MFMA_F16_PEAK_TF = 2500.0      # dense fp16 MFMA peak: the pipe the default plan's fp16x3 contractions run on
 # The default plan spends THREE f16 products per algorithmic MAC (w1 x2 + w2 x1 + w1 x1), so its ceiling in algorithmic
 # flops is a third of the f16 peak; the ridge that decides `bound` follows from that ceiling.
+# the plan of the measured handles: the default one unless the caller's environment asks for another (YFV2_BF6=0 etc. - the library itself
+# reads no environment; yolo_fastestv2_amd._lib.plan_from_env maps these onto yfv2_plan)
 FP16X3 = os.environ.get("YFV2_BF6", "1") != "0"
 PIPE_PEAK_TF, PIPE_COST = (MFMA_F16_PEAK_TF, 3.0) if FP16X3 else (MFMA_F32_PEAK_TF, 1.0)
 RIDGE_FLOP_PER_BYTE = (PIPE_PEAK_TF / PIPE_COST) * 1e12 / (HBM_PEAK_GBS * 1e9)   # 104 flop/B (fp16x3), 19.7 (fp32 MFMA)
@@ -111,6 +113,7 @@ def profile_lookup(prof, kernel, field, launches, mean=False):
     if mean:
         return round(sum(vals) / len(vals), 2)
     return sum(vals) * launches      # per-launch means -> bytes per forward (a '+' step launches each of its kernels once)
+PLAN = {}
 ANCHORS = [12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87]  # data/coco.data:17
 
 
@@ -123,10 +126,12 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.3)
     ap.add_argument("--iou", type=float, default=0.4)
     ap.add_argument("--profile-iters", type=int, default=5)
-    ap.add_argument("--blocks", type=int, default=5, help="back-to-back timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--blocks", type=int, default=15, help="back-to-back timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--inputs", type=int, default=3, help="distinct resident input batches the steps rotate over (3 x 381 MB exceeds the 256 MB Infinity Cache: "
+                                                          "the streaming front end provably reads HBM)")
     ap.add_argument("--spinup-seconds", type=float, default=2.0, help="set-up: hold the device under load this long before the warm-up (a fresh process runs its first steps 8-10 %% slower until the device has left its idle power state)")
     ap.add_argument("--pipeline", type=int, default=3, help="handles / HIP streams consecutive steps rotate over (1 = one handle, one stream)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg (one instance; the concurrent-instances figure takes about as long again)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-plan, COCO and training extras (counter passes)")
     ap.add_argument("--weights", choices=("random", "coco"), default="random")
@@ -151,6 +156,28 @@ def batch_from_reference_images(images_u8, n, seed):
         gain = 0.8 + 0.4 * float(torch.rand(1, generator=g))
         out.append((x * gain).clamp(0, 1))
     return torch.stack(out)
+
+
+def _cpu_instance(args):
+    """cpu_baseline's concurrent-instances leg: ONE oracle instance of `threads` threads in its own process (spawned: no GPU state),
+    batches of `bs` seeded synthetic images through forward (ATen CPU) + decode + NMS for about `seconds`.  Returns (images, seconds)
+    of its own loop (after its own warm-up): the instances' rates are summed."""
+    threads, seconds, bs, conf, iou, seed = args
+    import torch as T
+    T.set_num_threads(threads)
+    sys.path.insert(0, REPO)
+    import yolo_fastestv2_amd as yfv2
+    from oracle import yfv2_oracle as oracle
+    sd = yfv2.random_state_dict(0)
+    x = T.rand(bs, 3, 352, 352, generator=T.Generator().manual_seed(seed))
+    oracle.forward(sd, x[:4])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.detect(sd, x, ANCHORS, 352, conf, iou)
+        n += bs
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            return n, el
 
 
 def timed(fn, steps, sync, barrier, finish=None):
@@ -346,6 +373,9 @@ def main():
         return launcher_selftest(a, rank, world)
     import torch.distributed as dist
     import yolo_fastestv2_amd as yfv2
+    from yolo_fastestv2_amd._lib import plan_from_env
+    global PLAN
+    PLAN = plan_from_env()
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
     dev = torch.device("cuda", local)
@@ -376,11 +406,19 @@ def main():
     # launch (one workgroup per image, a last round of waves on a third of the SIMDs) overlap the neighbours' launches.
     # tools/pipeline_probe.py: 1 / 2 / 3 / 4 handles = 0.78-0.79 / 0.72-0.74 / 0.70-0.71 / 0.72-0.74 ms per step on one box.
     # `single_stream_img_s` reports the same steps on one handle and one stream.
-    pipe = yfv2.DetectPipeline(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch, depth=max(1, a.pipeline))
+    pipe = yfv2.DetectPipeline(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch, depth=max(1, a.pipeline), plan=PLAN)
     pipe.load_state_dict(sd)
     eng, engs, streams = pipe.engines[0], pipe.engines, pipe.streams
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.rand(a.batch, 3, 352, 352, device=dev, generator=g)  # resident in HBM before timing
+    # resident in HBM before timing.  SEVERAL distinct batches, rotated step by step: one 381 MB batch read again and again could sit in
+    # the 256 MiB Infinity Cache (FETCH_SIZE counts L2 -> fabric requests, cache hits included); three of them cannot
+    xs = [torch.rand(a.batch, 3, 352, 352, device=dev, generator=g) for _ in range(max(1, a.inputs))]
+    x = xs[0]                                                       # (the single-input extras: profile pass, forward-only, fp32 plan)
+    nx = [0]
+
+    def next_x():
+        nx[0] += 1
+        return xs[nx[0] % len(xs)]
     det_bufs = pipe.buffers[0]
     logit_bufs = [torch.empty(s, device=dev) for s in eng.logit_shapes(a.batch)]
     side = torch.cuda.Stream(device=dev)      # the clock probe's stream
@@ -396,12 +434,12 @@ def main():
             if works[j] is not None:
                 works[j].wait_host()      # issued len(sets) steps ago; the gathered result stays packed in recv[j] (sharded.rank_views)
                 works[j] = None
-            d, i, c = e.detect(x, a.conf, a.iou, out=bufs)     # (looks at the range guard first: Engine.detect check=True, a host memory read)
+            d, i, c = e.detect(next_x(), a.conf, a.iou, out=bufs)     # (looks at the range guard first: Engine.detect check=True, a host memory read)
             if use_dist:
                 works[j] = yfv2.gather_detections(d, i, c, force=True, async_op=True, out=recv[j])
 
     def step_single():
-        eng.detect(x, a.conf, a.iou, out=det_bufs)
+        eng.detect(next_x(), a.conf, a.iou, out=det_bufs)
 
     def finish():
         for j, w in enumerate(works):
@@ -447,7 +485,7 @@ def main():
     while time.perf_counter() - t_spin < a.spinup_seconds:
         for _ in range(20):
             with pipe.slot() as (j, e, bufs):
-                e.detect(x, a.conf, a.iou, out=bufs)
+                e.detect(next_x(), a.conf, a.iou, out=bufs)
         n_spin += 20
         if rank == 0 and "sysfs_under_pipelined_load" not in box and time.perf_counter() - t_spin > 0.6 * a.spinup_seconds:
             box["sysfs_under_pipelined_load"] = sysfs_power_clock(pci)     # the 20 steps just queued are still running
@@ -499,11 +537,7 @@ def main():
         sync()
 
     # ONE call per batch on ONE handle whose calls cut the batch into two slices on internal streams (YFV2_LANES=2)
-    os.environ["YFV2_LANES"] = "2"
-    try:
-        eng_l = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch)
-    finally:
-        os.environ.pop("YFV2_LANES", None)
+    eng_l = yfv2.Engine(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch, plan=dict(PLAN, lanes=2))
     eng_l.load_state_dict(sd)
     for _ in range(3):
         eng_l.detect(x, a.conf, a.iou, out=det_bufs)
@@ -613,11 +647,7 @@ def main():
         # reference's own arithmetic (fp32 convolutions, model/detector.py:21-47) costs on this box, same weights, same input, same run
         fp32 = None
         if world == 1 and FP16X3 and not a.no_extras:
-            os.environ["YFV2_BF6"] = "0"
-            try:
-                pipe32 = yfv2.DetectPipeline(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch, depth=max(1, a.pipeline))
-            finally:
-                os.environ.pop("YFV2_BF6", None)
+            pipe32 = yfv2.DetectPipeline(dev, 352, 352, 80, 3, anchors=ANCHORS, max_batch=a.batch, depth=max(1, a.pipeline), plan=dict(PLAN, fp32_matrix=1))
             pipe32.load_state_dict(sd)
 
             def step32():
@@ -705,12 +735,31 @@ def main():
                 el = time.perf_counter() - t0
                 if el >= a.cpu_seconds or n_img >= 8192:
                     break
+            # ... and what the HOST as a whole does with this path: floor(host threads / N) such instances at once, each in its own
+            # process (the reference's CPU path has no batch-level parallelism of its own; a user with a queue of batches would
+            # run several).  Bounded like the single instance; a stated baseline, never the target.
+            many = None
+            n_inst = min(max(1, ncores // best_t), 32)
+            if n_inst > 1:
+                try:
+                    import concurrent.futures as cf
+                    import multiprocessing as mp
+                    with cf.ProcessPoolExecutor(max_workers=n_inst, mp_context=mp.get_context("spawn")) as ex:
+                        res = list(ex.map(_cpu_instance, [(best_t, min(a.cpu_seconds, 10.0), 32, a.conf, a.iou, 77 + k) for k in range(n_inst)]))
+                    many = {"instances": n_inst, "threads_each": best_t, "images_s_sum": round(sum(n / t for n, t in res), 1),
+                            "images_s_per_instance": [round(n / t, 1) for n, t in res]}
+                except Exception as e:      # noqa: BLE001 - a baseline, best effort
+                    many = {"error": repr(e)[:200]}
             cpu = {"value": round(n_img / el, 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                    "host_threads_available": ncores,
-                   "sample": "%d synthetic images in batches of %d through oracle forward(ATen CPU)+decode+NMS, %.1f s, "
-                             "thread count chosen by a 16-image probe over %s; kind 'port' because /root/reference does not exist on "
+                   "what": "ONE %d-thread instance of the CPU oracle (of the %d host threads this process may use)" % (best_t, ncores),
+                   "concurrent_instances": many,
+                   "sample": "ONE %d-thread instance: %d synthetic images in batches of %d through oracle forward(ATen CPU)+decode+NMS, %.1f s, "
+                             "thread count chosen by a 16-image probe over %s (more threads per instance only get slower: these convs are tiny); "
+                             "`concurrent_instances` = floor(host threads / %d) such instances at once, one process each, rates summed; "
+                             "kind 'port' because /root/reference does not exist on "
                              "the GPU box - the oracle runs the same ATen CPU ops and is bit-identical to the reference's own modules "
-                             "where both exist (asserted by tests/golden/make_golden.py)" % (n_img, bs, el, cands)}
+                             "where both exist (asserted by tests/golden/make_golden.py)" % (best_t, n_img, bs, el, cands, best_t)}
 
         # ---- BASELINE configs[4]: one train.py iteration at batch 64 - train-mode forward, compute_loss,
         # backward to all 225 parameters, SGD - through the drop-in surface; an extra, never `value`
@@ -768,7 +817,8 @@ def main():
                                    % (a.batch, a.conf, a.iou, " + one RCCL all-gather of the padded detections per step, overlapped with the next step" if use_dist else "",
                                       len(engs), a.batch, len(engs)),
                        "global_batch": world * a.batch, "batches_in_flight": len(engs), "single_stream_img_s": round(a.batch * a.steps / dt_s, 1),
-                       "weights": a.weights, "parallelism": "batch-sharded x%d" % world},
+                       "weights": a.weights + (" (yfv2.random_state_dict(0))" if a.weights == "random" else ""), "parallelism": "batch-sharded x%d" % world,
+                       "distinct_input_batches": len(xs)},
             "blocks": blocks,
             "spinup": {"seconds": round(spin_s, 2), "steps": n_spin, "why": "set-up, before the W warm-up steps: the device is held under load until it has left its idle power state"},
             "box": box,
@@ -777,6 +827,9 @@ def main():
             "single_stream_ms_per_step": round(1e3 * dt_s / a.steps, 4),
             "single_call_two_lanes_img_s": round(a.batch * a.steps / dt_l, 1), "single_call_two_lanes_ms_per_step": round(1e3 * dt_l / a.steps, 4),
             "forward_only_img_s": round(fwd_img_s, 1), "forward_only_ms": round(1e3 * dt_f / a.steps, 4),
+            "forward_only_note": "BASELINE.json configs[1] names `random-init weights`; timed here: yfv2.random_state_dict(0) (He-style seeded init of every tensor, "
+                                 "the same shapes) - NOT the literal Detector(80, 3, load_param=False), which loads model/backbone/backbone.pth for the backbone "
+                                 "(/root/reference/model/backbone/shufflenetv2.py:111-114; that file is not in this repository).  Speed does not depend on the values.",
             "forward_from_uint8_hwc_img_s": round(fwd_u8_img_s, 1), "forward_from_uint8_hwc_ms": round(1e3 * dt_u / a.steps, 4),
             "fp32_mfma_plan": fp32,
             "roofline": roof, "cpu_baseline": cpu,

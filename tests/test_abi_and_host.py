@@ -705,6 +705,12 @@ def test_bench_gpus_2_launches_itself(tmp_path):
     j = json.loads(lines[0])
     assert j["selftest"] is True and j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2 and j["blocks"] == 3
     assert j["launched_by"] == "torch.distributed.run" and j["scaling"] == "weak"
+    # ... the driver's largest case: --gpus 8 (eight gloo ranks of the same control flow; every rank's slice checked in the gathered buffer)
+    r8 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--launcher-selftest", "--steps", "3", "--warmup", "1", "--blocks", "2"],
+                        capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="1"), cwd=str(tmp_path))
+    assert r8.returncode == 0, (r8.stdout[-1000:], r8.stderr[-3000:])
+    lines8 = [ln for ln in r8.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines8) == 1 and json.loads(lines8[0])["n_gpus"] == 8 and json.loads(lines8[0])["launched_by"] == "torch.distributed.run"
     # ... and a plain N = 1 call stays in-process
     r1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--launcher-selftest", "--steps", "2", "--blocks", "1"],
                         capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
