@@ -668,7 +668,7 @@ constexpr int TP_XS = 2 * 512 + 16;                                    // exchan
 constexpr int TP_XB_FL = 8 * TP_XS;
 constexpr int TP_TAPS2 = TH_KC * 4 * 27 * 4 + 16;                      // offset of the pair tap table behind th_lds_img(MH): [s 5][pair 8][64]:
                                                                        // floats 2t + e = tap t of channel 16s + 2 pair + e, 50 + e = BN scale x 16, 52 + e = BN shift x 16
-__host__ __device__ constexpr int tp_lds_floats(int MH) { return th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + TP_DUMP_FL; }
+__host__ __device__ constexpr int tp_lds_floats(int MH) { return th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + TP_DUMP_FL + 2 * 384; }
 typedef float yfv2_f8 __attribute__((ext_vector_type(8)));
 typedef float yfv2_f16v __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(4))) const yfv2_f16v yfv2_cf16;
@@ -684,7 +684,6 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   constexpr int NF = FORM == 0 ? KC : MH;                      // filter / accumulator tiles
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* WP_ = lds;
-  float* CS = lds + TH_CS;
   float* WH = lds + TH_WH;
   float* XB = lds + th_lds_img(MH);
   float* TIN = XB + TP_XB_FL;
@@ -692,10 +691,16 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   const float invW = 1.0f / (float)W;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gpj = jobs.par ? jobs.gpj : (int)gridDim.x;
+  // Work items of a workgroup (round 6, second step): with side-by-side jobs (jobs.par: the cls and the reg tower's halves) a workgroup
+  // runs ALL of them for its image, one after the other - item (job j, image b) is followed by (j + 1, b), then (0, b + grid) - and an
+  // item's last two chunks already request the next item's first slices, filter fragments, constants and taps: one prologue per
+  // workgroup instead of one per job (12 k of a 47-60 k cycle job at batch 256), and the second job's input is the first one's
+  // (the FPN map: L2 hits).
+  // (Small batches - fewer items than CUs - get one workgroup per item instead: the launcher's grid is then nj x B.)
+  const int nj = jobs.par ? jobs.n : 1;
+  const bool spread = (int)gridDim.x == nj * a.B && nj > 1;     // one item per workgroup, job-major
+  const int grid = (int)gridDim.x;
   const int bid = blockIdx.x;
-  const int jidx = __builtin_amdgcn_readfirstlane(jobs.par ? (bid >= gpj) + (bid >= 2 * gpj) + (bid >= 3 * gpj) : 0);
-  const int grid = gpj;
   YFV2_WSTAMP(0);
 
   // ---- staging map (as towerh_kernel: eight consecutive lanes = eight consecutive pixels of one quad); a piece = (pixel, quad) is
@@ -750,12 +755,12 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   for (int nt = 0; nt < NT; ++nt) opix[nt] = 16 * (wv * NT + nt) + p;
 
   typedef const __attribute__((address_space(4))) TowerArgs JobArgs;
-  JobArgs& ja = ((JobArgs*)__builtin_amdgcn_kernarg_segment_ptr())[jidx];
-  const float* taps2 = ja.img16 + th_lds_img(MH) + TP_TAPS2;
-  int b = bid - jidx * gpj;
+  JobArgs* kj = (JobArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int TAPS2 = th_lds_img(MH) + TP_TAPS2;             // offset of the pair tap table in a job's image
+  int b = spread ? bid % a.B : bid, jc = spread ? bid / a.B : 0;   // the current item: image b, job jc
   Yfv2Watch watch;
   f32x4 pre[NT];
-  stage_load(ja.in, b < a.B ? b : 0, 0, pre);
+  stage_load(kj[jc].in, b < a.B ? b : 0, 0, pre);
 
   // ---- the filter fragments a wave carries into LDS: chunk s's pointwise phase reads only that chunk's fragments (NF tiles x 1 KB, + the
   // previous chunk's in odd chunks), so set s + 1 is written during chunk s's pointwise phase from a register loaded a chunk earlier (wave
@@ -764,6 +769,12 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   auto frag_off = [&](int sc) { return (FORM == 0 ? 0 : TH_WH) + (((wv < NF ? wv : 0) * KC + sc) * 64 + lane) * 4; };
   auto frag_dst = [&](int sc) { return wv < NF ? frag_off(sc) : fdump; };
   f32x4 fpre;
+  // the 1.5 KB of constants: waves NF, NF + 1 carry their 96 16-byte pieces (lanes 0..63, 0..31); TWO copies in LDS (behind the dump
+  // area), item i reads copy i & 1 while the next item's is written under its last chunk
+  const bool cs_w = wv == NF || (wv == NF + 1 && lane < 32);
+  const int cs_i = cs_w ? (wv == NF ? lane : 64 + lane) : 0;
+  constexpr int CS2 = th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + TP_DUMP_FL;      // float offset of the two copies (2 x 384)
+  f32x4 cpre;
   // ---- prologue: fragment set 0 and the constants -> LDS, exchange and planes zeroed (the halo stays zero for the whole job)
   {
     // this wave's tap records -> scalar cache: one request per 64-byte line, issued back to back NOW (nothing waits for them:
@@ -771,9 +782,10 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
     // set-up, where scalar registers are short, the compiler serialises them: 2.8 k cycles in front of the first chunk
 #define YFV2_L(p, o) "s_load_dword s40, %" #p ", " #o "\n\t"
 #define YFV2_R(p, o) YFV2_L(p, o + 0) YFV2_L(p, o + 64) YFV2_L(p, o + 128) YFV2_L(p, o + 192)
-    {
-      const float* tq = taps2 + wv * 64;
-      const float* tq4 = taps2 + (4 * 8 + (wv & 3)) * 64;
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+      const float* tq = kj[j].img16 + TAPS2 + wv * 64;
+      const float* tq4 = kj[j].img16 + TAPS2 + (4 * 8 + (wv & 3)) * 64;
       asm volatile(YFV2_R(0, 0) YFV2_R(0, 2048) YFV2_R(0, 4096) YFV2_R(0, 6144) YFV2_R(1, 0) :: "s"(tq), "s"(tq4) : "s40", "memory");
     }
 #undef YFV2_R
@@ -782,38 +794,41 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
     // 72 x 72 filter at all) in the burst in which every CU of the chip fills at ~11 bytes per cycle.
     constexpr int NZ = (TP_XB_FL + TP_TIN_FL + TP_DUMP_FL) / 4;
     for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // waves NF, NF + 1: the 96 16-byte pieces of the constants (lanes 0..63, 0..31)
-    const bool cs_w = wv == NF || (wv == NF + 1 && lane < 32);
-    const int cs_i = cs_w ? (wv == NF ? lane : 64 + lane) : 0;
-    const f32x4 f0 = *reinterpret_cast<const f32x4*>(ja.img16 + (wv < NF ? frag_off(0) : TH_CS + 4 * cs_i));
-    fpre = *reinterpret_cast<const f32x4*>(ja.img16 + frag_off(1));
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(kj[jc].img16 + (wv < NF ? frag_off(0) : TH_CS + 4 * cs_i));
+    fpre = *reinterpret_cast<const f32x4*>(kj[jc].img16 + frag_off(1));
     // (every lane stores: what is not part of the image goes where nothing reads - a store behind a lane predicate leaves the
     // compiler a path on which the load is still pending, and it then guards the registers with vmcnt(0) behind the NEXT requests)
-    *reinterpret_cast<f32x4*>(lds + (wv < NF ? frag_off(0) : cs_w ? TH_CS + 4 * cs_i : fdump)) = f0;
+    *reinterpret_cast<f32x4*>(lds + (wv < NF ? frag_off(0) : cs_w ? CS2 + 4 * cs_i : fdump)) = f0;
   }
   __syncthreads();
   YFV2_WSTAMP(1);
   if (b < a.B) {
     stage_store(0, pre);
-    stage_load(ja.in, b, 1, pre);
+    stage_load(kj[jc].in, b, 1, pre);
   }
 
-  const int hmh = MH ? ja.mh : 0;
-  const int mlive = (hmh + 15) >> 4;                           // output-channel tiles of the merged matrix (wave-uniform)
   // this wave's depthwise unit of the coming chunk: the pair's 25 taps + BN constants in 56 SGPRs
   yfv2_f16v t0, t1, t2;
   yfv2_f8 t3;
-  auto load_taps = [&](int s) __attribute__((always_inline)) {
+  auto load_taps = [&](const float* img16, int s) __attribute__((always_inline)) {
     const int pair = s == KC - 1 ? (wv & 3) : wv;
-    const yfv2_cf16* tp = (const yfv2_cf16*)(taps2 + (s * 8 + pair) * 64);
+    const yfv2_cf16* tp = (const yfv2_cf16*)(img16 + TAPS2 + (s * 8 + pair) * 64);
     t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
     t3 = *(const yfv2_cf8*)(tp + 3);
     __builtin_amdgcn_sched_barrier(0);                         // (requested HERE: invariant loads move freely otherwise)
   };
-  load_taps(0);
-  // (a fused job is launched with one workgroup per image and tower: no image loop - out of a loop the compiler hoists the address
-  // arithmetic of every unrolled chunk copy, ~40 registers spilled in the set-up and reloaded in every phase)
-  for (; b < a.B; b += grid) {
+  load_taps(kj[jc].img16, 0);
+  int item = 0;
+  for (; b < a.B; ++item) {
+    // this item's job and the next item (its first slices, fragments, constants and taps are requested under this item's last chunks)
+    JobArgs& ja = kj[jc];
+    const int jn = spread ? jc : (jc + 1 < nj ? jc + 1 : 0), bn = spread ? a.B : (jn ? b : b + grid);
+    const bool more = bn < a.B;
+    JobArgs& jx = kj[more ? jn : jc];                             // (no next item: harmless re-requests of this one's)
+    const int bx = more ? bn : b;
+    const float* CS = lds + CS2 + (item & 1) * 384;
+    const int hmh = MH ? ja.mh : 0;
+    const int mlive = (hmh + 15) >> 4;                           // output-channel tiles of the merged matrix (wave-uniform)
     f32x4 acc[NF][NT];                                         // form 0: output-channel tile x pixel tile (lane: 4 channels of 1 pixel);
                                                                // form 1: pixel tile x output-channel tile, transposed (lane: 4 pixels of 1 channel)
 #pragma unroll
@@ -918,18 +933,20 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       // filter fragments: tile m + 1's requested in front of tile m's MFMAs (two tiles = 16 registers in flight, not all 2 x NF: 201 / 227
       // registers instead of 252 / 255).  All tiles, also where a job's output conv is narrower - the image holds zero tiles there
       auto frag = [&](int m, int sc) { return *reinterpret_cast<const u32x4*>(FB + ((m * KC + sc) * 64 + lane) * 4); };
-      u32x4 wfn = frag(0, s), w0n;
+      u32x4 wfn = frag(0, s), w0n = {0u, 0u, 0u, 0u};
       if constexpr (ODD) w0n = frag(0, s - 1);
       // the next chunk's filter fragments -> LDS (requested a chunk ago), the set after that into the register
       *reinterpret_cast<f32x4*>(lds + frag_dst(s + 1 < KC ? s + 1 : 0)) = fpre;
-      fpre = *reinterpret_cast<const f32x4*>(ja.img16 + frag_off(s + 2 < KC ? s + 2 : s + 2 - KC));
-      // the next slice -> TIN, the one after into registers (of the next image after the last chunk)
-      if (s + 1 < KC || b + grid < a.B) stage_store(s + 1 < KC ? s + 1 : 0, pre);
-      {
-        int ns = s + 2, nb = b;
-        if (ns >= KC) { ns -= KC; nb += grid; }
-        stage_load(ja.in, nb < a.B ? nb : b, ns, pre);
+      fpre = *reinterpret_cast<const f32x4*>((s + 2 < KC ? ja.img16 : jx.img16) + frag_off(s + 2 < KC ? s + 2 : s + 2 - KC));
+      if constexpr (LAST) {   // the next item's constants -> the other copy
+        *reinterpret_cast<f32x4*>(lds + (cs_w ? CS2 + ((item + 1) & 1) * 384 + 4 * cs_i : fdump)) = cpre;
+      } else if (s == KC - 2) {
+        cpre = *reinterpret_cast<const f32x4*>(jx.img16 + TH_CS + 4 * cs_i);
       }
+      // the next slice -> TIN, the one after into registers (the next ITEM's behind this one's last)
+      if (s + 1 < KC || more) stage_store(s + 1 < KC ? s + 1 : 0, pre);
+      if (s + 2 < KC) stage_load(ja.in, b, s + 2, pre);
+      else stage_load(jx.in, bx, s + 2 - KC, pre);
 #pragma unroll
       for (int m = 0; m < NF; ++m) {
         const u32x4 wf = wfn, w0 = w0n;
@@ -968,7 +985,7 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       // the NEXT chunk's taps (of the next image's first chunk behind the last): requested here, behind this phase's last LDS
       // wait - scalar loads and LDS reads share one counter, a scalar load in flight turns every LDS wait into "wait for everything" -
       // and landed (a scalar-cache miss is an L2 round trip) by the time the matrix pipe has drained and the barrier opens
-      load_taps(LAST ? 0 : s + 1);
+      load_taps(LAST ? jx.img16 : ja.img16, LAST ? 0 : s + 1);
       YFV2_WSTAMP(stamp0 + 2);
     };
 
@@ -1040,8 +1057,9 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       }
     }
     YFV2_WSTAMP(18);
+    jc = jn; b = bn;
   }
-  watch.report(ja.nonfinite);
+  watch.report(kj[0].nonfinite);
 }
 
 template <int MH>
@@ -1128,7 +1146,10 @@ static void launch_towerp(TowerJobs jobs, hipStream_t s) {
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerp_kernel<MH>), lds_ok);
   const int B = jobs.j[0].B;
-  jobs.gpj = B < 256 ? B : 256;
+  // a workgroup runs every side-by-side job of its images (one prologue, the next item's data requested under the current one) - unless
+  // there are fewer items than CUs: then one workgroup per item
+  const int njobs = jobs.par ? jobs.n : 1;
+  jobs.gpj = (njobs > 1 && njobs * B <= 256) ? njobs * B : (B < 256 ? B : 256);
   {
     static std::mutex mu;
     static std::map<int, std::array<unsigned char, 128>> cache;
@@ -1144,7 +1165,7 @@ static void launch_towerp(TowerJobs jobs, hipStream_t s) {
     }
     std::copy(it->second.begin(), it->second.end(), jobs.lane_patch);
   }
-  hipLaunchKernelGGL((towerp_kernel<MH>), dim3(jobs.gpj * (jobs.par ? jobs.n : 1)), dim3(512), lds, s, jobs);
+  hipLaunchKernelGGL((towerp_kernel<MH>), dim3(jobs.gpj), dim3(512), lds, s, jobs);
 }
 
 // 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
