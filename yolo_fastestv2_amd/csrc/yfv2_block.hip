@@ -84,6 +84,11 @@ constexpr int CH6_IMG_FL = 2 * CH6_WP_FL + S1Cfg<48>::DW_FL + S1Cfg<48>::CST_FL 
 
 // row pitch of the patch-parity tile in 16-byte slots: both column parities of a haloed row (2 (PW + 1) slots), = PW mod 16
 __host__ __device__ constexpr int s1chain_pitch(int PW) { return 2 * (PW + 1) + ((PW - 2 * (PW + 1)) % 16 + 16) % 16; }
+// slots per plane, a multiple of 16 (round 6): ds_read_b128 / ds_write_b128 are serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32
+// (tools/ubench/ldsgroups.hip) - a group mixes lanes of two channel groups g, g + 1, i.e. of two PLANES.  With consecutive patches on
+// consecutive slots a group is conflict-free only if the plane stride is 0 mod 16 slots (22x22: 2 x 12 x 27 = 648 = 8 mod 16 put lanes
+// 20-27 on exactly the banks of lanes 0-3, 12-15: every such access took two passes)
+__host__ __device__ constexpr int s1chain_plane(int PH, int PW) { return (2 * (PH + 1) * s1chain_pitch(PW) + 15) & ~15; }
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args a) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
   const int PH = H >> 1, PW = W >> 1;
   const int CP1 = PW + 1;                                   // slots of one column parity (haloed columns 0 .. 2 PW + 1)
   const int RPT = s1chain_pitch(PW);
-  const int PL = 2 * (PH + 1) * RPT;                        // slots per plane
+  const int PL = s1chain_plane(PH, PW);                     // slots per plane
   const float invPW = 1.0f / (float)PW;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4, wave = tid >> 6;
   YFV2_WSTAMP(0);
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1chain6_kernel(BlockS1Args 
 }
 
 static long s1chain_lds_floats(int H, int W) {
-  const long pl = 2L * (H / 2 + 1) * s1chain_pitch(W / 2);   // 16-byte slots per plane: [row parity][haloed row / 2][pitch]
+  const long pl = s1chain_plane(H / 2, W / 2);               // 16-byte slots per plane: [row parity][haloed row / 2][pitch], rounded up to 16
   return (long)CH6_IMG_FL + 12L * pl * 4;
 }
 

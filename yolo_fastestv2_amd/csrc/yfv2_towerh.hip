@@ -427,15 +427,20 @@ __global__ __launch_bounds__(512) void towerh_kernel(TowerJobs jobs) {   // runs
 //     them: an input value is read five times (once per output row it feeds) instead of 25, every read is 64 consecutive
 //     channels of one pixel (256 contiguous bytes: conflict-free), the 25 taps and the BN constants are per-lane registers
 //     read from the tap table the job's filter image brings into LDS;
-//   * exchange: BN + ReLU results as fp32 [pixel][76] (pitch 76 = 12 mod 64 banks: the pointwise phase's 16-byte reads of 16
-//     pixels x 4 lane groups are conflict-free), split into two fp16 terms by the reader;
+//   * exchange: BN + ReLU results as fp32 [pixel][72] (TS_CP below: the pitch that keeps the pointwise phase's 16-byte reads of 16
+//     pixels x 4 lane groups conflict-free in ds_read_b128's service groups), split into two fp16 terms by the reader;
 //   * pointwise (K = 72 in one go) and the transposed output conv as in towerh_kernel.
 // Three barriers per job.
+// exchange pitch (floats per pixel).  The pointwise phase reads 16 bytes at slot 18 p + 4 chunk + g per lane (p, g); ds_read_b128's service
+// groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: tools/ubench/ldsgroups.hip) mix the pixels {0-3, 12-15} of channel group g with
+// the pixels {4-11} of g + 1: a pitch of 2 mod 16 slots puts the former on even, the latter on odd slot residues, each set distinct.
+// (Until round 6: 76 floats = 19 slots, free of conflicts for 16 CONSECUTIVE lanes - which is not how the instruction is serviced.)
+constexpr int TS_CP = 72;
 template <int MH>
 __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
   struct { int B, H, W; long long* trace; } a;
   a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
-  constexpr int KC = TH_KC, C = TH_C, NQ = C / 4, MAXW = 11, CP = 76, MAXPX = 128;
+  constexpr int KC = TH_KC, C = TH_C, NQ = C / 4, MAXW = 11, CP = TS_CP, MAXPX = 128;
   constexpr int TAPS_FL = NQ * 27 * 4;
   constexpr int LDS_IMG = th_lds_img(MH) + TAPS_FL;               // pointwise filter, constants, output-conv filter, tap table: one straight copy
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
   float* CS = lds + TH_CS;
   float* WH = lds + TH_WH;
   float* IN = lds + LDS_IMG;                                      // [row + 2][W][72]: two zero rows above and below the image
-  float* X32 = IN + (MAXW + 4) * MAXW * C;                        // [pixel][76]; rows past H*W stay zero
+  float* X32 = IN + (MAXW + 4) * MAXW * C;                        // [pixel][TS_CP]; rows past H*W stay zero
   const int H = a.H, W = a.W, HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
 template <int MH>
 static void launch_towers(const TowerJobs& jobs, hipStream_t s) {
   const int B = jobs.j[0].B;
-  const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + (TH_C / 4) * 27 * 4 + 15 * 11 * TH_C + 128 * 76);
+  const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + (TH_C / 4) * 27 * 4 + 15 * 11 * TH_C + 128 * TS_CP);
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&towers_kernel<MH>), lds_ok);
   hipLaunchKernelGGL((towers_kernel<MH>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
