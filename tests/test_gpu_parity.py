@@ -742,9 +742,9 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     elif "YFV2_TPAIR" in env:
         assert len(names) == 15 and not any("side by side" in n for n in names), names   # cls a, cls b, reg a, reg b at 22x22
     elif "YFV2_FRONT" in env:
-        assert len(names) == 14 and sum("side by side" in n for n in names) == 2 and names[0].startswith("stem conv"), names
+        assert len(names) == 13 and sum("four halves of an image" in n for n in names) == 1 and names[0].startswith("stem conv"), names
     else:
-        assert len(names) == 13 and sum("side by side" in n for n in names) == 2 and names[0].startswith("stem + backbone.stage2.0 in one launch"), names
+        assert len(names) == 12 and sum("four halves of an image" in n for n in names) == 1 and names[0].startswith("stem + backbone.stage2.0 in one launch"), names
         eng.set_anchors([12.64, 19.39, 37.88, 51.48, 55.71, 138.31, 126.91, 78.23, 131.57, 214.55, 279.92, 258.87])
         r1, i1 = yfv2.unpack_detections(*eng.detect(x.to(dev), 0.3, 0.4))                 # decode_kernel<compact> + nms_kernel<1>
         r2, i2 = yfv2.unpack_detections(*eng.nms(eng.decode(eng.forward(x.to(dev))), 0.3, 0.4))

@@ -1558,6 +1558,25 @@ struct PlanBuilder {
         m.bytes_ext = ext;
         out.push_back(m);
         i += 4;
+      } else if (i + 4 <= h->plan.size() && h->plan[i].kind == STEP_TOWER && pair_level(h->plan[i].tw.H, h->plan[i].tw.W) && pairable(i) &&
+                 !((h->plan[i].tw.H | h->plan[i].tw.W) & 1)) {
+        // cls a, cls b, reg a, reg b  ->  ONE step {cls a, reg a, cls b, reg b} (towerp_kernel: even maps).  At batches that fill the chip it is
+        // one launch whose workgroups run their image's four halves back to back (yfv2_launch_towerh decides per call: small batches run
+        // the a halves and the b halves as two launches of independent items)
+        Step m = h->plan[i + 1];
+        m.jobs = {h->plan[i], h->plan[i + 2], h->plan[i + 1], h->plan[i + 3]};
+        m.par = true;
+        m.tw_tiles = std::max(h->plan[i + 1].tw_tiles, h->plan[i + 3].tw_tiles);
+        m.name = "fpn towers " + std::to_string(m.tw.H) + "x" + std::to_string(m.tw.W) + ": cls_head (dw5x5+bn+relu -> pw+bn, twice) -> output_obj+output_cls | reg_head -> output_reg, the four halves of an image in one workgroup";
+        m.flops = 0; m.bytes = 0;
+        double ext = 0;
+        for (const Step& j : m.jobs) {
+          m.flops += j.flops; m.bytes += j.bytes;
+          ext += 4.0 * j.tw.H * j.tw.W * (j.has_head ? (double)j.tw.mh : 72.0);   // the a halves read the FPN map, the b halves write logits; the tensors between them are the launch's own scratch
+        }
+        m.bytes_ext = ext;
+        out.push_back(m);
+        i += 4;
       } else if (i + 4 <= h->plan.size() && h->plan[i].kind == STEP_TOWER && pair_level(h->plan[i].tw.H, h->plan[i].tw.W) && pairable(i)) {
         // cls a, cls b, reg a, reg b  ->  (cls a | reg a), (cls b | reg b)
         for (int half = 0; half < 2; ++half) {
@@ -1708,7 +1727,8 @@ std::string step_kernel(const Step& st) {
     case STEP_DW: return "dw_kernel<" + std::to_string(st.ksize) + ", " + std::to_string(st.stride) + ">";
     case STEP_TOWER:
       if (st.img_off3 && !st.jobs.empty() && !st.par) return "towers_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, maps up to 11x11
-      if (st.img_off3 && (st.tw.H > 11 || st.tw.W > 11) && !((st.tw.H | st.tw.W) & 1)) return "towerp_kernel<" + std::to_string(st.tw_tiles) + ">";   // default plan, even maps up to 22x22
+      if (st.img_off3 && (st.tw.H > 11 || st.tw.W > 11) && !((st.tw.H | st.tw.W) & 1))   // default plan, even maps up to 22x22
+        return "towerp_kernel<" + std::to_string(st.tw_tiles) + (st.par && st.jobs.size() == 4 ? ", true>" : ", false>");
       if (st.img_off3) return "towerh_kernel<" + std::to_string(st.tw_tiles) + ", " + (st.tw.H > 11 || st.tw.W > 11 ? "2, 4>" : "1, 1>");
       return "tower2_kernel<" + std::to_string(!st.has_head ? 0 : ((st.tw.mh + 15) / 16 <= 1 ? 1 : 6)) + ", 512, " + (st.tw.H * st.tw.W > 128 ? "4, 4," : "1, 1,");
     case STEP_S2: return st.img_off3 ? std::string(st.c2 == 96 ? "s4h_kernel" : "s3h2_kernel") : (st.c2 == 96 ? std::string("block_s2w_kernel<") : "block_s2_kernel<" + std::to_string(st.c2) + ",");

@@ -679,14 +679,22 @@ typedef float yfv2_f16v __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(4))) const yfv2_f16v yfv2_cf16;
 typedef __attribute__((address_space(4))) const yfv2_f8 yfv2_cf8;
 
-template <int MH>
+template <int MH, bool BOTH>
 __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
+  // BOTH (round 6, third step): ONE launch for a whole level - a workgroup's items are the four halves of its image, cls a, reg a, cls b,
+  // reg b.  The b halves read what the a halves of the SAME workgroup wrote two items earlier (same CU, same L1, tens of thousands
+  // of cycles and many barriers apart), so no launch boundary is needed between them: one prologue per image instead of two, no drain /
+  // ramp between two launches.  An item's FORM (0: 72 -> 72 pointwise conv, a halves; 1: merged matrix, b halves) is then a
+  // per-item property (TowerArgs::has_head); the two forms are two instantiations of the item body below.
+  static_assert(!BOTH || MH > 0, "the b halves end in an output conv");
   struct { int B, H, W; long long* trace; } a;
   a.B = jobs.j[0].B; a.H = jobs.j[0].H; a.W = jobs.j[0].W; a.trace = jobs.j[0].trace;
   constexpr int KC = TH_KC, C = TH_C, NT = 4, P = TP_P;
-  constexpr int FORM = MH == 0 ? 0 : 1;                        // 0: the 72 -> 72 pointwise conv (accumulators = output-channel tiles x pixel tiles);
-                                                               // 1: the merged matrix, transposed (a lane holds four pixels of one output channel)
-  constexpr int NF = FORM == 0 ? KC : MH;                      // filter / accumulator tiles
+  // form 0: the 72 -> 72 pointwise conv (accumulators = output-channel tiles x pixel tiles); form 1: the merged matrix, transposed (a lane
+  // holds four pixels of one output channel).  Filter / accumulator tiles: KC / MH.  Without BOTH every item has the form MH implies.
+  constexpr int FORM1 = MH == 0 ? 0 : 1;
+  auto form_of = [&](int j) { return BOTH ? (int)(((const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[j].has_head != 0) : FORM1; };
+  auto nf_of = [](int form) { return form == 0 ? KC : MH; };
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* WP_ = lds;
   float* WH = lds + TH_WH;
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   // (the FPN map: L2 hits).
   // (Small batches - fewer items than CUs - get one workgroup per item instead: the launcher's grid is then nj x B.)
   const int nj = jobs.par ? jobs.n : 1;
-  const bool spread = (int)gridDim.x == nj * a.B && nj > 1;     // one item per workgroup, job-major
+  const bool spread = !BOTH && (int)gridDim.x == nj * a.B && nj > 1;     // one item per workgroup, job-major (independent jobs only)
   const int grid = (int)gridDim.x;
   const int bid = blockIdx.x;
   YFV2_WSTAMP(0);
@@ -761,7 +769,9 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
 
   typedef const __attribute__((address_space(4))) TowerArgs JobArgs;
   JobArgs* kj = (JobArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  constexpr int TAPS2 = th_lds_img(MH) + TP_TAPS2;             // offset of the pair tap table in a job's image
+  // offset of the pair tap table in a job's image (a job is packed for the launch it was planned for: under BOTH the a halves as a launch
+  // without output conv)
+  auto taps_off = [&](int form) { return th_lds_img((BOTH && form == 0) ? 0 : MH) + TP_TAPS2; };
   int b = spread ? bid % a.B : bid, jc = spread ? bid / a.B : 0;   // the current item: image b, job jc
   Yfv2Watch watch;
   f32x4 pre[NT];
@@ -771,13 +781,14 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   // previous chunk's in odd chunks), so set s + 1 is written during chunk s's pointwise phase from a register loaded a chunk earlier (wave
   // m < NF carries tile m's fragment, one 16-byte piece per lane).  form 0: the 72 x 72 filter WP (5 tiles), form 1: the merged matrix WH
   const int fdump = th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + 4 * (lane & 15);
-  auto frag_off = [&](int sc) { return (FORM == 0 ? 0 : TH_WH) + (((wv < NF ? wv : 0) * KC + sc) * 64 + lane) * 4; };
-  auto frag_dst = [&](int sc) { return wv < NF ? frag_off(sc) : fdump; };
+  auto frag_off = [&](int form, int sc) { return (form == 0 ? 0 : TH_WH) + (((wv < nf_of(form) ? wv : 0) * KC + sc) * 64 + lane) * 4; };
+  auto frag_dst = [&](int form, int sc) { return wv < nf_of(form) ? frag_off(form, sc) : fdump; };
   f32x4 fpre;
-  // the 1.5 KB of constants: waves NF, NF + 1 carry their 96 16-byte pieces (lanes 0..63, 0..31); TWO copies in LDS (behind the dump
-  // area), item i reads copy i & 1 while the next item's is written under its last chunk
-  const bool cs_w = wv == NF || (wv == NF + 1 && lane < 32);
-  const int cs_i = cs_w ? (wv == NF ? lane : 64 + lane) : 0;
+  // the 1.5 KB of constants: waves 6, 7 carry their 96 16-byte pieces (lanes 0..63, 0..31; the fragment carriers are waves 0 .. 5 at
+  // most); TWO copies in LDS (behind the dump area), item i reads copy i & 1 while the next item's is written under its last chunk
+  static_assert(MH <= 6, "waves 6 and 7 carry the constants");
+  const bool cs_w = wv == 6 || (wv == 7 && lane < 32);
+  const int cs_i = cs_w ? (wv == 6 ? lane : 64 + lane) : 0;
   constexpr int CS2 = th_lds_img(MH) + TP_XB_FL + TP_TIN_FL + TP_DUMP_FL;      // float offset of the two copies (2 x 384)
   f32x4 cpre;
   // ---- prologue: fragment set 0 and the constants -> LDS, exchange and planes zeroed (the halo stays zero for the whole job)
@@ -789,8 +800,8 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
 #define YFV2_R(p, o) YFV2_L(p, o + 0) YFV2_L(p, o + 64) YFV2_L(p, o + 128) YFV2_L(p, o + 192)
 #pragma unroll 1
     for (int j = 0; j < nj; ++j) {
-      const float* tq = kj[j].img16 + TAPS2 + wv * 64;
-      const float* tq4 = kj[j].img16 + TAPS2 + (4 * 8 + (wv & 3)) * 64;
+      const float* tq = kj[j].img16 + taps_off(form_of(j)) + wv * 64;
+      const float* tq4 = kj[j].img16 + taps_off(form_of(j)) + (4 * 8 + (wv & 3)) * 64;
       asm volatile(YFV2_R(0, 0) YFV2_R(0, 2048) YFV2_R(0, 4096) YFV2_R(0, 6144) YFV2_R(1, 0) :: "s"(tq), "s"(tq4) : "s40", "memory");
     }
 #undef YFV2_R
@@ -799,11 +810,12 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
     // 72 x 72 filter at all) in the burst in which every CU of the chip fills at ~11 bytes per cycle.
     constexpr int NZ = (TP_XB_FL + TP_TIN_FL + TP_DUMP_FL) / 4;
     for (int i = tid; i < NZ; i += 512) reinterpret_cast<f32x4*>(XB)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4 f0 = *reinterpret_cast<const f32x4*>(kj[jc].img16 + (wv < NF ? frag_off(0) : TH_CS + 4 * cs_i));
-    fpre = *reinterpret_cast<const f32x4*>(kj[jc].img16 + frag_off(1));
+    const int f0m = form_of(jc);
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(kj[jc].img16 + (cs_w ? TH_CS + 4 * cs_i : frag_off(f0m, 0)));
+    fpre = *reinterpret_cast<const f32x4*>(kj[jc].img16 + frag_off(f0m, 1));
     // (every lane stores: what is not part of the image goes where nothing reads - a store behind a lane predicate leaves the
     // compiler a path on which the load is still pending, and it then guards the registers with vmcnt(0) behind the NEXT requests)
-    *reinterpret_cast<f32x4*>(lds + (wv < NF ? frag_off(0) : cs_w ? CS2 + 4 * cs_i : fdump)) = f0;
+    *reinterpret_cast<f32x4*>(lds + (cs_w ? CS2 + 4 * cs_i : frag_dst(f0m, 0))) = f0;
   }
   __syncthreads();
   YFV2_WSTAMP(1);
@@ -815,24 +827,27 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
   // this wave's depthwise unit of the coming chunk: the pair's 25 taps + BN constants in 56 SGPRs
   yfv2_f16v t0, t1, t2;
   yfv2_f8 t3;
-  auto load_taps = [&](const float* img16, int s) __attribute__((always_inline)) {
+  auto load_taps = [&](const float* img16, int form, int s) __attribute__((always_inline)) {
     const int pair = s == KC - 1 ? (wv & 3) : wv;
-    const yfv2_cf16* tp = (const yfv2_cf16*)(img16 + TAPS2 + (s * 8 + pair) * 64);
+    const yfv2_cf16* tp = (const yfv2_cf16*)(img16 + taps_off(form) + (s * 8 + pair) * 64);
     t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
     t3 = *(const yfv2_cf8*)(tp + 3);
     __builtin_amdgcn_sched_barrier(0);                         // (requested HERE: invariant loads move freely otherwise)
   };
-  load_taps(kj[jc].img16, 0);
+  load_taps(kj[jc].img16, form_of(jc), 0);
   int item = 0;
-  for (; b < a.B; ++item) {
+  // one item: five chunks and the form's epilogue
+  auto run_item = [&]<int FORM>() __attribute__((always_inline)) {
+    constexpr int NF = FORM == 0 ? KC : MH;
     // this item's job and the next item (its first slices, fragments, constants and taps are requested under this item's last chunks)
     JobArgs& ja = kj[jc];
     const int jn = spread ? jc : (jc + 1 < nj ? jc + 1 : 0), bn = spread ? a.B : (jn ? b : b + grid);
     const bool more = bn < a.B;
     JobArgs& jx = kj[more ? jn : jc];                             // (no next item: harmless re-requests of this one's)
     const int bx = more ? bn : b;
+    const int fx = form_of(more ? jn : jc);                       // the next item's form
     const float* CS = lds + CS2 + (item & 1) * 384;
-    const int hmh = MH ? ja.mh : 0;
+    const int hmh = FORM ? ja.mh : 0;
     const int mlive = (hmh + 15) >> 4;                           // output-channel tiles of the merged matrix (wave-uniform)
     f32x4 acc[NF][NT];                                         // form 0: output-channel tile x pixel tile (lane: 4 channels of 1 pixel);
                                                                // form 1: pixel tile x output-channel tile, transposed (lane: 4 pixels of 1 channel)
@@ -941,8 +956,8 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       u32x4 wfn = frag(0, s), w0n = {0u, 0u, 0u, 0u};
       if constexpr (ODD) w0n = frag(0, s - 1);
       // the next chunk's filter fragments -> LDS (requested a chunk ago), the set after that into the register
-      *reinterpret_cast<f32x4*>(lds + frag_dst(s + 1 < KC ? s + 1 : 0)) = fpre;
-      fpre = *reinterpret_cast<const f32x4*>((s + 2 < KC ? ja.img16 : jx.img16) + frag_off(s + 2 < KC ? s + 2 : s + 2 - KC));
+      *reinterpret_cast<f32x4*>(lds + (s + 1 < KC ? frag_dst(FORM, s + 1) : frag_dst(fx, 0))) = fpre;
+      fpre = *reinterpret_cast<const f32x4*>(s + 2 < KC ? ja.img16 + frag_off(FORM, s + 2) : jx.img16 + frag_off(fx, s + 2 - KC));
       if constexpr (LAST) {   // the next item's constants -> the other copy
         *reinterpret_cast<f32x4*>(lds + (cs_w ? CS2 + ((item + 1) & 1) * 384 + 4 * cs_i : fdump)) = cpre;
       } else if (s == KC - 2) {
@@ -990,7 +1005,7 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       // the NEXT chunk's taps (of the next image's first chunk behind the last): requested here, behind this phase's last LDS
       // wait - scalar loads and LDS reads share one counter, a scalar load in flight turns every LDS wait into "wait for everything" -
       // and landed (a scalar-cache miss is an L2 round trip) by the time the matrix pipe has drained and the barrier opens
-      load_taps(LAST ? jx.img16 : ja.img16, LAST ? 0 : s + 1);
+      load_taps(LAST ? jx.img16 : ja.img16, LAST ? fx : FORM, LAST ? 0 : s + 1);
       YFV2_WSTAMP(stamp0 + 2);
     };
 
@@ -1036,7 +1051,7 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
       asm volatile("" : "+s"(hn0), "+s"(hn1));
       const int hsplit = ja.split;
 #pragma unroll
-      for (int m = 0; m < MH; ++m) {
+      for (int m = 0; m < (FORM ? MH : 1); ++m) {
         if (m >= mlive) break;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) watch.see((acc[m][nt][0] + acc[m][nt][1]) + (acc[m][nt][2] + acc[m][nt][3]));   // transposed: a lane's four values are four PIXELS
@@ -1063,6 +1078,14 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
     }
     YFV2_WSTAMP(18);
     jc = jn; b = bn;
+  };
+  for (; b < a.B; ++item) {
+    if constexpr (BOTH) {
+      if (form_of(jc) == 0) run_item.template operator()<0>();
+      else run_item.template operator()<1>();
+    } else {
+      run_item.template operator()<FORM1>();
+    }
   }
   watch.report(kj[0].nonfinite);
 }
@@ -1145,16 +1168,16 @@ static void towerp_lane_patches(int H, int W, unsigned char (&tbl)[128]) {
   }
 }
 
-template <int MH>
+template <int MH, bool BOTH>
 static void launch_towerp(TowerJobs jobs, hipStream_t s) {
   const size_t lds = sizeof(float) * (size_t)tp_lds_floats(MH);
   static std::atomic<unsigned long long> lds_ok{0};
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerp_kernel<MH>), lds_ok);
+  yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerp_kernel<MH, BOTH>), lds_ok);
   const int B = jobs.j[0].B;
   // a workgroup runs every side-by-side job of its images (one prologue, the next item's data requested under the current one) - unless
   // there are fewer items than CUs: then one workgroup per item
   const int njobs = jobs.par ? jobs.n : 1;
-  jobs.gpj = (njobs > 1 && njobs * B <= 256) ? njobs * B : (B < 256 ? B : 256);
+  jobs.gpj = (!BOTH && njobs > 1 && njobs * B <= 256) ? njobs * B : (B < 256 ? B : 256);
   {
     static std::mutex mu;
     static std::map<int, std::array<unsigned char, 128>> cache;
@@ -1170,7 +1193,7 @@ static void launch_towerp(TowerJobs jobs, hipStream_t s) {
     }
     std::copy(it->second.begin(), it->second.end(), jobs.lane_patch);
   }
-  hipLaunchKernelGGL((towerp_kernel<MH>), dim3(jobs.gpj), dim3(512), lds, s, jobs);
+  hipLaunchKernelGGL((towerp_kernel<MH, BOTH>), dim3(jobs.gpj), dim3(512), lds, s, jobs);
 }
 
 // 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
@@ -1202,10 +1225,24 @@ bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
     if (mh_tiles == 0) launch_towerh<0, 2, 4>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 2, 4>(jobs, s);
     else launch_towerh<6, 2, 4>(jobs, s);
+  } else if (jobs.par && jobs.n == 4 && mh_tiles != 0 && !jobs.j[0].has_head && !jobs.j[1].has_head && jobs.j[2].has_head && jobs.j[3].has_head) {
+    // a whole level: {cls a, reg a, cls b, reg b}.  Batches that fill the chip (two workgroups' worth of items per CU and more): ONE launch, a
+    // workgroup runs its image's four halves back to back; smaller batches: the a halves and the b halves as two launches of independent
+    // items (one workgroup per item - a single image's four halves in sequence would take twice as long as two rounds of two)
+    if (2 * a.B > 256) {
+      if (mh_tiles == 1) launch_towerp<1, true>(jobs, s);
+      else launch_towerp<6, true>(jobs, s);
+    } else {
+      TowerJobs ja = jobs, jb = jobs;
+      ja.n = 2; jb.n = 2; jb.j[0] = jobs.j[2]; jb.j[1] = jobs.j[3];
+      launch_towerp<0, false>(ja, s);
+      if (mh_tiles == 1) launch_towerp<1, false>(jb, s);
+      else launch_towerp<6, false>(jb, s);
+    }
   } else {
-    if (mh_tiles == 0) launch_towerp<0>(jobs, s);
-    else if (mh_tiles == 1) launch_towerp<1>(jobs, s);
-    else launch_towerp<6>(jobs, s);
+    if (mh_tiles == 0) launch_towerp<0, false>(jobs, s);
+    else if (mh_tiles == 1) launch_towerp<1, false>(jobs, s);
+    else launch_towerp<6, false>(jobs, s);
   }
   return true;
 }
