@@ -5,6 +5,9 @@ Tolerances (BASELINE.md 5 / SURVEY.md 8(c); north_star says 1e-4 fp32):
   logits            |d| <= 1e-4
   obj / cls scores  |d| <= 1e-5
   box coords        |d| <= 1e-4 * max(1, |ref|)
+  decode on IDENTICAL logits (test_decode_from_golden_logits), per field in ulps of the reference's result (DECODE_ULP):
+                    centre within 2 ulp of the sigmoid it is formed from, size 12, obj 4, cls 20 (measured 1 / 6 / 2 / 10)
+  logits where they are large (random-init weights): K x the REFERENCE's own fp32 error against its float64 evaluation
   NMS (identical decoded tensor in): rows and survivor indices BIT-EXACT
   end-to-end at test.py thresholds (0.3/0.4): identical survivor indices
 """
