@@ -447,7 +447,8 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
   float* WP_ = lds;
   float* CS = lds + TH_CS;
   float* WH = lds + TH_WH;
-  float* IN = lds + LDS_IMG;                                      // [row + 2][W][72]: two zero rows above and below the image
+  float* IN = lds + LDS_IMG;                                      // [row + 2][MAXW][72]: two zero rows above and below the image, zero columns right of it
+                                                                  // (a fixed pitch: every row read of the depthwise is unconditional, two pixels per ds_read2_b64)
   float* X32 = IN + (MAXW + 4) * MAXW * C;                        // [pixel][TS_CP]; rows past H*W stay zero
   const int H = a.H, W = a.W, HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
@@ -456,8 +457,6 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
   YFV2_WSTAMP(0);
   const int opix = 16 * wv + p;                                   // pointwise tile: 16 pixels per wave
   const bool pv = opix < HW;
-  for (int i = tid; i < ((MAXW + 4) * MAXW * C + MAXPX * CP) / 4; i += 512) reinterpret_cast<f32x4*>(IN)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   constexpr int N4 = LDS_IMG / 4, NIT = (N4 + 511) / 512;
   const __attribute__((address_space(4))) TowerArgs* kj = (const __attribute__((address_space(4))) TowerArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   Yfv2Watch watch;                                                // range guard of the fp16x3 products (yfv2_internal.h)
@@ -467,22 +466,30 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
   }
+  // an item's image: requested while the item before it computes (its own first thing otherwise: 3 k cycles of exposed latency per job)
+  constexpr int NPF = (MAXPX * NQ + 511) / 512;                   // 16-byte pieces of the image per thread (5)
+  f32x4 pre[NPF];
+  auto load_pre = [&](const float* in, int bb) __attribute__((always_inline)) {
+    const f32x4* img = reinterpret_cast<const f32x4*>(in + (size_t)bb * HW * C);
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) { const int i = tid + j * 512; pre[j] = img[i < HW * NQ ? i : 0]; }
+  };
+  bool have_pre = false;
+#pragma unroll
+  for (int j = 0; j < NPF; ++j) pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!(kj[0].chain & 1) && (int)blockIdx.x < a.B) { load_pre(kj[0].in, blockIdx.x); have_pre = true; }
+  // (the zeroing behind the requests, not in front of them)
+  for (int i = tid; i < ((MAXW + 4) * MAXW * C + MAXPX * CP) / 4; i += 512) reinterpret_cast<f32x4*>(IN)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int ji = 0; ji < jobs.n; ++ji) {
   const __attribute__((address_space(4))) TowerArgs& ja = kj[ji];
   const float* tapsf = lds + th_lds_img(MH);                      // [quad][27][4]: 25 taps, BN scale x 16, BN shift x 16 (in LDS: as per-lane
                                                                   // global gathers the 54 loads of a wave cost the job ~7 k cycles of address traffic)
-  constexpr int NPF = (MAXPX * NQ + 511) / 512;                   // 16-byte pieces of the image per thread (5)
 #pragma unroll 1
   for (int b = blockIdx.x; b < a.B; b += grid) {
     // ---- everything the job needs from memory is requested at once
     const bool in_lds = (ja.chain & 1) != 0, out_lds = (ja.chain & 2) != 0;   // half a -> half b of a tower: the 72-channel tensor between them never leaves LDS
-    f32x4 pre[NPF];
-    if (!in_lds) {
-      const f32x4* img = reinterpret_cast<const f32x4*>(ja.in + (size_t)b * HW * C);
-#pragma unroll
-      for (int j = 0; j < NPF; ++j) { const int i = tid + j * 512; pre[j] = img[i < HW * NQ ? i : 0]; }
-    }
+    if (!in_lds && !have_pre) load_pre(ja.in, b);
     const bool first_image = b == (int)blockIdx.x;
     // this lane's depthwise unit: (output row, channel PAIR) - H x 36 units <= 396 lanes, ONE round (round 6; until then (row, channel):
     // 792 units on 512 lanes, the second round 45 % empty, every FMA a plain one)
@@ -490,22 +497,37 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
     const bool uon = 64 * wv < H * (C / 2), ulane = UL < H * (C / 2);
     const int uy = yfv2_fdiv(ulane ? UL : 0, 1.0f / (float)(C / 2)), uc = 2 * ((ulane ? UL : 0) - uy * (C / 2));
     __syncthreads();                                              // the previous job / image is done with LDS
-    if (!in_lds) {
+    // (every thread stores every register it carries, on every path - what is not wanted goes where nothing reads: behind a predicate the
+    // compiler keeps "this register may still have a load in flight" alive on the other path and answers with s_waitcnt vmcnt(0) at the
+    // next requests further down - i.e. it waits for the first prefetch before it issues the second: a full memory latency per job)
+    float* const dump = X32 + MAXPX * CP + 4 * lane;
 #pragma unroll
-      for (int j = 0; j < NPF; ++j) { const int i = tid + j * 512; if (i < HW * NQ) reinterpret_cast<f32x4*>(IN + 2 * W * C)[i] = pre[j]; }
+    for (int j = 0; j < NPF; ++j) {
+      const int i = tid + j * 512;
+      const bool ok = !in_lds && i < HW * NQ;
+      const int px = yfv2_fdiv(ok ? i : 0, 1.0f / (float)NQ), qd = i - px * NQ;
+      const int y = yfv2_fdiv(px, 1.0f / (float)W), x = px - y * W;
+      *reinterpret_cast<f32x4*>(ok ? IN + ((y + 2) * MAXW + x) * C + 4 * qd : dump) = pre[j];
     }
-    if (first_image) {
 #pragma unroll
-      for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; if (i < N4) reinterpret_cast<f32x4*>(lds)[i] = tmp[k]; }
-    }
+    for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; *reinterpret_cast<f32x4*>(first_image && i < N4 ? lds + 4 * i : dump) = tmp[k]; }
     __syncthreads();                                              // image and filters in LDS
-    YFV2_WSTAMP(1);
-    if (first_image && ji + 1 < jobs.n) {                         // the next job's filter image: off its critical path
-      const f32x4* src = reinterpret_cast<const f32x4*>(kj[ji + 1].img16);
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) { const int i = tid + k * 512; tmp[k] = src[i < N4 ? i : 0]; }
-    }
-
+    YFV2_WSTAMP(1 + 4 * ji);
+    // ---- prefetches, issued BETWEEN the depthwise rows (all 13 requests of a wave up front keep it 2-3 k cycles in front of the
+    // vector-memory issue port before its first FMA: 8 waves x 13 KB at 64 bytes per cycle): (1) the next item's image, unless this
+    // job is what produces it (an a half whose b half reads it back from memory); (2) the next job's filter image
+    const bool pf_same = b + grid < a.B;
+    const int pf_jn = pf_same ? ji : ji + 1, pf_bn = pf_same ? b + grid : (int)blockIdx.x;
+    have_pre = pf_jn < jobs.n && !(kj[pf_jn].chain & 1) && (pf_same || kj[pf_jn].in != ja.out);
+    const f32x4* pf_img = reinterpret_cast<const f32x4*>((have_pre ? kj[pf_jn].in : ja.in) + (size_t)(have_pre ? pf_bn : b) * HW * C);
+    const f32x4* pf_flt = reinterpret_cast<const f32x4*>(kj[ji + 1 < jobs.n ? ji + 1 : ji].img16);
+    const bool pf_filters = first_image && ji + 1 < jobs.n;
+    auto prefetch = [&](int k) __attribute__((always_inline)) {     // k = 0 .. NPF + NIT - 1 (wave-uniform conditions)
+      if (k < NPF) { if (have_pre) { const int i = tid + k * 512; pre[k] = pf_img[i < HW * NQ ? i : 0]; } }
+      else if (k < NPF + NIT) { if (pf_filters) { const int i = tid + (k - NPF) * 512; tmp[k - NPF] = pf_flt[i < N4 ? i : 0]; } }
+    };
+    constexpr int PF_ROW = (NPF + NIT + 4) / 5;                   // requests per depthwise row
+    YFV2_WSTAMP(17 + 3 * ji);
     // ---- depthwise: a lane = (output row, channel pair): packed FMAs on (c, c + 1) against the tap pair (the table holds a quad's
     // taps side by side: the pair is one 8-byte read), row by row with the next input row and tap row in flight.  Per output the
     // products are added in the order tap row, tap column - as before, bit for bit
@@ -517,9 +539,9 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
         for (int kx = 0; kx < 5; ++kx) t[kx] = *reinterpret_cast<const f32x2*>(tl + 4 * (r * 5 + kx));
       };
       auto ld_row = [&](int r, f32x2 (&v)[MAXW]) {
-        const float* rp = IN + (y + r) * W * C + c;               // row y + r - 2 of the image: the halo rows are zero, every read is inside the buffer
+        const float* rp = IN + (y + r) * MAXW * C + c;            // row y + r - 2 of the image: the halo rows and the columns right of the image are zero
 #pragma unroll
-        for (int x = 0; x < MAXW; ++x) { const f32x2 t = *reinterpret_cast<const f32x2*>(rp + x * C); v[x] = x < W ? t : (f32x2){0.f, 0.f}; }
+        for (int x = 0; x < MAXW; ++x) v[x] = *reinterpret_cast<const f32x2*>(rp + x * C);
       };
       f32x2 acc[MAXW];
 #pragma unroll
@@ -529,16 +551,21 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         if (r + 1 < 5) { ld_row(r + 1, v[(r + 1) & 1]); ld_taps(r + 1, tw[(r + 1) & 1]); }
+        // (tap column outermost: eleven independent accumulators between two FMAs of one output - with the output outermost the
+        // compiler keeps the source order and issues every output's five FMAs back to back, each waiting for the one before it)
 #pragma unroll
-        for (int x = 0; x < MAXW; ++x)
+        for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
-          for (int kx = 0; kx < 5; ++kx) {
+          for (int x = 0; x < MAXW; ++x) {
             const int xi = x + kx - 2;
             if (xi >= 0 && xi < MAXW) acc[x] = __builtin_elementwise_fma(v[r & 1][xi], tw[r & 1][kx], acc[x]);
           }
         // (two rows in flight: left alone the scheduler requests all five rows and tap rows first - 164 registers)
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]) :: "memory");
+#pragma unroll
+        for (int k = 0; k < PF_ROW; ++k) prefetch(r * PF_ROW + k);
       }
+      YFV2_WSTAMP(18 + 3 * ji);
       const f32x2 bsc = *reinterpret_cast<const f32x2*>(tl + 4 * 25), bsh = *reinterpret_cast<const f32x2*>(tl + 4 * 26);
       if (ulane) {
 #pragma unroll
@@ -549,9 +576,13 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
             *reinterpret_cast<f32x2*>(X32 + (y * W + x) * CP + c) = uu;
           }
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPF + NIT; ++k) prefetch(k);
     }
+    YFV2_WSTAMP(19 + 3 * ji);
     __syncthreads();                                              // exchange complete
-    YFV2_WSTAMP(2);
+    YFV2_WSTAMP(2 + 4 * ji);
 
     // ---- pointwise: K = 72 in one go.  A half that ends in an output conv applies the host-merged matrix (output conv x BN x
     // pointwise conv, see towerh_kernel) to these operand entries directly, transposed.
@@ -585,15 +616,16 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
       acc[mt] = __builtin_elementwise_fma(acc[mt], sc, sh);
     }
     watch.see(acc[0][0]);
-    YFV2_WSTAMP(3);
+    YFV2_WSTAMP(3 + 4 * ji);
       if (pv) {                                                   // (every depthwise read of IN is behind the exchange barrier)
-        float* dst = out_lds ? IN + (2 * W + opix) * C : ja.out + ((size_t)b * HW + opix) * C;
+        const int oy = yfv2_fdiv(opix, 1.0f / (float)W);
+        float* dst = out_lds ? IN + ((oy + 2) * MAXW + (opix - oy * W)) * C : ja.out + ((size_t)b * HW + opix) * C;
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt)
           if (16 * mt + 4 * g < C) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = acc[mt];
       }
     } else {
-      YFV2_WSTAMP(3);
+      YFV2_WSTAMP(3 + 4 * ji);
       const float us = CS[3 * 96];
       const bool vec = (HW & 3) == 0;
       // (both plane pointers in scalar registers BEFORE the lane-dependent choice: left to itself the compiler turns the choice
@@ -602,38 +634,58 @@ __global__ __launch_bounds__(512) void towers_kernel(TowerJobs jobs) {
       float* hn0 = ja.nchw0; float* hn1 = ja.nchw1;
       asm volatile("" : "+s"(hn0), "+s"(hn1));
       const int hmh = ja.mh, hsplit = ja.split;
+      // two output tiles per step: two independent chains of eight MFMAs (one tile at a time, every MFMA waits for the one before it:
+      // 1.5 k cycles per tile, 9.4 k for the six tiles of the cls tower's obj + cls conv)
+      constexpr int TW = MH > 1 ? 2 : 1;
 #pragma unroll 1
-      for (int m = 0; m < MH; ++m) {
+      for (int m = 0; m < MH; m += TW) {
         if (16 * m >= hmh) break;
-        u32x4 wf[KC];
+        u32x4 wf[TW][KC];
 #pragma unroll
-        for (int sc = 0; sc < KC; ++sc) wf[sc] = *reinterpret_cast<const u32x4*>(WH + ((m * KC + sc) * 64 + lane) * 4);
-        f32x4 hacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TW; ++t)
 #pragma unroll
-        for (int sc = 0; sc < KC; ++sc) hacc = mfma_cross(xb[sc], wf[sc], hacc);
+          for (int sc = 0; sc < KC; ++sc) wf[t][sc] = *reinterpret_cast<const u32x4*>(WH + (((m + t < MH ? m + t : m) * KC + sc) * 64 + lane) * 4);
+        f32x4 hacc[TW];
 #pragma unroll
-        for (int sc = 0; sc + 1 < KC; sc += 2) hacc = mfma_main2(xb[sc], xb[sc + 1], (yfv2_u2){wf[sc][0], wf[sc][1]}, wf[sc + 1], hacc);
-        hacc = mfma_main1(xb[KC - 1], wf[KC - 1], hacc);
-        watch.see((hacc[0] + hacc[1]) + (hacc[2] + hacc[3]));      // transposed: a lane's four values are four PIXELS
-        const int co = 16 * m + p;
-        if (co < hmh) {
-          const float bias = CS[2 * 96 + co];
-          float* plane = co < hsplit ? hn0 + ((size_t)b * hsplit + co) * HW : hn1 + ((size_t)b * (hmh - hsplit) + (co - hsplit)) * HW;
-          const int px0 = 16 * wv + 4 * g;
-          f32x4 y;
+        for (int t = 0; t < TW; ++t) hacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(hacc[r], us, bias);
-          if (vec) {
-            if (px0 < HW) *reinterpret_cast<f32x4*>(plane + px0) = y;
-          } else {
+        for (int sc = 0; sc < KC; ++sc)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (px0 + r < HW) plane[px0 + r] = y[r];
+          for (int t = 0; t < TW; ++t) hacc[t] = mfma_cross(xb[sc], wf[t][sc], hacc[t]);
+#pragma unroll
+        for (int sc = 0; sc + 1 < KC; sc += 2)
+#pragma unroll
+          for (int t = 0; t < TW; ++t) hacc[t] = mfma_main2(xb[sc], xb[sc + 1], (yfv2_u2){wf[t][sc][0], wf[t][sc][1]}, wf[t][sc + 1], hacc[t]);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) hacc[t] = mfma_main1(xb[KC - 1], wf[t][KC - 1], hacc[t]);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          if (16 * (m + t) >= hmh) break;
+          watch.see((hacc[t][0] + hacc[t][1]) + (hacc[t][2] + hacc[t][3]));      // transposed: a lane's four values are four PIXELS
+          const int co = 16 * (m + t) + p;
+          if (co < hmh) {
+            const float bias = CS[2 * 96 + co];
+            float* plane = co < hsplit ? hn0 + ((size_t)b * hsplit + co) * HW : hn1 + ((size_t)b * (hmh - hsplit) + (co - hsplit)) * HW;
+            const int px0 = 16 * wv + 4 * g;
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(hacc[t][r], us, bias);
+            // (a lane's four pixels as ONE 16-byte store also where the planes are only 4-byte aligned - 11x11 = 121 floats per plane:
+            // global memory takes dword-aligned multi-dword stores; four predicated dword stores per tile were 24 scattered store
+            // instructions per wave for the cls tower's six tiles)
+            typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            if (vec || px0 + 3 < HW) {
+              if (px0 < HW) *reinterpret_cast<f32x4_a4*>(plane + px0) = y;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (px0 + r < HW) plane[px0 + r] = y[r];
+            }
           }
         }
       }
     }
-    YFV2_WSTAMP(4);
+    YFV2_WSTAMP(4 + 4 * ji);
   }
   __syncthreads();                                                // the next job reads what this one wrote for the same image: workgroup scope is
                                                                   // enough (same CU, same L1); an agent-scope __threadfence() here wrote back and
@@ -1093,7 +1145,7 @@ __global__ __launch_bounds__(512) void towerp_kernel(TowerJobs jobs) {
 template <int MH>
 static void launch_towers(const TowerJobs& jobs, hipStream_t s) {
   const int B = jobs.j[0].B;
-  const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + (TH_C / 4) * 27 * 4 + 15 * 11 * TH_C + 128 * TS_CP);
+  const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + (TH_C / 4) * 27 * 4 + 15 * 11 * TH_C + 128 * TS_CP + 256);   // (+ 1 KB where unwanted stores go)
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&towers_kernel<MH>), lds_ok);
   hipLaunchKernelGGL((towers_kernel<MH>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
