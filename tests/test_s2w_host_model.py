@@ -146,11 +146,13 @@ def _presplit_general(fr, MT, K):
     return terms[0] + terms[1]
 
 
-@pytest.mark.parametrize("name,K,key", [("fpn.conv1x1_3 pw192", 192, "fpn.conv1x1_3.0.weight"), ("fpn.conv1x1_2 up2x", 288, "fpn.conv1x1_2.0.weight")])
-def test_streamed_pointwise_filters_are_packed_presplit(name, K, key):
-    """pw_kernel<K = 192 / 288, PRE>: the FPN reduces' filters arrive as two fp16 terms x 2^sw per chunk pair (fp16x3); their
-    sum must reproduce the scaled fp32 filter to 2^-22 of its largest entry (largest entry in (2^13, 2^14]), the BN scale
-    must carry the exact 2^-(sw+4), the C2 columns of conv1x1_2 in the chain's channel order."""
+@pytest.mark.parametrize("case", ["conv1x1_3", "conv1x1_2 C3 part", "conv1x1_2 C2 part", "conv1x1_2 K=288 (layer by layer)"])
+def test_streamed_pointwise_filters_are_packed_presplit(case):
+    """pw_kernel<.., PRE>: the FPN reduces' filters arrive as two fp16 terms x 2^sw per chunk pair (fp16x3); their sum must
+    reproduce the scaled fp32 filter to 2^-22 of its largest entry (largest entry in (2^13, 2^14]), the BN scale must carry the
+    exact 2^-(sw+4), the C2 columns of conv1x1_2 in the chain's channel order.  Default plan (round 6): conv1x1_3 and the C3
+    columns of conv1x1_2 are ONE ten-tile launch on C3 (PW_DUAL), the C2 columns a K = 96 launch (PW_FPNQ) whose
+    epilogue adds the former; the layer-by-layer plan keeps conv1x1_2 as one K = 288 launch."""
     w = yfv2.random_state_dict(12)
     host = {k: v.float().contiguous() for k, v in w.items() if v.is_floating_point()}
     arr = (TensorDesc * len(host))()
@@ -159,29 +161,43 @@ def test_streamed_pointwise_filters_are_packed_presplit(name, K, key):
     cfg = Config()
     cfg.classes, cfg.anchor_num, cfg.height, cfg.width, cfg.max_batch, cfg.device = 80, 3, 352, 352, 1, 0
     L = _lib.lib()
+    plan = _lib.make_plan({"layer_by_layer": 1} if "288" in case else {})
     ns, nb = C.c_int32(0), C.c_int64(0)
-    assert L.yfv2_debug_plan_dryrun(C.byref(cfg), arr, len(host), C.byref(ns), C.byref(nb)) == 0
+    assert L.yfv2_debug_plan_dryrun_ex(C.byref(cfg), C.byref(plan), arr, len(host), C.byref(ns), C.byref(nb)) == 0
     MT = 5
+    name, K, half = {"conv1x1_3": ("fpn.conv1x1_3 pw192", 192, 0), "conv1x1_2 C3 part": ("fpn.conv1x1_3 pw192", 192, 1),
+                     "conv1x1_2 C2 part": ("fpn.conv1x1_2 pw96", 96, 0), "conv1x1_2 K=288 (layer by layer)": ("fpn.conv1x1_2 up2x", 288, 0)}[case]
     fl = MT * (K // 32) * 2 * 256 + 2 * 16 * MT
-    buf = np.zeros(fl, np.float32)
+    nimg = 2 if K == 192 else 1
+    buf = np.zeros(nimg * fl, np.float32)
     nm = C.create_string_buffer(256)
     im = None
     for st in range(ns.value):
-        n = L.yfv2_debug_plan_image(C.byref(cfg), arr, len(host), st, nm, 256, buf.ctypes.data_as(C.c_void_p), buf.size)
+        n = L.yfv2_debug_plan_image_ex(C.byref(cfg), C.byref(plan), arr, len(host), st, nm, 256, buf.ctypes.data_as(C.c_void_p), buf.size)
         if n > 0 and name in nm.value.decode():
-            assert n == fl, (n, fl)
-            im = buf.copy()
+            assert n == nimg * fl, (n, nimg * fl)
+            if nimg == 2:   # PW_DUAL: fragments of the first conv, of the second, then scale[2][80], shift[2][80]
+                fr, r = fl - 2 * 16 * MT, 16 * MT
+                im = np.concatenate([buf[half * fr:(half + 1) * fr], buf[2 * fr + half * r:2 * fr + (half + 1) * r],
+                                     buf[2 * fr + 2 * r + half * r:2 * fr + 2 * r + (half + 1) * r]])
+            else:
+                im = buf.copy()
             break
     assert im is not None
     got = _presplit_general(im[:fl - 2 * 16 * MT], MT, K)[:72]
-    ref = w[key].reshape(72, K).numpy()
-    if K == 288:
-        lab = (C.c_int32 * 96)()
-        assert L.yfv2_debug_plan_c2_label(C.byref(cfg), arr, len(host), lab) == 1
-        ref = np.concatenate([ref[:, :192], ref[:, 192:][:, np.asarray(list(lab))]], 1)   # cat(up(C3), C2): C2 columns permuted
+    w2 = w["fpn.conv1x1_2.0.weight"].reshape(72, 288).numpy()
+    lab = (C.c_int32 * 96)()
+    assert L.yfv2_debug_plan_c2_label(C.byref(cfg), arr, len(host), lab) == 1
+    w2c2 = w2[:, 192:][:, np.asarray(list(lab))]                    # cat(up(C3), C2): C2 columns in the chain's channel order
+    if "288" in case:
+        w2c2 = w2[:, 192:]                                           # (layer by layer there is no chain kernel: the reference's own order)
+    ref = {"conv1x1_3": w["fpn.conv1x1_3.0.weight"].reshape(72, 192).numpy(), "conv1x1_2 C3 part": w2[:, :192], "conv1x1_2 C2 part": w2c2,
+           "conv1x1_2 K=288 (layer by layer)": np.concatenate([w2[:, :192], w2c2], 1)}[case]
     sw = 14 - int(np.ceil(np.log2(np.abs(ref).max())))
     assert 2.0 ** 13 < np.abs(got).max() <= 2.0 ** 14
     assert np.abs(got - ref.astype(np.float64) * 2.0 ** sw).max() <= 2.0 ** 14 * 2.0 ** -22
-    bn = "fpn.conv1x1_3.1" if K == 192 else "fpn.conv1x1_2.1"
+    bn = "fpn.conv1x1_3.1" if case == "conv1x1_3" else "fpn.conv1x1_2.1"
     scale = (w[bn + ".weight"] / torch.sqrt(w[bn + ".running_var"] + 1e-5)).numpy()
     assert np.allclose(im[fl - 2 * 16 * MT:fl - 16 * MT][:72] * 2.0 ** (sw + 4), scale, rtol=1e-6, atol=0)
+    shift = w[bn + ".bias"].numpy() - w[bn + ".running_mean"].numpy() * scale
+    assert np.allclose(im[fl - 16 * MT:][:72], shift, rtol=1e-5, atol=1e-7)

@@ -77,7 +77,7 @@ struct yfv2_ctx {
   std::vector<Step> plan;
 
   // workspace (NHWC fp32), sized for cfg.max_batch
-  Buf a1, s2[2], s3[2], s4[2], t1, t2, t3, f2, f3, ta, tb;
+  Buf a1, s2[2], s3[2], s4[2], t1, t2, t3, f2, f3, fq, ta, tb;
   Buf s2pp;  // stage 2 in pair planes: an image's two buffers back to back, [max_batch][2][24 pairs][H/8][W/8][2] (every offset a kernel adds to an
              // image base stays below 2 x 48 x H/8 x W/8 floats whatever max_batch is: no batch bound from 32-bit buffer offsets)
   // pair-plane bookkeeping at the END of stage 2 (for the stride-2 consumer and for yfv2_debug_activation)
@@ -290,8 +290,27 @@ struct WeightPacker {
   }
   // pw_kernel: filter fragments [MT][K/16][64 lanes][4] (+ an 8-channel tail [MT][64 lanes][2]), scale[MT*16], shift[MT*16]
   size_t image_pw(const Folded& f, int M, int K, int MT /* the M tiles of the kernel instantiation, yfv2_pw_tiles */, bool presplit = false) {
-    const int rows = MT * 16, K16 = K / 16;
     std::vector<float> im;
+    build_pw(im, f, M, K, MT, presplit);
+    return put(im);
+  }
+  // PW_DUAL: two convs on the same input as ONE image of 2 MT output tiles - fragments of the first, fragments of the second (each filter
+  // with its own power-of-two scale), then scale[2 MT 16], shift[2 MT 16]
+  size_t image_pw_dual(const Folded& f0, const Folded& f1, int M, int K, int MT) {
+    std::vector<float> i0, i1, im;
+    build_pw(i0, f0, M, K, MT, true);
+    build_pw(i1, f1, M, K, MT, true);
+    const size_t fr = i0.size() - 2 * (size_t)MT * 16, r = (size_t)MT * 16;
+    im.insert(im.end(), i0.begin(), i0.begin() + fr);
+    im.insert(im.end(), i1.begin(), i1.begin() + fr);
+    im.insert(im.end(), i0.begin() + fr, i0.begin() + fr + r);
+    im.insert(im.end(), i1.begin() + fr, i1.begin() + fr + r);
+    im.insert(im.end(), i0.begin() + fr + r, i0.end());
+    im.insert(im.end(), i1.begin() + fr + r, i1.end());
+    return put(im);
+  }
+  void build_pw(std::vector<float>& im, const Folded& f, int M, int K, int MT, bool presplit) {
+    const int rows = MT * 16, K16 = K / 16;
     int sw = 0;
     if (presplit) {
       // pw_kernel<.., PRE>: the filter x 2^sw as two fp16 terms, [mt][chunk pair][term][64 lanes][4 dwords]: dwords 0,1 = K
@@ -327,7 +346,14 @@ struct WeightPacker {
     if (presplit) for (int i = 0; i < rows; ++i) im.push_back(i < M ? std::ldexp(blob[f.scale + i], -(sw + 4)) : 0.f);   // the accumulators carry 2^(sw+4): undone exactly inside the BN scale
     else push_vec(im, &blob[f.scale], M, rows);
     push_vec(im, &blob[f.shift], M, rows);
-    return put(im);
+  }
+  // columns [c0, c0 + n) of a folded conv's filter as a conv of its own (same BN scale / shift)
+  Folded pw_columns(const Folded& f, int co, int ci, int c0, int n) {
+    Folded g = f;
+    g.w = reserve((size_t)co * n);
+    for (int r = 0; r < co; ++r)
+      for (int k = 0; k < n; ++k) blob[g.w + (size_t)r * n + k] = blob[f.w + (size_t)r * ci + c0 + k];
+    return g;
   }
   // block_s1chain6_kernel: a 48x48 filter as [mt (3)][six 16-byte operands][64 lanes][4 dwords]: hi / mid / lo quads of the
   // chunk PAIR (chunks 0, 1: the 32 k-slots of one bf16 MFMA), then {hi,hi} {mid,mid} {hi,lo} of the single chunk 2 (the
@@ -1689,7 +1715,29 @@ struct PlanBuilder {
       for (int k = 0; k < 96; ++k) lab[192 + k] = 192 + h->c2_label[k];
       f = wp.permuted_pw_inputs(f, 72, 288, lab);
     }
-    {
+    // Default plan (round 6): a 1x1 conv commutes with the nearest-neighbour upsample (fpn.py:57-59), so conv1x1_2's 192 upsampled channels
+    // are applied ONCE per coarse pixel - Q = scale2 (W2[:, :192] C3) + shift2, by the launch that computes conv1x1_3 from the same C3 - and
+    // the fine-map launch is a K = 96 conv over C2 whose epilogue adds Q at (y / 2, x / 2): a third of the matrix-core work and 25 MB less
+    // traffic than the K = 288 form (which the fp32-matrix and the layer-by-layer plans keep).  Like the BatchNorm folding a
+    // re-association inside one linear map: S2 = relu(scale2 (W2b C2) + Q) instead of relu(scale2 (W2a up(C3) + W2b C2) + shift2).
+    const bool fpn_split = fused && h->bf6 && ok && h->fq.p && yfv2_pw_presplit_supported(192, PW_DUAL, 72) && yfv2_pw_presplit_supported(96, PW_FPNQ, 72);
+    if (fpn_split) {
+      Step& s3 = h->plan.back();                                     // conv1x1_3 just added: it becomes the dual launch
+      Folded fa = wp.pw_columns(f, 72, 288, 0, 192), fb = wp.pw_columns(f, 72, 288, 192, 96);
+      Folded f3;
+      ok &= wp.pw("fpn.conv1x1_3.0", "fpn.conv1x1_3.1", 72, 192, &f3);
+      s3.mode = PW_DUAL;
+      s3.pw.copy = h->fq.p; s3.pw.copy_stride = 72; s3.pw.copy_off = 0;
+      s3.pw.presplit = 1;
+      s3.img_off = wp.image_pw_dual(f3, fa, 72, 192, 5);
+      s3.name = "fpn.conv1x1_3 pw192->72+bn+relu | the C3 part of fpn.conv1x1_2 (W2[:, :192] C3, scale + shift of its bn), one launch";
+      Step& s = add_pw("fpn.conv1x1_2 pw96 over C2 + the C3 part at (y/2, x/2) +bn+relu  [= up2x(C3)+cat(C2)+pw288->72+bn+relu]", 96, PW_FPNQ, 72, h2 * w2,
+                       c2->p, 96, 0, h->f2.p, 72, 0, true, fb);
+      s.pw.in2 = h->fq.p;
+      s.pw.H = h2; s.pw.W = w2;
+      s.flops = 2.0 * h2 * w2 * 288 * 72;                             // (the reference layer's count, as for every fused or re-associated launch)
+      s.bytes = 4.0 * (h3 * w3 * 192.0 + h2 * w2 * 96.0 + h2 * w2 * 72.0);
+    } else {
       Step& s = add_pw("fpn.conv1x1_2 up2x(C3)+cat(C2)+pw288->72+bn+relu", 288, PW_FPN, 72, h2 * w2, c3->p, 192, 0,
                        h->f2.p, 72, 0, true, f);
       s.pw.in2 = c2->p;
@@ -1973,6 +2021,7 @@ int setup_ctx(yfv2_ctx* h, const yfv2_config* cfg, int rows, Alloc alloc) {
   A(&h->t3, (H / 4) * (W / 4) * 24);
   A(&h->f2, (H / 16) * (W / 16) * 72);
   A(&h->f3, (H / 32) * (W / 32) * 72);
+  A(&h->fq, (H / 32) * (W / 32) * 72);   // the C3 part of fpn.conv1x1_2 (PW_DUAL -> PW_FPNQ)
   A(&h->ta, (H / 16) * (W / 16) * 72);
   A(&h->tb, (H / 16) * (W / 16) * 72);
   for (int i = 0; i < 6; ++i) A(&h->logits[i], logit_elems(h, i));
@@ -2239,7 +2288,7 @@ void yfv2_destroy(yfv2_handle h) {
   for (int i = 0; i < 2; ++i) { free_buf(&h->s2[i]); free_buf(&h->s3[i]); free_buf(&h->s4[i]); }
   free_buf(&h->s2pp);
   free_buf(&h->t1); free_buf(&h->t2); free_buf(&h->t3);
-  free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->ta); free_buf(&h->tb);
+  free_buf(&h->f2); free_buf(&h->f3); free_buf(&h->fq); free_buf(&h->ta); free_buf(&h->tb);
   for (int i = 0; i < 6; ++i) free_buf(&h->logits[i]);
   free_buf(&h->cand);
   if (h->d_classes) (void)hipFree(h->d_classes);

@@ -63,10 +63,15 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x;
 
+  // PW_DUAL: two convs on the same input in one launch - output tiles 0 .. MT/2-1 -> out (ReLU as asked), tiles MT/2 .. MT-1 -> copy (no
+  // ReLU).  A wave loads and splits its pixels ONCE for both (as two interleaved grids of MT/2-tile workgroups: 17.6 us against 13.2 for
+  // the one conv; this form: the operand traffic, the K loop's round trips and the prologue are shared)
+  static_assert(MODE != PW_DUAL || MT % 2 == 0, "two convs of MT / 2 tiles each");
+  const float* const img = a.img;
   {  // prologue: one coalesced copy of the image, up to nine 16-byte loads per thread in flight at a time (the plain
      // load -> wait -> store loop the compiler makes of `dst[i] = src[i]` is one global round trip per 16 bytes and thread:
      // 17 of them for the 135 KB pre-split K = 288 filter)
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.img);
+    const f32x4* src = reinterpret_cast<const f32x4*>(img);
     f32x4* dst = reinterpret_cast<f32x4*>(wl);
     constexpr int N4 = FILT_FL / 4;
     constexpr int PER = (N4 + THREADS - 1) / THREADS;            // THREADS == blockDim.x (pw_launch)
@@ -88,8 +93,8 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   f32x4 sc[MT], sh[MT];  // padded to MT*16 on the host: unconditional 16-byte loads
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    sc[mt] = *reinterpret_cast<const f32x4*>(a.img + FILT_FL + 16 * mt + 4 * g);
-    sh[mt] = *reinterpret_cast<const f32x4*>(a.img + FILT_FL + MT * 16 + 16 * mt + 4 * g);
+    sc[mt] = *reinterpret_cast<const f32x4*>(img + FILT_FL + 16 * mt + 4 * g);
+    sh[mt] = *reinterpret_cast<const f32x4*>(img + FILT_FL + MT * 16 + 16 * mt + 4 * g);
   }
 
   Yfv2Watch watch;   // range guard of the fp16x3 form (yfv2_internal.h)
@@ -102,11 +107,12 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int pixv[NT];
+    f32x4 qv[MODE == PW_FPNQ ? MT : 1];
 
     if constexpr (STREAM) {
       // ---- large K (192 / 288): stream the 16-channel chunks with a one-chunk-ahead
       // prefetch instead of holding K/4 registers per pixel tile
-      static_assert(!STREAM || (KT == 0 && (MODE == PW_PLAIN || MODE == PW_FPN)), "STREAM: K % 16 == 0, plain/fpn only");
+      static_assert(!STREAM || (KT == 0 && (MODE == PW_PLAIN || MODE == PW_FPN || MODE == PW_DUAL || MODE == PW_FPNQ)), "STREAM: K % 16 == 0, plain/fpn only");
       const float* src0[NT];
       const float* src1[NT];
 #pragma unroll
@@ -126,9 +132,72 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
         }
       }
       constexpr int SPLIT = MODE == PW_FPN ? 12 : K16;
+      if constexpr (MODE == PW_FPNQ) {   // the coarse map's share of the sum, requested in front of the K loop
+        static_assert(NT == 1, "one pixel tile per wave");
+        const int pc = pixv[0] < a.P ? pixv[0] : a.P - 1;
+        const int hw = a.H * a.W;
+        const int b = pc / hw, rem = pc - b * hw;
+        const int y = rem / a.W, x = rem - y * a.W;
+        const float* q = a.in2 + ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.M + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) qv[mt] = 16 * mt + 4 * g < a.M ? *reinterpret_cast<const f32x4*>(q + 16 * mt) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
       if constexpr (PRE) {
         constexpr int KP = K16 / 2;
         static_assert(SPLIT % 2 == 0, "a chunk pair does not straddle the two inputs");
+        // one chunk pair: the pair's filter fragments from LDS, the pixel's two quads split into two fp16 terms, three products
+        auto pair_step = [&](int sp, const f32x4 (&bq)[NT][2]) __attribute__((always_inline)) {
+          yfv2_h8 b1[NT], b2[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            u32x4 t1, t2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const f32x4 v = bq[nt][e] * 16.0f;                                          // fp16's absolute floor: 2^-25 -> 2^-29
+              const yfv2_h4 h1 = __builtin_convertvector(v, yfv2_h4);                       // v_cvt_pk_f16_f32 (RN)
+              const yfv2_h4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4), yfv2_h4);   // the difference is exact
+              const yfv2_u2 u1 = __builtin_bit_cast(yfv2_u2, h1), u2 = __builtin_bit_cast(yfv2_u2, h2);
+              t1[2 * e] = u1[0]; t1[2 * e + 1] = u1[1];
+              t2[2 * e] = u2[0]; t2[2 * e + 1] = u2[1];
+            }
+            b1[nt] = __builtin_bit_cast(yfv2_h8, t1);
+            b2[nt] = __builtin_bit_cast(yfv2_h8, t2);
+          }
+          // three products, the small ones first; MG * NT independent accumulators: no MFMA waits for the one before it.  Output tiles in
+          // groups of at most five (PW_DUAL's ten: 80 fragment registers at once otherwise)
+          constexpr int MG = MT > 5 ? MT / 2 : MT;
+#pragma unroll
+          for (int m0 = 0; m0 < MT; m0 += MG) {
+            if (m0) __builtin_amdgcn_sched_barrier(0);
+            yfv2_h8 a1[MG], a2[MG];
+#pragma unroll
+            for (int mt = 0; mt < MG; ++mt) {
+              const float* wq2 = wl + ((((m0 + mt) * KP + sp) * 2) * 64 + lane) * 4;
+              a1[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2));
+              a2[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2 + 256));
+            }
+#define PW_PROD(A_, B_)                                                \
+  _Pragma("unroll") for (int mt = 0; mt < MG; ++mt)                    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[m0 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[mt], B_[nt], acc[m0 + mt][nt], 0, 0, 0);
+            PW_PROD(a1, b2) PW_PROD(a2, b1) PW_PROD(a1, b1)
+#undef PW_PROD
+          }
+        };
+        if constexpr (KP <= 3) {
+          // short K (fpn.conv1x1_2's C2 part, K = 96): the pixel's whole K requested at once - one memory round trip per tile
+          f32x4 ball[KP][NT][2];
+#pragma unroll
+          for (int sp = 0; sp < KP; ++sp)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) ball[sp][nt][e] = *reinterpret_cast<const f32x4*>((2 * sp < SPLIT ? src0[nt] : src1[nt]) + 16 * (2 * sp + e));
+#pragma unroll
+          for (int sp = 0; sp < KP; ++sp) {
+            __builtin_amdgcn_sched_barrier(0);                     // (pair by pair: the fragment reads of all pairs would be hoisted to the top otherwise)
+            pair_step(sp, ball[sp]);
+          }
+        } else {
         f32x4 bcur[NT][2], bnxt[NT][2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -142,38 +211,12 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
 #pragma unroll
               for (int e = 0; e < 2; ++e) bnxt[nt][e] = *reinterpret_cast<const f32x4*>((2 * sp + 2 < SPLIT ? src0[nt] : src1[nt]) + 16 * (2 * sp + 2 + e));
           }
-          yfv2_h8 a1[MT], a2[MT], b1[NT], b2[NT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float* wq2 = wl + (((mt * KP + sp) * 2) * 64 + lane) * 4;
-            a1[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2));
-            a2[mt] = __builtin_bit_cast(yfv2_h8, *reinterpret_cast<const u32x4*>(wq2 + 256));
-          }
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            u32x4 t1, t2;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const f32x4 v = bcur[nt][e] * 16.0f;                                        // fp16's absolute floor: 2^-25 -> 2^-29
-              const yfv2_h4 h1 = __builtin_convertvector(v, yfv2_h4);                       // v_cvt_pk_f16_f32 (RN)
-              const yfv2_h4 h2 = __builtin_convertvector(v - __builtin_convertvector(h1, f32x4), yfv2_h4);   // the difference is exact
-              const yfv2_u2 u1 = __builtin_bit_cast(yfv2_u2, h1), u2 = __builtin_bit_cast(yfv2_u2, h2);
-              t1[2 * e] = u1[0]; t1[2 * e + 1] = u1[1];
-              t2[2 * e] = u2[0]; t2[2 * e + 1] = u2[1];
-            }
-            b1[nt] = __builtin_bit_cast(yfv2_h8, t1);
-            b2[nt] = __builtin_bit_cast(yfv2_h8, t2);
-          }
-          // three products, the small ones first; MT * NT independent accumulators: no MFMA waits for the one before it
-#define PW_PROD(A_, B_)                                                \
-  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                    \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[mt], B_[nt], acc[mt][nt], 0, 0, 0);
-          PW_PROD(a1, b2) PW_PROD(a2, b1) PW_PROD(a1, b1)
-#undef PW_PROD
+          pair_step(sp, bcur);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 2; ++e) bcur[nt][e] = bnxt[nt][e];
+        }
         }
       } else {
       f32x4 bcur[NT], bnxt[NT];
@@ -331,16 +374,20 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
           }
       } else {
         float* dst = a.out + (size_t)pix * a.out_stride + a.out_off;
+        float* dst2 = MODE == PW_DUAL ? a.copy + (size_t)pix * a.copy_stride + a.copy_off : dst;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          if (16 * mt + 4 * g < a.M) {  // M % 4 == 0 for every NHWC destination
+          constexpr int MH = MODE == PW_DUAL ? MT / 2 : MT;
+          const bool second = mt >= MH;                               // (compile-time per unrolled tile)
+          const bool relu = a.relu && !second;
+          if (16 * (mt % MH) + 4 * g < a.M) {  // M % 4 == 0 for every NHWC destination
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              y[r] = __builtin_fmaf(acc[mt][nt][r], sc[mt][r], sh[mt][r]);
-              if (a.relu) y[r] = y[r] > 0.f ? y[r] : 0.f;
+              y[r] = __builtin_fmaf(acc[mt][nt][r], sc[mt][r], MODE == PW_FPNQ ? qv[mt][r] : sh[mt][r]);
+              if (relu) y[r] = y[r] > 0.f ? y[r] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * g) = y;
+            *reinterpret_cast<f32x4*>((second ? dst2 : dst) + 16 * (mt % MH) + 4 * g) = y;
           }
         }
       }
@@ -363,6 +410,11 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   // bf16x6 for the instantiations the default plans use (the streamed large-K forms and the small biased heads); the fully
   // unrolled 6-tile forms of the layer-by-layer fallback would spill with the split operands and stay on the fp32 MFMA
   constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
+  if constexpr (MODE == PW_DUAL || MODE == PW_FPNQ) {   // only the pre-split fp16x3 form exists (yfv2_launch_pw asks for nothing else)
+    static std::atomic<unsigned long long> lds_ok2{0};
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), lds_ok2);
+    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds, s, a);
+  } else {
   if constexpr (STREAM && K % 32 == 0 && K >= 192) if (a.bf6 && a.presplit) {
     static std::atomic<unsigned long long> lds_ok2{0};
     const size_t lds_pre = lds;   // two fp16 terms: the size of the fp32 image
@@ -377,12 +429,13 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   }
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
   hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
+  }
 }
 
 // does yfv2_launch_pw have a pre-split (PRE) instantiation for this launch?  (the planner then packs the filter pre-split)
 bool yfv2_pw_presplit_supported(int K, int mode, int M) {
   const int MT = (M + 15) / 16;
-  return MT == 5 && ((mode == PW_PLAIN && K == 192) || (mode == PW_FPN && K == 288));
+  return MT == 5 && (((mode == PW_PLAIN || mode == PW_DUAL) && K == 192) || (mode == PW_FPN && K == 288) || (mode == PW_FPNQ && K == 96));   // (PW_DUAL: M = each conv's rows)
 }
 
 // M tiles of the instantiation yfv2_launch_pw picks: the host packs the filter image for exactly that many
@@ -412,6 +465,10 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
     // runs the 512-thread form below.
     if (K == 288 && MT == 5 && a.bf6 && a.presplit) { pw_launch<288, 5, 1, PW_FPN, 1024, true>(a, s); return true; }
     if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }
+  } else if (mode == PW_DUAL) {
+    if (K == 192 && MT == 5 && a.bf6 && a.presplit) { pw_launch<192, 10, 1, PW_DUAL, 512, true>(a, s); return true; }
+  } else if (mode == PW_FPNQ) {
+    if (K == 96 && MT == 5 && a.bf6 && a.presplit) { pw_launch<96, 5, 1, PW_FPNQ, 1024, true>(a, s); return true; }
   } else if (mode == PW_HEAD) {
     if (K == 72 && MT == 1) { pw_launch<72, 1, 4, PW_HEAD>(a, s); return true; }
     if (K == 72 && MT <= 6) { pw_launch<72, 6, 2, PW_HEAD>(a, s); return true; }

@@ -135,7 +135,12 @@ struct StemArgs {
 };
 
 // ---- pointwise 1x1 conv on the fp32 MFMA, NHWC
-enum { PW_PLAIN = 0, PW_SHUFFLE = 1, PW_FPN = 2, PW_HEAD = 3 };
+enum { PW_PLAIN = 0, PW_SHUFFLE = 1, PW_FPN = 2, PW_HEAD = 3,
+       // round 6: fpn.conv1x1_2 without its 192 upsampled channels.  A 1x1 conv commutes with the nearest-neighbour upsample, so the C3 part of
+       // conv1x1_2 (fpn.py:57-59) is computed ONCE per coarse pixel - Q = scale2 * (W2[:, :192] C3) + shift2, by the launch that computes
+       // conv1x1_3 from the same C3 (PW_DUAL: two filter images, even workgroups the first, odd workgroups the second -> `copy`, no ReLU) -
+       // and the fine-map launch is a K = 96 conv over C2 whose epilogue adds Q at (y / 2, x / 2) (PW_FPNQ: `in2` = Q)
+       PW_DUAL = 4, PW_FPNQ = 5 };
 struct PwArgs {
   const float* in;     // NHWC activations (PW_FPN: C3, coarse map)
   const float* in2;    // PW_FPN only: C2, fine map
