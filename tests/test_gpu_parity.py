@@ -717,8 +717,9 @@ def test_other_input_size_320(yfv2, dev):
         assert np.array_equal(rows[b].numpy().view(np.uint32), o_rows[b].view(np.uint32)) and np.array_equal(idx[b].numpy(), o_idx[b])
 
 
-@pytest.mark.parametrize("env", [{"YFV2_FUSED": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_TPAIR": "0"}, {"YFV2_FRONT": "0"}],
-                         ids=["layer-by-layer", "fp32-mfma-everywhere", "two-launch-post", "tower-halves-as-four-launches", "stem-and-stage2.0-as-two-launches"])
+@pytest.mark.parametrize("env", [{"YFV2_FUSED": "0"}, {"YFV2_BF6": "0"}, {"YFV2_POSTFUSE": "0"}, {"YFV2_TPAIR": "0"}, {"YFV2_FRONT": "0"}, {"YFV2_FUSED": "0", "YFV2_BF6": "0"}],
+                         ids=["layer-by-layer", "fp32-mfma-everywhere", "two-launch-post", "tower-halves-as-four-launches", "stem-and-stage2.0-as-two-launches",
+                              "layer-by-layer-on-the-fp32-mfma"])
 def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     """The three plan switches that remain: everything layer by layer - also what a shape outside a fused
     kernel's static bounds gets, block by block; every pointwise conv on the fp32 MFMA; decode and NMS as two launches.
@@ -738,7 +739,9 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
             else:
                 os.environ[k] = v
     names = [s["name"] for s in eng.stages()]
-    if "YFV2_FUSED" in env:
+    if "YFV2_FUSED" in env and "YFV2_BF6" in env:
+        assert len(names) >= 70 and not any("chain of" in n or "lane-per-pixel" in n for n in names), names
+    elif "YFV2_FUSED" in env:
         assert len(names) >= 70 and not any("chain of" in n or "lane-per-pixel" in n for n in names), names
     elif "YFV2_BF6" in env:
         assert not any("chain of 7" in n for n in names) and any("resident in LDS" in n for n in names), names
@@ -757,6 +760,31 @@ def test_fallback_plans_match_oracle(yfv2, dev, images_u8, coco_weights, env):
     for g, r, k in zip(got, ref, LOGIT_KEYS):
         err = float((g.cpu() - r).abs().max())
         assert err <= LOGIT_ATOL, "%s: max abs err %g" % (k, err)
+    # the uint8 (B,H,W,3) entry point of the same plan (the fp32-matrix plans run their own uint8 stem, stem_px_kernel<.., U8>)
+    x8 = torch.from_numpy(images_u8[:3]).permute(0, 2, 3, 1).contiguous()
+    got8 = eng.forward(x8.to(dev))
+    for g, r, k in zip(got8, ref, LOGIT_KEYS):
+        err = float((g.cpu() - r).abs().max())
+        assert err <= LOGIT_ATOL, "uint8 input, %s: max abs err %g" % (k, err)
+
+
+def test_narrow_class_head_level_as_one_launch(yfv2, dev):
+    """towerp_kernel<1, true>: a class head of at most 15 classes (obj + cls = one 16-channel tile) on a batch that fills the chip - the
+    whole 22x22 level as ONE launch in its one-tile instantiation.  The same images in a batch of 8 go through the two-launch form
+    (towerp_kernel<0 / 1, false>, pinned against the oracle by the class-count cases): the logits must be bit-identical."""
+    w = yfv2.random_state_dict(21, classes=5)
+    m = yfv2.Detector(5, 3, True).to(dev)
+    m.load_state_dict(w)
+    m.eval()
+    torch.manual_seed(4)
+    x = torch.rand(136, 3, 352, 352)
+    big = [t.cpu() for t in m(x.to(dev))]
+    names = [s["name"] for s in m.engine_for(x.to(dev)).stages()]
+    assert sum("four halves of an image" in n for n in names) == 1, names
+    small = [t.cpu() for t in m(x[:8].to(dev))]
+    for a, b, k in zip(big, small, LOGIT_KEYS):
+        assert torch.equal(a[:8], b), k
+    _assert_logits_within_noise_floor([t[:3] for t in big], w, x[:3], "5 classes, batch 136")
 
 
 def test_uint8_hwc_input_matches_float_path(yfv2, model, dev, images_u8, coco_weights, cfg):

@@ -340,3 +340,25 @@ def test_advice_r04_rebind_after_handle_recreation_pickled_optimizer_frozen_para
     loss.backward()
     opt.step()
     assert torch.isfinite(loss.detach()).all()
+
+
+def test_single_tensor_sgd_step_is_torch_sgd():
+    """yfv2_sgd_step (one tensor; since round 6 a table of one through the multi-tensor kernel): torch.optim.SGD(momentum 0.949,
+    weight_decay 5e-4) on the same numbers, first step (buffer uninitialised) and a later one, to fp32 rounding (the kernel may contract
+    momentum * buf + d into one FMA)."""
+    import yolo_fastestv2_amd as yfv2
+    dev = torch.device("cuda:0")
+    eng = yfv2.Engine(dev, 352, 352, 80, 3, max_batch=1)
+    torch.manual_seed(7)
+    p0, g1, g2 = torch.randn(1000), torch.randn(1000), torch.randn(1000)
+    p = p0.clone().to(dev)
+    buf = torch.full((1000,), float("nan"), device=dev)
+    eng.sgd_step(p, g1.to(dev), buf, 0.01, 0.949, 5e-4, True)
+    eng.sgd_step(p, g2.to(dev), buf, 0.01, 0.949, 5e-4, False)
+    torch.cuda.synchronize()
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.949, weight_decay=5e-4)
+    for g in (g1, g2):
+        ref.grad = g.clone()
+        opt.step()
+    assert torch.allclose(p.cpu(), ref.detach(), rtol=2e-6, atol=1e-7), float((p.cpu() - ref.detach()).abs().max())

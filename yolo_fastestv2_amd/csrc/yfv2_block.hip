@@ -859,7 +859,7 @@ struct S2Cfg {
   static constexpr int MAXT = CIN <= 24 ? 10 : 6;     // pw1 pixel tiles per wave
 };
 
-template <int CIN, int THREADS, bool PPIN, bool BF6 = false>
+template <int CIN, int THREADS, bool PPIN>
 __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
   using Cfg = S2Cfg<CIN>;
   constexpr int KC = Cfg::KC, CP = Cfg::CP, KS = KC * 16;
@@ -1076,15 +1076,13 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
     // came from, so no barrier separates reads from writes; the next tile's B fragments are fetched before the
     // current tile's MFMAs (same scheme as block_s1_kernel's phase A).
     {
-      // (BF6: bf16x6, yfv2_internal.h - the KC*KC fragments are split once per item and stay in registers as operand quads)
-      f32x4 aw[BF6 ? 1 : KC][KC], sc1[KC], sh1[KC];
-      Bf3A aw3[BF6 ? KC : 1][KC];
+      f32x4 aw[KC][KC], sc1[KC], sh1[KC];
 #pragma unroll
       for (int mt = 0; mt < KC; ++mt) {
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
           const f32x4 fr = *reinterpret_cast<const f32x4*>(W1 + ((mt * KC + s) * 64 + lane) * 4);
-          if constexpr (BF6) aw3[mt][s] = yfv2_split_a(fr); else aw[mt][s] = fr;
+          aw[mt][s] = fr;
         }
         sc1[mt] = *reinterpret_cast<const f32x4*>(CS + 0 * KS + 16 * mt + 4 * g);
         sh1[mt] = *reinterpret_cast<const f32x4*>(CS + 1 * KS + 16 * mt + 4 * g);
@@ -1116,18 +1114,7 @@ __global__ __launch_bounds__(THREADS) void block_s2_kernel(BlockS2Args a) {
         f32x4 accA[KC];
 #pragma unroll
         for (int mt = 0; mt < KC; ++mt) accA[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (BF6) {
-#pragma unroll
-          for (int s = 0; s < KC; ++s) {
-            const Bf3B b3 = yfv2_split_b(bf[s]);
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt) accA[mt] = yfv2_mfma6_step<0>(aw3[mt][s], b3, accA[mt]);
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt) accA[mt] = yfv2_mfma6_step<1>(aw3[mt][s], b3, accA[mt]);
-#pragma unroll
-            for (int mt = 0; mt < KC; ++mt) accA[mt] = yfv2_mfma6_step<2>(aw3[mt][s], b3, accA[mt]);
-          }
-        } else {
+        {
 #pragma unroll
         for (int s = 0; s < KC; ++s)
 #pragma unroll
@@ -1197,11 +1184,14 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
   if (blocks > 256) blocks = 256;
   static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0}, lds_ok2{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, false>), lds_ok0);
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true>), lds_ok1);
-  yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true, true>), lds_ok2);
-  if (a.pp_in && a.bf6) hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true, true>), dim3(blocks), dim3(512), lds, s, a);   // pw1 on the bf16 matrix cores
-  else if (a.pp_in) hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true>), dim3(blocks), dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
+  if constexpr (CIN == 48) {   // the pair-plane input forms: stage3.0 behind the lane-per-pixel stage 2 (stage2.0 reads the stem's planes in s2px / s2h / front2)
+    // (fp32 MFMA whatever the handle's arithmetic: with fp16x3 this block is s3h2_kernel's - the staged form is reached only by the
+    // fp32-matrix plan and by stage-2 maps wider than 480 columns, where it is correct at any range.  Its bf16x6 variant is gone.)
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true>), lds_ok1);
+    if (a.pp_in) { hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true>), dim3(blocks), dim3(512), lds, s, a); return; }
+  }
+  if (a.pp_in) return;   // (never planned: WeightPacker sets pp_in for the 48-channel block only)
+  hipLaunchKernelGGL((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 // ============================================================================

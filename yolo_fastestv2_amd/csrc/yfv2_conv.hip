@@ -396,7 +396,9 @@ __global__ __launch_bounds__(THREADS) void pw_kernel(PwArgs a) {
   if constexpr (PRE) watch.report(a.nonfinite);
 }
 
-template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false>
+// FORMS: 0 = whatever the handle's plan asks for (fp32 MFMA / split on the fly / pre-split filter); 1 = the pre-split fp16x3 form only,
+// 2 = the fp32-MFMA form only (instantiations the launcher picks for one plan: nothing else is compiled into the library)
+template <int K, int MT, int NT, int MODE, int THREADS = 256, bool STREAM = false, int FORMS = 0>
 static void pw_launch(const PwArgs& a, hipStream_t s) {
   const size_t lds = (size_t)MT * 16 * K * sizeof(float);   // K/16 fragments of 256 floats + (K%16 == 8) 128 per M tile
   const int n_super = (a.P + NT * 16 - 1) / (NT * 16);
@@ -410,19 +412,22 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   // bf16x6 for the instantiations the default plans use (the streamed large-K forms and the small biased heads); the fully
   // unrolled 6-tile forms of the layer-by-layer fallback would spill with the split operands and stay on the fp32 MFMA
   constexpr bool kBf6 = STREAM || (MT * (K / 16 + 1) <= 12);
-  if constexpr (MODE == PW_DUAL || MODE == PW_FPNQ) {   // only the pre-split fp16x3 form exists (yfv2_launch_pw asks for nothing else)
+  if constexpr (FORMS == 1) {   // only the pre-split fp16x3 form (yfv2_launch_pw asks for nothing else)
     static std::atomic<unsigned long long> lds_ok2{0};
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), lds_ok2);
     hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds, s, a);
+  } else if constexpr (FORMS == 2) {
+    yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
+    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
   } else {
-  if constexpr (STREAM && K % 32 == 0 && K >= 192) if (a.bf6 && a.presplit) {
+  if constexpr (STREAM && K % 32 == 0 && K >= 192) if (a.bf6) {   // (the planner packs these filters pre-split whenever the handle runs fp16x3)
     static std::atomic<unsigned long long> lds_ok2{0};
     const size_t lds_pre = lds;   // two fp16 terms: the size of the fp32 image
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), lds_ok2);
     hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds_pre, s, a);
     return;
   }
-  if constexpr (kBf6) if (a.bf6) {
+  if constexpr (kBf6 && !(STREAM && K % 32 == 0 && K >= 192)) if (a.bf6) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), lds_ok1);
     hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), dim3(blocks), dim3(THREADS), lds, s, a);
     return;
@@ -463,12 +468,12 @@ bool yfv2_launch_pw(int K, int mode, const PwArgs& a, hipStream_t s) {
     // at 1024 threads (28 spilled registers), four tiles per wave at 512 (the same 31 us), and a form with a tile's whole K in
     // flight in two register sets (pwf_kernel, round 4: 32.0 us - the launch is not bound by that latency).  The fp32-matrix plan
     // runs the 512-thread form below.
-    if (K == 288 && MT == 5 && a.bf6 && a.presplit) { pw_launch<288, 5, 1, PW_FPN, 1024, true>(a, s); return true; }
-    if (K == 288 && MT == 5) { pw_launch<288, 5, 2, PW_FPN, 512, true>(a, s); return true; }
+    if (K == 288 && MT == 5 && a.bf6 && a.presplit) { pw_launch<288, 5, 1, PW_FPN, 1024, true, 1>(a, s); return true; }
+    if (K == 288 && MT == 5 && !a.bf6) { pw_launch<288, 5, 2, PW_FPN, 512, true, 2>(a, s); return true; }
   } else if (mode == PW_DUAL) {
-    if (K == 192 && MT == 5 && a.bf6 && a.presplit) { pw_launch<192, 10, 1, PW_DUAL, 512, true>(a, s); return true; }
+    if (K == 192 && MT == 5 && a.bf6 && a.presplit) { pw_launch<192, 10, 1, PW_DUAL, 512, true, 1>(a, s); return true; }
   } else if (mode == PW_FPNQ) {
-    if (K == 96 && MT == 5 && a.bf6 && a.presplit) { pw_launch<96, 5, 1, PW_FPNQ, 1024, true>(a, s); return true; }
+    if (K == 96 && MT == 5 && a.bf6 && a.presplit) { pw_launch<96, 5, 1, PW_FPNQ, 1024, true, 1>(a, s); return true; }
   } else if (mode == PW_HEAD) {
     if (K == 72 && MT == 1) { pw_launch<72, 1, 4, PW_HEAD>(a, s); return true; }
     if (K == 72 && MT <= 6) { pw_launch<72, 6, 2, PW_HEAD>(a, s); return true; }

@@ -1270,9 +1270,11 @@ bool yfv2_launch_towerh(const TowerJobs& jobs, int mh_tiles, hipStream_t s) {
     if (mh_tiles == 1) launch_towers<1>(jobs, s);
     else launch_towers<6>(jobs, s);
   } else if (a.H <= 11 && a.W <= 11) {
+    // single halves of a small map: only what the planner leaves unmerged - a class head wider than 96 channels (its b half without merged
+    // matrix: 0 tiles, the output convs as pointwise launches) beside the reg tower (1 tile).  Everything else at this size is towers_kernel's
     if (mh_tiles == 0) launch_towerh<0, 1, 1>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 1, 1>(jobs, s);
-    else launch_towerh<6, 1, 1>(jobs, s);
+    else return false;
   } else if ((a.H & 1) || (a.W & 1)) {   // odd maps (13x13 at 416x416): towerh_kernel<.., 2, 4> (towerp_kernel's 16-byte patch-row records want even sizes)
     if (mh_tiles == 0) launch_towerh<0, 2, 4>(jobs, s);
     else if (mh_tiles == 1) launch_towerh<1, 2, 4>(jobs, s);

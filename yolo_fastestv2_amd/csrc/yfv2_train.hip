@@ -36,35 +36,6 @@ struct V {
 
 struct ConvP { V in, out; const float* w; const float* bias; int k, stride, pad, dw, B; };
 
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP a) {
-  const int OH = a.out.H, OW = a.out.W;
-  const size_t n = (size_t)a.B * a.out.C * OH * OW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int ox = i % OW, oy = (i / OW) % OH, co = (i / ((size_t)OW * OH)) % a.out.C, b = i / ((size_t)OW * OH * a.out.C);
-  float acc = a.bias ? a.bias[co] : 0.f;
-  const int k = a.k;
-  if (a.dw) {
-    for (int ky = 0; ky < k; ++ky) {
-      const int iy = oy * a.stride - a.pad + ky;
-      if (iy < 0 || iy >= a.in.H) continue;
-      for (int kx = 0; kx < k; ++kx) {
-        const int ix = ox * a.stride - a.pad + kx;
-        if (ix >= 0 && ix < a.in.W) acc = __builtin_fmaf(a.w[(co * k + ky) * k + kx], a.in.p[a.in.at(b, co, iy, ix)], acc);
-      }
-    }
-  } else {
-    for (int ci = 0; ci < a.in.C; ++ci)
-      for (int ky = 0; ky < k; ++ky) {
-        const int iy = oy * a.stride - a.pad + ky;
-        if (iy < 0 || iy >= a.in.H) continue;
-        for (int kx = 0; kx < k; ++kx) {
-          const int ix = ox * a.stride - a.pad + kx;
-          if (ix >= 0 && ix < a.in.W) acc = __builtin_fmaf(a.w[(((size_t)co * a.in.C + ci) * k + ky) * k + kx], a.in.p[a.in.at(b, ci, iy, ix)], acc);
-        }
-      }
-  }
-  a.out.p[a.out.at(b, co, oy, ox)] = acc;
-}
 
 // Depthwise convs (3 x 3 and 5 x 5, stride 1 or 2; pad K / 2), forward and data gradient: a block stays inside ONE (image, channel)
 // plane - the filter and the plane bases are wave-uniform, a thread divides once - with the generic kernels' summation order
@@ -150,67 +121,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(ConvP a) {
   for (int co = 0; co < 24; ++co) a.out.p[a.out.at(b, co, oy, ox)] = acc[co];
 }
 
-// d in += conv^T(d out): a.in = gradient view of the input (accumulated into), a.out = gradient of the output
-__global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvP a) {
-  const int IH = a.in.H, IW = a.in.W;
-  const size_t n = (size_t)a.B * a.in.C * IH * IW, i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int ix = i % IW, iy = (i / IW) % IH, ci = (i / ((size_t)IW * IH)) % a.in.C, b = i / ((size_t)IW * IH * a.in.C);
-  const int k = a.k;
-  float acc = 0.f;
-  for (int ky = 0; ky < k; ++ky) {
-    const int ny = iy + a.pad - ky;
-    if (ny < 0 || ny % a.stride) continue;
-    const int oy = ny / a.stride;
-    if (oy >= a.out.H) continue;
-    for (int kx = 0; kx < k; ++kx) {
-      const int nx = ix + a.pad - kx;
-      if (nx < 0 || nx % a.stride) continue;
-      const int ox = nx / a.stride;
-      if (ox >= a.out.W) continue;
-      if (a.dw) acc = __builtin_fmaf(a.w[(ci * k + ky) * k + kx], a.out.p[a.out.at(b, ci, oy, ox)], acc);
-      else
-        for (int co = 0; co < a.out.C; ++co) acc = __builtin_fmaf(a.w[(((size_t)co * a.in.C + ci) * k + ky) * k + kx], a.out.p[a.out.at(b, co, oy, ox)], acc);
-    }
-  }
-  a.in.p[a.in.at(b, ci, iy, ix)] += acc;
-}
 
-// dW[co][ci][ky][kx] += sum_{b, oy, ox} dOut * In   (a.in = the input VALUES, a.out = gradient of the output, a.w unused);
-// one block per (co, ci, segment of the (b, oy, ox) range) - (channel, 0, segment) for depthwise.  With one segment every
-// filter entry is written by exactly one block; with several (layers with few filter entries and a long reduction: the stem,
-// the depthwise convs - one block per entry left 24..192 blocks on 256 CUs) the partial sums meet in a float atomic.
-__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvP a, float* dw_out) {
-  __shared__ double red[256];
-  const int co = blockIdx.x, ci = a.dw ? co : (int)blockIdx.y, cig = a.dw ? 0 : ci, cin_g = a.dw ? 1 : a.in.C;
-  const int k = a.k, kk = k * k, OH = a.out.H, OW = a.out.W;
-  double acc[25];
-  for (int t = 0; t < kk; ++t) acc[t] = 0.0;
-  const int n = a.B * OH * OW, nseg = gridDim.z, len = (n + nseg - 1) / nseg;
-  const int i0 = blockIdx.z * len, i1 = i0 + len < n ? i0 + len : n;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-    const int ox = i % OW, oy = (i / OW) % OH, b = i / (OW * OH);
-    const float g = a.out.p[a.out.at(b, co, oy, ox)];
-    for (int ky = 0; ky < k; ++ky) {
-      const int iy = oy * a.stride - a.pad + ky;
-      if (iy < 0 || iy >= a.in.H) continue;
-      for (int kx = 0; kx < k; ++kx) {
-        const int ix = ox * a.stride - a.pad + kx;
-        if (ix >= 0 && ix < a.in.W) acc[ky * k + kx] += (double)g * (double)a.in.p[a.in.at(b, ci, iy, ix)];
-      }
-    }
-  }
-  for (int t = 0; t < kk; ++t) {
-    red[threadIdx.x] = acc[t];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) {
-      float* dst = dw_out + ((size_t)co * cin_g + cig) * kk + t;
-      if (nseg == 1) *dst += (float)red[0]; else atomicAdd(dst, (float)red[0]);
-    }
-    __syncthreads();
-  }
-}
 // segments for a reduction of n elements next to `others` independent blocks: about 2048 blocks in all, at least 2048 elements each
 inline unsigned reduce_segments(size_t n, size_t others) {
   size_t s = others >= 2048 ? 1 : 2048 / (others ? others : 1);
@@ -419,15 +330,6 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(V dsrc, V ddst, int 
                                  ddst.p[ddst.at(b, c, 2 * y + 1, 2 * x + 1)];
 }
 
-// torch.optim.SGD, one parameter tensor: d = g + wd p; buf = first ? d : momentum buf + d; p -= lr buf
-__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, int first) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float d = g[i] + wd * p[i];
-  const float bb = first ? d : momentum * buf[i] + d;
-  buf[i] = bb;
-  p[i] = p[i] - lr * bb;
-}
 
 
 // ---- round 4: the pointwise (1x1, stride 1) convolutions - 51 of the 79 convs and 73 % of the step's arithmetic - as GEMMs on
@@ -797,8 +699,9 @@ struct Train {
       if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_kernel<3, 1>), grid, dim3(256), 0, s, c);
       else if (k == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, 2>), grid, dim3(256), 0, s, c);
       else if (stride == 1) hipLaunchKernelGGL((dw_fwd_kernel<5, 1>), grid, dim3(256), 0, s, c);
-      else hipLaunchKernelGGL((dw_fwd_kernel<5, 2>), grid, dim3(256), 0, s, c);
-    } else hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks_for((size_t)B * Cout * OH * OW)), dim3(256), 0, s, c);
+      else { if (err.empty()) err = "yfv2_train: no kernel for a 5x5 stride-2 depthwise conv (" + conv + ")"; return; }
+    } else { if (err.empty()) err = "yfv2_train: no kernel for conv " + conv + " (pointwise, depthwise 3x3 / 5x5 and the stem only)"; return; }   // (round 3's
+    // one-thread-per-output conv_fwd / conv_bwd_data / conv_bwd_weight kernels served every layer; nothing of this network reaches them since round 4)
     double* ds = dscr + dscr_used; dscr_used += 4 * (size_t)Cout;
     if (dscr_used > dscr_n) { if (err.empty()) err = "yfv2_train: BatchNorm scratch exhausted"; return; }
     const unsigned nseg = reduce_segments((size_t)B * OH * OW, Cout);
@@ -818,7 +721,7 @@ struct Train {
         double* scr = wgrad_scratch(gw, Cout * k * k);
         if (scr && k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3>), grid, dim3(256), 0, st2, cw, scr);
         else if (scr) hipLaunchKernelGGL((dw_wgrad_kernel<5>), grid, dim3(256), 0, st2, cw, scr);
-      } else hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(Cout, dw ? 1 : Cin, reduce_segments((size_t)Bc * OH * OW, (size_t)Cout * (dw ? 1 : Cin))), dim3(256), 0, st2, cw, gw);
+      }
       if (need_din) {
         ConvP cd{view(tin, true, in_coff, in_cstride, Cin), view(y, true), w, nullptr, k, stride, pad, dw ? 1 : 0, Bc};
         if (pw) pw_data_grad(cd.in, cd.out, w, Bc, st2);
@@ -826,9 +729,8 @@ struct Train {
           const dim3 grid((tin.H * tin.W + 255) / 256, Bc * Cin);
           if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_bwd_data_kernel<3, 1>), grid, dim3(256), 0, st2, cd);
           else if (k == 3) hipLaunchKernelGGL((dw_bwd_data_kernel<3, 2>), grid, dim3(256), 0, st2, cd);
-          else if (stride == 1) hipLaunchKernelGGL((dw_bwd_data_kernel<5, 1>), grid, dim3(256), 0, st2, cd);
-          else hipLaunchKernelGGL((dw_bwd_data_kernel<5, 2>), grid, dim3(256), 0, st2, cd);
-        } else hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(blocks_for((size_t)Bc * Cin * tin.H * tin.W)), dim3(256), 0, st2, cd);
+          else hipLaunchKernelGGL((dw_bwd_data_kernel<5, 1>), grid, dim3(256), 0, st2, cd);
+        }
       }
     });
   }
@@ -1150,10 +1052,8 @@ int yfv2_sgd_step(yfv2_handle h, float* param, const float* grad, float* momentu
                   int32_t first_step, void* stream) {
   if (!h || !param || !grad || !momentum_buf || n < 0) return yfv2_ctx_fail(h, YFV2_ERR_ARG, "yfv2_sgd_step: bad argument");
   if (n == 0) return YFV2_OK;
-  hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, momentum_buf, (long long)n, lr, momentum,
-                     weight_decay, first_step ? 1 : 0);
-  if (hipGetLastError() != hipSuccess) return yfv2_ctx_fail(h, YFV2_ERR_DEVICE, "yfv2_sgd_step: launch failed");
-  return YFV2_OK;
+  const yfv2_sgd_item one{param, grad, momentum_buf, n, first_step ? 1 : 0, 0};   // (one tensor = a table of one: the same kernel)
+  return yfv2_sgd_step_multi(h, &one, 1, lr, momentum, weight_decay, stream);
 }
 
 int yfv2_sgd_step_multi(yfv2_handle h, const yfv2_sgd_item* items, int32_t n_items, float lr, float momentum, float weight_decay, void* stream) {
