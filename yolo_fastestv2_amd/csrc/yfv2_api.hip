@@ -1918,7 +1918,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       BlockS1Args a = st.s1;
       a.B = B;
       a.img = params + st.img_off;
-      a.trace = nullptr;
+      a.trace = (h->trace_step == (int)i) ? h->d_trace : nullptr;
       a.nonfinite = h->d_nonfinite;
       if (!yfv2_launch_block_s1pool(a, s))
         return fail(h, YFV2_ERR_CONFIG, "no pool-chain kernel for step '" + st.name + "'");

@@ -555,6 +555,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
   float* ppix = POOL + pxc * P96_CPP;
   static_assert(NW * 16 >= P96_MAXPX, "one tile per wave");
 
+  YFV2_WSTAMP(0);
   for (int i = tid; i < (H + 2) * WP * P96_TP / 4; i += THREADS) reinterpret_cast<f32x4*>(T)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
       for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) reinterpret_cast<f32x4*>(IMG)[i] = ti[k]; }
     }
     __syncthreads();
+    YFV2_WSTAMP(1);
 
 #pragma unroll 1
     for (int blk = 0; blk < NB; ++blk) {
@@ -680,7 +682,9 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
             }
           }
         }
+        if (blk == 0) YFV2_WSTAMP(2 + 4 * th);
         __syncthreads();   // the depthwise windows reach into the neighbours' pixels
+        if (blk == 0) YFV2_WSTAMP(3 + 4 * th);
         // ---- dw3x3 (+BN) in registers -> pw2 partial sums over this third's 32 input channels
         if constexpr (PRE) {
           f32x4 bfr2[2];
@@ -753,12 +757,14 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
             for (int c = 0; c < 4; ++c) { const float u = __builtin_fmaf(acc2[mt][c], sc[c], sh[c]); acc2[mt][c] = u > 0.f ? u : 0.f; }
           }
         }
+        if (blk == 0) YFV2_WSTAMP(4 + 4 * th);
         __syncthreads();   // T and IMG are free
         if (more) {
 #pragma unroll
           for (int k = 0; k < NIT; ++k) { const int i = tid + k * THREADS; if (i < N4) reinterpret_cast<f32x4*>(IMG)[i] = nimg[k]; }
         }
         if (th < P96_TH - 1) __syncthreads();            // (after the last third the barriers of the pool rewrite follow)
+        if (blk == 0) YFV2_WSTAMP(5 + 4 * th);
       }
       // ---- pool <- cat(even channels, fresh): evens gathered through registers between two barriers
       {
@@ -788,6 +794,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
           for (int mt = 0; mt < P96_KC; ++mt) *reinterpret_cast<f32x4*>(ppix + P96_C2 + 16 * mt + 4 * g) = acc2[mt];
         }
         __syncthreads();
+        YFV2_WSTAMP(14 + blk);
       }
     }
     // ---- the pool out (coalesced), then the barrier that frees it for the next image
@@ -798,6 +805,7 @@ __global__ __launch_bounds__(THREADS, 2) void block_s1pool_kernel(BlockS1Args a)
         dst[i] = *reinterpret_cast<const f32x4*>(POOL + ipx * P96_CPP + 4 * q);
       }
     }
+    YFV2_WSTAMP(17);
     __syncthreads();
   }
   watch.report(a.nonfinite);
