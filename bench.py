@@ -39,8 +39,11 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings):
   roofline   the kernel that owns the most forward time (sum over its launches, the
              top row of a rocprofv3 --stats table): algorithmic bytes (SURVEY.md 8(d):
              EXTERNAL reads + writes for a fused launch) and flops of its launches /
-             their summed duration, measured with hipEvent pairs on the launch stream
-             inside this process (yfv2_profile_forward); `bound` follows its arithmetic
+             their summed duration, measured with HIP events on the launch stream inside
+             this process (yfv2_profile_forward: every launch records its OWN begin and end
+             into a hipEvent pair - hipExtLaunchKernel's start / stop events, the dispatch
+             timestamps a rocprofv3 trace reports; events recorded in front of and behind
+             a launch read 3-12 us more); `bound` follows its arithmetic
              intensity.  `traffic` = HBM bytes per launch from the PMC passes under
              profiles/ (tools/gpu_traffic.sh) IF that profile was taken on this very
              source tree (fingerprint match), else null.

@@ -274,9 +274,11 @@ YFV2_API int yfv2_stage_info(yfv2_handle h, int32_t i, char* name, int32_t name_
 YFV2_API int yfv2_stage_kernel(yfv2_handle h, int32_t i, char* name, int32_t name_cap);
 
 /* Measurement helper (synchronises once, at the end): one untimed pass, then
- * `iters` passes of the forward queued back to back on `stream` with a hipEvent
- * pair around every launch; the mean duration of each launch in milliseconds
- * goes to ms[0..num_stages).  Between two passes the decode + NMS launch of
+ * `iters` passes of the forward queued back to back on `stream`, every launch
+ * recording its own begin and end into a hipEvent pair (hipExtLaunchKernel start /
+ * stop events: the dispatch's timestamps, as a rocprofv3 trace reports them; a step
+ * of several launches: first begin to last end); the mean duration of each step in
+ * milliseconds goes to ms[0..num_stages).  Between two passes the decode + NMS launch of
  * yfv2_detect runs untimed (thresholds 0.3 / 0.4, results discarded) where the
  * configuration has the fused form, so that a pass's first launch follows what it
  * follows in a detect loop. */

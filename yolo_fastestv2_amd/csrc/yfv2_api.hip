@@ -20,6 +20,8 @@
 #include "../../include/yfv2.h"
 #include "yfv2_internal.h"
 
+thread_local Yfv2LaunchProbe yfv2_launch_probe;   // (yfv2_internal.h: YFV2_LAUNCH)
+
 namespace {
 
 thread_local std::string g_tls_error;
@@ -1834,10 +1836,11 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
     return fail(h, YFV2_ERR_ARG, x_u8 ? "input images: the uint8 tensor must be 4-byte aligned" : "input images: the fp32 tensor must be 16-byte aligned");
   const float* params = h->d_params;
   const hipStream_t s = main_stream;
+  struct ProbeScope { ~ProbeScope() { yfv2_launch_probe = Yfv2LaunchProbe{}; } } probe_scope;   // (cleared on every path out, error returns included)
   for (size_t i = 0; i < h->plan.size(); ++i) {
     if (only_step >= 0 && (int)i != only_step) continue;
     Step& st = h->plan[i];
-    if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i], s));
+    yfv2_launch_probe = ev ? Yfv2LaunchProbe{ev[2 * i], ev[2 * i + 1], 0} : Yfv2LaunchProbe{};   // (profile pass: the step's launches stamp themselves)
     auto stem_args = [&](const Step& ss) {
       StemArgs a = ss.stem;
       a.x = x; a.B = B; a.u8_in = x_u8 ? 1 : 0;
@@ -1961,7 +1964,7 @@ int run_plan(yfv2_ctx* h, const void* x, bool x_u8, int B, float* const out6[6],
       if (!yfv2_launch_dw(st.ksize, st.stride, a, s))
         return fail(h, YFV2_ERR_CONFIG, "no depthwise kernel for step '" + st.name + "'");
     }
-    if (ev) HIP_TRY(h, hipEventRecord(ev[2 * i + 1], s));
+    yfv2_launch_probe = Yfv2LaunchProbe{};
   }
   if (only_step < 0) { h->last_x = x; h->last_B = B; h->last_u8 = x_u8; }
   HIP_TRY(h, hipGetLastError());

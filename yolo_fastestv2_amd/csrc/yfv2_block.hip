@@ -498,7 +498,7 @@ bool yfv2_launch_block_s1chain(const BlockS1Args& a, hipStream_t s) {
   const int blocks = a.B < 256 ? a.B : 256;
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1chain6_kernel<512>), lds_ok);
-  hipLaunchKernelGGL((block_s1chain6_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  YFV2_LAUNCH((block_s1chain6_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
   return true;
 }
 
@@ -825,10 +825,10 @@ bool yfv2_launch_block_s1pool(const BlockS1Args& a, hipStream_t s) {
   static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
   if (a.presplit) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1pool_kernel<512, true>), lds_ok1);
-    hipLaunchKernelGGL((block_s1pool_kernel<512, true>), dim3(blocks), dim3(512), lds, s, a);
+    YFV2_LAUNCH((block_s1pool_kernel<512, true>), dim3(blocks), dim3(512), lds, s, a);
   } else {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s1pool_kernel<512, false>), lds_ok0);
-    hipLaunchKernelGGL((block_s1pool_kernel<512, false>), dim3(blocks), dim3(512), lds, s, a);
+    YFV2_LAUNCH((block_s1pool_kernel<512, false>), dim3(blocks), dim3(512), lds, s, a);
   }
   return true;
 }
@@ -1196,10 +1196,10 @@ static void launch_s2(const BlockS2Args& a, hipStream_t s) {
     // (fp32 MFMA whatever the handle's arithmetic: with fp16x3 this block is s3h2_kernel's - the staged form is reached only by the
     // fp32-matrix plan and by stage-2 maps wider than 480 columns, where it is correct at any range.  Its bf16x6 variant is gone.)
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2_kernel<CIN, 512, true>), lds_ok1);
-    if (a.pp_in) { hipLaunchKernelGGL((block_s2_kernel<CIN, 512, true>), dim3(blocks), dim3(512), lds, s, a); return; }
+    if (a.pp_in) { YFV2_LAUNCH((block_s2_kernel<CIN, 512, true>), dim3(blocks), dim3(512), lds, s, a); return; }
   }
   if (a.pp_in) return;   // (never planned: WeightPacker sets pp_in for the 48-channel block only)
-  hipLaunchKernelGGL((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
+  YFV2_LAUNCH((block_s2_kernel<CIN, 512, false>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 // ============================================================================
@@ -1580,7 +1580,7 @@ static void launch_s2w(const BlockS2Args& a, hipStream_t s) {
   if (blocks > 256) blocks = 256;
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&block_s2w_kernel<512>), lds_ok);
-  hipLaunchKernelGGL((block_s2w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
+  YFV2_LAUNCH((block_s2w_kernel<512>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 bool yfv2_launch_block_s2(int cin, const BlockS2Args& a, hipStream_t s) {
@@ -1863,11 +1863,11 @@ static void launch_tower2(const TowerArgs& a, hipStream_t s) {
   static std::atomic<unsigned long long> lds_ok0{0}, lds_ok1{0};
   if (a.bf6) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF, true>), lds_ok1);
-    hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF, true>), dim3(blocks), dim3(THREADS), lds, s, a);
+    YFV2_LAUNCH((tower2_kernel<MH, THREADS, NT, NPF, true>), dim3(blocks), dim3(THREADS), lds, s, a);
     return;
   }
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&tower2_kernel<MH, THREADS, NT, NPF, false>), lds_ok0);
-  hipLaunchKernelGGL((tower2_kernel<MH, THREADS, NT, NPF, false>), dim3(blocks), dim3(THREADS), lds, s, a);
+  YFV2_LAUNCH((tower2_kernel<MH, THREADS, NT, NPF, false>), dim3(blocks), dim3(THREADS), lds, s, a);
 }
 
 bool yfv2_tower2_supported(int H, int W) { return H * W <= 16 * 4 * 8; }

@@ -415,25 +415,25 @@ static void pw_launch(const PwArgs& a, hipStream_t s) {
   if constexpr (FORMS == 1) {   // only the pre-split fp16x3 form (yfv2_launch_pw asks for nothing else)
     static std::atomic<unsigned long long> lds_ok2{0};
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), lds_ok2);
-    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds, s, a);
+    YFV2_LAUNCH((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds, s, a);
   } else if constexpr (FORMS == 2) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
-    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
+    YFV2_LAUNCH((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
   } else {
   if constexpr (STREAM && K % 32 == 0 && K >= 192) if (a.bf6) {   // (the planner packs these filters pre-split whenever the handle runs fp16x3)
     static std::atomic<unsigned long long> lds_ok2{0};
     const size_t lds_pre = lds;   // two fp16 terms: the size of the fp32 image
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), lds_ok2);
-    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds_pre, s, a);
+    YFV2_LAUNCH((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true, true>), dim3(blocks), dim3(THREADS), lds_pre, s, a);
     return;
   }
   if constexpr (kBf6 && !(STREAM && K % 32 == 0 && K >= 192)) if (a.bf6) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), lds_ok1);
-    hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), dim3(blocks), dim3(THREADS), lds, s, a);
+    YFV2_LAUNCH((pw_kernel<K, MT, NT, MODE, THREADS, STREAM, true>), dim3(blocks), dim3(THREADS), lds, s, a);
     return;
   }
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), lds_ok0);
-  hipLaunchKernelGGL((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
+  YFV2_LAUNCH((pw_kernel<K, MT, NT, MODE, THREADS, STREAM>), dim3(blocks), dim3(THREADS), lds, s, a);
   }
 }
 
@@ -534,8 +534,8 @@ bool yfv2_launch_dw(int ksize, int stride, const DwArgs& a, hipStream_t s) {
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
   if (blocks < 1) blocks = 1;
-  if (ksize == 3 && stride == 1) { hipLaunchKernelGGL((dw_kernel<3, 1>), dim3(blocks), dim3(256), 0, s, a); return true; }
-  if (ksize == 3 && stride == 2) { hipLaunchKernelGGL((dw_kernel<3, 2>), dim3(blocks), dim3(256), 0, s, a); return true; }
-  if (ksize == 5 && stride == 1) { hipLaunchKernelGGL((dw_kernel<5, 1>), dim3(blocks), dim3(256), 0, s, a); return true; }
+  if (ksize == 3 && stride == 1) { YFV2_LAUNCH((dw_kernel<3, 1>), dim3(blocks), dim3(256), 0, s, a); return true; }
+  if (ksize == 3 && stride == 2) { YFV2_LAUNCH((dw_kernel<3, 2>), dim3(blocks), dim3(256), 0, s, a); return true; }
+  if (ksize == 5 && stride == 1) { YFV2_LAUNCH((dw_kernel<5, 1>), dim3(blocks), dim3(256), 0, s, a); return true; }
   return false;
 }

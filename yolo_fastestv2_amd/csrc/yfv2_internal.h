@@ -2,6 +2,7 @@
 // units and the host-side plan (yfv2_api.hip).  Not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -19,6 +20,19 @@ __device__ __forceinline__ int yfv2_fdiv(int n, float inv_d) { return (int)(((fl
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-(function, device) attribute: raise it to the 160 KiB cap the first
 // time a function is launched on each device (`done` = the call site's bit mask of devices already served).
 #include <atomic>
+
+// Every launch of the forward path goes through YFV2_LAUNCH.  Normally a plain launch; while yfv2_profile_forward runs a plan step, the
+// step's FIRST launch records its own begin and every launch its own end into the calling thread's event pair (hipExtLaunchKernel: the
+// dispatch's own timestamps - what rocprofv3 reports - instead of hipEventRecord packets in front of and behind the launch, which
+// read 3-12 us more per launch: round 6, profiles/r06_experiments.txt 14).
+struct Yfv2LaunchProbe { hipEvent_t start = nullptr, stop = nullptr; int launches = 0; };
+extern thread_local Yfv2LaunchProbe yfv2_launch_probe;
+#define YFV2_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                        \
+  do {                                                                                                                             \
+    Yfv2LaunchProbe& yfv2_lp_ = yfv2_launch_probe;                                                                                 \
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, yfv2_lp_.launches++ == 0 ? yfv2_lp_.start : nullptr, yfv2_lp_.stop, 0, \
+                          __VA_ARGS__);                                                                                            \
+  } while (0)
 inline void yfv2_allow_full_lds(const void* fn, std::atomic<unsigned long long>& done) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;

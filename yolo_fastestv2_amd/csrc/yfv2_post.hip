@@ -261,16 +261,16 @@ void yfv2_launch_decode(const DecodeArgs& a, hipStream_t s) {
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<false>), lds_ok0);
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<true>), lds_ok1);
     if (a.cand)
-      hipLaunchKernelGGL(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), 0, s, a, b0, b1);
+      YFV2_LAUNCH(decode_kernel<true>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), 0, s, a, b0, b1);
     else
-      hipLaunchKernelGGL(decode_kernel<false>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
+      YFV2_LAUNCH(decode_kernel<false>, dim3(a.B * (b0 + b1)), dim3(DEC_THREADS), lds, s, a, b0, b1);
   } else {   // up to 255 classes: 64 class slots per lane, 32 cells per workgroup ([32][3][260] floats of LDS)
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<false, 64>), lds_ok2);
     yfv2_allow_full_lds(reinterpret_cast<const void*>(&decode_kernel<true, 64>), lds_ok3);
     if (a.cand)
-      hipLaunchKernelGGL((decode_kernel<true, 64>), dim3(a.B * (b0 + b1)), dim3(4 * cells), 0, s, a, b0, b1);
+      YFV2_LAUNCH((decode_kernel<true, 64>), dim3(a.B * (b0 + b1)), dim3(4 * cells), 0, s, a, b0, b1);
     else
-      hipLaunchKernelGGL((decode_kernel<false, 64>), dim3(a.B * (b0 + b1)), dim3(4 * cells), lds, s, a, b0, b1);
+      YFV2_LAUNCH((decode_kernel<false, 64>), dim3(a.B * (b0 + b1)), dim3(4 * cells), lds, s, a, b0, b1);
   }
 }
 // the fused decode + NMS launch (nms_kernel<2>) holds a lane's class slice in 24 registers and the image's rows in LDS
@@ -674,14 +674,14 @@ void yfv2_launch_nms(const NmsArgs& a, hipStream_t s) {
   const DecodeArgs none{};
   if (a.rows <= NMS_CAP) {
     if (a.compact)
-      hipLaunchKernelGGL(nms_kernel<1>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+      YFV2_LAUNCH(nms_kernel<1>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
     else
-      hipLaunchKernelGGL(nms_kernel<0>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+      YFV2_LAUNCH(nms_kernel<0>, dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
   } else {   // up to 4096 rows: four sort keys per thread (the configuration check admits no more)
     if (a.compact)
-      hipLaunchKernelGGL((nms_kernel<1, 4>), dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+      YFV2_LAUNCH((nms_kernel<1, 4>), dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
     else
-      hipLaunchKernelGGL((nms_kernel<0, 4>), dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
+      YFV2_LAUNCH((nms_kernel<0, 4>), dim3(a.B), dim3(NMS_THREADS), 0, s, a, none);
   }
 }
 
@@ -696,7 +696,7 @@ void yfv2_launch_decode_nms(const DecodeArgs& d, const NmsArgs& a, hipStream_t s
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CAP * 8 * (int)sizeof(float));
     done.fetch_or(1ull << dev);
   }
-  hipLaunchKernelGGL(nms_kernel<2>, dim3(a.B), dim3(NMS_THREADS), (size_t)a.rows * 8 * sizeof(float), s, a, d);
+  YFV2_LAUNCH(nms_kernel<2>, dim3(a.B), dim3(NMS_THREADS), (size_t)a.rows * 8 * sizeof(float), s, a, d);
 }
 
 // ============================================================================
@@ -769,4 +769,4 @@ __global__ __launch_bounds__(64) void stats_kernel(StatsArgs a) {
   }
 }
 
-void yfv2_launch_stats(const StatsArgs& a, hipStream_t s) { hipLaunchKernelGGL(stats_kernel, dim3(a.B), dim3(64), 0, s, a); }
+void yfv2_launch_stats(const StatsArgs& a, hipStream_t s) { YFV2_LAUNCH(stats_kernel, dim3(a.B), dim3(64), 0, s, a); }

@@ -398,8 +398,8 @@ void yfv2_launch_s2px(const S2PxArgs& a0, hipStream_t s) {
     a.nb = (OH + a.R - 1) / a.R;
     const int units = a.nstrips * a.nb;
     const dim3 grid(a.B * ((units + 3) / 4));
-    if (role) hipLaunchKernelGGL(s2px_main_kernel, grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(s2px_proj_kernel, grid, dim3(64), 0, s, a);
+    if (role) YFV2_LAUNCH(s2px_main_kernel, grid, dim3(64), 0, s, a);
+    else YFV2_LAUNCH(s2px_proj_kernel, grid, dim3(64), 0, s, a);
   }
 }
 
@@ -412,5 +412,5 @@ void yfv2_launch_s1px(const S1PxArgs& a0, hipStream_t s) {
   a.nb = 5;   // 3 strips x 5 bands = 15 units = 4 waves per image: 1024 waves at 256 images, 11 steps each (4 bands: 768 waves x 13 steps measured 7 % slower, 6 or 8 bands 15-30 % slower)
   a.R = (a.H + a.nb - 1) / a.nb;
   const int units = a.nstrips * a.nb;
-  hipLaunchKernelGGL(s1px_kernel, dim3(a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
+  YFV2_LAUNCH(s1px_kernel, dim3(a.B * ((units + 3) / 4)), dim3(64), 0, s, a);
 }

@@ -235,7 +235,7 @@ void yfv2_launch_s1h(const S1PxArgs& a0, hipStream_t s) {
                               // each, same box as 30-32 - neither the stores' place in the in-order vmcnt queue nor bytes in flight limit it)
   a.R = (a.H + a.nb - 1) / a.nb;
   a.nb = (a.H + a.R - 1) / a.R;
-  hipLaunchKernelGGL(s1h_kernel, dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
+  YFV2_LAUNCH(s1h_kernel, dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
 }
 
 // ============================================================================
@@ -415,7 +415,7 @@ void yfv2_launch_s2h(const S2PxArgs& a0, hipStream_t s) {
   a.nb = OH >= 16 ? 4 : 1;
   a.R = (OH + a.nb - 1) / a.nb;
   a.nb = (OH + a.R - 1) / a.R;
-  hipLaunchKernelGGL(s2h_kernel, dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
+  YFV2_LAUNCH(s2h_kernel, dim3(a.B * a.nstrips * a.nb), dim3(64), 0, s, a);
 }
 
 // ============================================================================
@@ -888,8 +888,8 @@ void yfv2_launch_front(const FrontArgs& a0, hipStream_t s) {
   a.s2.R = (OH + a.s2.nb - 1) / a.s2.nb;
   a.s2.nb = (OH + a.s2.R - 1) / a.s2.R;
   const unsigned units = a.s2.B * a.s2.nstrips * a.s2.nb;
-  if (a.u8_in) hipLaunchKernelGGL(front2_kernel<true>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
-  else hipLaunchKernelGGL(front2_kernel<false>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
+  if (a.u8_in) YFV2_LAUNCH(front2_kernel<true>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
+  else YFV2_LAUNCH(front2_kernel<false>, dim3((units + 3) / 4), dim3(256), F2_FLOATS * sizeof(float), s, a);
 }
 
 // ============================================================================
@@ -1121,7 +1121,7 @@ void yfv2_launch_s3h(const BlockS2Args& a0, hipStream_t s) {
   const int units = nstrips * nb;
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&s3h2_kernel), lds_ok);
-  hipLaunchKernelGGL(s3h2_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), S3H2_FLOATS * sizeof(float), s, a);
+  YFV2_LAUNCH(s3h2_kernel, dim3(a.B * ((units + 3) / 4)), dim3(256), S3H2_FLOATS * sizeof(float), s, a);
 }
 
 // ============================================================================
@@ -1338,6 +1338,6 @@ void yfv2_launch_s4h(const BlockS2Args& a0, hipStream_t s) {
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&s4h_kernel), lds_ok);
   a.s4_main_bands = (nstrips == 1 && OH >= 6) ? 3 : 0;   // (wider or very low maps: two bands x two roles per workgroup, round 4's form)
-  if (a.s4_main_bands) { hipLaunchKernelGGL(s4h_kernel, dim3(a.B), dim3(256), 3 * S4H_WFL * sizeof(float), s, a); return; }
-  hipLaunchKernelGGL(s4h_kernel, dim3(a.B * ((units + 1) / 2)), dim3(256), 3 * S4H_WFL * sizeof(float), s, a);
+  if (a.s4_main_bands) { YFV2_LAUNCH(s4h_kernel, dim3(a.B), dim3(256), 3 * S4H_WFL * sizeof(float), s, a); return; }
+  YFV2_LAUNCH(s4h_kernel, dim3(a.B * ((units + 1) / 2)), dim3(256), 3 * S4H_WFL * sizeof(float), s, a);
 }

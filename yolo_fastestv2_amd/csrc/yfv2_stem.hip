@@ -240,10 +240,10 @@ void yfv2_launch_stem(const StemArgs& a, hipStream_t s) {
   const int strips = (PW - 1 + 14) / 15;
   const dim3 grid(a.B * ((strips * nb + 3) / 4));
   if (a.u8_in) {
-    if (a.pp_out) hipLaunchKernelGGL((stem_px_kernel<true, true>), grid, dim3(64), 0, s, b);
-    else hipLaunchKernelGGL((stem_px_kernel<false, true>), grid, dim3(64), 0, s, b);
+    if (a.pp_out) YFV2_LAUNCH((stem_px_kernel<true, true>), grid, dim3(64), 0, s, b);
+    else YFV2_LAUNCH((stem_px_kernel<false, true>), grid, dim3(64), 0, s, b);
   } else {
-    if (a.pp_out) hipLaunchKernelGGL((stem_px_kernel<true, false>), grid, dim3(64), 0, s, b);
-    else hipLaunchKernelGGL((stem_px_kernel<false, false>), grid, dim3(64), 0, s, b);
+    if (a.pp_out) YFV2_LAUNCH((stem_px_kernel<true, false>), grid, dim3(64), 0, s, b);
+    else YFV2_LAUNCH((stem_px_kernel<false, false>), grid, dim3(64), 0, s, b);
   }
 }

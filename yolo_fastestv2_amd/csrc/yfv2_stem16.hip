@@ -381,6 +381,6 @@ void yfv2_launch_stem16(const StemArgs& a, hipStream_t s) {
   b.R = PH / nb;
   const int strips = (PW - 1 + 14) / 15;
   const dim3 grid(a.B * strips * nb);
-  if (a.u8_in) hipLaunchKernelGGL(stem_h3u_kernel, grid, dim3(64), 0, s, b);
-  else hipLaunchKernelGGL(stem_h3_kernel, grid, dim3(64), 0, s, b);
+  if (a.u8_in) YFV2_LAUNCH(stem_h3u_kernel, grid, dim3(64), 0, s, b);
+  else YFV2_LAUNCH(stem_h3_kernel, grid, dim3(64), 0, s, b);
 }

@@ -1148,7 +1148,7 @@ static void launch_towers(const TowerJobs& jobs, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)th_lds_img(MH) + (TH_C / 4) * 27 * 4 + 15 * 11 * TH_C + 128 * TS_CP + 256);   // (+ 1 KB where unwanted stores go)
   static std::atomic<unsigned long long> lds_ok{0};
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&towers_kernel<MH>), lds_ok);
-  hipLaunchKernelGGL((towers_kernel<MH>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
+  YFV2_LAUNCH((towers_kernel<MH>), dim3(B < 256 ? B : 256), dim3(512), lds, s, jobs);
 }
 
 template <int MH, int PS, int NT>
@@ -1158,7 +1158,7 @@ static void launch_towerh(TowerJobs jobs, hipStream_t s) {
   yfv2_allow_full_lds(reinterpret_cast<const void*>(&towerh_kernel<MH, PS, NT>), lds_ok);
   const int B = jobs.j[0].B;
   jobs.gpj = B < 256 ? B : 256;
-  hipLaunchKernelGGL((towerh_kernel<MH, PS, NT>), dim3(jobs.gpj * (jobs.par ? jobs.n : 1)), dim3(512), lds, s, jobs);
+  YFV2_LAUNCH((towerh_kernel<MH, PS, NT>), dim3(jobs.gpj * (jobs.par ? jobs.n : 1)), dim3(512), lds, s, jobs);
 }
 
 // towerp_kernel's lane -> patch table.  ds_read_b128 is serviced in four groups of 16 lanes, one LDS cycle per group when the 16
@@ -1245,7 +1245,7 @@ static void launch_towerp(TowerJobs jobs, hipStream_t s) {
     }
     std::copy(it->second.begin(), it->second.end(), jobs.lane_patch);
   }
-  hipLaunchKernelGGL((towerp_kernel<MH, BOTH>), dim3(jobs.gpj), dim3(512), lds, s, jobs);
+  YFV2_LAUNCH((towerp_kernel<MH, BOTH>), dim3(jobs.gpj), dim3(512), lds, s, jobs);
 }
 
 // 2x2 patches: up to 22x22 with at most 128 patches; single pixels: up to 11x11
